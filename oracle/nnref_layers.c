@@ -1,0 +1,261 @@
+/*
+ * oracle/nnref_layers.c -- CPU ORACLE (test infrastructure, not product code).
+ * Restates layers/conv_1d.c, batch_norm.c, activation_default.c, gru.c, lstm.c,
+ * dense.c, time_distributed_dense.c (forward/inference only) in the reference's
+ * operation order.  "Parity unpinned" for these paths: see nnref.h header.
+ */
+#include "nnref.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---------------------------------------------------------- activations --- */
+
+/* layers/activation_default.c:28-33 sigmoid (neg, exp, +1, reciprocal),
+ * :65-67 tanh, :98-103 identity, :123-129 relu (max then optional scale),
+ * :149-167 softmax (no max subtraction; size = number of vectors). */
+void ref_activation(int kind, float relu_a, int softmax_vector_size,
+                    const float *in, float *out, int size) {
+    switch (kind) {
+    case REF_ACT_IDENTITY:
+        if (in != out) memmove(out, in, sizeof(float) * (size_t)size);
+        break;
+    case REF_ACT_SIGMOID:
+        for (int i = 0; i < size; ++i) {
+            float v = -in[i];
+            v = expf(v);
+            v = v + 1;
+            out[i] = 1 / v;
+        }
+        break;
+    case REF_ACT_TANH:
+        for (int i = 0; i < size; ++i) out[i] = tanhf(in[i]);
+        break;
+    case REF_ACT_RELU:
+        for (int i = 0; i < size; ++i) out[i] = fmaxf(in[i], 0);
+        if (relu_a != 1.0)
+            for (int i = 0; i < size; ++i) out[i] = out[i] * relu_a;
+        break;
+    case REF_ACT_SOFTMAX:
+        for (int v = 0; v < size; ++v) {
+            const float *x = in + (size_t)v * softmax_vector_size;
+            float *y = out + (size_t)v * softmax_vector_size;
+            for (int i = 0; i < softmax_vector_size; ++i) y[i] = expf(x[i]);
+            float sum = 0.0f;
+            for (int i = 0; i < softmax_vector_size; ++i) sum += y[i];
+            for (int i = 0; i < softmax_vector_size; ++i) y[i] = y[i] / sum;
+        }
+        break;
+    default: break;
+    }
+}
+
+/* ---------------------------------------------------------------- conv1d --- */
+
+/* layers/conv_1d.c:77-87 */
+int ref_conv1d_output_size(int input_size, int kernel_size, int stride) {
+    return (input_size - (kernel_size - stride)) / stride;
+}
+
+/* layers/conv_1d.c:122-147: transpose [T,Cin]->[Cin,T], then per (o, x):
+ * result = 0; for i: result += dot_k(row_i[x*s ..], W[o,i,:]); result += b[o] */
+void ref_conv1d(const float *in, const float *W, const float *b, float *out,
+                int T, int Cin, int Cout, int k, int stride) {
+    int Tout = ref_conv1d_output_size(T, k, stride);
+    float *tr = (float *)malloc(sizeof(float) * (size_t)T * Cin);
+    ref_op_mat_transp(in, tr, Cin, T);
+    for (int o = 0; o < Cout; ++o) {
+        const float *Wo = W + (size_t)o * Cin * k;
+        for (int x = 0; x < Tout; ++x) {
+            float result = 0.0f;
+            int off = x * stride;
+            for (int i = 0; i < Cin; ++i)
+                result += ref_op_vec_dot(tr + (size_t)i * T + off, Wo + i * k, k);
+            result += b[o];
+            out[(size_t)x * Cout + o] = result;
+        }
+    }
+    free(tr);
+}
+
+/* layers/conv_1d.c:167-183 forward part */
+void ref_conv1d_batch(const float *in, const float *W, const float *b, float *out,
+                      int B, int T, int Cin, int Cout, int k, int stride) {
+    int Tout = ref_conv1d_output_size(T, k, stride);
+    for (int n = 0; n < B; ++n)
+        ref_conv1d(in + (size_t)n * T * Cin, W, b, out + (size_t)n * Tout * Cout, T, Cin, Cout, k, stride);
+}
+
+/* ------------------------------------------------------------ batch norm --- */
+
+/* layers/batch_norm.c:140-163, :166-189:
+ * ((x - mean) / sqrt(var + eps)) * gamma + beta, each op a separate rounding */
+void ref_batch_norm(const float *in, const float *gamma, const float *beta,
+                    const float *mean, const float *variance, float *out,
+                    float epsilon, int count, int C) {
+    for (int r = 0; r < count; ++r) {
+        const float *x = in + (size_t)r * C;
+        float *y = out + (size_t)r * C;
+        for (int c = 0; c < C; ++c) {
+            float x_mu = x[c] - mean[c];
+            float var_eps = variance[c] + epsilon;
+            float sqrt_var = sqrtf(var_eps);
+            float x_norm = x_mu / sqrt_var;
+            float gx = x_norm * gamma[c];
+            y[c] = gx + beta[c];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------- GRU --- */
+
+static void vec_add(const float *a, const float *b, float *c, int n) {
+    for (int i = 0; i < n; ++i) c[i] = a[i] + b[i];
+}
+static void vec_mul(const float *a, const float *b, float *c, int n) {
+    for (int i = 0; i < n; ++i) c[i] = a[i] * b[i];
+}
+
+/* layers/gru.c:129-187 (GRUCellForward).  buf needs 14*H floats. */
+static void gru_cell(const float *x, const float *W, const float *U, const float *b_i, const float *b_h,
+                     const float *h_pr, float *ht, float *buf, int in, int H,
+                     int act_z, int act_h, int act_r) {
+    float *Z_zr = buf;               /* 6H: Z_z, Z_r, Z_h~, z, r, h~ */
+    float *x_W = buf + 6 * H;        /* 3H */
+    ref_op_mat_mul(x, W, x_W, 1, 3 * H, in);
+    vec_add(x_W, b_i, x_W, 3 * H);
+    float *h_pr_U = x_W + 3 * H;     /* 3H */
+    ref_op_mat_mul(h_pr, U, h_pr_U, 1, 3 * H, H);
+    vec_add(h_pr_U, b_h, h_pr_U, 3 * H);
+    vec_add(x_W, h_pr_U, Z_zr, 2 * H);
+    float *z = Z_zr + 3 * H;
+    float *r = z + H;
+    ref_activation(act_z, 1.0f, 0, Z_zr, z, H);
+    ref_activation(act_r, 1.0f, 0, Z_zr + H, r, H);
+    float *Z_h = Z_zr + 2 * H;
+    float *h_tilda = r + H;
+    vec_mul(r, h_pr_U + 2 * H, Z_h, H);
+    vec_add(Z_h, x_W + 2 * H, Z_h, H);
+    ref_activation(act_h, 1.0f, 0, Z_h, h_tilda, H);
+    float *minus_z = h_pr_U + 3 * H; /* H */
+    for (int i = 0; i < H; ++i) minus_z[i] = -z[i];
+    for (int i = 0; i < H; ++i) minus_z[i] = minus_z[i] + 1;
+    vec_mul(minus_z, h_tilda, minus_z, H);
+    float *z_h = minus_z + H;        /* H */
+    vec_mul(z, h_pr, z_h, H);
+    vec_add(minus_z, z_h, ht, H);
+}
+
+/* layers/gru.c:189-204 (GRUApplyInference): state carried in h_state */
+void ref_gru_sequence(const float *x, const float *W, const float *U,
+                      const float *b_i, const float *b_h, float *h_state, float *out,
+                      int T, int in, int H, int return_sequences,
+                      int act_z, int act_h, int act_r) {
+    float *buf = (float *)calloc((size_t)14 * H, sizeof(float));
+    for (int t = 0; t < T; ++t) {
+        float *o = out + (return_sequences ? (size_t)t * H : 0);
+        gru_cell(x + (size_t)t * in, W, U, b_i, b_h, h_state, o, buf, in, H, act_z, act_h, act_r);
+        memcpy(h_state, o, sizeof(float) * (size_t)H);
+    }
+    free(buf);
+}
+
+/* layers/gru.c:246-293 forward semantics: zero state per sequence (:260) */
+void ref_gru_batch(const float *x, const float *W, const float *U,
+                   const float *b_i, const float *b_h, float *out,
+                   int B, int T, int in, int H, int return_sequences,
+                   int act_z, int act_h, int act_r) {
+    float *h = (float *)malloc(sizeof(float) * (size_t)H);
+    for (int n = 0; n < B; ++n) {
+        memset(h, 0, sizeof(float) * (size_t)H);
+        float *o = out + (return_sequences ? (size_t)n * T * H : (size_t)n * H);
+        ref_gru_sequence(x + (size_t)n * T * in, W, U, b_i, b_h, h, o, T, in, H, return_sequences,
+                         act_z, act_h, act_r);
+    }
+    free(h);
+}
+
+/* ------------------------------------------------------------------ LSTM --- */
+
+/* layers/lstm.c:185-239 (LSTMCellForward).  buf needs 15*H floats. */
+static void lstm_cell(const float *x, const float *W, const float *U, const float *b_i, const float *b_h,
+                      const float *c_prev, const float *h_prev, float *c, float *h, float *buf,
+                      int in, int H, int v2, int act_i, int act_f, int act_g, int act_o, int act_out) {
+    float *Z = buf;                  /* 8H: Z(4H), i, f, g, o */
+    float *u_H = buf + 8 * H;        /* 4H, then i_g, f_c_pr, c_tanh */
+    ref_op_mat_mul(x, W, Z, 1, 4 * H, in);
+    vec_add(Z, b_i, Z, 4 * H);
+    ref_op_mat_mul(h_prev, U, u_H, 1, 4 * H, H);
+    if (v2) vec_add(u_H, b_h, u_H, 4 * H);
+    vec_add(Z, u_H, Z, 4 * H);
+    float *ig = Z + 4 * H;
+    ref_activation(act_i, 1.0f, 0, Z, ig, H);
+    float *fg = ig + H;
+    ref_activation(act_f, 1.0f, 0, Z + H, fg, H);
+    float *gg = fg + H;
+    ref_activation(act_g, 1.0f, 0, Z + 2 * H, gg, H);
+    float *og = gg + H;
+    ref_activation(act_o, 1.0f, 0, Z + 3 * H, og, H);
+    float *i_g = u_H + 4 * H;
+    vec_mul(ig, gg, i_g, H);
+    float *f_c = i_g + H;
+    vec_mul(fg, c_prev, f_c, H);
+    vec_add(f_c, i_g, c, H);
+    float *c_t = f_c + H;
+    ref_activation(act_out, 1.0f, 0, c, c_t, H);
+    vec_mul(og, c_t, h, H);
+}
+
+/* layers/lstm.c:241-268 (LSTMApplyInference) */
+void ref_lstm_sequence(const float *x, const float *W, const float *U,
+                       const float *b_i, const float *b_h, float *h_state, float *c_state,
+                       float *out, int T, int in, int H, int return_sequences, int v2,
+                       int act_i, int act_f, int act_g, int act_o, int act_out) {
+    float *buf = (float *)calloc((size_t)15 * H, sizeof(float));
+    float *state = (float *)malloc(sizeof(float) * (size_t)H);
+    for (int t = 0; t < T; ++t) {
+        float *o = out + (return_sequences ? (size_t)t * H : 0);
+        lstm_cell(x + (size_t)t * in, W, U, b_i, b_h, c_state, h_state, state, o, buf, in, H, v2,
+                  act_i, act_f, act_g, act_o, act_out);
+        memcpy(h_state, o, sizeof(float) * (size_t)H);
+        memcpy(c_state, state, sizeof(float) * (size_t)H);
+    }
+    free(buf); free(state);
+}
+
+/* layers/lstm.c:426-475 forward semantics: zero state per sequence (:439) */
+void ref_lstm_batch(const float *x, const float *W, const float *U,
+                    const float *b_i, const float *b_h, float *out,
+                    int B, int T, int in, int H, int return_sequences, int v2,
+                    int act_i, int act_f, int act_g, int act_o, int act_out) {
+    float *h = (float *)malloc(sizeof(float) * (size_t)H);
+    float *c = (float *)malloc(sizeof(float) * (size_t)H);
+    for (int n = 0; n < B; ++n) {
+        memset(h, 0, sizeof(float) * (size_t)H);
+        memset(c, 0, sizeof(float) * (size_t)H);
+        float *o = out + (return_sequences ? (size_t)n * T * H : (size_t)n * H);
+        ref_lstm_sequence(x + (size_t)n * T * in, W, U, b_i, b_h, h, c, o, T, in, H, return_sequences, v2,
+                          act_i, act_f, act_g, act_o, act_out);
+    }
+    free(h); free(c);
+}
+
+/* ----------------------------------------------------------------- dense --- */
+
+/* layers/dense.c:122-142: z = x*W + b ; a = activation(z) (or copy if none).
+ * The activation handle carries its own size (act_size), as in the reference. */
+void ref_dense(const float *x, const float *W, const float *b, float *out,
+               int in, int out_size, int act_kind, float relu_a, int softmax_vector_size, int act_size) {
+    ref_op_mat_mul(x, W, out, 1, out_size, in);
+    vec_add(out, b, out, out_size);
+    if (act_kind >= 0) ref_activation(act_kind, relu_a, softmax_vector_size, out, out, act_size);
+}
+
+/* layers/time_distributed_dense.c:52-58 */
+void ref_time_distributed_dense(const float *x, const float *W, const float *b, float *out,
+                                int ts, int in, int out_size,
+                                int act_kind, float relu_a, int softmax_vector_size, int act_size) {
+    for (int t = 0; t < ts; ++t)
+        ref_dense(x + (size_t)t * in, W, b, out + (size_t)t * out_size, in, out_size,
+                  act_kind, relu_a, softmax_vector_size, act_size);
+}
