@@ -1,0 +1,271 @@
+/*
+ * nntoolkitcore_hip.h -- the drop-in C boundary of the MI355X-native
+ * implementation of NNToolkitCore's time-series inference path
+ *   Spectrogram -> Conv1d -> BatchNorm/Activation -> GRU/LSTM -> TimeDistributedDense.
+ *
+ * PART 1 re-declares the reference's own layer create/apply API for that path
+ * (same symbol names, argument meaning, by-value struct layouts and 0 / -1 error
+ * convention), so an application that includes the reference headers links
+ * against libnntoolkitcore_hip.so unchanged.  Each block cites the reference
+ * header it replaces.  The struct layouts are checked against the reference's
+ * real headers by tests/test_abi.py (golden: tests/golden/ref_probe.json).
+ *
+ * PART 2 is ADDITIVE: batched [batch, time, feature] entry points, device-pointer
+ * variants (so a stack chains on the GPU without host round trips), fused
+ * Conv1d+BatchNorm+ReLU, weight re-sync, stream / device selection and an error
+ * string for the void functions.  No HIP or torch type appears in any signature:
+ * device buffers are plain `float *` holding device addresses, streams `void *`.
+ *
+ * Host code above this header stays C; the kernels are hand-written HIP for
+ * gfx950 behind the thin shim in nntoolkitcore_amd/csrc/hip/nntk_shim.h.
+ * There is NO CPU fallback: if the HIP runtime or a GPU is missing, Apply calls
+ * fail (-1 / nntk_last_error()).
+ */
+#ifndef NNTOOLKITCORE_HIP_H
+#define NNTOOLKITCORE_HIP_H
+
+#include <stdbool.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ======================================================================= */
+/* PART 1 -- reference API                                                   */
+/* ======================================================================= */
+
+/* ---- nntoolkitcore/layers/shared.h:12-34 ------------------------------- */
+typedef struct { int mini_batch_size; } DefaultTrainingConfig;
+typedef struct { int w; int b; int sum; } DefaultWeightsSize;
+typedef struct { float *W; float *b; } DefaultWeights;
+
+/* ---- nntoolkitcore/layers/activation.h:19-30 --------------------------- */
+typedef void (*ActivationFunctionImpl)(void *, const float *, float *, int);
+typedef void (*ActivationFunctionDerivative)(void *, const float *, const float *, float *, int);
+typedef void (*ActivationImplementerDestroy)(void *);
+typedef struct ActivationFunctionStruct *ActivationFunction;
+
+/* Custom (host-callback) activations are accepted here for ABI compatibility
+ * but cannot run on the device: a layer configured with one fails with -1. */
+ActivationFunction ActivationFunctionCreate(int size, ActivationImplementerDestroy destroy_fn, void *implementer,
+                                            ActivationFunctionImpl function, ActivationFunctionDerivative derivative,
+                                            ActivationFunctionDerivative cached_derivative);
+void ActivationFunctionDestroy(ActivationFunction filter);
+/* host pointers; size fixed at create time (activation.c:23) */
+void ActivationFunctionApply(ActivationFunction filter, const float *input, float *output);
+
+/* ---- nntoolkitcore/layers/activation_default.h:19-27 ------------------- */
+ActivationFunction ActivationFunctionCreateIdentity(int input_size);
+ActivationFunction ActivationFunctionCreateSoftmax(int input_size, int vector_size);
+ActivationFunction ActivationFunctionCreateSigmoid(int input_size);
+ActivationFunction ActivationFunctionCreateReLU(int input_size, float a);
+ActivationFunction ActivationFunctionCreateTanh(int input_size);
+
+/* ---- nntoolkitcore/layers/conv_1d.h:22-55 ------------------------------ */
+typedef struct {
+    int input_feature_channels;
+    int output_feature_channels;
+    int kernel_size;
+    int stride;
+    int input_size;
+    int output_size;
+} Conv1dConfig;
+typedef DefaultWeights ConvWeights;
+typedef struct Conv1dStruct *Conv1d;
+
+Conv1dConfig Conv1dConfigCreate(int input_feature_channels, int output_feature_channels, int kernel_size,
+                                int stride, int inputSize);
+Conv1d Conv1dCreateForInference(Conv1dConfig config);
+ConvWeights *Conv1dGetWeights(Conv1d filter);            /* W [Cout][Cin][k] then b [Cout], one block */
+int  Conv1dApplyInference(Conv1d filter, const float *input, float *output);   /* host, one sequence */
+void Conv1dDestroy(Conv1d filter);
+
+/* ---- nntoolkitcore/layers/batch_norm.h:19-66 --------------------------- */
+typedef struct { float *gamma; float *beta; float *moving_mean; float *moving_variance; } BatchNormWeights;
+typedef struct { int feature_channels; float epsilon; int count; } BatchNormConfig;
+typedef struct BatchNormFilterStruct *BatchNorm;
+
+BatchNormConfig BatchNormConfigCreate(int feature_channels, float epsilon, int count);
+BatchNorm BatchNormCreateForInference(BatchNormConfig config);
+BatchNormWeights *BatchNormGetWeights(BatchNorm filter);
+int  BatchNormApplyInference(BatchNorm filter, const float *input, float *output);
+void BatchNormDestroy(BatchNorm filter);
+
+/* ---- nntoolkitcore/layers/recurrent.h:17-56 ---------------------------- */
+typedef struct { int w; int u; int b_i; int b_h; int sum; } RecurrentWeightsSize;
+typedef struct { float *W; float *U; float *b_i; float *b_h; } RecurrentWeights;
+typedef struct {
+    int input_feature_channels;
+    int output_feature_channels;
+    bool return_sequences;
+    int timesteps;
+} RecurrentConfig;
+RecurrentConfig RecurrentConfigCreate(int input_feature_channels, int output_feature_channels,
+                                      bool return_sequences, int timesteps);
+
+/* ---- nntoolkitcore/layers/gru.h:22-71 ---------------------------------- */
+typedef RecurrentWeights GRUWeights;
+typedef struct {
+    ActivationFunction z_gate_activation;
+    ActivationFunction h_gate_activation;
+    ActivationFunction r_gate_activation;
+} GRUActivations;
+typedef struct { RecurrentConfig base; GRUActivations activations; } GRUConfig;
+typedef struct GRUStruct *GRU;
+
+GRUActivations GRUActivationsCreate(ActivationFunction z_gate_activation, ActivationFunction h_gate_activation,
+                                    ActivationFunction r_gate_activation);
+GRUActivations GRUActivationsCreateDefault(int size);
+void GRUActivationsDestroy(GRUActivations activations);
+GRUConfig GRUConfigCreate(int input_feature_channels, int output_feature_channels, bool return_sequences,
+                          int timesteps, GRUActivations activations);
+GRUWeights *GRUGetWeights(GRU filter);                   /* W [in,3H] | U [H,3H] | b_i [3H] | b_h [3H]; gates z,r,h */
+GRU  GRUCreateForInference(GRUConfig config);
+int  GRUApplyInference(GRU filter, const float *input, float *output);  /* host, one sequence, STATEFUL */
+void GRUDestroy(GRU filter);
+
+/* ---- nntoolkitcore/layers/lstm.h:20-75 --------------------------------- */
+typedef RecurrentWeights LSTMWeights;
+typedef struct {
+    ActivationFunction candidate_gate_activation;
+    ActivationFunction input_gate_activation;
+    ActivationFunction forget_gate_activation;
+    ActivationFunction output_gate_activation;
+    ActivationFunction output_activation;
+} LSTMActivations;
+typedef struct { RecurrentConfig base; bool v2; LSTMActivations activations; } LSTMConfig;
+typedef struct LSTMStruct *LSTM;
+
+LSTMActivations LSTMActivationsCreate(ActivationFunction input_gate_activation,
+                                      ActivationFunction forget_gate_activation,
+                                      ActivationFunction candidate_gate_activation,
+                                      ActivationFunction output_gate_activation,
+                                      ActivationFunction output_activation);
+LSTMActivations LSTMActivationsCreateDefault(int size);
+void LSTMActivationsDestroy(LSTMActivations activations);
+LSTMConfig LSTMConfigCreate(int input_feature_channels, int output_feature_channels, bool return_sequences,
+                            int timesteps, bool v2, LSTMActivations activations);
+LSTMWeights *LSTMGetWeights(LSTM filter);                /* W [in,4H] | U [H,4H] | b_i | b_h; gates i,f,g,o */
+LSTM LSTMCreateForInference(LSTMConfig config);
+int  LSTMApplyInference(LSTM filter, const float *input, float *output); /* host, one sequence, STATEFUL */
+void LSTMDestroy(LSTM filter);
+
+/* ---- nntoolkitcore/layers/dense.h:21-55 -------------------------------- */
+typedef DefaultWeights DenseWeights;
+typedef struct { int input_size; int output_size; ActivationFunction activation; } DenseConfig;
+typedef struct DenseStruct *Dense;
+
+DenseConfig DenseConfigCreate(int input_size, int output_size, ActivationFunction activation);
+Dense DenseCreateForInference(DenseConfig config);
+DenseWeights *DenseGetWeights(Dense filter);             /* W [in,out] row-major then b [out] */
+int  DenseApplyInference(Dense filter, const float *input, float *output);
+void DenseDestroy(Dense filter);
+
+/* ---- nntoolkitcore/layers/time_distributed_dense.h:19-45 --------------- */
+typedef struct { DenseConfig dense; int ts; } TimeDistributedDenseConfig;
+typedef struct TimeDistributedDenseStruct *TimeDistributedDense;
+
+TimeDistributedDenseConfig TimeDistributedDenseConfigCreate(int ts, DenseConfig dense);
+TimeDistributedDense TimeDistributedDenseCreateForInference(TimeDistributedDenseConfig config);
+DenseWeights *TimeDistributedDenseGetWeights(TimeDistributedDense filter);
+int  TimeDistributedDenseApplyInference(TimeDistributedDense filter, const float *input, float *output);
+void TimeDistributedDenseDestroy(TimeDistributedDense filter);
+
+/* ---- nntoolkitcore/signal/window.h:17-29 ------------------------------- */
+typedef void (*window_fn)(float *, int);
+void hamming_window(float *vector, int size);
+void hann_window(float *vector, int size);
+void ones(float *vector, int size);
+void periodic_hamming_window(float *vector, int size);
+void periodic_hann_window(float *vector, int size);
+void blackman_window(float *vector, int size);
+
+/* ---- nntoolkitcore/signal/spectrogram.h:20-44 -------------------------- */
+typedef struct {
+    int nfft;
+    int window_size;
+    int noverlap;
+    int step;
+    int input_size;
+    int nfreq;
+    int ntime_series;
+    float fft_normalization_factor;
+} SpectrogramConfig;
+typedef struct SpectrogramStruct *Spectrogram;
+
+SpectrogramConfig SpectrogramConfigCreate(int nfft, int window_size, int noverlap, int input_size,
+                                          float fft_normalization_factor);
+Spectrogram SpectrogramCreatePSD(SpectrogramConfig config, int fs);
+Spectrogram SpectrogramCreateMagnitude(SpectrogramConfig config);
+SpectrogramConfig SpectrogramGetConfig(Spectrogram filter);
+void SpectrogramSetWindowFunc(Spectrogram filter, window_fn fn);
+void SpectrogramSetScaleFactor(Spectrogram filter, float factor);
+void SpectrogramApply(Spectrogram filter, const float *input, float *output);  /* host; errors via nntk_last_error() */
+void SpectrogramDestroy(Spectrogram filter);
+
+/* ======================================================================= */
+/* PART 2 -- additive MI355X entry points                                    */
+/* ======================================================================= */
+
+/* ---- runtime ----------------------------------------------------------- */
+int         nntk_hip_device_count(void);
+int         nntk_hip_set_device(int device);          /* 0 ok, -1 error */
+void        nntk_hip_set_stream(void *hip_stream);    /* all later launches use it; NULL = default stream */
+void       *nntk_hip_get_stream(void);
+int         nntk_hip_synchronize(void);               /* waits for the current stream */
+const char *nntk_last_error(void);                    /* "" when the last call succeeded */
+const char *nntk_version(void);
+
+/* raw device memory helpers for C callers that chain layers on the GPU */
+float *nntk_device_alloc(size_t n_floats);
+void   nntk_device_free(float *ptr);
+int    nntk_device_upload(float *dst_device, const float *src_host, size_t n_floats);
+int    nntk_device_download(float *dst_host, const float *src_device, size_t n_floats);
+
+/* Re-upload the host weight block after the caller edited it.  The host-pointer
+ * Apply* functions of Part 1 detect edits themselves (they compare the block with
+ * the last uploaded copy); the *Device functions below do not. */
+int Conv1dSyncWeights(Conv1d filter);
+int BatchNormSyncWeights(BatchNorm filter);
+int GRUSyncWeights(GRU filter);
+int LSTMSyncWeights(LSTM filter);
+int DenseSyncWeights(Dense filter);
+int TimeDistributedDenseSyncWeights(TimeDistributedDense filter);
+
+/* ---- batched host-pointer forms: semantics of the reference's
+ *      *ApplyTrainingBatch forward pass (conv_1d.c:167, gru.c:246, lstm.c:426,
+ *      dense.c:144) without the training caches: input [batch, T, in],
+ *      zero initial recurrent state per sequence. --------------------------- */
+int Conv1dApplyInferenceBatch(Conv1d filter, const float *input, float *output, int batch);
+int GRUApplyInferenceBatch(GRU filter, const float *input, float *output, int batch);
+int LSTMApplyInferenceBatch(LSTM filter, const float *input, float *output, int batch);
+int TimeDistributedDenseApplyInferenceBatch(TimeDistributedDense filter, const float *input, float *output, int batch);
+int SpectrogramApplyBatch(Spectrogram filter, const float *input, float *output, int batch);
+
+/* ---- device-pointer forms (all pointers are device addresses; asynchronous
+ *      on the current stream; 0 ok, -1 error) ------------------------------ */
+int SpectrogramApplyDevice(Spectrogram filter, const float *d_input /*[batch,input_size]*/,
+                           float *d_output /*[batch,ntime_series,nfreq]*/, int batch);
+int Conv1dApplyDevice(Conv1d filter, const float *d_input /*[batch,T,Cin]*/,
+                      float *d_output /*[batch,Tout,Cout]*/, int batch);
+/* fused Conv1d -> BatchNorm(inference) -> activation in one kernel; bn and/or act may be NULL */
+int Conv1dBatchNormActivationApplyDevice(Conv1d filter, BatchNorm bn, ActivationFunction act,
+                                         const float *d_input, float *d_output, int batch);
+int BatchNormApplyDevice(BatchNorm filter, const float *d_input, float *d_output, int rows);
+int ActivationFunctionApplyDevice(ActivationFunction filter, const float *d_input, float *d_output, int size);
+int GRUApplyDevice(GRU filter, const float *d_input /*[batch,T,in]*/, float *d_output, int batch);
+int LSTMApplyDevice(LSTM filter, const float *d_input /*[batch,T,in]*/, float *d_output, int batch);
+int DenseApplyDevice(Dense filter, const float *d_input /*[rows,in]*/, float *d_output /*[rows,out]*/, int rows);
+int TimeDistributedDenseApplyDevice(TimeDistributedDense filter, const float *d_input, float *d_output, int batch);
+
+/* recurrent state of the stateful single-sequence API (gru.c:201, lstm.c:264-265) */
+int GRUResetState(GRU filter);
+int LSTMResetState(LSTM filter);
+int GRUGetState(GRU filter, float *h_host);
+int LSTMGetState(LSTM filter, float *h_host, float *c_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NNTOOLKITCORE_HIP_H */

@@ -1,0 +1,68 @@
+"""Build libnntoolkitcore_hip.so in-tree: C host layer with gcc, kernels with hipcc for gfx950.
+
+The shared object lands in ``nntoolkitcore_amd/lib/`` (git-ignored, but it travels to
+the GPU box with the gpurun snapshot).  hipcc cross-compiles without a GPU.
+"""
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+OBJ = os.path.join(PKG, "lib", "obj")
+LIB = os.path.join(PKG, "lib", "libnntoolkitcore_hip.so")
+
+HOST_SRC = ["runtime.c", "activation.c", "conv_1d.c", "recurrent.c", "dense.c", "spectrogram.c"]
+HIP_SRC = ["runtime.hip", "conv1d.hip", "recurrent.hip", "spectrogram.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+
+def _newer(src_list, target):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in src_list)
+
+
+def _run(cmd):
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        sys.stderr.write(res.stdout)
+        raise RuntimeError("build step failed: " + " ".join(cmd))
+    return res.stdout
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(ROOT, "include", "nntoolkitcore_hip.h"),
+               os.path.join(CSRC, "hip", "nntk_shim.h"),
+               os.path.join(CSRC, "hip", "nntk_common.hpp"),
+               os.path.join(CSRC, "host", "nntk_internal.h")]
+    objs = []
+    for f in HOST_SRC:
+        src = os.path.join(CSRC, "host", f)
+        obj = os.path.join(OBJ, f + ".o")
+        objs.append(obj)
+        if force or _newer([src] + headers, obj):
+            out = _run(["gcc", "-O2", "-fPIC", "-std=gnu11", "-Wall", "-Wextra", "-Wno-unused-parameter",
+                        "-fvisibility=default", "-I" + os.path.join(ROOT, "include"), "-c", src, "-o", obj])
+            if verbose and out:
+                print(out)
+    for f in HIP_SRC:
+        src = os.path.join(CSRC, "hip", f)
+        obj = os.path.join(OBJ, f + ".o")
+        objs.append(obj)
+        if force or _newer([src] + headers, obj):
+            out = _run([HIPCC, "-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-Wall",
+                        "-Wno-unused-function", "-c", src, "-o", obj])
+            if verbose and out:
+                print(out)
+    if force or _newer(objs, LIB):
+        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

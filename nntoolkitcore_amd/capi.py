@@ -1,0 +1,226 @@
+"""ctypes binding of libnntoolkitcore_hip.so -- the C boundary declared in
+include/nntoolkitcore_hip.h.  This is exactly the binding a maintainer of a Python
+caller of the reference would write; nothing here computes anything.
+
+Loading fails loudly (ImportError) when the shared library has not been built:
+there is no Python or CPU fallback for the product path.
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libnntoolkitcore_hip.so")
+
+fp = C.POINTER(C.c_float)
+vp = C.c_void_p
+
+
+# ---- by-value config structs (layouts checked against the reference headers in tests/test_abi.py)
+class Conv1dConfig(C.Structure):
+    _fields_ = [("input_feature_channels", C.c_int), ("output_feature_channels", C.c_int),
+                ("kernel_size", C.c_int), ("stride", C.c_int), ("input_size", C.c_int), ("output_size", C.c_int)]
+
+
+class DefaultWeights(C.Structure):
+    _fields_ = [("W", fp), ("b", fp)]
+
+
+class BatchNormWeights(C.Structure):
+    _fields_ = [("gamma", fp), ("beta", fp), ("moving_mean", fp), ("moving_variance", fp)]
+
+
+class BatchNormConfig(C.Structure):
+    _fields_ = [("feature_channels", C.c_int), ("epsilon", C.c_float), ("count", C.c_int)]
+
+
+class RecurrentWeights(C.Structure):
+    _fields_ = [("W", fp), ("U", fp), ("b_i", fp), ("b_h", fp)]
+
+
+class RecurrentConfig(C.Structure):
+    _fields_ = [("input_feature_channels", C.c_int), ("output_feature_channels", C.c_int),
+                ("return_sequences", C.c_bool), ("timesteps", C.c_int)]
+
+
+class GRUActivations(C.Structure):
+    _fields_ = [("z_gate_activation", vp), ("h_gate_activation", vp), ("r_gate_activation", vp)]
+
+
+class GRUConfig(C.Structure):
+    _fields_ = [("base", RecurrentConfig), ("activations", GRUActivations)]
+
+
+class LSTMActivations(C.Structure):
+    _fields_ = [("candidate_gate_activation", vp), ("input_gate_activation", vp), ("forget_gate_activation", vp),
+                ("output_gate_activation", vp), ("output_activation", vp)]
+
+
+class LSTMConfig(C.Structure):
+    _fields_ = [("base", RecurrentConfig), ("v2", C.c_bool), ("activations", LSTMActivations)]
+
+
+class DenseConfig(C.Structure):
+    _fields_ = [("input_size", C.c_int), ("output_size", C.c_int), ("activation", vp)]
+
+
+class TimeDistributedDenseConfig(C.Structure):
+    _fields_ = [("dense", DenseConfig), ("ts", C.c_int)]
+
+
+class SpectrogramConfig(C.Structure):
+    _fields_ = [("nfft", C.c_int), ("window_size", C.c_int), ("noverlap", C.c_int), ("step", C.c_int),
+                ("input_size", C.c_int), ("nfreq", C.c_int), ("ntime_series", C.c_int),
+                ("fft_normalization_factor", C.c_float)]
+
+
+WINDOW_FN = C.CFUNCTYPE(None, fp, C.c_int)
+ACT_IMPL_FN = C.CFUNCTYPE(None, vp, fp, fp, C.c_int)
+
+# name -> (restype, argtypes); this table is also the list of symbols the library must export
+SIGNATURES = {
+    # activation.h / activation_default.h
+    "ActivationFunctionCreate": (vp, [C.c_int, vp, vp, vp, vp, vp]),
+    "ActivationFunctionDestroy": (None, [vp]),
+    "ActivationFunctionApply": (None, [vp, fp, fp]),
+    "ActivationFunctionCreateIdentity": (vp, [C.c_int]),
+    "ActivationFunctionCreateSoftmax": (vp, [C.c_int, C.c_int]),
+    "ActivationFunctionCreateSigmoid": (vp, [C.c_int]),
+    "ActivationFunctionCreateReLU": (vp, [C.c_int, C.c_float]),
+    "ActivationFunctionCreateTanh": (vp, [C.c_int]),
+    # conv_1d.h
+    "Conv1dConfigCreate": (Conv1dConfig, [C.c_int] * 5),
+    "Conv1dCreateForInference": (vp, [Conv1dConfig]),
+    "Conv1dGetWeights": (C.POINTER(DefaultWeights), [vp]),
+    "Conv1dApplyInference": (C.c_int, [vp, fp, fp]),
+    "Conv1dDestroy": (None, [vp]),
+    # batch_norm.h
+    "BatchNormConfigCreate": (BatchNormConfig, [C.c_int, C.c_float, C.c_int]),
+    "BatchNormCreateForInference": (vp, [BatchNormConfig]),
+    "BatchNormGetWeights": (C.POINTER(BatchNormWeights), [vp]),
+    "BatchNormApplyInference": (C.c_int, [vp, fp, fp]),
+    "BatchNormDestroy": (None, [vp]),
+    # recurrent.h / gru.h
+    "RecurrentConfigCreate": (RecurrentConfig, [C.c_int, C.c_int, C.c_bool, C.c_int]),
+    "GRUActivationsCreate": (GRUActivations, [vp, vp, vp]),
+    "GRUActivationsCreateDefault": (GRUActivations, [C.c_int]),
+    "GRUActivationsDestroy": (None, [GRUActivations]),
+    "GRUConfigCreate": (GRUConfig, [C.c_int, C.c_int, C.c_bool, C.c_int, GRUActivations]),
+    "GRUGetWeights": (C.POINTER(RecurrentWeights), [vp]),
+    "GRUCreateForInference": (vp, [GRUConfig]),
+    "GRUApplyInference": (C.c_int, [vp, fp, fp]),
+    "GRUDestroy": (None, [vp]),
+    # lstm.h
+    "LSTMActivationsCreate": (LSTMActivations, [vp] * 5),
+    "LSTMActivationsCreateDefault": (LSTMActivations, [C.c_int]),
+    "LSTMActivationsDestroy": (None, [LSTMActivations]),
+    "LSTMConfigCreate": (LSTMConfig, [C.c_int, C.c_int, C.c_bool, C.c_int, C.c_bool, LSTMActivations]),
+    "LSTMGetWeights": (C.POINTER(RecurrentWeights), [vp]),
+    "LSTMCreateForInference": (vp, [LSTMConfig]),
+    "LSTMApplyInference": (C.c_int, [vp, fp, fp]),
+    "LSTMDestroy": (None, [vp]),
+    # dense.h / time_distributed_dense.h
+    "DenseConfigCreate": (DenseConfig, [C.c_int, C.c_int, vp]),
+    "DenseCreateForInference": (vp, [DenseConfig]),
+    "DenseGetWeights": (C.POINTER(DefaultWeights), [vp]),
+    "DenseApplyInference": (C.c_int, [vp, fp, fp]),
+    "DenseDestroy": (None, [vp]),
+    "TimeDistributedDenseConfigCreate": (TimeDistributedDenseConfig, [C.c_int, DenseConfig]),
+    "TimeDistributedDenseCreateForInference": (vp, [TimeDistributedDenseConfig]),
+    "TimeDistributedDenseGetWeights": (C.POINTER(DefaultWeights), [vp]),
+    "TimeDistributedDenseApplyInference": (C.c_int, [vp, fp, fp]),
+    "TimeDistributedDenseDestroy": (None, [vp]),
+    # window.h / spectrogram.h
+    "hamming_window": (None, [fp, C.c_int]),
+    "hann_window": (None, [fp, C.c_int]),
+    "ones": (None, [fp, C.c_int]),
+    "periodic_hamming_window": (None, [fp, C.c_int]),
+    "periodic_hann_window": (None, [fp, C.c_int]),
+    "blackman_window": (None, [fp, C.c_int]),
+    "SpectrogramConfigCreate": (SpectrogramConfig, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),
+    "SpectrogramCreatePSD": (vp, [SpectrogramConfig, C.c_int]),
+    "SpectrogramCreateMagnitude": (vp, [SpectrogramConfig]),
+    "SpectrogramGetConfig": (SpectrogramConfig, [vp]),
+    "SpectrogramSetWindowFunc": (None, [vp, vp]),
+    "SpectrogramSetScaleFactor": (None, [vp, C.c_float]),
+    "SpectrogramApply": (None, [vp, fp, fp]),
+    "SpectrogramDestroy": (None, [vp]),
+    # ---- additive API
+    "nntk_hip_device_count": (C.c_int, []),
+    "nntk_hip_set_device": (C.c_int, [C.c_int]),
+    "nntk_hip_set_stream": (None, [vp]),
+    "nntk_hip_get_stream": (vp, []),
+    "nntk_hip_synchronize": (C.c_int, []),
+    "nntk_last_error": (C.c_char_p, []),
+    "nntk_version": (C.c_char_p, []),
+    "nntk_device_alloc": (vp, [C.c_size_t]),
+    "nntk_device_free": (None, [vp]),
+    "nntk_device_upload": (C.c_int, [vp, fp, C.c_size_t]),
+    "nntk_device_download": (C.c_int, [fp, vp, C.c_size_t]),
+    "Conv1dSyncWeights": (C.c_int, [vp]),
+    "BatchNormSyncWeights": (C.c_int, [vp]),
+    "GRUSyncWeights": (C.c_int, [vp]),
+    "LSTMSyncWeights": (C.c_int, [vp]),
+    "DenseSyncWeights": (C.c_int, [vp]),
+    "TimeDistributedDenseSyncWeights": (C.c_int, [vp]),
+    "Conv1dApplyInferenceBatch": (C.c_int, [vp, fp, fp, C.c_int]),
+    "GRUApplyInferenceBatch": (C.c_int, [vp, fp, fp, C.c_int]),
+    "LSTMApplyInferenceBatch": (C.c_int, [vp, fp, fp, C.c_int]),
+    "TimeDistributedDenseApplyInferenceBatch": (C.c_int, [vp, fp, fp, C.c_int]),
+    "SpectrogramApplyBatch": (C.c_int, [vp, fp, fp, C.c_int]),
+    "SpectrogramApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
+    "Conv1dApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
+    "Conv1dBatchNormActivationApplyDevice": (C.c_int, [vp, vp, vp, vp, vp, C.c_int]),
+    "BatchNormApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
+    "ActivationFunctionApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
+    "GRUApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
+    "LSTMApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
+    "DenseApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
+    "TimeDistributedDenseApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
+    "GRUResetState": (C.c_int, [vp]),
+    "LSTMResetState": (C.c_int, [vp]),
+    "GRUGetState": (C.c_int, [vp, fp]),
+    "LSTMGetState": (C.c_int, [vp, fp, fp]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the product library and declare every entry point.  Needs libamdhip64
+    (ROCm) at load time but no GPU: only Apply/alloc calls touch the device."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libnntoolkitcore_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `python nntoolkitcore_amd/_build.py`. There is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: torch-ROCm bundles its own libamdhip64.so.7.  Import it
+    # first so our NEEDED libamdhip64.so.7 binds to the copy torch already loaded --
+    # otherwise torch streams / device pointers would belong to a different runtime
+    # instance than the one our launches go through.  (A plain C caller without torch
+    # simply gets the system ROCm runtime.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().nntk_last_error().decode()
+
+
+class NNTKError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise NNTKError("%s failed (rc=%d): %s" % (what, rc, last_error()))

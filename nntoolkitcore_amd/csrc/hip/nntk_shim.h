@@ -1,0 +1,97 @@
+/*
+ * nntk_shim.h -- the thin C-ABI between the C host layer (csrc/host) and the
+ * hand-written HIP kernels (csrc/hip).  Plain pointers and ints only; no
+ * HIP types.  All `d_` pointers are device addresses.  Every launcher enqueues on
+ * the current stream (nntk_shim_stream) and returns 0, or -1 after recording a
+ * message retrievable with nntk_shim_error().
+ */
+#ifndef NNTK_SHIM_H
+#define NNTK_SHIM_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* activation kinds understood by the device code */
+enum {
+    NNTK_ACT_NONE     = -1,   /* no activation handle (dense.c:127-133 copy branch) */
+    NNTK_ACT_IDENTITY = 0,
+    NNTK_ACT_SIGMOID  = 1,
+    NNTK_ACT_TANH     = 2,
+    NNTK_ACT_RELU     = 3,
+    NNTK_ACT_SOFTMAX  = 4,
+    NNTK_ACT_CUSTOM   = 100   /* host callback: not runnable on the device */
+};
+
+/* ---- runtime --------------------------------------------------------------- */
+int         nntk_shim_device_count(void);
+int         nntk_shim_set_device(int device);
+void        nntk_shim_set_stream(void *stream);
+void       *nntk_shim_get_stream(void);
+int         nntk_shim_synchronize(void);
+const char *nntk_shim_error(void);
+void        nntk_shim_set_error(const char *msg);
+void        nntk_shim_clear_error(void);
+
+void *nntk_shim_malloc(size_t bytes);
+void  nntk_shim_free(void *d_ptr);
+void *nntk_shim_host_alloc(size_t bytes);              /* pinned, zero-filled */
+void  nntk_shim_host_free(void *ptr);
+int   nntk_shim_upload(void *d_dst, const void *h_src, size_t bytes);     /* blocking */
+int   nntk_shim_download(void *h_dst, const void *d_src, size_t bytes);   /* blocking */
+int   nntk_shim_copy_d2d(void *d_dst, const void *d_src, size_t bytes);   /* async on stream */
+int   nntk_shim_memset(void *d_ptr, int value, size_t bytes);             /* async on stream */
+
+/* ---- K2/K3: implicit-GEMM conv1d / dense on f32 MFMA with fused epilogue ----
+ * out[b, x, o] = act( bn( bias[o] + sum_{kk,i} in[b, x*stride+kk, i] * Wp[(kk*Cin_p + i), o] ) )
+ *   d_in   [B, T, Cin]           channels-last
+ *   d_wp   packed weights [k*Cin_p, Cout_p] (see nntk_shim_conv_pack_sizes)
+ *   d_bias [Cout]
+ *   d_bn   NULL or 4*Cout floats: gamma | beta | mean | variance (batch_norm.c:79-84 order)
+ *   out_mode 0: out[b, x, :] at row b*Tout + x;  1: time-major row x*B + b (for recurrent input projections)
+ * Dense / TimeDistributedDense / input projection = the k=1, stride=1 case with T = rows.
+ */
+void nntk_shim_conv_pack_sizes(int Cin, int Cout, int k, int *Cin_p, int *Cout_p);
+int  nntk_shim_conv1d(const float *d_in, const float *d_wp, const float *d_bias, const float *d_bn,
+                      float bn_eps, int act_kind, float relu_a, float *d_out,
+                      int B, int T, int Cin, int Cout, int k, int stride, int Tout, int out_mode);
+
+/* ---- standalone BatchNorm (batch_norm.c:140-163 op order) and activations -- */
+int nntk_shim_batch_norm(const float *d_in, const float *d_bn /*gamma|beta|mean|var*/, float eps,
+                         float *d_out, long rows, int C);
+int nntk_shim_activation(int kind, float relu_a, int softmax_vector_size,
+                         const float *d_in, float *d_out, long n_elems);
+
+/* ---- K4: recurrent layers -------------------------------------------------
+ * d_xw   [T, B, G*H] time-major input projections INCLUDING b_i (from nntk_shim_conv1d out_mode 1)
+ * d_ut   packed recurrent weights U^T: [G*H, H] (row n = column n of U)
+ * d_bh   [G*H] recurrent bias (NULL = none; LSTM v2=false)
+ * d_h0 / d_c0  [B, H] initial state or NULL for zeros
+ * d_out  [B, T, H] if return_sequences else [B, H]
+ * d_hT / d_cT  [B, H] final state (may be NULL)
+ * d_work scratch >= nntk_shim_recurrent_work_floats(B, H) floats
+ * acts   GRU: {z, h, r};  LSTM: {i, f, g, o, out}
+ */
+size_t nntk_shim_recurrent_work_floats(int B, int H);
+int nntk_shim_gru(const float *d_xw, const float *d_ut, const float *d_bh,
+                  const float *d_h0, float *d_out, float *d_hT, float *d_work,
+                  int B, int T, int H, int return_sequences, const int acts[3]);
+int nntk_shim_lstm(const float *d_xw, const float *d_ut, const float *d_bh,
+                   const float *d_h0, const float *d_c0, float *d_out, float *d_hT, float *d_cT,
+                   float *d_work, int B, int T, int H, int return_sequences, const int acts[5]);
+
+/* ---- K1: framed STFT magnitude / PSD ---------------------------------------
+ * d_in [B, input_size], d_window [window_size], d_out [B, nts, nfreq]
+ * d_twiddle [nfft] complex interleaved: exp(-2*pi*i*m/nfft), evaluated in double on the host
+ * mode 0: sqrt(re^2+im^2)/scale   mode 1: psd (spectrogram.c:41-47)
+ */
+int nntk_shim_spectrogram(const float *d_in, const float *d_window, const float *d_twiddle, float *d_out,
+                          int B, int input_size, int nfft, int window_size, int step,
+                          int nfreq, int nts, float fft_norm, int mode, float scale);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,215 @@
+// runtime.hip -- device/stream/memory plumbing behind nntk_shim.h, plus the
+// memory-bound elementwise kernels (standalone BatchNorm, activations, softmax).
+#include "nntk_common.hpp"
+#include <stdio.h>
+#include <string.h>
+
+static hipStream_t g_stream = nullptr;
+static thread_local char g_err[512] = "";
+
+hipStream_t nntk_stream() { return g_stream; }
+
+int nntk_fail(const char *what, hipError_t err) {
+    snprintf(g_err, sizeof(g_err), "HIP error in %s: %s", what, hipGetErrorString(err));
+    return -1;
+}
+int nntk_fail_msg(const char *what) {
+    snprintf(g_err, sizeof(g_err), "%s", what);
+    return -1;
+}
+
+extern "C" {
+
+const char *nntk_shim_error(void) { return g_err; }
+void nntk_shim_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg ? msg : ""); }
+void nntk_shim_clear_error(void) { g_err[0] = 0; }
+
+int nntk_shim_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int nntk_shim_set_device(int device) {
+    NNTK_HIP_TRY(hipSetDevice(device));
+    return 0;
+}
+void nntk_shim_set_stream(void *stream) { g_stream = (hipStream_t)stream; }
+void *nntk_shim_get_stream(void) { return (void *)g_stream; }
+int nntk_shim_synchronize(void) {
+    NNTK_HIP_TRY(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+void *nntk_shim_malloc(size_t bytes) {
+    void *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) { nntk_fail("hipMalloc", e); return nullptr; }
+    return p;
+}
+void nntk_shim_free(void *p) { if (p) (void)hipFree(p); }
+
+void *nntk_shim_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { nntk_fail("hipHostMalloc", e); return nullptr; }
+    memset(p, 0, bytes);
+    return p;
+}
+void nntk_shim_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+int nntk_shim_upload(void *d_dst, const void *h_src, size_t bytes) {
+    if (!bytes) return 0;
+    NNTK_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, g_stream));
+    NNTK_HIP_TRY(hipStreamSynchronize(g_stream));
+    return 0;
+}
+int nntk_shim_download(void *h_dst, const void *d_src, size_t bytes) {
+    if (!bytes) return 0;
+    NNTK_HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, g_stream));
+    NNTK_HIP_TRY(hipStreamSynchronize(g_stream));
+    return 0;
+}
+int nntk_shim_copy_d2d(void *d_dst, const void *d_src, size_t bytes) {
+    if (!bytes) return 0;
+    NNTK_HIP_TRY(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, g_stream));
+    return 0;
+}
+int nntk_shim_memset(void *d_ptr, int value, size_t bytes) {
+    if (!bytes) return 0;
+    NNTK_HIP_TRY(hipMemsetAsync(d_ptr, value, bytes, g_stream));
+    return 0;
+}
+
+}  // extern "C"
+
+// ----------------------------------------------------------------------------
+// Standalone BatchNorm (inference): layers/batch_norm.c:140-163 in its op order
+//   ((x - mean) / sqrt(var + eps)) * gamma + beta
+// HBM-bound: one read + one write of the [rows, C] tensor; the 4*C parameter
+// block stays in L1/L2.  Grid-stride over float elements; when C % 4 == 0 each
+// lane moves 16 B.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_kernel_vec4(const float4 *in, const float *__restrict__ bn,
+                                                      float eps, float4 *out, long n4, int C) {
+    const float *gamma = bn, *beta = bn + C, *mean = bn + 2 * C, *var = bn + 3 * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)((i * 4) % C);
+        float4 x = in[i];
+        float v[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = sqrtf(var[c + j] + eps);
+            v[j] = ((v[j] - mean[c + j]) / s) * gamma[c + j] + beta[c + j];
+        }
+        out[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_kernel(const float *in, const float *__restrict__ bn, float eps,
+                                                 float *out, long n, int C) {
+    const float *gamma = bn, *beta = bn + C, *mean = bn + 2 * C, *var = bn + 3 * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        float s = sqrtf(var[c] + eps);
+        out[i] = ((in[i] - mean[c]) / s) * gamma[c] + beta[c];
+    }
+}
+
+// elementwise activations (activation_default.c), 16 B per lane where aligned
+__global__ __launch_bounds__(256) void act_kernel(int kind, float relu_a, const float *in,
+                                                  float *out, long n) {
+    long n4 = n / 4;
+    const float4 *in4 = reinterpret_cast<const float4 *>(in);
+    float4 *out4 = reinterpret_cast<float4 *>(out);
+    long stride = (long)gridDim.x * blockDim.x;
+    long tid = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    for (long i = tid; i < n4; i += stride) {
+        float4 x = in4[i];
+        out4[i] = make_float4(nntk_act(kind, x.x, relu_a), nntk_act(kind, x.y, relu_a),
+                              nntk_act(kind, x.z, relu_a), nntk_act(kind, x.w, relu_a));
+    }
+    for (long i = n4 * 4 + tid; i < n; i += stride) out[i] = nntk_act(kind, in[i], relu_a);
+}
+
+__global__ __launch_bounds__(256) void act_kernel_scalar(int kind, float relu_a, const float *in,
+                                                         float *out, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = nntk_act(kind, in[i], relu_a);
+}
+
+// softmax WITHOUT max subtraction (activation_default.c:149-154): exp, sum, divide.
+// One wavefront per vector; 64-lane shuffle reduction of the exp sum.
+__global__ __launch_bounds__(256) void softmax_kernel(const float *in, float *out,
+                                                      long vectors, int vsize) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long v = wave; v < vectors; v += nwaves) {
+        const float *x = in + v * vsize;
+        float *y = out + v * vsize;
+        float sum = 0.0f;
+        for (int i = lane; i < vsize; i += 64) {
+            float e = expf(x[i]);
+            y[i] = e;
+            sum += e;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        for (int i = lane; i < vsize; i += 64) y[i] = y[i] / sum;
+    }
+}
+
+static int grid_for(long work_items, int block) {
+    long g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;   // 256 CUs x 8 blocks; grid-stride beyond
+    return (int)g;
+}
+
+extern "C" {
+
+int nntk_shim_batch_norm(const float *d_in, const float *d_bn, float eps, float *d_out, long rows, int C) {
+    if (rows <= 0 || C <= 0) return 0;
+    long n = rows * C;
+    bool vec = (C % 4 == 0) && (((size_t)d_in | (size_t)d_out) % 16 == 0);
+    if (vec) {
+        hipLaunchKernelGGL(bn_kernel_vec4, dim3(grid_for(n / 4, 256)), dim3(256), 0, nntk_stream(),
+                           (const float4 *)d_in, d_bn, eps, (float4 *)d_out, n / 4, C);
+    } else {
+        hipLaunchKernelGGL(bn_kernel, dim3(grid_for(n, 256)), dim3(256), 0, nntk_stream(), d_in, d_bn, eps, d_out, n, C);
+    }
+    NNTK_LAUNCH_CHECK("bn_kernel");
+    return 0;
+}
+
+int nntk_shim_activation(int kind, float relu_a, int softmax_vector_size, const float *d_in, float *d_out,
+                         long n_elems) {
+    if (n_elems <= 0) return 0;
+    if (kind == NNTK_ACT_SOFTMAX) {
+        if (softmax_vector_size <= 0) return nntk_fail_msg("softmax: vector_size must be > 0");
+        long vectors = n_elems / softmax_vector_size;
+        hipLaunchKernelGGL(softmax_kernel, dim3(grid_for(vectors * 64, 256)), dim3(256), 0, nntk_stream(),
+                           d_in, d_out, vectors, softmax_vector_size);
+        NNTK_LAUNCH_CHECK("softmax_kernel");
+        return 0;
+    }
+    if (kind == NNTK_ACT_IDENTITY || kind == NNTK_ACT_NONE) {
+        if (d_in != d_out) return nntk_shim_copy_d2d(d_out, d_in, (size_t)n_elems * sizeof(float));
+        return 0;
+    }
+    if (kind != NNTK_ACT_SIGMOID && kind != NNTK_ACT_TANH && kind != NNTK_ACT_RELU)
+        return nntk_fail_msg("activation: custom host-callback activations cannot run on the device");
+    bool aligned = (((size_t)d_in | (size_t)d_out) % 16 == 0);
+    if (aligned)
+        hipLaunchKernelGGL(act_kernel, dim3(grid_for(n_elems / 4 + 1, 256)), dim3(256), 0, nntk_stream(),
+                           kind, relu_a, d_in, d_out, n_elems);
+    else
+        hipLaunchKernelGGL(act_kernel_scalar, dim3(grid_for(n_elems, 256)), dim3(256), 0, nntk_stream(),
+                           kind, relu_a, d_in, d_out, n_elems);
+    NNTK_LAUNCH_CHECK("act_kernel");
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,241 @@
+/*
+ * conv_1d.c + batch_norm host layer -- reference: layers/conv_1d.{h,c} (forward,
+ * :77-165) and layers/batch_norm.{h,c} (inference, :61-189).  Handles own the
+ * caller-visible weight block; the device copy is packed for the implicit-GEMM
+ * kernel (csrc/hip/conv1d.hip) on first use.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "nntk_internal.h"
+
+/* =============================== Conv1d =================================== */
+
+struct Conv1dStruct {
+    Conv1dConfig config;
+    ConvWeights *weights;
+    nntk_wblock wb;
+    float *d_wp, *d_bias;
+    nntk_devbuf d_in, d_out;
+};
+
+/* conv_1d.c:77-87 */
+Conv1dConfig Conv1dConfigCreate(int input_feature_channels, int output_feature_channels, int kernel_size,
+                                int stride, int inputSize) {
+    Conv1dConfig c;
+    c.input_feature_channels = input_feature_channels;
+    c.output_feature_channels = output_feature_channels;
+    c.kernel_size = kernel_size;
+    c.stride = stride;
+    c.input_size = inputSize;
+    c.output_size = (inputSize - (kernel_size - stride)) / stride;
+    return c;
+}
+
+/* conv_1d.c:89-102 with the weight block of weights_private.c:16-21: W then b */
+Conv1d Conv1dCreateForInference(Conv1dConfig config) {
+    nntk_shim_clear_error();
+    Conv1d f = (Conv1d)calloc(1, sizeof(struct Conv1dStruct));
+    if (!f) return NULL;
+    f->config = config;
+    size_t w = (size_t)config.kernel_size * config.input_feature_channels * config.output_feature_channels;
+    if (nntk_wblock_init(&f->wb, w + config.output_feature_channels)) { free(f); return NULL; }
+    f->weights = (ConvWeights *)malloc(sizeof(ConvWeights));
+    f->weights->W = f->wb.host;
+    f->weights->b = f->wb.host + w;
+    return f;
+}
+
+ConvWeights *Conv1dGetWeights(Conv1d filter) { return filter->weights; }
+
+void Conv1dDestroy(Conv1d filter) {
+    if (!filter) return;
+    nntk_shim_synchronize();
+    nntk_shim_free(filter->d_wp);
+    nntk_shim_free(filter->d_bias);
+    nntk_devbuf_free(&filter->d_in);
+    nntk_devbuf_free(&filter->d_out);
+    nntk_wblock_free(&filter->wb);
+    free(filter->weights);
+    free(filter);
+}
+
+/* W [Cout][Cin][k] (conv_1d.c:129-139 indexing) -> Wp [(kk*Cin_p + i), Cout_p] */
+static int conv_upload(Conv1d f) {
+    const Conv1dConfig *c = &f->config;
+    int Cin = c->input_feature_channels, Cout = c->output_feature_channels, k = c->kernel_size;
+    int Cin_p, Cout_p;
+    nntk_shim_conv_pack_sizes(Cin, Cout, k, &Cin_p, &Cout_p);
+    size_t n = (size_t)k * Cin_p * Cout_p;
+    float *tmp = (float *)calloc(n, sizeof(float));
+    if (!tmp) NNTK_FAIL("out of host memory while packing conv weights");
+    const float *W = f->weights->W;
+    for (int o = 0; o < Cout; ++o)
+        for (int i = 0; i < Cin; ++i)
+            for (int kk = 0; kk < k; ++kk)
+                tmp[((size_t)kk * Cin_p + i) * Cout_p + o] = W[((size_t)o * Cin + i) * k + kk];
+    int rc = nntk_upload_floats(&f->d_wp, tmp, n);
+    free(tmp);
+    if (rc) return rc;
+    if (nntk_upload_floats(&f->d_bias, f->weights->b, (size_t)Cout)) return -1;
+    nntk_wblock_mark_uploaded(&f->wb);
+    return 0;
+}
+
+static int conv_ensure(Conv1d f, int check_edits) {
+    if (nntk_wblock_dirty(&f->wb, check_edits)) return conv_upload(f);
+    return 0;
+}
+
+int Conv1dSyncWeights(Conv1d filter) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("Conv1dSyncWeights: NULL handle");
+    nntk_shim_synchronize();
+    return conv_upload(filter);
+}
+
+static int conv_launch(Conv1d f, const float *d_bn, float eps, int act_kind, float relu_a,
+                       const float *d_in, float *d_out, int batch) {
+    const Conv1dConfig *c = &f->config;
+    return nntk_shim_conv1d(d_in, f->d_wp, f->d_bias, d_bn, eps, act_kind, relu_a, d_out, batch, c->input_size,
+                            c->input_feature_channels, c->output_feature_channels, c->kernel_size, c->stride,
+                            c->output_size, 0);
+}
+
+int Conv1dApplyDevice(Conv1d filter, const float *d_input, float *d_output, int batch) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("Conv1dApplyDevice: NULL handle");
+    if (conv_ensure(filter, 0)) return -1;
+    return conv_launch(filter, NULL, 0.f, NNTK_ACT_IDENTITY, 1.f, d_input, d_output, batch);
+}
+
+int Conv1dBatchNormActivationApplyDevice(Conv1d filter, BatchNorm bn, ActivationFunction act,
+                                         const float *d_input, float *d_output, int batch) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("Conv1dBatchNormActivationApplyDevice: NULL conv handle");
+    if (conv_ensure(filter, 0)) return -1;
+    const float *d_bn = NULL;
+    float eps = 0.f;
+    if (bn) {
+        if (nntk_batch_norm_channels(bn) != filter->config.output_feature_channels)
+            NNTK_FAIL("fused conv+bn: BatchNorm feature_channels must equal conv output channels");
+        d_bn = nntk_batch_norm_device_block(bn, 0);
+        if (!d_bn) return -1;
+        eps = nntk_batch_norm_epsilon(bn);
+    }
+    if (!nntk_act_fusable(act)) NNTK_FAIL("fused conv+bn+act: activation must be identity/sigmoid/tanh/relu");
+    int kind = act ? act->kind : NNTK_ACT_IDENTITY;
+    float a = act ? act->relu_a : 1.0f;
+    return conv_launch(filter, d_bn, eps, kind, a, d_input, d_output, batch);
+}
+
+int Conv1dApplyInferenceBatch(Conv1d filter, const float *input, float *output, int batch) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("Conv1dApplyInferenceBatch: NULL handle");
+    if (batch <= 0) return 0;
+    const Conv1dConfig *c = &filter->config;
+    if (conv_ensure(filter, 1)) return -1;
+    size_t n_in = (size_t)batch * c->input_size * c->input_feature_channels;
+    size_t n_out = (size_t)batch * c->output_size * c->output_feature_channels;
+    float *d_in = nntk_devbuf_reserve(&filter->d_in, n_in);
+    float *d_out = nntk_devbuf_reserve(&filter->d_out, n_out);
+    if (!d_in || !d_out) return -1;
+    if (nntk_shim_upload(d_in, input, n_in * sizeof(float))) return -1;
+    if (conv_launch(filter, NULL, 0.f, NNTK_ACT_IDENTITY, 1.f, d_in, d_out, batch)) return -1;
+    return nntk_shim_download(output, d_out, n_out * sizeof(float));
+}
+
+/* conv_1d.c:149-155: one [T, Cin] sequence -> [Tout, Cout] */
+int Conv1dApplyInference(Conv1d filter, const float *input, float *output) {
+    return Conv1dApplyInferenceBatch(filter, input, output, 1);
+}
+
+/* ============================== BatchNorm ================================= */
+
+struct BatchNormFilterStruct {
+    BatchNormConfig config;
+    BatchNormWeights *weights;
+    nntk_wblock wb;           /* gamma | beta | moving_mean | moving_variance (batch_norm.c:79-84) */
+    float *d_block;
+    nntk_devbuf d_io;
+};
+
+/* batch_norm.c:65-71 */
+BatchNormConfig BatchNormConfigCreate(int feature_channels, float epsilon, int count) {
+    BatchNormConfig c;
+    c.feature_channels = feature_channels;
+    c.epsilon = epsilon;
+    c.count = count;
+    return c;
+}
+
+/* batch_norm.c:73-86: all four vectors zero-initialised, gamma included */
+BatchNorm BatchNormCreateForInference(BatchNormConfig config) {
+    nntk_shim_clear_error();
+    BatchNorm f = (BatchNorm)calloc(1, sizeof(struct BatchNormFilterStruct));
+    if (!f) return NULL;
+    f->config = config;
+    int C = config.feature_channels;
+    if (nntk_wblock_init(&f->wb, (size_t)4 * C)) { free(f); return NULL; }
+    f->weights = (BatchNormWeights *)malloc(sizeof(BatchNormWeights));
+    f->weights->gamma = f->wb.host;
+    f->weights->beta = f->wb.host + C;
+    f->weights->moving_mean = f->wb.host + 2 * C;
+    f->weights->moving_variance = f->wb.host + 3 * C;
+    return f;
+}
+
+BatchNormWeights *BatchNormGetWeights(BatchNorm filter) { return filter->weights; }
+
+void BatchNormDestroy(BatchNorm filter) {
+    if (!filter) return;
+    nntk_shim_synchronize();
+    nntk_shim_free(filter->d_block);
+    nntk_devbuf_free(&filter->d_io);
+    nntk_wblock_free(&filter->wb);
+    free(filter->weights);
+    free(filter);
+}
+
+static int bn_upload(BatchNorm f) {
+    if (nntk_upload_floats(&f->d_block, f->wb.host, f->wb.n)) return -1;
+    nntk_wblock_mark_uploaded(&f->wb);
+    return 0;
+}
+
+const float *nntk_batch_norm_device_block(BatchNorm bn, int check_edits) {
+    if (nntk_wblock_dirty(&bn->wb, check_edits) && bn_upload(bn)) return NULL;
+    return bn->d_block;
+}
+int nntk_batch_norm_channels(BatchNorm bn) { return bn->config.feature_channels; }
+float nntk_batch_norm_epsilon(BatchNorm bn) { return bn->config.epsilon; }
+
+int BatchNormSyncWeights(BatchNorm filter) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("BatchNormSyncWeights: NULL handle");
+    nntk_shim_synchronize();
+    return bn_upload(filter);
+}
+
+int BatchNormApplyDevice(BatchNorm filter, const float *d_input, float *d_output, int rows) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("BatchNormApplyDevice: NULL handle");
+    const float *blk = nntk_batch_norm_device_block(filter, 0);
+    if (!blk) return -1;
+    return nntk_shim_batch_norm(d_input, blk, filter->config.epsilon, d_output, rows, filter->config.feature_channels);
+}
+
+/* batch_norm.c:166-189: `count` rows of `feature_channels` */
+int BatchNormApplyInference(BatchNorm filter, const float *input, float *output) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("BatchNormApplyInference: NULL handle");
+    const float *blk = nntk_batch_norm_device_block(filter, 1);
+    if (!blk) return -1;
+    size_t n = (size_t)filter->config.count * filter->config.feature_channels;
+    if (n == 0) return 0;
+    float *d = nntk_devbuf_reserve(&filter->d_io, n);
+    if (!d) return -1;
+    if (nntk_shim_upload(d, input, n * sizeof(float))) return -1;
+    if (nntk_shim_batch_norm(d, blk, filter->config.epsilon, d, filter->config.count, filter->config.feature_channels))
+        return -1;
+    return nntk_shim_download(output, d, n * sizeof(float));
+}

@@ -1,0 +1,66 @@
+/*
+ * nntk_internal.h -- private helpers of the C host layer.  The host layer owns
+ * handles, the caller-visible (pinned) weight blocks, lazy upload / repacking and
+ * the recurrent state; all GPU work goes through csrc/hip/nntk_shim.h.
+ */
+#ifndef NNTK_INTERNAL_H
+#define NNTK_INTERNAL_H
+
+#include <stddef.h>
+#include "nntoolkitcore_hip.h"
+#include "../hip/nntk_shim.h"
+
+/* One contiguous, zero-initialised, caller-visible weight block (the reference's
+ * f_malloc'd block: weights_private.c:16-21, recurrent_private.c:29-36,
+ * batch_norm.c:79-84), pinned for fast upload, plus a shadow of what the device
+ * currently holds so host-pointer Apply calls can detect in-place edits. */
+typedef struct {
+    float *host;
+    float *shadow;
+    size_t n;
+    int uploaded;
+} nntk_wblock;
+
+int  nntk_wblock_init(nntk_wblock *wb, size_t n_floats);
+void nntk_wblock_free(nntk_wblock *wb);
+/* 1 if the device copy is missing or (check_edits && host != shadow) */
+int  nntk_wblock_dirty(const nntk_wblock *wb, int check_edits);
+void nntk_wblock_mark_uploaded(nntk_wblock *wb);
+
+/* growable device scratch */
+typedef struct { float *p; size_t cap; } nntk_devbuf;
+float *nntk_devbuf_reserve(nntk_devbuf *b, size_t n_floats);
+void   nntk_devbuf_free(nntk_devbuf *b);
+
+/* upload a host array into a fresh/reused device buffer */
+int nntk_upload_floats(float **d_dst, const float *h_src, size_t n);
+
+/* pack a row-major [K, N] matrix into the conv/GEMM kernel's [K_p, N_p] layout and upload */
+int nntk_upload_gemm_weights(float **d_wp, const float *W, int K, int N);
+
+struct ActivationFunctionStruct {
+    int kind;                 /* NNTK_ACT_* */
+    int input_size;
+    float relu_a;
+    int vector_size;          /* softmax */
+    /* custom host-callback activations (activation.h:19-26) */
+    void *implementer;
+    ActivationImplementerDestroy destroy_fn;
+    ActivationFunctionImpl function;
+    ActivationFunctionDerivative derivative;
+    ActivationFunctionDerivative cached_derivative;
+};
+
+/* kind usable inside a fused kernel epilogue? (identity / sigmoid / tanh / relu, or NULL handle) */
+int nntk_act_fusable(ActivationFunction a);
+int nntk_act_kind(ActivationFunction a);   /* NNTK_ACT_NONE for NULL */
+
+/* accessors used across host files */
+const float *nntk_batch_norm_device_block(BatchNorm bn, int check_edits);   /* gamma|beta|mean|var or NULL on error */
+int   nntk_batch_norm_channels(BatchNorm bn);
+float nntk_batch_norm_epsilon(BatchNorm bn);
+
+void nntk_set_error(const char *msg);
+#define NNTK_FAIL(msg) do { nntk_set_error(msg); return -1; } while (0)
+
+#endif

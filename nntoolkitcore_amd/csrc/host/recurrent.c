@@ -1,0 +1,363 @@
+/*
+ * recurrent.c -- GRU and LSTM host layer.  Reference: layers/recurrent.{h,c},
+ * layers/private/recurrent_private.c:29-36 (one block W | U | b_i | b_h),
+ * layers/gru.c (forward :13-19, :51-61, :110-204), layers/lstm.c (forward
+ * :17-26, :55-65, :110-268).
+ *
+ * Device plan per Apply:
+ *   1. xW + b_i for all timesteps: one MFMA GEMM, written time-major [T, B, G*H]
+ *   2. T fused step kernels (csrc/hip/recurrent.hip) carrying h (and c)
+ * The single-sequence API is stateful exactly like the reference (gru.c:201,
+ * lstm.c:264-265): h/c persist in the handle between calls; the batched forms
+ * start every sequence from zeros (gru.c:260, lstm.c:439).
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "nntk_internal.h"
+
+/* recurrent.c:7-19 */
+RecurrentConfig RecurrentConfigCreate(int input_feature_channels, int output_feature_channels,
+                                      bool return_sequences, int timesteps) {
+    RecurrentConfig c;
+    memset(&c, 0, sizeof(c));
+    c.input_feature_channels = input_feature_channels;
+    c.output_feature_channels = output_feature_channels;
+    c.return_sequences = return_sequences;
+    c.timesteps = timesteps;
+    return c;
+}
+
+/* shared core of both layers */
+typedef struct {
+    int G;                      /* 3 (GRU) or 4 (LSTM) */
+    int in, H, T;
+    bool return_sequences;
+    RecurrentWeights *weights;
+    nntk_wblock wb;
+    float *d_wp, *d_bi, *d_ut, *d_bh;
+    float *d_h, *d_c;           /* persistent single-sequence state [H] */
+    nntk_devbuf d_in, d_out, d_xw, d_work;
+} rec_core;
+
+static int core_init(rec_core *c, int G, RecurrentConfig base) {
+    memset(c, 0, sizeof(*c));
+    c->G = G;
+    c->in = base.input_feature_channels;
+    c->H = base.output_feature_channels;
+    c->T = base.timesteps;
+    c->return_sequences = base.return_sequences;
+    size_t w = (size_t)c->in * G * c->H, u = (size_t)c->H * G * c->H, b = (size_t)G * c->H;
+    if (nntk_wblock_init(&c->wb, w + u + 2 * b)) return -1;
+    c->weights = (RecurrentWeights *)malloc(sizeof(RecurrentWeights));
+    c->weights->W = c->wb.host;
+    c->weights->U = c->weights->W + w;
+    c->weights->b_i = c->weights->U + u;
+    c->weights->b_h = c->weights->b_i + b;
+    c->d_h = (float *)nntk_shim_malloc((size_t)c->H * sizeof(float));
+    c->d_c = (float *)nntk_shim_malloc((size_t)c->H * sizeof(float));
+    if (!c->d_h || !c->d_c) return -1;
+    if (nntk_shim_memset(c->d_h, 0, (size_t)c->H * sizeof(float))) return -1;
+    if (nntk_shim_memset(c->d_c, 0, (size_t)c->H * sizeof(float))) return -1;
+    return 0;
+}
+
+static void core_free(rec_core *c) {
+    nntk_shim_synchronize();
+    nntk_shim_free(c->d_wp); nntk_shim_free(c->d_bi); nntk_shim_free(c->d_ut); nntk_shim_free(c->d_bh);
+    nntk_shim_free(c->d_h); nntk_shim_free(c->d_c);
+    nntk_devbuf_free(&c->d_in); nntk_devbuf_free(&c->d_out); nntk_devbuf_free(&c->d_xw); nntk_devbuf_free(&c->d_work);
+    nntk_wblock_free(&c->wb);
+    free(c->weights);
+}
+
+/* W [in, G*H] is already the GEMM's [K, N]; U [H, G*H] is stored transposed per
+ * gate as U^T [G][Hj_p][Hk_p] so each output column's K vector is contiguous. */
+static int core_upload(rec_core *c) {
+    int G = c->G, H = c->H;
+    if (nntk_upload_gemm_weights(&c->d_wp, c->weights->W, c->in, G * H)) return -1;
+    if (nntk_upload_floats(&c->d_bi, c->weights->b_i, (size_t)G * H)) return -1;
+    if (nntk_upload_floats(&c->d_bh, c->weights->b_h, (size_t)G * H)) return -1;
+    int Hj_p = (H + 15) & ~15, Hk_p = (H + 31) & ~31;
+    size_t n = (size_t)G * Hj_p * Hk_p;
+    float *tmp = (float *)calloc(n, sizeof(float));
+    if (!tmp) NNTK_FAIL("out of host memory while packing recurrent weights");
+    const float *U = c->weights->U;
+    for (int k = 0; k < H; ++k)
+        for (int g = 0; g < G; ++g)
+            for (int j = 0; j < H; ++j)
+                tmp[((size_t)g * Hj_p + j) * Hk_p + k] = U[(size_t)k * G * H + (size_t)g * H + j];
+    int rc = nntk_upload_floats(&c->d_ut, tmp, n);
+    free(tmp);
+    if (rc) return rc;
+    nntk_wblock_mark_uploaded(&c->wb);
+    return 0;
+}
+
+static int core_ensure(rec_core *c, int check_edits) {
+    if (nntk_wblock_dirty(&c->wb, check_edits)) return core_upload(c);
+    return 0;
+}
+
+/* stateful != 0: continue from / store into the handle's state (B must be 1) */
+static int core_apply_device(rec_core *c, int is_lstm, int use_bh, const int *acts,
+                             const float *d_in, float *d_out, int B, int stateful) {
+    int G = c->G, H = c->H, T = c->T;
+    if (B <= 0 || T <= 0) return 0;
+    float *d_xw = nntk_devbuf_reserve(&c->d_xw, (size_t)T * B * G * H);
+    float *d_work = nntk_devbuf_reserve(&c->d_work, nntk_shim_recurrent_work_floats(B, H));
+    if (!d_xw || !d_work) return -1;
+    /* input projection, rows (b, t) written at time-major row t*B + b */
+    if (nntk_shim_conv1d(d_in, c->d_wp, c->d_bi, NULL, 0.f, NNTK_ACT_IDENTITY, 1.f, d_xw,
+                         B, T, c->in, G * H, 1, 1, T, 1))
+        return -1;
+    const float *bh = use_bh ? c->d_bh : NULL;
+    if (is_lstm)
+        return nntk_shim_lstm(d_xw, c->d_ut, bh, stateful ? c->d_h : NULL, stateful ? c->d_c : NULL, d_out,
+                              stateful ? c->d_h : NULL, stateful ? c->d_c : NULL, d_work, B, T, H,
+                              c->return_sequences, acts);
+    return nntk_shim_gru(d_xw, c->d_ut, bh, stateful ? c->d_h : NULL, d_out, stateful ? c->d_h : NULL, d_work,
+                         B, T, H, c->return_sequences, acts);
+}
+
+static int core_apply_host(rec_core *c, int is_lstm, int use_bh, const int *acts,
+                           const float *input, float *output, int B, int stateful) {
+    if (B <= 0) return 0;
+    if (core_ensure(c, 1)) return -1;
+    size_t n_in = (size_t)B * c->T * c->in;
+    size_t n_out = c->return_sequences ? (size_t)B * c->T * c->H : (size_t)B * c->H;
+    float *d_in = nntk_devbuf_reserve(&c->d_in, n_in);
+    float *d_out = nntk_devbuf_reserve(&c->d_out, n_out);
+    if (!d_in || !d_out) return -1;
+    if (nntk_shim_upload(d_in, input, n_in * sizeof(float))) return -1;
+    if (core_apply_device(c, is_lstm, use_bh, acts, d_in, d_out, B, stateful)) return -1;
+    return nntk_shim_download(output, d_out, n_out * sizeof(float));
+}
+
+static int gate_kind(ActivationFunction a, int *out) {
+    if (!a) NNTK_FAIL("recurrent layer: NULL gate activation");
+    if (!nntk_act_fusable(a))
+        NNTK_FAIL("recurrent layer: gate activations must be built-in identity/sigmoid/tanh/relu "
+                  "(custom host callbacks and softmax cannot run inside the device step kernel)");
+    *out = a->kind;
+    return 0;
+}
+
+/* ================================= GRU ==================================== */
+
+struct GRUStruct {
+    GRUConfig config;
+    rec_core core;
+};
+
+/* gru.c:13-19 */
+GRUConfig GRUConfigCreate(int input_feature_channels, int output_feature_channels, bool return_sequences,
+                          int timesteps, GRUActivations activations) {
+    GRUConfig c;
+    memset(&c, 0, sizeof(c));
+    c.base = RecurrentConfigCreate(input_feature_channels, output_feature_channels, return_sequences, timesteps);
+    c.activations = activations;
+    return c;
+}
+
+/* gru.c:206-212 */
+GRUActivations GRUActivationsCreateDefault(int size) {
+    GRUActivations a;
+    a.z_gate_activation = ActivationFunctionCreateSigmoid(size);
+    a.r_gate_activation = ActivationFunctionCreateSigmoid(size);
+    a.h_gate_activation = ActivationFunctionCreateTanh(size);
+    return a;
+}
+/* gru.c:220-230: argument order is (z, h, r) */
+GRUActivations GRUActivationsCreate(ActivationFunction z_gate_activation, ActivationFunction h_gate_activation,
+                                    ActivationFunction r_gate_activation) {
+    GRUActivations a;
+    a.z_gate_activation = z_gate_activation;
+    a.h_gate_activation = h_gate_activation;
+    a.r_gate_activation = r_gate_activation;
+    return a;
+}
+void GRUActivationsDestroy(GRUActivations activations) {
+    ActivationFunctionDestroy(activations.z_gate_activation);
+    ActivationFunctionDestroy(activations.r_gate_activation);
+    ActivationFunctionDestroy(activations.h_gate_activation);
+}
+
+GRU GRUCreateForInference(GRUConfig config) {
+    nntk_shim_clear_error();
+    GRU f = (GRU)calloc(1, sizeof(struct GRUStruct));
+    if (!f) return NULL;
+    f->config = config;
+    if (core_init(&f->core, 3, config.base)) { free(f); return NULL; }
+    return f;
+}
+GRUWeights *GRUGetWeights(GRU filter) { return filter->core.weights; }
+void GRUDestroy(GRU filter) {
+    if (!filter) return;
+    core_free(&filter->core);   /* activations stay with the caller (gru.c:116-126) */
+    free(filter);
+}
+
+static int gru_acts(GRU f, int acts[3]) {
+    if (gate_kind(f->config.activations.z_gate_activation, &acts[0])) return -1;
+    if (gate_kind(f->config.activations.h_gate_activation, &acts[1])) return -1;
+    if (gate_kind(f->config.activations.r_gate_activation, &acts[2])) return -1;
+    return 0;
+}
+
+int GRUSyncWeights(GRU filter) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("GRUSyncWeights: NULL handle");
+    nntk_shim_synchronize();
+    return core_upload(&filter->core);
+}
+
+/* gru.c:189-204 */
+int GRUApplyInference(GRU filter, const float *input, float *output) {
+    nntk_shim_clear_error();
+    int acts[3];
+    if (!filter) NNTK_FAIL("GRUApplyInference: NULL handle");
+    if (gru_acts(filter, acts)) return -1;
+    return core_apply_host(&filter->core, 0, 1, acts, input, output, 1, 1);
+}
+/* gru.c:246-293 forward semantics */
+int GRUApplyInferenceBatch(GRU filter, const float *input, float *output, int batch) {
+    nntk_shim_clear_error();
+    int acts[3];
+    if (!filter) NNTK_FAIL("GRUApplyInferenceBatch: NULL handle");
+    if (gru_acts(filter, acts)) return -1;
+    return core_apply_host(&filter->core, 0, 1, acts, input, output, batch, 0);
+}
+int GRUApplyDevice(GRU filter, const float *d_input, float *d_output, int batch) {
+    nntk_shim_clear_error();
+    int acts[3];
+    if (!filter) NNTK_FAIL("GRUApplyDevice: NULL handle");
+    if (gru_acts(filter, acts)) return -1;
+    if (core_ensure(&filter->core, 0)) return -1;
+    return core_apply_device(&filter->core, 0, 1, acts, d_input, d_output, batch, 0);
+}
+int GRUResetState(GRU filter) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("GRUResetState: NULL handle");
+    return nntk_shim_memset(filter->core.d_h, 0, (size_t)filter->core.H * sizeof(float));
+}
+int GRUGetState(GRU filter, float *h_host) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("GRUGetState: NULL handle");
+    return nntk_shim_download(h_host, filter->core.d_h, (size_t)filter->core.H * sizeof(float));
+}
+
+/* ================================= LSTM =================================== */
+
+struct LSTMStruct {
+    LSTMConfig config;
+    rec_core core;
+};
+
+/* lstm.c:17-26: argument order (input, forget, candidate, output_gate, output) */
+LSTMActivations LSTMActivationsCreate(ActivationFunction input_gate_activation,
+                                      ActivationFunction forget_gate_activation,
+                                      ActivationFunction candidate_gate_activation,
+                                      ActivationFunction output_gate_activation,
+                                      ActivationFunction output_activation) {
+    LSTMActivations a;
+    a.candidate_gate_activation = candidate_gate_activation;
+    a.input_gate_activation = input_gate_activation;
+    a.forget_gate_activation = forget_gate_activation;
+    a.output_gate_activation = output_gate_activation;
+    a.output_activation = output_activation;
+    return a;
+}
+/* lstm.c:110-118 */
+LSTMActivations LSTMActivationsCreateDefault(int size) {
+    return LSTMActivationsCreate(ActivationFunctionCreateSigmoid(size), ActivationFunctionCreateSigmoid(size),
+                                 ActivationFunctionCreateTanh(size), ActivationFunctionCreateSigmoid(size),
+                                 ActivationFunctionCreateTanh(size));
+}
+void LSTMActivationsDestroy(LSTMActivations activations) {
+    ActivationFunctionDestroy(activations.input_gate_activation);
+    ActivationFunctionDestroy(activations.forget_gate_activation);
+    ActivationFunctionDestroy(activations.candidate_gate_activation);
+    ActivationFunctionDestroy(activations.output_gate_activation);
+    ActivationFunctionDestroy(activations.output_activation);
+}
+/* lstm.c:132-138 */
+LSTMConfig LSTMConfigCreate(int input_feature_channels, int output_feature_channels, bool return_sequences,
+                            int timesteps, bool v2, LSTMActivations activations) {
+    LSTMConfig c;
+    memset(&c, 0, sizeof(c));
+    c.base = RecurrentConfigCreate(input_feature_channels, output_feature_channels, return_sequences, timesteps);
+    c.v2 = v2;
+    c.activations = activations;
+    return c;
+}
+
+LSTM LSTMCreateForInference(LSTMConfig config) {
+    nntk_shim_clear_error();
+    LSTM f = (LSTM)calloc(1, sizeof(struct LSTMStruct));
+    if (!f) return NULL;
+    f->config = config;
+    if (core_init(&f->core, 4, config.base)) { free(f); return NULL; }
+    return f;
+}
+LSTMWeights *LSTMGetWeights(LSTM filter) { return filter->core.weights; }
+void LSTMDestroy(LSTM filter) {
+    if (!filter) return;
+    core_free(&filter->core);
+    free(filter);
+}
+
+static int lstm_acts(LSTM f, int acts[5]) {
+    const LSTMActivations *a = &f->config.activations;
+    if (gate_kind(a->input_gate_activation, &acts[0])) return -1;
+    if (gate_kind(a->forget_gate_activation, &acts[1])) return -1;
+    if (gate_kind(a->candidate_gate_activation, &acts[2])) return -1;
+    if (gate_kind(a->output_gate_activation, &acts[3])) return -1;
+    if (gate_kind(a->output_activation, &acts[4])) return -1;
+    return 0;
+}
+
+int LSTMSyncWeights(LSTM filter) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("LSTMSyncWeights: NULL handle");
+    nntk_shim_synchronize();
+    return core_upload(&filter->core);
+}
+
+/* lstm.c:241-268 */
+int LSTMApplyInference(LSTM filter, const float *input, float *output) {
+    nntk_shim_clear_error();
+    int acts[5];
+    if (!filter) NNTK_FAIL("LSTMApplyInference: NULL handle");
+    if (lstm_acts(filter, acts)) return -1;
+    return core_apply_host(&filter->core, 1, filter->config.v2, acts, input, output, 1, 1);
+}
+/* lstm.c:426-475 forward semantics */
+int LSTMApplyInferenceBatch(LSTM filter, const float *input, float *output, int batch) {
+    nntk_shim_clear_error();
+    int acts[5];
+    if (!filter) NNTK_FAIL("LSTMApplyInferenceBatch: NULL handle");
+    if (lstm_acts(filter, acts)) return -1;
+    return core_apply_host(&filter->core, 1, filter->config.v2, acts, input, output, batch, 0);
+}
+int LSTMApplyDevice(LSTM filter, const float *d_input, float *d_output, int batch) {
+    nntk_shim_clear_error();
+    int acts[5];
+    if (!filter) NNTK_FAIL("LSTMApplyDevice: NULL handle");
+    if (lstm_acts(filter, acts)) return -1;
+    if (core_ensure(&filter->core, 0)) return -1;
+    return core_apply_device(&filter->core, 1, filter->config.v2, acts, d_input, d_output, batch, 0);
+}
+/* lstm.c:270-274 (lstm_zero_state) */
+int LSTMResetState(LSTM filter) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("LSTMResetState: NULL handle");
+    if (nntk_shim_memset(filter->core.d_h, 0, (size_t)filter->core.H * sizeof(float))) return -1;
+    return nntk_shim_memset(filter->core.d_c, 0, (size_t)filter->core.H * sizeof(float));
+}
+int LSTMGetState(LSTM filter, float *h_host, float *c_host) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("LSTMGetState: NULL handle");
+    if (h_host && nntk_shim_download(h_host, filter->core.d_h, (size_t)filter->core.H * sizeof(float))) return -1;
+    if (c_host && nntk_shim_download(c_host, filter->core.d_c, (size_t)filter->core.H * sizeof(float))) return -1;
+    return 0;
+}

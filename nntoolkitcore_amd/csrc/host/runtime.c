@@ -1,0 +1,89 @@
+/*
+ * runtime.c -- additive runtime entry points of nntoolkitcore_hip.h (device /
+ * stream selection, error string, raw device memory) and the shared weight-block
+ * and scratch helpers of the host layer.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "nntk_internal.h"
+
+void nntk_set_error(const char *msg) { nntk_shim_set_error(msg); }
+
+int nntk_hip_device_count(void) { return nntk_shim_device_count(); }
+int nntk_hip_set_device(int device) { return nntk_shim_set_device(device); }
+void nntk_hip_set_stream(void *hip_stream) { nntk_shim_set_stream(hip_stream); }
+void *nntk_hip_get_stream(void) { return nntk_shim_get_stream(); }
+int nntk_hip_synchronize(void) { return nntk_shim_synchronize(); }
+const char *nntk_last_error(void) { return nntk_shim_error(); }
+const char *nntk_version(void) { return "nntoolkitcore_hip 0.1 (gfx950)"; }
+
+float *nntk_device_alloc(size_t n_floats) { return (float *)nntk_shim_malloc(n_floats * sizeof(float)); }
+void nntk_device_free(float *ptr) { nntk_shim_free(ptr); }
+int nntk_device_upload(float *dst_device, const float *src_host, size_t n_floats) {
+    return nntk_shim_upload(dst_device, src_host, n_floats * sizeof(float));
+}
+int nntk_device_download(float *dst_host, const float *src_device, size_t n_floats) {
+    return nntk_shim_download(dst_host, src_device, n_floats * sizeof(float));
+}
+
+/* ---- weight blocks ---- */
+int nntk_wblock_init(nntk_wblock *wb, size_t n_floats) {
+    wb->n = n_floats;
+    wb->uploaded = 0;
+    wb->host = (float *)nntk_shim_host_alloc(n_floats * sizeof(float));
+    wb->shadow = (float *)calloc(n_floats ? n_floats : 1, sizeof(float));
+    return (wb->host && wb->shadow) ? 0 : -1;
+}
+void nntk_wblock_free(nntk_wblock *wb) {
+    nntk_shim_host_free(wb->host);
+    free(wb->shadow);
+    wb->host = wb->shadow = NULL;
+}
+int nntk_wblock_dirty(const nntk_wblock *wb, int check_edits) {
+    if (!wb->uploaded) return 1;
+    if (check_edits && memcmp(wb->host, wb->shadow, wb->n * sizeof(float)) != 0) return 1;
+    return 0;
+}
+void nntk_wblock_mark_uploaded(nntk_wblock *wb) {
+    memcpy(wb->shadow, wb->host, wb->n * sizeof(float));
+    wb->uploaded = 1;
+}
+
+/* ---- device scratch ---- */
+float *nntk_devbuf_reserve(nntk_devbuf *b, size_t n_floats) {
+    if (n_floats == 0) n_floats = 4;
+    if (b->cap >= n_floats && b->p) return b->p;
+    if (b->p) {
+        /* the old buffer may still be in use by queued kernels */
+        nntk_shim_synchronize();
+        nntk_shim_free(b->p);
+    }
+    b->p = (float *)nntk_shim_malloc(n_floats * sizeof(float));
+    b->cap = b->p ? n_floats : 0;
+    return b->p;
+}
+void nntk_devbuf_free(nntk_devbuf *b) {
+    nntk_shim_free(b->p);
+    b->p = NULL;
+    b->cap = 0;
+}
+
+int nntk_upload_floats(float **d_dst, const float *h_src, size_t n) {
+    if (!*d_dst) {
+        *d_dst = (float *)nntk_shim_malloc(n * sizeof(float));
+        if (!*d_dst) return -1;
+    }
+    return nntk_shim_upload(*d_dst, h_src, n * sizeof(float));
+}
+
+int nntk_upload_gemm_weights(float **d_wp, const float *W, int K, int N) {
+    int K_p, N_p;
+    nntk_shim_conv_pack_sizes(K, N, 1, &K_p, &N_p);
+    size_t n = (size_t)K_p * N_p;
+    float *tmp = (float *)calloc(n, sizeof(float));
+    if (!tmp) NNTK_FAIL("out of host memory while packing weights");
+    for (int k = 0; k < K; ++k) memcpy(tmp + (size_t)k * N_p, W + (size_t)k * N, (size_t)N * sizeof(float));
+    int rc = nntk_upload_floats(d_wp, tmp, n);
+    free(tmp);
+    return rc;
+}

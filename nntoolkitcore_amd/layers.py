@@ -1,0 +1,347 @@
+"""Thin Python mirror of the reference's layer protocol over the C boundary
+(capi.py): ``XConfigCreate -> XCreateForInference -> XGetWeights (copy weights in)
+-> XApply* -> XDestroy``.  Names and argument meaning follow the reference's C API
+(conv_1d.h, batch_norm.h, gru.h, lstm.h, dense.h, time_distributed_dense.h,
+spectrogram.h) so parity tests read like a C caller.  No arithmetic happens here.
+
+``apply(np_array)`` uses the host-pointer C entry points; ``apply_device(tensor)``
+passes torch-ROCm device pointers to the ``*ApplyDevice`` entry points (torch is
+only the owner of HBM buffers and streams).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import check, fp
+
+ACT_IDENTITY, ACT_SIGMOID, ACT_TANH, ACT_RELU, ACT_SOFTMAX = "identity", "sigmoid", "tanh", "relu", "softmax"
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return a.ctypes.data_as(fp)
+
+
+def _fill(ptr, arr):
+    arr = _f32(arr).ravel()
+    C.memmove(ptr, arr.ctypes.data, arr.nbytes)
+
+
+def _dp(t):
+    """device pointer of a contiguous float32 torch tensor"""
+    assert t.is_cuda and t.is_contiguous() and t.dtype.is_floating_point and t.element_size() == 4
+    return C.c_void_p(t.data_ptr())
+
+
+def use_torch_stream():
+    """Route every launch to torch's current HIP stream so torch events/timing see the kernels."""
+    import torch
+    capi.load().nntk_hip_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+
+class Activation:
+    def __init__(self, kind, size, a=1.0, vector_size=0):
+        L = capi.load()
+        self.kind, self.size, self.vector_size = kind, size, vector_size
+        if kind == ACT_IDENTITY:
+            self.h = L.ActivationFunctionCreateIdentity(size)
+        elif kind == ACT_SIGMOID:
+            self.h = L.ActivationFunctionCreateSigmoid(size)
+        elif kind == ACT_TANH:
+            self.h = L.ActivationFunctionCreateTanh(size)
+        elif kind == ACT_RELU:
+            self.h = L.ActivationFunctionCreateReLU(size, C.c_float(a))
+        elif kind == ACT_SOFTMAX:
+            self.h = L.ActivationFunctionCreateSoftmax(size, vector_size)
+        else:
+            raise ValueError(kind)
+
+    def apply(self, x):
+        x = _f32(x)
+        out = np.empty_like(x)
+        capi.load().ActivationFunctionApply(self.h, _p(x), _p(out))
+        err = capi.last_error()
+        if err:
+            raise capi.NNTKError(err)
+        return out
+
+    def apply_device(self, x, out=None, size=0):
+        out = x.new_empty(x.shape) if out is None else out
+        check(capi.load().ActivationFunctionApplyDevice(self.h, _dp(x), _dp(out), size), "ActivationFunctionApplyDevice")
+        return out
+
+    def destroy(self):
+        if self.h:
+            capi.load().ActivationFunctionDestroy(self.h)
+            self.h = None
+
+
+class Conv1d:
+    def __init__(self, cin, cout, k, stride, input_size):
+        L = capi.load()
+        self.cfg = L.Conv1dConfigCreate(cin, cout, k, stride, input_size)
+        self.h = L.Conv1dCreateForInference(self.cfg)
+        if not self.h:
+            raise capi.NNTKError("Conv1dCreateForInference: " + capi.last_error())
+
+    def set_weights(self, W, b):
+        w = capi.load().Conv1dGetWeights(self.h).contents
+        _fill(w.W, W)
+        _fill(w.b, b)
+
+    @property
+    def out_shape(self):
+        return (self.cfg.output_size, self.cfg.output_feature_channels)
+
+    def apply(self, x):
+        x = _f32(x)
+        L = capi.load()
+        if x.ndim == 2:
+            out = np.empty(self.out_shape, np.float32)
+            check(L.Conv1dApplyInference(self.h, _p(x), _p(out)), "Conv1dApplyInference")
+        else:
+            out = np.empty((x.shape[0],) + self.out_shape, np.float32)
+            check(L.Conv1dApplyInferenceBatch(self.h, _p(x), _p(out), x.shape[0]), "Conv1dApplyInferenceBatch")
+        return out
+
+    def apply_device(self, x, out=None, bn=None, act=None):
+        B = x.shape[0]
+        if out is None:
+            out = x.new_empty((B,) + self.out_shape)
+        L = capi.load()
+        if bn is None and act is None:
+            check(L.Conv1dApplyDevice(self.h, _dp(x), _dp(out), B), "Conv1dApplyDevice")
+        else:
+            check(L.Conv1dBatchNormActivationApplyDevice(self.h, bn.h if bn else None, act.h if act else None,
+                                                         _dp(x), _dp(out), B), "Conv1dBatchNormActivationApplyDevice")
+        return out
+
+    def sync_weights(self):
+        check(capi.load().Conv1dSyncWeights(self.h), "Conv1dSyncWeights")
+
+    def destroy(self):
+        if self.h:
+            capi.load().Conv1dDestroy(self.h)
+            self.h = None
+
+
+class BatchNorm:
+    def __init__(self, channels, epsilon, count):
+        L = capi.load()
+        self.cfg = L.BatchNormConfigCreate(channels, C.c_float(epsilon), count)
+        self.h = L.BatchNormCreateForInference(self.cfg)
+
+    def set_weights(self, gamma, beta, mean, var):
+        w = capi.load().BatchNormGetWeights(self.h).contents
+        _fill(w.gamma, gamma)
+        _fill(w.beta, beta)
+        _fill(w.moving_mean, mean)
+        _fill(w.moving_variance, var)
+
+    def apply(self, x):
+        x = _f32(x)
+        out = np.empty_like(x)
+        check(capi.load().BatchNormApplyInference(self.h, _p(x), _p(out)), "BatchNormApplyInference")
+        return out
+
+    def apply_device(self, x, out=None):
+        out = x.new_empty(x.shape) if out is None else out
+        rows = x.numel() // self.cfg.feature_channels
+        check(capi.load().BatchNormApplyDevice(self.h, _dp(x), _dp(out), rows), "BatchNormApplyDevice")
+        return out
+
+    def destroy(self):
+        if self.h:
+            capi.load().BatchNormDestroy(self.h)
+            self.h = None
+
+
+class _Recurrent:
+    def set_weights(self, W, U, b_i, b_h):
+        w = self._get_weights(self.h).contents
+        _fill(w.W, W)
+        _fill(w.U, U)
+        _fill(w.b_i, b_i)
+        _fill(w.b_h, b_h)
+
+    def _out(self, x_shape_prefix, alloc):
+        T, H = self.cfg.base.timesteps, self.cfg.base.output_feature_channels
+        tail = (T, H) if self.cfg.base.return_sequences else (H,)
+        return alloc(tuple(x_shape_prefix) + tail)
+
+    def apply(self, x):
+        x = _f32(x)
+        if x.ndim == 2:     # one sequence, stateful
+            out = self._out((), lambda s: np.empty(s, np.float32))
+            check(self._apply(self.h, _p(x), _p(out)), type(self).__name__ + "ApplyInference")
+        else:
+            out = self._out((x.shape[0],), lambda s: np.empty(s, np.float32))
+            check(self._apply_batch(self.h, _p(x), _p(out), x.shape[0]), type(self).__name__ + "ApplyInferenceBatch")
+        return out
+
+    def apply_device(self, x, out=None):
+        if out is None:
+            out = self._out((x.shape[0],), lambda s: x.new_empty(s))
+        check(self._apply_device(self.h, _dp(x), _dp(out), x.shape[0]), type(self).__name__ + "ApplyDevice")
+        return out
+
+    def sync_weights(self):
+        check(self._sync(self.h), "SyncWeights")
+
+    def reset_state(self):
+        check(self._reset(self.h), "ResetState")
+
+    def destroy(self):
+        if self.h:
+            self._destroy(self.h)
+            self._acts_destroy(self.acts)
+            self.h = None
+
+
+class GRU(_Recurrent):
+    def __init__(self, in_features, hidden, return_sequences, timesteps, acts=None):
+        L = capi.load()
+        self.acts = L.GRUActivationsCreateDefault(hidden) if acts is None else acts
+        self.cfg = L.GRUConfigCreate(in_features, hidden, return_sequences, timesteps, self.acts)
+        self.h = L.GRUCreateForInference(self.cfg)
+        self._get_weights, self._apply, self._apply_batch = L.GRUGetWeights, L.GRUApplyInference, L.GRUApplyInferenceBatch
+        self._apply_device, self._sync, self._reset = L.GRUApplyDevice, L.GRUSyncWeights, L.GRUResetState
+        self._destroy, self._acts_destroy = L.GRUDestroy, L.GRUActivationsDestroy
+
+    def state(self):
+        h = np.empty(self.cfg.base.output_feature_channels, np.float32)
+        check(capi.load().GRUGetState(self.h, _p(h)), "GRUGetState")
+        return h
+
+
+class LSTM(_Recurrent):
+    def __init__(self, in_features, hidden, return_sequences, timesteps, v2=True, acts=None):
+        L = capi.load()
+        self.acts = L.LSTMActivationsCreateDefault(hidden) if acts is None else acts
+        self.cfg = L.LSTMConfigCreate(in_features, hidden, return_sequences, timesteps, v2, self.acts)
+        self.h = L.LSTMCreateForInference(self.cfg)
+        self._get_weights, self._apply, self._apply_batch = L.LSTMGetWeights, L.LSTMApplyInference, L.LSTMApplyInferenceBatch
+        self._apply_device, self._sync, self._reset = L.LSTMApplyDevice, L.LSTMSyncWeights, L.LSTMResetState
+        self._destroy, self._acts_destroy = L.LSTMDestroy, L.LSTMActivationsDestroy
+
+    def state(self):
+        H = self.cfg.base.output_feature_channels
+        h, c = np.empty(H, np.float32), np.empty(H, np.float32)
+        check(capi.load().LSTMGetState(self.h, _p(h), _p(c)), "LSTMGetState")
+        return h, c
+
+
+class TimeDistributedDense:
+    def __init__(self, ts, in_features, out_features, act=None):
+        L = capi.load()
+        self.act = act
+        dense = L.DenseConfigCreate(in_features, out_features, act.h if act else None)
+        self.cfg = L.TimeDistributedDenseConfigCreate(ts, dense)
+        self.h = L.TimeDistributedDenseCreateForInference(self.cfg)
+
+    def set_weights(self, W, b):
+        w = capi.load().TimeDistributedDenseGetWeights(self.h).contents
+        _fill(w.W, W)
+        _fill(w.b, b)
+
+    def apply(self, x):
+        x = _f32(x)
+        L = capi.load()
+        ts, out = self.cfg.ts, self.cfg.dense.output_size
+        if x.ndim == 2:
+            o = np.empty((ts, out), np.float32)
+            check(L.TimeDistributedDenseApplyInference(self.h, _p(x), _p(o)), "TimeDistributedDenseApplyInference")
+        else:
+            o = np.empty((x.shape[0], ts, out), np.float32)
+            check(L.TimeDistributedDenseApplyInferenceBatch(self.h, _p(x), _p(o), x.shape[0]),
+                  "TimeDistributedDenseApplyInferenceBatch")
+        return o
+
+    def apply_device(self, x, out=None):
+        if out is None:
+            out = x.new_empty((x.shape[0], self.cfg.ts, self.cfg.dense.output_size))
+        check(capi.load().TimeDistributedDenseApplyDevice(self.h, _dp(x), _dp(out), x.shape[0]),
+              "TimeDistributedDenseApplyDevice")
+        return out
+
+    def destroy(self):
+        if self.h:
+            capi.load().TimeDistributedDenseDestroy(self.h)
+            self.h = None
+
+
+class Dense:
+    def __init__(self, in_features, out_features, act=None):
+        L = capi.load()
+        self.act = act
+        self.cfg = L.DenseConfigCreate(in_features, out_features, act.h if act else None)
+        self.h = L.DenseCreateForInference(self.cfg)
+
+    def set_weights(self, W, b):
+        w = capi.load().DenseGetWeights(self.h).contents
+        _fill(w.W, W)
+        _fill(w.b, b)
+
+    def apply(self, x):
+        x = _f32(x)
+        o = np.empty(self.cfg.output_size, np.float32)
+        check(capi.load().DenseApplyInference(self.h, _p(x), _p(o)), "DenseApplyInference")
+        return o
+
+    def destroy(self):
+        if self.h:
+            capi.load().DenseDestroy(self.h)
+            self.h = None
+
+
+_WINDOWS = ("ones", "hann_window", "hamming_window", "periodic_hann_window", "periodic_hamming_window",
+            "blackman_window")
+
+
+def window(name, size):
+    assert name in _WINDOWS
+    v = np.empty(size, np.float32)
+    getattr(capi.load(), name)(_p(v), size)
+    return v
+
+
+class Spectrogram:
+    def __init__(self, nfft, window_size, noverlap, input_size, mode="magnitude", fs=16000, fft_norm=1.0,
+                 window_name="hann_window"):
+        L = capi.load()
+        self.cfg = L.SpectrogramConfigCreate(nfft, window_size, noverlap, input_size, C.c_float(fft_norm))
+        self.h = L.SpectrogramCreateMagnitude(self.cfg) if mode == "magnitude" else L.SpectrogramCreatePSD(self.cfg, fs)
+        if window_name:
+            L.SpectrogramSetWindowFunc(self.h, C.cast(getattr(L, window_name), C.c_void_p))
+
+    @property
+    def out_shape(self):
+        return (self.cfg.ntime_series, self.cfg.nfreq)
+
+    def apply(self, x):
+        x = _f32(x)
+        L = capi.load()
+        if x.ndim == 1:
+            out = np.full(self.out_shape, np.nan, np.float32)
+            L.SpectrogramApply(self.h, _p(x), _p(out))
+            if capi.last_error():
+                raise capi.NNTKError(capi.last_error())
+        else:
+            out = np.empty((x.shape[0],) + self.out_shape, np.float32)
+            check(L.SpectrogramApplyBatch(self.h, _p(x), _p(out), x.shape[0]), "SpectrogramApplyBatch")
+        return out
+
+    def apply_device(self, x, out=None):
+        if out is None:
+            out = x.new_empty((x.shape[0],) + self.out_shape)
+        check(capi.load().SpectrogramApplyDevice(self.h, _dp(x), _dp(out), x.shape[0]), "SpectrogramApplyDevice")
+        return out
+
+    def destroy(self):
+        if self.h:
+            capi.load().SpectrogramDestroy(self.h)
+            self.h = None

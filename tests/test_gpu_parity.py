@@ -1,0 +1,403 @@
+"""GPU parity: every hot-path layer, called through the C boundary
+(libnntoolkitcore_hip.so), against the CPU oracle on the same seeded inputs.
+
+Tolerances (fp32 everywhere; SURVEY 4 / BASELINE.md 2): the oracle accumulates
+left-to-right in fp32, the kernels accumulate in MFMA k-order, so results differ by
+rounding only.  ATOL 1e-5 / RTOL 1e-5 for single layers, 1e-4 for T=1000 recurrences
+and the chained stack (hardware exp/tanh rounding compounds over time).
+"""
+import numpy as np
+import pytest
+
+import oracle as O
+from nntoolkitcore_amd import capi, layers as NL
+
+pytestmark = pytest.mark.gpu
+
+ATOL, RTOL = 1e-5, 1e-5
+
+
+def rng(seed):
+    return np.random.default_rng(seed)
+
+
+def u(r, *shape, sc=1.0):
+    return r.uniform(-sc, sc, shape).astype(np.float32)
+
+
+def close(a, b, atol=ATOL, rtol=RTOL):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.isfinite(a).all()
+    err = np.abs(a - b)
+    bad = err > atol + rtol * np.abs(b)
+    assert not bad.any(), "max abs err %.3e (rel %.3e) at %d/%d elements" % (
+        err.max(), (err / (np.abs(b) + 1e-30)).max(), bad.sum(), bad.size)
+
+
+# ------------------------------------------------------------------ conv1d ---
+
+@pytest.mark.parametrize("cin,cout,k,stride,T", [
+    (1, 16, 9, 1, 16000),      # BASELINE config 1 shape (VALU path: K = 9)
+    (40, 128, 5, 1, 1000),     # config 3 shape, one utterance (MFMA 128x128 tile)
+    (3, 4, 5, 2, 23),          # stride 2, tiny, ragged
+    (40, 64, 5, 1, 300),       # BN = 64 tile
+    (33, 32, 3, 1, 130),       # odd Cin (padded K), BN = 32 tile, partial second x tile
+    (7, 100, 4, 1, 257),       # Cout not a multiple of 32
+    (257, 128, 5, 1, 200),     # config 5 conv shape: many channel chunks
+    (16, 48, 3, 2, 99),        # stride 2 with enough K for the MFMA path selection logic
+    (5, 7, 1, 1, 11),          # k = 1
+])
+def test_conv1d_single_sequence(gpu, cin, cout, k, stride, T):
+    r = rng(cin * 1000 + cout)
+    x, W, b = u(r, T, cin), u(r, cout, cin, k, sc=(cin * k) ** -0.5), u(r, cout, sc=0.2)
+    conv = NL.Conv1d(cin, cout, k, stride, T)
+    conv.set_weights(W, b)
+    close(conv.apply(x), O.conv1d(x, W, b, stride))
+    conv.destroy()
+
+
+def test_conv1d_output_shorter_than_kernel_is_empty(gpu):
+    conv = NL.Conv1d(2, 3, 5, 1, 4)        # output_size = 0 (conv_1d.c:84)
+    assert conv.cfg.output_size == 0
+    out = conv.apply(np.zeros((4, 2), np.float32))
+    assert out.shape == (0, 3)
+    conv.destroy()
+
+
+def test_conv1d_batch_and_weight_edit_detection(gpu):
+    r = rng(5)
+    B, T, cin, cout, k = 5, 140, 40, 128, 5
+    x, W, b = u(r, B, T, cin), u(r, cout, cin, k, sc=0.1), u(r, cout, sc=0.2)
+    conv = NL.Conv1d(cin, cout, k, 1, T)
+    # weights are zero-initialised like f_malloc (weights_private.c:18): output == 0
+    assert np.all(conv.apply(x) == 0.0)
+    conv.set_weights(W, b)                 # in-place edit, no notification (like a C caller's memcpy)
+    close(conv.apply(x), O.conv1d(x, W, b, 1))
+    conv.destroy()
+
+
+def test_fused_conv_bn_relu_matches_chain_and_oracle(gpu):
+    import torch
+    r = rng(11)
+    B, T, cin, cout, k = 4, 333, 40, 128, 5
+    x, W, b = u(r, B, T, cin), u(r, cout, cin, k, sc=0.1), u(r, cout, sc=0.2)
+    g, be, mu, var = 1 + u(r, cout, sc=0.5), u(r, cout, sc=0.5), u(r, cout, sc=0.1), 1 + u(r, cout, sc=0.5)
+    conv = NL.Conv1d(cin, cout, k, 1, T)
+    conv.set_weights(W, b)
+    Tc = conv.out_shape[0]
+    bn = NL.BatchNorm(cout, 1e-3, B * Tc)
+    bn.set_weights(g, be, mu, var)
+    relu = NL.Activation("relu", B * Tc * cout, 0.5)      # a is an OUTPUT scale (activation_default.c:123-129)
+    xd = torch.from_numpy(x).cuda()
+    fused = conv.apply_device(xd, bn=bn, act=relu).cpu().numpy()
+    chain = relu.apply_device(bn.apply_device(conv.apply_device(xd))).cpu().numpy()
+    ref = O.activation(O.ACT_RELU, O.batch_norm(O.conv1d(x, W, b, 1), g, be, mu, var, 1e-3), relu_a=0.5)
+    close(fused, ref)
+    close(chain, ref)
+    for o in (conv, bn, relu):
+        o.destroy()
+
+
+# -------------------------------------------------------- batchnorm / acts ---
+
+@pytest.mark.parametrize("C,rows", [(128, 996), (7, 13), (4, 1)])
+def test_batch_norm(gpu, C, rows):
+    r = rng(C)
+    x = u(r, rows, C, sc=3)
+    g, be, mu, var = 1 + u(r, C, sc=0.5), u(r, C, sc=0.5), u(r, C, sc=0.3), 1 + u(r, C, sc=0.9)
+    bn = NL.BatchNorm(C, 1e-3, rows)
+    # default weights are all zero, gamma included (batch_norm.c:79): 0/sqrt(eps)*0+0
+    assert np.all(bn.apply(x) == O.batch_norm(x, *[np.zeros(C, np.float32)] * 4, 1e-3))
+    bn.set_weights(g, be, mu, var)
+    got, ref = bn.apply(x), O.batch_norm(x, g, be, mu, var, 1e-3)
+    close(got, ref, atol=1e-6, rtol=1e-6)
+    bn.destroy()
+
+
+@pytest.mark.parametrize("kind,okind", [("sigmoid", O.ACT_SIGMOID), ("tanh", O.ACT_TANH),
+                                        ("identity", O.ACT_IDENTITY), ("relu", O.ACT_RELU)])
+@pytest.mark.parametrize("n", [1, 257, 4096])
+def test_elementwise_activations(gpu, kind, okind, n):
+    x = u(rng(n), n, sc=6)
+    act = NL.Activation(kind, n, a=0.25)
+    close(act.apply(x), O.activation(okind, x, relu_a=0.25), atol=1e-6, rtol=1e-6)
+    act.destroy()
+
+
+def test_softmax_no_max_subtraction(gpu):
+    x = u(rng(3), 6, 1000, sc=4)
+    act = NL.Activation("softmax", 6, vector_size=1000)
+    got = act.apply(x)
+    close(got, O.activation(O.ACT_SOFTMAX, x, softmax_vector_size=1000), atol=1e-7, rtol=1e-5)
+    # like the reference (activation_default.c:149-154) large logits overflow: exp(100) = inf -> nan/0
+    big = np.full((6, 1000), 100.0, np.float32)
+    assert np.isnan(act.apply(big)).all()
+    act.destroy()
+
+
+def test_custom_activation_is_called_on_host_and_rejected_in_layers(gpu):
+    import ctypes as C
+    L = capi.load()
+    calls = []
+
+    @capi.ACT_IMPL_FN
+    def twice(impl, inp, out, n):
+        calls.append(n)
+        for i in range(n):
+            out[i] = 2.0 * inp[i]
+
+    h = L.ActivationFunctionCreate(4, None, None, C.cast(twice, C.c_void_p), None, None)
+    x = np.arange(4, dtype=np.float32)
+    out = np.empty(4, np.float32)
+    L.ActivationFunctionApply(h, x.ctypes.data_as(capi.fp), out.ctypes.data_as(capi.fp))
+    assert calls == [4] and np.all(out == 2 * x)
+    # a GRU configured with a host-callback gate cannot run on the device: -1, like a wrong-mode handle
+    sig = L.ActivationFunctionCreateSigmoid(4)
+    acts = L.GRUActivationsCreate(h, sig, sig)
+    gru = NL.GRU(3, 4, True, 5, acts=acts)
+    rc = L.GRUApplyInference(gru.h, np.zeros(15, np.float32).ctypes.data_as(capi.fp),
+                             np.zeros(20, np.float32).ctypes.data_as(capi.fp))
+    assert rc == -1 and "activation" in capi.last_error()
+    L.GRUDestroy(gru.h)
+    L.ActivationFunctionDestroy(h)
+    L.ActivationFunctionDestroy(sig)
+
+
+# --------------------------------------------------------------- recurrent ---
+
+def gru_weights(r, I, H):
+    return u(r, I, 3 * H, sc=I ** -0.5), u(r, H, 3 * H, sc=H ** -0.5), u(r, 3 * H, sc=0.1), u(r, 3 * H, sc=0.1)
+
+
+def lstm_weights(r, I, H):
+    return u(r, I, 4 * H, sc=I ** -0.5), u(r, H, 4 * H, sc=H ** -0.5), u(r, 4 * H, sc=0.1), u(r, 4 * H, sc=0.1)
+
+
+@pytest.mark.parametrize("I,H,T", [(5, 7, 11), (128, 256, 40), (33, 48, 17), (16, 20, 9)])
+@pytest.mark.parametrize("seq", [True, False])
+def test_gru_single_sequence_stateful(gpu, I, H, T, seq):
+    r = rng(I + H)
+    W, U, bi, bh = gru_weights(r, I, H)
+    x1, x2 = u(r, T, I), u(r, T, I)
+    gru = NL.GRU(I, H, seq, T)
+    gru.set_weights(W, U, bi, bh)
+    o1, h1 = O.gru(x1, W, U, bi, bh, return_sequences=seq)
+    o2, h2 = O.gru(x2, W, U, bi, bh, h0=h1, return_sequences=seq)
+    close(gru.apply(x1), o1)
+    close(gru.state(), h1)
+    close(gru.apply(x2), o2)          # second call continues from the carried state (gru.c:201)
+    gru.reset_state()
+    close(gru.apply(x1), o1)
+    gru.destroy()
+
+
+@pytest.mark.parametrize("B,I,H,T,seq", [(3, 5, 7, 11, True), (70, 128, 256, 25, True), (65, 40, 32, 12, False),
+                                         (1, 8, 16, 5, True)])
+def test_gru_batch_zero_state(gpu, B, I, H, T, seq):
+    r = rng(B + H)
+    W, U, bi, bh = gru_weights(r, I, H)
+    x = u(r, B, T, I)
+    gru = NL.GRU(I, H, seq, T)
+    gru.set_weights(W, U, bi, bh)
+    close(gru.apply(x), O.gru(x, W, U, bi, bh, return_sequences=seq))
+    gru.destroy()
+
+
+@pytest.mark.parametrize("v2", [True, False])
+@pytest.mark.parametrize("I,H,T,seq", [(5, 7, 11, True), (128, 512, 20, True), (24, 40, 13, False)])
+def test_lstm_single_sequence_stateful(gpu, v2, I, H, T, seq):
+    r = rng(I * H + int(v2))
+    W, U, bi, bh = lstm_weights(r, I, H)
+    x1, x2 = u(r, T, I), u(r, T, I)
+    lstm = NL.LSTM(I, H, seq, T, v2=v2)
+    lstm.set_weights(W, U, bi, bh)
+    o1, h1, c1 = O.lstm(x1, W, U, bi, bh, return_sequences=seq, v2=v2)
+    o2, h2, c2 = O.lstm(x2, W, U, bi, bh, h0=h1, c0=c1, return_sequences=seq, v2=v2)
+    close(lstm.apply(x1), o1)
+    h, c = lstm.state()
+    close(h, h1)
+    close(c, c1)
+    close(lstm.apply(x2), o2)
+    lstm.destroy()
+
+
+@pytest.mark.parametrize("B,I,H,T,seq,v2", [(4, 5, 7, 11, True, True), (66, 128, 512, 12, True, True),
+                                            (9, 20, 36, 10, False, False)])
+def test_lstm_batch_zero_state(gpu, B, I, H, T, seq, v2):
+    r = rng(B * 7 + H)
+    W, U, bi, bh = lstm_weights(r, I, H)
+    x = u(r, B, T, I)
+    lstm = NL.LSTM(I, H, seq, T, v2=v2)
+    lstm.set_weights(W, U, bi, bh)
+    close(lstm.apply(x), O.lstm(x, W, U, bi, bh, return_sequences=seq, v2=v2))
+    lstm.destroy()
+
+
+def test_gru_nondefault_gate_activations(gpu):
+    L = capi.load()
+    I, H, T = 6, 10, 8
+    r = rng(77)
+    W, U, bi, bh = gru_weights(r, I, H)
+    x = u(r, T, I)
+    # GRUActivationsCreate argument order is (z, h, r) (gru.c:220-230)
+    acts = L.GRUActivationsCreate(L.ActivationFunctionCreateTanh(H), L.ActivationFunctionCreateReLU(H, 1.0),
+                                  L.ActivationFunctionCreateSigmoid(H))
+    gru = NL.GRU(I, H, True, T, acts=acts)
+    gru.set_weights(W, U, bi, bh)
+    ref, _ = O.gru(x, W, U, bi, bh, acts=(O.ACT_TANH, O.ACT_RELU, O.ACT_SIGMOID))
+    close(gru.apply(x), ref)
+    gru.destroy()
+
+
+def test_recurrent_long_sequence_T1000(gpu):
+    """BASELINE config 4 geometry on a few utterances: 2-layer GRU(128->256->256), T=1000."""
+    r = rng(1000)
+    B, T, I, H = 2, 1000, 128, 256
+    x = u(r, B, T, I)
+    W1, U1, bi1, bh1 = gru_weights(r, I, H)
+    W2, U2, bi2, bh2 = gru_weights(r, H, H)
+    g1, g2 = NL.GRU(I, H, True, T), NL.GRU(H, H, True, T)
+    g1.set_weights(W1, U1, bi1, bh1)
+    g2.set_weights(W2, U2, bi2, bh2)
+    got = g2.apply(g1.apply(x))
+    ref = O.gru(O.gru(x, W1, U1, bi1, bh1), W2, U2, bi2, bh2)
+    close(got, ref, atol=1e-4, rtol=1e-4)
+    g1.destroy()
+    g2.destroy()
+
+
+# ------------------------------------------------------------------- dense ---
+
+@pytest.mark.parametrize("ts,I,Ov,act", [(9, 5, 7, None), (40, 512, 1000, None), (13, 64, 96, "relu"),
+                                         (6, 32, 50, "softmax"), (5, 20, 33, "sigmoid")])
+def test_time_distributed_dense(gpu, ts, I, Ov, act):
+    r = rng(ts * I)
+    W, b, x = u(r, I, Ov, sc=I ** -0.5), u(r, Ov, sc=0.2), u(r, ts, I)
+    a, okind, kw = None, O.ACT_NONE, {}
+    if act == "softmax":
+        a, okind, kw = NL.Activation("softmax", 1, vector_size=Ov), O.ACT_SOFTMAX, dict(softmax_vector_size=Ov)
+    elif act is not None:
+        a = NL.Activation(act, Ov, a=0.5)
+        okind, kw = {"relu": O.ACT_RELU, "sigmoid": O.ACT_SIGMOID}[act], dict(relu_a=0.5)
+    tdd = NL.TimeDistributedDense(ts, I, Ov, act=a)
+    tdd.set_weights(W, b)
+    close(tdd.apply(x), O.time_distributed_dense(x, W, b, act=okind, **kw))
+    xb = u(r, 3, ts, I)
+    close(tdd.apply(xb), O.time_distributed_dense(xb, W, b, act=okind, **kw))
+    tdd.destroy()
+
+
+def test_dense_single_vector(gpu):
+    r = rng(8)
+    W, b, x = u(r, 12, 5, sc=0.3), u(r, 5), u(r, 12)
+    d = NL.Dense(12, 5)
+    d.set_weights(W, b)
+    close(d.apply(x), O.time_distributed_dense(x[None], W, b)[0])
+    d.destroy()
+
+
+# ------------------------------------------------------------- spectrogram ---
+
+WIN = {"ones": "ones", "hann_window": "hann", "hamming_window": "hamming", "periodic_hann_window": "periodic_hann",
+       "periodic_hamming_window": "periodic_hamming", "blackman_window": "blackman"}
+
+
+@pytest.mark.parametrize("wname", list(WIN))
+@pytest.mark.parametrize("mode", ["magnitude", "psd"])
+def test_spectrogram_512_all_windows(gpu, wname, mode):
+    r = rng(len(wname))
+    x = (0.1 * r.standard_normal(16000)).astype(np.float32)
+    sp = NL.Spectrogram(512, 400, 240, 16000, mode=mode, fs=16000, window_name=wname)
+    assert sp.out_shape == (98, 257)
+    ref = O.spectrogram(x, O.window(WIN[wname], 400), 512, 240, mode=mode, fs=16000)
+    close(sp.apply(x), ref, atol=1e-6 * float(np.abs(ref).max()), rtol=2e-5)
+    sp.destroy()
+
+
+@pytest.mark.parametrize("nfft,win,nov,N,B", [(512, 400, 240, 16000, 5), (512, 512, 0, 5120, 2), (512, 400, 399, 900, 3),
+                                              (256, 200, 120, 8000, 2), (64, 48, 16, 1000, 3), (60, 45, 15, 777, 2),
+                                              (16, 16, 8, 40, 1)])
+def test_spectrogram_batch_geometries(gpu, nfft, win, nov, N, B):
+    r = rng(nfft + N)
+    x = (0.1 * r.standard_normal((B, N))).astype(np.float32)
+    sp = NL.Spectrogram(nfft, win, nov, N, fft_norm=0.5)
+    ref = O.spectrogram(x, O.window("hann", win), nfft, nov, fft_norm=0.5)
+    close(sp.apply(x), ref, atol=1e-6 * float(np.abs(ref).max()), rtol=2e-5)
+    sp.destroy()
+
+
+def test_spectrogram_default_window_is_ones_and_scale_override(gpu):
+    L = capi.load()
+    x = (0.1 * rng(2).standard_normal(4000)).astype(np.float32)
+    sp = NL.Spectrogram(512, 400, 240, 4000, window_name=None)      # spectrogram.c:96 installs `ones`
+    ref = O.spectrogram(x, O.window("ones", 400), 512, 240)
+    close(sp.apply(x), ref, atol=1e-6 * float(np.abs(ref).max()), rtol=2e-5)
+    L.SpectrogramSetScaleFactor(sp.h, 2.0)                            # spectrogram.c:100
+    ref2 = O.spectrogram(x, O.window("ones", 400), 512, 240, scale=2.0)
+    close(sp.apply(x), ref2, atol=1e-6 * float(np.abs(ref2).max()), rtol=2e-5)
+    sp.destroy()
+
+
+def test_parseval_property_full_size(gpu):
+    """Size-independent property at BASELINE config 2 size (256 x 16000): with a `ones`
+    window of nfft samples, sum_k |X_k|^2 over the full spectrum = nfft * sum x^2 per frame."""
+    import torch
+    B, N = 256, 16000
+    x = torch.randn(B, N, device="cuda") * 0.1
+    sp = NL.Spectrogram(512, 512, 352, N, mode="psd", fs=1, window_name=None)     # step 160
+    out = sp.apply_device(x)                                        # psd = |X|^2 * (2 or 1) / (fs * sum w^2)
+    nts = sp.out_shape[0]
+    frames = x.unfold(1, 512, 160)[:, :nts]
+    energy = (frames.double() ** 2).sum(-1)                         # = (1/nfft) sum_k |X_k|^2 = sum over one-sided psd
+    one_sided = out.double().sum(-1)
+    torch.testing.assert_close(one_sided, energy, rtol=1e-4, atol=1e-6)
+    sp.destroy()
+
+
+# -------------------------------------------------------------- full stack ---
+
+def test_full_stack_config5_geometry_small_batch(gpu):
+    """Spectrogram -> Conv1d(257->128,k=5)+BN+ReLU -> LSTM(512) -> TDD(1000) on 2 utterances of 100 frames."""
+    import torch
+    r = rng(55)
+    B, frames = 2, 100
+    N = 240 + 160 * frames
+    audio = (0.1 * r.standard_normal((B, N))).astype(np.float32)
+    spec = NL.Spectrogram(512, 400, 240, N)
+    T, F = spec.out_shape
+    assert (T, F) == (frames, 257)
+    conv = NL.Conv1d(F, 128, 5, 1, T)
+    Tc = conv.out_shape[0]
+    bn, relu = NL.BatchNorm(128, 1e-3, Tc), NL.Activation("relu", Tc * 128, 1.0)
+    lstm, tdd = NL.LSTM(128, 512, True, Tc, v2=True), NL.TimeDistributedDense(Tc, 512, 1000)
+    Wc, bc = u(r, 128, F, 5, sc=(F * 5) ** -0.5), u(r, 128, sc=0.1)
+    g, be, mu, var = 1 + u(r, 128, sc=0.5), u(r, 128, sc=0.5), u(r, 128, sc=0.1), 1 + u(r, 128, sc=0.5)
+    Wl, Ul, bi, bh = lstm_weights(r, 128, 512)
+    Wd, bd = u(r, 512, 1000, sc=512 ** -0.5), u(r, 1000, sc=0.1)
+    conv.set_weights(Wc, bc); bn.set_weights(g, be, mu, var); lstm.set_weights(Wl, Ul, bi, bh); tdd.set_weights(Wd, bd)
+    xd = torch.from_numpy(audio).cuda()
+    y = tdd.apply_device(lstm.apply_device(conv.apply_device(spec.apply_device(xd), bn=bn, act=relu))).cpu().numpy()
+    rs = O.spectrogram(audio, O.window("hann", 400), 512, 240)
+    rc = O.activation(O.ACT_RELU, O.batch_norm(O.conv1d(rs, Wc, bc, 1), g, be, mu, var, 1e-3))
+    ry = O.time_distributed_dense(O.lstm(rc, Wl, Ul, bi, bh, v2=True), Wd, bd)
+    close(y, ry, atol=1e-4, rtol=1e-4)
+    for o in (spec, conv, bn, relu, lstm, tdd):
+        o.destroy()
+
+
+def test_sharding_is_bit_identical(gpu):
+    """Utterances are independent: processing a batch in two shards gives bit-identical
+    outputs to processing it whole (the multi-GPU correctness argument)."""
+    import torch
+    r = rng(99)
+    B, T, I, H = 6, 30, 40, 64
+    x = torch.from_numpy(u(r, B, T, I)).cuda()
+    W, U, bi, bh = gru_weights(r, I, H)
+    gru = NL.GRU(I, H, True, T)
+    gru.set_weights(W, U, bi, bh)
+    whole = gru.apply_device(x).clone()
+    a = gru.apply_device(x[:3].contiguous()).clone()
+    b = gru.apply_device(x[3:].contiguous()).clone()
+    assert torch.equal(whole, torch.cat([a, b]))
+    gru.destroy()
