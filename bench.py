@@ -1,0 +1,350 @@
+#!/usr/bin/env python3
+"""bench.py -- audio frames/sec of the NNToolkitCore time-series inference hot path on MI355X.
+
+A "step" is one pass of the hot path over one batch of synthetic 16 kHz audio, through
+the C boundary (libnntoolkitcore_hip.so, device-pointer entry points).  Default workload
+= BASELINE.json configs[4] ("stack"):
+    Spectrogram(win 400, hop 160, nfft 512) -> Conv1d(257->128,k=5)+BatchNorm+ReLU
+      -> LSTM(512, v2) -> TimeDistributedDense(1000)
+with 512 utterances x 1000 frames PER GPU (weak scaling: 8 GPUs = the named batch 4096).
+Other BASELINE configs are selectable with --workload {spectrogram,conv,gru} for the
+per-kernel roofline lines in BASELINE.md / DESIGN.md.
+
+Contract: W untimed warm-up steps, then exactly K timed steps bracketed by barrier +
+torch.cuda.synchronize() on both sides, MAX over ranks, rank 0 prints ONE JSON line.
+Inputs are resident in HBM before the timed region.  `value` = whole-job frames/s.
+`roofline` describes the dominant kernel from HIP-event timings taken inside this run;
+`cpu_baseline` times the CPU oracle (oracle/, a restatement of the reference's
+single-threaded scalar path) on a bounded sample of the same workload, rank 0, N=1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: exact-f32 MFMA = f32 vector peak
+HBM_PEAK_GBS = 8000.0            # HBM3E spec (6290 GB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="stack", choices=["stack", "spectrogram", "conv", "gru"])
+    ap.add_argument("--batch-per-gpu", type=int, default=0, help="utterances per GPU (0 = the BASELINE shape)")
+    ap.add_argument("--frames", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=1)
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------ weights ---
+
+def make_weights(workload, seed):
+    """Synthetic random-init weights, U(-1/sqrt(fan_in), 1/sqrt(fan_in)), as one
+    flat fp32 vector so that rank 0 can broadcast it over RCCL in a single collective."""
+    r = np.random.default_rng(seed)
+    u = lambda shape, fan: r.uniform(-fan ** -0.5, fan ** -0.5, shape).astype(np.float32)
+    parts = {}
+    if workload in ("stack", "conv"):
+        cin = 257 if workload == "stack" else 40
+        parts["conv_W"], parts["conv_b"] = u((128, cin, 5), cin * 5), u((128,), cin * 5)
+        parts["bn_gamma"] = r.uniform(0.5, 1.5, 128).astype(np.float32)
+        parts["bn_beta"] = r.uniform(-0.5, 0.5, 128).astype(np.float32)
+        parts["bn_mean"] = (0.1 * r.standard_normal(128)).astype(np.float32)
+        parts["bn_var"] = r.uniform(0.5, 1.5, 128).astype(np.float32)
+    if workload == "stack":
+        parts["lstm_W"], parts["lstm_U"] = u((128, 2048), 128), u((512, 2048), 512)
+        parts["lstm_bi"], parts["lstm_bh"] = u((2048,), 512), u((2048,), 512)
+        parts["tdd_W"], parts["tdd_b"] = u((512, 1000), 512), u((1000,), 512)
+    if workload == "gru":
+        parts["g1_W"], parts["g1_U"], parts["g1_bi"], parts["g1_bh"] = u((128, 768), 128), u((256, 768), 256), u((768,), 256), u((768,), 256)
+        parts["g2_W"], parts["g2_U"], parts["g2_bi"], parts["g2_bh"] = u((256, 768), 256), u((256, 768), 256), u((768,), 256), u((768,), 256)
+    return parts
+
+
+def pack(parts):
+    return np.concatenate([v.ravel() for v in parts.values()]) if parts else np.zeros(1, np.float32)
+
+
+def unpack(flat, parts):
+    out, o = {}, 0
+    for k, v in parts.items():
+        out[k] = flat[o:o + v.size].reshape(v.shape)
+        o += v.size
+    return out
+
+
+# ---------------------------------------------------------------- workloads ---
+
+class Workload:
+    """Builds the layer handles through the reference-shaped C API and runs one step."""
+
+    def __init__(self, name, B, frames, weights, torch, NL):
+        self.name, self.B, self.frames, self.torch, self.NL = name, B, frames, torch, NL
+        self.layers = []
+        w = weights
+        dev = "cuda"
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234 + int(os.environ.get("RANK", "0")))
+        if name in ("stack", "spectrogram"):
+            N = 16000 if name == "spectrogram" else 240 + 160 * frames
+            self.spec = NL.Spectrogram(512, 400, 240, N)
+            self.layers.append(self.spec)
+            self.x = (0.1 * torch.randn(B, N, device=dev, generator=g)).clamp_(-1, 1)
+            self.frames_per_utt = self.spec.out_shape[0]
+            self.spec_out = torch.empty((B,) + self.spec.out_shape, device=dev)
+        if name in ("stack", "conv"):
+            cin = 257 if name == "stack" else 40
+            T = self.spec.out_shape[0] if name == "stack" else frames
+            self.conv = NL.Conv1d(cin, 128, 5, 1, T)
+            Tc = self.conv.out_shape[0]
+            self.bn = NL.BatchNorm(128, 1e-3, Tc)
+            self.relu = NL.Activation("relu", Tc * 128, 1.0)
+            self.conv.set_weights(w["conv_W"], w["conv_b"])
+            self.bn.set_weights(w["bn_gamma"], w["bn_beta"], w["bn_mean"], w["bn_var"])
+            self.layers += [self.conv, self.bn, self.relu]
+            self.conv_out = torch.empty((B, Tc, 128), device=dev)
+            if name == "conv":
+                self.x = torch.randn(B, T, cin, device=dev, generator=g)
+                self.frames_per_utt = T
+        if name == "stack":
+            Tc = self.conv.out_shape[0]
+            self.lstm = NL.LSTM(128, 512, True, Tc, v2=True)
+            self.lstm.set_weights(w["lstm_W"], w["lstm_U"], w["lstm_bi"], w["lstm_bh"])
+            self.tdd = NL.TimeDistributedDense(Tc, 512, 1000)
+            self.tdd.set_weights(w["tdd_W"], w["tdd_b"])
+            self.layers += [self.lstm, self.tdd]
+            self.lstm_out = torch.empty((B, Tc, 512), device=dev)
+            self.tdd_out = torch.empty((B, Tc, 1000), device=dev)
+        if name == "gru":
+            self.g1 = NL.GRU(128, 256, True, frames)
+            self.g2 = NL.GRU(256, 256, True, frames)
+            self.g1.set_weights(w["g1_W"], w["g1_U"], w["g1_bi"], w["g1_bh"])
+            self.g2.set_weights(w["g2_W"], w["g2_U"], w["g2_bi"], w["g2_bh"])
+            self.layers += [self.g1, self.g2]
+            self.x = torch.randn(B, frames, 128, device=dev, generator=g)
+            self.h1 = torch.empty((B, frames, 256), device=dev)
+            self.h2 = torch.empty((B, frames, 256), device=dev)
+            self.frames_per_utt = frames
+        self.phase_ms = {}
+
+    def step(self, timed=False):
+        t = self.torch
+        ev = []
+
+        def mark(name):
+            if timed:
+                e = t.cuda.Event(enable_timing=True)
+                e.record()
+                ev.append((name, e))
+
+        mark("start")
+        if self.name in ("stack", "spectrogram"):
+            self.spec.apply_device(self.x, out=self.spec_out)
+            mark("spectrogram")
+        if self.name == "stack":
+            self.conv.apply_device(self.spec_out, out=self.conv_out, bn=self.bn, act=self.relu)
+            mark("conv_bn_relu")
+            self.lstm.apply_device(self.conv_out, out=self.lstm_out)
+            mark("lstm")
+            self.tdd.apply_device(self.lstm_out, out=self.tdd_out)
+            mark("tdd")
+        if self.name == "conv":
+            self.conv.apply_device(self.x, out=self.conv_out, bn=self.bn, act=self.relu)
+            mark("conv_bn_relu")
+        if self.name == "gru":
+            self.g1.apply_device(self.x, out=self.h1)
+            mark("gru1")
+            self.g2.apply_device(self.h1, out=self.h2)
+            mark("gru2")
+        return ev
+
+    def destroy(self):
+        for l in self.layers:
+            l.destroy()
+
+
+def roofline_for(wl, phase_ms, prof):
+    """Dominant-kernel roofline from live HIP-event timings (ms per launch)."""
+    B = wl.B
+    if wl.name == "spectrogram":
+        nts, nfreq = wl.spec.out_shape
+        bytes_ = B * (wl.x.shape[1] * 4 + nts * nfreq * 4)
+        ms = phase_ms["spectrogram"]
+        ach = bytes_ / (ms * 1e-3) / 1e9
+        return {"kernel": "spectrogram512_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": None, "ms_per_launch": ms, "algorithmic_bytes": bytes_}
+    if wl.name == "conv":
+        Tc = wl.conv.out_shape[0]
+        cin = wl.conv.cfg.input_feature_channels
+        flops = 2.0 * cin * 5 * 128 * Tc * B
+        bytes_ = B * (wl.conv.cfg.input_size * cin + Tc * 128) * 4
+        ms = phase_ms["conv_bn_relu"]
+        ach = flops / (ms * 1e-3) / 1e12
+        return {"kernel": "conv1d_mfma_kernel<2,2,2,2>", "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None, "ms_per_launch": ms,
+                "algorithmic_flops": flops, "algorithmic_bytes": bytes_,
+                "hbm_frac": bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    # recurrent step kernel: one launch = one timestep of hU = h[B,H] x U[H,G*H] + fused gates
+    if wl.name == "stack":
+        H, G, kern, key = 512, 4, "rec_step_kernel<4,true>", "lstm"
+    else:
+        H, G, kern, key = 256, 3, "rec_step_kernel<3,false>", "gru2"
+    flops = 2.0 * B * H * G * H
+    ms = prof.get("rec_step_ms", None)
+    if ms is None:
+        return None
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"kernel": kern, "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None, "ms_per_launch": ms, "algorithmic_flops": flops,
+            "launches_per_step": prof.get("rec_step_launches")}
+
+
+def cpu_baseline(workload, weights, frames, seed):
+    """Times the CPU oracle (restatement of the reference's scalar single-thread path) on a
+    bounded sample: ONE utterance of the same per-utterance shape."""
+    import oracle as O
+    r = np.random.default_rng(seed)
+    w = weights
+    t0 = time.perf_counter()
+    if workload == "spectrogram":
+        n_utt = 16
+        x = (0.1 * r.standard_normal((n_utt, 16000))).astype(np.float32)
+        t0 = time.perf_counter()
+        out = O.spectrogram(x, O.window("hann", 400), 512, 240)
+        nframes = out.shape[0] * out.shape[1]
+        sample = "%d utterances x 16000 samples (98 frames each)" % n_utt
+    elif workload == "conv":
+        n_utt = 1
+        x = r.standard_normal((n_utt, frames, 40)).astype(np.float32)
+        t0 = time.perf_counter()
+        O.activation(O.ACT_RELU, O.batch_norm(O.conv1d(x, w["conv_W"], w["conv_b"], 1), w["bn_gamma"], w["bn_beta"],
+                                              w["bn_mean"], w["bn_var"], 1e-3))
+        nframes = n_utt * frames
+        sample = "%d utterance x %d frames x 40" % (n_utt, frames)
+    elif workload == "gru":
+        n_utt, fr = 1, min(frames, 1000)
+        x = r.standard_normal((n_utt, fr, 128)).astype(np.float32)
+        t0 = time.perf_counter()
+        h1 = O.gru(x, w["g1_W"], w["g1_U"], w["g1_bi"], w["g1_bh"])
+        O.gru(h1, w["g2_W"], w["g2_U"], w["g2_bi"], w["g2_bh"])
+        nframes = n_utt * fr
+        sample = "%d utterance x %d frames x 128" % (n_utt, fr)
+    else:
+        n_utt, fr = 1, min(frames, 250)
+        x = (0.1 * r.standard_normal((n_utt, 240 + 160 * fr))).astype(np.float32)
+        t0 = time.perf_counter()
+        s = O.spectrogram(x, O.window("hann", 400), 512, 240)
+        c = O.activation(O.ACT_RELU, O.batch_norm(O.conv1d(s, w["conv_W"], w["conv_b"], 1), w["bn_gamma"], w["bn_beta"],
+                                                  w["bn_mean"], w["bn_var"], 1e-3))
+        h = O.lstm(c, w["lstm_W"], w["lstm_U"], w["lstm_bi"], w["lstm_bh"], v2=True)
+        O.time_distributed_dense(h, w["tdd_W"], w["tdd_b"])
+        nframes = n_utt * fr
+        sample = "%d utterance x %d frames of the same stack" % (n_utt, fr)
+    dt = time.perf_counter() - t0
+    return {"value": nframes / dt, "unit": "frames/s", "cores": 1, "kind": "port", "sample": sample,
+            "seconds": round(dt, 2)}
+
+
+def main():
+    a = parse()
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)     # "nccl" is RCCL on ROCm
+    assert a.gpus == world, "--gpus must equal WORLD_SIZE (launch N>1 with torch.distributed.run)"
+
+    from nntoolkitcore_amd import capi, layers as NL
+    from nntoolkitcore_amd.sharding import broadcast_weights
+    L = capi.load()
+    assert L.nntk_hip_set_device(local) == 0, capi.last_error()
+    NL.use_torch_stream()
+    L.nntk_hip_profile_enable(1)
+
+    defaults = {"stack": 512, "spectrogram": 256, "conv": 1024, "gru": 1024}
+    B = a.batch_per_gpu or defaults[a.workload]
+    frames = a.frames
+
+    # rank 0 owns the weights; one RCCL broadcast of the packed blob over xGMI (off the timed path)
+    parts = make_weights(a.workload, a.seed + 2)
+    flat = pack(parts) if rank == 0 else np.zeros_like(pack(parts))
+    flat = broadcast_weights(flat, torch, dist)
+    weights = unpack(flat, parts)
+
+    wl = Workload(a.workload, B, frames, weights, torch, NL)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        wl.step()
+    barrier()
+    t0 = time.perf_counter()
+    events = []
+    for i in range(a.steps):
+        events.append(wl.step(timed=True))
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-phase HIP-event times (ms), averaged over the timed steps
+    phase_ms = {}
+    for ev in events:
+        for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):
+            phase_ms[n1] = phase_ms.get(n1, 0.0) + e0.elapsed_time(e1) / a.steps
+    prof = {}
+    ms = C.c_double()
+    cnt = C.c_long()
+    if L.nntk_hip_profile_get(b"rec_step", C.byref(ms), C.byref(cnt)) == 0 and cnt.value > 0:
+        prof["rec_step_ms"] = ms.value / cnt.value
+        prof["rec_step_launches"] = cnt.value // max(1, a.steps + a.warmup)
+
+    total_frames = world * B * wl.frames_per_utt * a.steps
+    value = total_frames / dt
+    out = {
+        "metric": "audio frames/sec (whole node)", "value": value, "unit": "frames/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": {
+            "stack": "BASELINE configs[4]: Spectrogram(400/160/512)->Conv1d(257->128,k=5)+BN+ReLU->LSTM(512,v2)->TDD(1000)",
+            "spectrogram": "BASELINE configs[1]: Spectrogram(400/160/512) on batch x 16000",
+            "conv": "BASELINE configs[2]: Conv1d(40->128,k=5)+BN+ReLU on batch x frames x 40",
+            "gru": "BASELINE configs[3]: 2-layer GRU(128->256->256) on batch x frames x 128"}[a.workload],
+            "utterances_per_gpu": B, "frames_per_utterance": wl.frames_per_utt, "global_batch": B * world,
+            "parallelism": "utterance shards, dp%d, no data-path collective" % world},
+        "phase_ms": {k: round(v, 4) for k, v in phase_ms.items()},
+    }
+    if rank == 0:
+        out["roofline"] = roofline_for(wl, phase_ms, prof)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.workload, weights, frames, a.seed)
+        print(json.dumps(out), flush=True)
+    wl.destroy()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

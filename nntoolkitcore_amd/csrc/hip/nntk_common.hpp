@@ -7,6 +7,8 @@
 hipStream_t nntk_stream();
 int nntk_fail(const char *what, hipError_t err);
 int nntk_fail_msg(const char *what);
+int nntk_prof_span_begin();                       // -1 when profiling is off
+void nntk_prof_span_end(int idx, long launches);
 
 #define NNTK_HIP_TRY(expr)                                             \
     do {                                                               \

@@ -35,6 +35,10 @@ const char *nntk_shim_error(void);
 void        nntk_shim_set_error(const char *msg);
 void        nntk_shim_clear_error(void);
 
+/* HIP-event spans around the recurrent step launches (off by default) */
+void nntk_shim_profile_enable(int on);
+int  nntk_shim_profile_get(const char *name, double *total_ms, long *launches);
+
 void *nntk_shim_malloc(size_t bytes);
 void  nntk_shim_free(void *d_ptr);
 void *nntk_shim_host_alloc(size_t bytes);              /* pinned, zero-filled */

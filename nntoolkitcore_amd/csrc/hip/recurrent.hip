@@ -210,6 +210,7 @@ static int run_recurrent(const float *d_xw, const float *d_ut, const float *d_bh
     p.a0 = acts[0]; p.a1 = acts[1]; p.a2 = acts[2];
     p.a3 = nacts > 3 ? acts[3] : 0; p.a4 = nacts > 4 ? acts[4] : 0;
     dim3 grid((unsigned)((B + REC_BM - 1) / REC_BM), (unsigned)(p.Hj_p / REC_HN));
+    const int span = nntk_prof_span_begin();
     for (int t = 0; t < T; ++t) {
         p.xw = d_xw + (size_t)t * B * G * H;
         p.h_prev = hbuf[t & 1];
@@ -219,6 +220,7 @@ static int run_recurrent(const float *d_xw, const float *d_ut, const float *d_bh
         else                  { p.out = nullptr; p.out_ld = 0; }
         hipLaunchKernelGGL((rec_step_kernel<G, IS_LSTM>), grid, dim3(256), 0, nntk_stream(), p);
     }
+    nntk_prof_span_end(span, T);
     NNTK_LAUNCH_CHECK("rec_step_kernel");
     if (d_hT) { if (nntk_shim_copy_d2d(d_hT, hbuf[T & 1], BH * 4)) return -1; }
     if (IS_LSTM && d_cT) { if (nntk_shim_copy_d2d(d_cT, cbuf, BH * 4)) return -1; }

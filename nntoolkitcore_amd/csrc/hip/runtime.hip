@@ -3,6 +3,7 @@
 #include "nntk_common.hpp"
 #include <stdio.h>
 #include <string.h>
+#include <vector>
 
 static hipStream_t g_stream = nullptr;
 static thread_local char g_err[512] = "";
@@ -18,7 +19,46 @@ int nntk_fail_msg(const char *what) {
     return -1;
 }
 
+// ---- optional HIP-event spans around launch sequences (bench.py's live roofline) ----
+struct ProfSpan { hipEvent_t a, b; long launches; };
+static std::vector<ProfSpan> g_spans;
+static bool g_prof = false;
+
+int nntk_prof_span_begin() {
+    if (!g_prof) return -1;
+    ProfSpan s;
+    s.launches = 0;
+    if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return -1;
+    (void)hipEventRecord(s.a, g_stream);
+    g_spans.push_back(s);
+    return (int)g_spans.size() - 1;
+}
+void nntk_prof_span_end(int idx, long launches) {
+    if (idx < 0 || idx >= (int)g_spans.size()) return;
+    (void)hipEventRecord(g_spans[idx].b, g_stream);
+    g_spans[idx].launches = launches;
+}
+
 extern "C" {
+
+void nntk_shim_profile_enable(int on) { g_prof = on != 0; }
+// Sums and clears the recorded spans ("rec_step": the per-timestep recurrent launches).
+int nntk_shim_profile_get(const char *name, double *total_ms, long *launches) {
+    (void)name;
+    *total_ms = 0.0;
+    *launches = 0;
+    for (auto &s : g_spans) {
+        float ms = 0.f;
+        if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            *total_ms += ms;
+            *launches += s.launches;
+        }
+        (void)hipEventDestroy(s.a);
+        (void)hipEventDestroy(s.b);
+    }
+    g_spans.clear();
+    return 0;
+}
 
 const char *nntk_shim_error(void) { return g_err; }
 void nntk_shim_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg ? msg : ""); }

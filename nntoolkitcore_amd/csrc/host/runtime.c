@@ -15,6 +15,10 @@ void nntk_hip_set_stream(void *hip_stream) { nntk_shim_set_stream(hip_stream); }
 void *nntk_hip_get_stream(void) { return nntk_shim_get_stream(); }
 int nntk_hip_synchronize(void) { return nntk_shim_synchronize(); }
 const char *nntk_last_error(void) { return nntk_shim_error(); }
+void nntk_hip_profile_enable(int on) { nntk_shim_profile_enable(on); }
+int nntk_hip_profile_get(const char *name, double *total_ms, long *launches) {
+    return nntk_shim_profile_get(name, total_ms, launches);
+}
 const char *nntk_version(void) { return "nntoolkitcore_hip 0.1 (gfx950)"; }
 
 float *nntk_device_alloc(size_t n_floats) { return (float *)nntk_shim_malloc(n_floats * sizeof(float)); }

@@ -1,0 +1,121 @@
+"""CPU-only: the C-ABI library loads, exports every symbol the header declares, and
+its by-value struct layouts / config geometry / window functions equal what the
+REAL reference returns (tests/golden/ref_probe.json, produced by oracle/ref_probe.c
+from the reference's own sources compiled in place -- `make -C oracle ref`)."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from nntoolkitcore_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_probe.json")))
+
+STRUCTS = {
+    "SpectrogramConfig": capi.SpectrogramConfig, "Conv1dConfig": capi.Conv1dConfig,
+    "BatchNormConfig": capi.BatchNormConfig, "RecurrentConfig": capi.RecurrentConfig,
+    "GRUActivations": capi.GRUActivations, "GRUConfig": capi.GRUConfig,
+    "LSTMActivations": capi.LSTMActivations, "LSTMConfig": capi.LSTMConfig,
+    "DenseConfig": capi.DenseConfig, "TimeDistributedDenseConfig": capi.TimeDistributedDenseConfig,
+    "DefaultWeights": capi.DefaultWeights, "RecurrentWeights": capi.RecurrentWeights,
+    "BatchNormWeights": capi.BatchNormWeights,
+}
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    header = open(os.path.join(ROOT, "include", "nntoolkitcore_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    header = re.sub(r"typedef[^;{]*(\{[^}]*\})?[^;]*;", "", header)      # drop typedefs (incl. fn-pointer types)
+    declared = set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", header))
+    assert len(declared) > 90
+    missing = [s for s in sorted(declared) if not hasattr(built_lib, s)]
+    assert not missing, missing
+    assert declared == set(capi.SIGNATURES), declared ^ set(capi.SIGNATURES)
+
+
+def test_struct_layouts_match_reference_headers():
+    abi = GOLD["abi"]
+    for name, st in STRUCTS.items():
+        assert C.sizeof(st) == abi["sizeof_" + name], name
+        for field, _ in st._fields_:
+            key = "offsetof_%s_%s" % (name, field)
+            if key in abi:
+                assert getattr(st, field).offset == abi[key], key
+
+
+def test_product_headers_compile_as_c_and_match_layouts(tmp_path):
+    """Compile a C probe against include/ (the drop-in headers at the reference's include paths)."""
+    src = tmp_path / "p.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "nntoolkitcore/layers/conv_1d.h"
+#include "nntoolkitcore/layers/batch_norm.h"
+#include "nntoolkitcore/layers/gru.h"
+#include "nntoolkitcore/layers/lstm.h"
+#include "nntoolkitcore/layers/time_distributed_dense.h"
+#include "nntoolkitcore/layers/activation_default.h"
+#include "nntoolkitcore/signal/spectrogram.h"
+int main(void){
+ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(SpectrogramConfig), sizeof(Conv1dConfig), sizeof(BatchNormConfig),
+   sizeof(RecurrentConfig), sizeof(GRUConfig), sizeof(LSTMConfig), sizeof(DenseConfig), sizeof(TimeDistributedDenseConfig),
+   offsetof(LSTMConfig, activations), offsetof(LSTMActivations, output_activation));
+ return 0; }''')
+    exe = tmp_path / "p"
+    import subprocess
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    a = GOLD["abi"]
+    want = [a["sizeof_SpectrogramConfig"], a["sizeof_Conv1dConfig"], a["sizeof_BatchNormConfig"], a["sizeof_RecurrentConfig"],
+            a["sizeof_GRUConfig"], a["sizeof_LSTMConfig"], a["sizeof_DenseConfig"], a["sizeof_TimeDistributedDenseConfig"],
+            a["offsetof_LSTMConfig_activations"], a["offsetof_LSTMActivations_output_activation"]]
+    assert got == want
+
+
+def test_config_geometry_matches_reference(built_lib):
+    for c in GOLD["spectrogram_config"]:
+        got = built_lib.SpectrogramConfigCreate(c["nfft"], c["window_size"], c["noverlap"], c["input_size"], 1.0)
+        assert (got.step, got.nfreq, got.ntime_series) == (c["step"], c["nfreq"], c["ntime_series"]), c
+    for c in GOLD["conv1d_config"]:
+        got = built_lib.Conv1dConfigCreate(c["cin"], c["cout"], c["k"], c["stride"], c["input_size"])
+        assert got.output_size == c["output_size"], c
+    r = built_lib.RecurrentConfigCreate(3, 4, True, 9)
+    assert (r.input_feature_channels, r.output_feature_channels, r.return_sequences, r.timesteps) == (3, 4, True, 9)
+
+
+@pytest.mark.parametrize("name,fn", [("ones", "ones"), ("hann", "hann_window"), ("hamming", "hamming_window"),
+                                     ("periodic_hann", "periodic_hann_window"),
+                                     ("periodic_hamming", "periodic_hamming_window"), ("blackman", "blackman_window")])
+def test_window_functions_bit_exact_vs_reference(built_lib, name, fn):
+    for key, n in (("windows16", 16), ("windows400", 400)):
+        v = np.empty(n, np.float32)
+        getattr(built_lib, fn)(v.ctypes.data_as(capi.fp), n)
+        want = np.array(GOLD[key][name], np.float32)
+        assert np.array_equal(v, want), (name, n)
+
+
+def test_no_gpu_means_loud_failure_not_fallback(built_lib):
+    """Without a device, creating a layer fails and reports why; nothing computes on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = built_lib.Conv1dCreateForInference(built_lib.Conv1dConfigCreate(1, 16, 9, 1, 100))
+    assert not h
+    assert "HIP error" in capi.last_error()
+
+
+def test_product_never_references_the_oracle():
+    """The product path must not import, link or call anything under oracle/."""
+    import subprocess
+    pkg = os.path.join(ROOT, "nntoolkitcore_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hip", ".hpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.lower() or f == "__init__.py" and False, os.path.join(dirpath, f)
+    syms = subprocess.check_output(["nm", "-D", capi.LIB_PATH], text=True)
+    assert "ref_" not in syms
