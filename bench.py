@@ -217,30 +217,30 @@ def cpu_baseline(workload, weights, frames, seed):
     w = weights
     t0 = time.perf_counter()
     if workload == "spectrogram":
-        n_utt = 16
+        n_utt = 12000
         x = (0.1 * r.standard_normal((n_utt, 16000))).astype(np.float32)
         t0 = time.perf_counter()
         out = O.spectrogram(x, O.window("hann", 400), 512, 240)
         nframes = out.shape[0] * out.shape[1]
         sample = "%d utterances x 16000 samples (98 frames each)" % n_utt
     elif workload == "conv":
-        n_utt = 1
+        n_utt = 1000
         x = r.standard_normal((n_utt, frames, 40)).astype(np.float32)
         t0 = time.perf_counter()
         O.activation(O.ACT_RELU, O.batch_norm(O.conv1d(x, w["conv_W"], w["conv_b"], 1), w["bn_gamma"], w["bn_beta"],
                                               w["bn_mean"], w["bn_var"], 1e-3))
         nframes = n_utt * frames
-        sample = "%d utterance x %d frames x 40" % (n_utt, frames)
+        sample = "%d utterances x %d frames x 40" % (n_utt, frames)
     elif workload == "gru":
-        n_utt, fr = 1, min(frames, 1000)
+        n_utt, fr = 32, min(frames, 1000)
         x = r.standard_normal((n_utt, fr, 128)).astype(np.float32)
         t0 = time.perf_counter()
         h1 = O.gru(x, w["g1_W"], w["g1_U"], w["g1_bi"], w["g1_bh"])
         O.gru(h1, w["g2_W"], w["g2_U"], w["g2_bi"], w["g2_bh"])
         nframes = n_utt * fr
-        sample = "%d utterance x %d frames x 128" % (n_utt, fr)
+        sample = "%d utterances x %d frames x 128" % (n_utt, fr)
     else:
-        n_utt, fr = 1, min(frames, 250)
+        n_utt, fr = 3, min(frames, 1000)
         x = (0.1 * r.standard_normal((n_utt, 240 + 160 * fr))).astype(np.float32)
         t0 = time.perf_counter()
         s = O.spectrogram(x, O.window("hann", 400), 512, 240)
@@ -249,7 +249,7 @@ def cpu_baseline(workload, weights, frames, seed):
         h = O.lstm(c, w["lstm_W"], w["lstm_U"], w["lstm_bi"], w["lstm_bh"], v2=True)
         O.time_distributed_dense(h, w["tdd_W"], w["tdd_b"])
         nframes = n_utt * fr
-        sample = "%d utterance x %d frames of the same stack" % (n_utt, fr)
+        sample = "%d utterances x %d frames of the same stack" % (n_utt, fr)
     dt = time.perf_counter() - t0
     return {"value": nframes / dt, "unit": "frames/s", "cores": 1, "kind": "port", "sample": sample,
             "seconds": round(dt, 2)}

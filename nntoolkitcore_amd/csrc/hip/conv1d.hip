@@ -26,7 +26,7 @@
 
 extern "C" void nntk_shim_conv_pack_sizes(int Cin, int Cout, int k, int *Cin_p, int *Cout_p) {
     (void)k;
-    *Cin_p = (Cin + 1) & ~1;          // K-steps of 2 never straddle a tap
+    *Cin_p = (Cin + 7) & ~7;          // the MFMA loop consumes 8 channels (4 K-steps of 2) per trip
     *Cout_p = (Cout + 31) & ~31;      // whole 32-wide MFMA column tiles
 }
 
@@ -46,15 +46,18 @@ struct ConvParams {
 };
 
 // WM x WN wavefronts, each computing TM x TN MFMA tiles of 32x32.
-template <int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvParams p) {
+// A4 = the window can be fetched with 16-byte loads (Cin % 4 == 0, 16-B aligned base).
+template <int WM, int WN, int TM, int TN, bool A4>
+__global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
     constexpr int BN = WN * TN * 32;
     static_assert(WM * WN == 4, "4 wavefronts per workgroup");
     static_assert(WM * TM * 32 == CONV_BM, "BM = 128");
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    // LDS carve (offsets from the one dynamic array, so every access stays a ds_* op):
+    //   window chunk [2][rows_a][AS] | weight chunk [2][KC][BN]
     const int a_elems = p.rows_a * CONV_AS;
-    float *As[2] = {smem, smem + a_elems};
-    float *Ws[2] = {smem + 2 * a_elems, smem + 2 * a_elems + CONV_KC * BN};
+    constexpr int w_elems = CONV_KC * BN;
+    const int w_base = 2 * a_elems;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -77,90 +80,106 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    // register staging
-    constexpr int W_PER_T = CONV_KC * BN / 4 / 256;           // float4 per thread for one W chunk
-    const int a_total = p.rows_a * CONV_KC;
-    constexpr int A_MAX = 24;                                  // rows_a*KC/256 must be <= A_MAX (host checks)
-    float4 wreg[W_PER_T];
-    float areg[A_MAX];
+    // ---- register staging (global -> VGPR now, VGPR -> LDS after the next barrier) ----
+    constexpr int W_PT = CONV_KC * BN / 4 / 256;     // float4 per thread per weight chunk
+    constexpr int A_PT = A4 ? 6 : 24;                // window: rows_a <= 192 (host checks)
+    float4 wreg[W_PT];
+    float4 areg4[A4 ? A_PT : 1];
+    float areg[A4 ? 1 : A_PT];
+    // thread -> window element mapping
+    const int ac = A4 ? (tid & 7) * 4 : (tid & 31);  // first channel inside the chunk
+    const int ar = A4 ? (tid >> 3) : (tid >> 5);     // first row; rows advance by 32 (A4) or 8
+    constexpr int AR_STEP = A4 ? 32 : 8;
 
     const int n_cchunks = (p.Cin_p + CONV_KC - 1) / CONV_KC;
     const int n_chunks = n_cchunks * p.k;
 
-    auto load_w = [&](int chunk) {
-        const int cc = chunk / p.k, kk = chunk % p.k;
+    auto load_w = [&](int cc, int kk) {
         const int i0 = cc * CONV_KC;
         const int len = min(CONV_KC, p.Cin_p - i0);
 #pragma unroll
-        for (int q = 0; q < W_PER_T; ++q) {
-            int e = tid + q * 256;                 // float4 index inside [KC, BN/4]
-            int r = e / (BN / 4), c4 = e % (BN / 4);
+        for (int q = 0; q < W_PT; ++q) {
+            const int e = tid + q * 256;             // float4 index inside [KC, BN/4]
+            const int r = e / (BN / 4), c4 = e % (BN / 4);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < len)
                 v = *reinterpret_cast<const float4 *>(p.wp + (size_t)(kk * p.Cin_p + i0 + r) * p.Cout_p + n0 + c4 * 4);
             wreg[q] = v;
         }
     };
-    auto store_w = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < W_PER_T; ++q) {
-            int e = tid + q * 256;
-            *reinterpret_cast<float4 *>(Ws[buf] + (size_t)e * 4) = wreg[q];
-        }
-    };
     auto load_a = [&](int cc) {
-        const int i0 = cc * CONV_KC;
+        const int ch = cc * CONV_KC + ac;
 #pragma unroll
-        for (int q = 0; q < A_MAX; ++q) {
-            int e = tid + q * 256;
-            float v = 0.0f;
-            if (e < a_total) {
-                int r = e / CONV_KC, c = e % CONV_KC;
-                int t = t0 + r, ch = i0 + c;
-                if (t < p.T && ch < p.Cin) v = in_b[(size_t)t * p.Cin + ch];
-            }
-            areg[q] = v;
-        }
-    };
-    auto store_a = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < A_MAX; ++q) {
-            int e = tid + q * 256;
-            if (e < a_total) {
-                int r = e / CONV_KC, c = e % CONV_KC;
-                As[buf][r * CONV_AS + c] = areg[q];
+        for (int q = 0; q < A_PT; ++q) {
+            const int r = ar + q * AR_STEP;
+            const int t = t0 + r;
+            const bool ok = r < p.rows_a && t < p.T && ch < p.Cin;
+            if (A4) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) v = *reinterpret_cast<const float4 *>(in_b + (size_t)t * p.Cin + ch);
+                areg4[q] = v;
+            } else {
+                areg[q] = ok ? in_b[(size_t)t * p.Cin + ch] : 0.0f;
             }
         }
     };
 
     load_a(0);
-    load_w(0);
-    int abuf = 0;
+    load_w(0, 0);
+    int cc = 0, kk = 0;
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
-        const int cc = chunk / p.k, kk = chunk % p.k;
         const int wbuf = chunk & 1;
-        if (kk == 0) { abuf = cc & 1; store_a(abuf); }
-        store_w(wbuf);
+        const int abuf = cc & 1;
+        if (kk == 0) {
+            float *As = smem + abuf * a_elems;
+#pragma unroll
+            for (int q = 0; q < A_PT; ++q) {
+                const int r = ar + q * AR_STEP;
+                if (r < p.rows_a) {
+                    if (A4) {
+                        float *d = As + r * CONV_AS + ac;
+                        d[0] = areg4[q].x; d[1] = areg4[q].y; d[2] = areg4[q].z; d[3] = areg4[q].w;
+                    } else {
+                        As[r * CONV_AS + ac] = areg[q];
+                    }
+                }
+            }
+        }
+        {
+            float *Ws = smem + w_base + wbuf * w_elems;
+#pragma unroll
+            for (int q = 0; q < W_PT; ++q) *reinterpret_cast<float4 *>(Ws + (size_t)(tid + q * 256) * 4) = wreg[q];
+        }
         __syncthreads();
+        // next chunk's coordinates; prefetch it while this one is multiplied
+        int ncc = cc, nkk = kk + 1;
+        if (nkk == p.k) { nkk = 0; ncc = cc + 1; }
         if (chunk + 1 < n_chunks) {
-            load_w(chunk + 1);
-            if ((chunk + 1) % p.k == 0) load_a((chunk + 1) / p.k);
+            load_w(ncc, nkk);
+            if (nkk == 0) load_a(ncc);
         }
-        const int len = min(CONV_KC, p.Cin_p - cc * CONV_KC);
-        const float *A = As[abuf] + ((wm * TM * 32 + l31) * p.stride + kk) * CONV_AS + kh;
-        const float *W = Ws[wbuf] + kh * BN + wn * TN * 32 + l31;
-        for (int s = 0; s < len; s += 2) {
-            float a[TM], w[TN];
+        const int len = min(CONV_KC, p.Cin_p - cc * CONV_KC);       // multiple of 8
+        const float *A = smem + abuf * a_elems + ((wm * TM * 32 + l31) * p.stride + kk) * CONV_AS + kh;
+        const float *W = smem + w_base + wbuf * w_elems + kh * BN + wn * TN * 32 + l31;
+        const int a_tile = 32 * p.stride * CONV_AS;
+        for (int s = 0; s < len; s += 8) {
+            float a[4][TM], w[4][TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = A[i * 32 * p.stride * CONV_AS + s];
+            for (int u = 0; u < 4; ++u) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) w[j] = W[s * BN + j * 32];
+                for (int i = 0; i < TM; ++i) a[u][i] = A[i * a_tile + s + 2 * u];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int j = 0; j < TN; ++j) w[u][j] = W[(s + 2 * u) * BN + j * 32];
+            }
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], w[j], acc[i][j], 0, 0, 0);
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], w[u][j], acc[i][j], 0, 0, 0);
         }
+        cc = ncc; kk = nkk;
     }
 
     // ---- epilogue: bias, BatchNorm (batch_norm.c:140-163 op order), activation ----
@@ -221,12 +240,12 @@ __global__ __launch_bounds__(256) void conv1d_valu_kernel(ConvParams p) {
     }
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool A4>
 static int launch_mfma(const ConvParams &p) {
     constexpr int BN = WN * TN * 32;
     size_t lds = (size_t)(2 * p.rows_a * CONV_AS + 2 * CONV_KC * BN) * sizeof(float);
     dim3 grid((unsigned)((long)p.B * p.tiles_per_seq), (unsigned)(p.Cout_p / BN));
-    auto kern = conv1d_mfma_kernel<WM, WN, TM, TN>;
+    auto kern = conv1d_mfma_kernel<WM, WN, TM, TN, A4>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return nntk_fail("hipFuncSetAttribute(conv1d)", e);
@@ -252,7 +271,7 @@ extern "C" int nntk_shim_conv1d(const float *d_in, const float *d_wp, const floa
     p.out_mode = out_mode;
     p.rows_a = (CONV_BM - 1) * stride + k;
 
-    const bool window_fits = (long)p.rows_a * CONV_KC <= 24L * 256;     // register staging budget (A_MAX)
+    const bool window_fits = p.rows_a <= 192;                          // register staging budget (A_PT)
     const long Kdim = (long)Cin * k;
     if (!window_fits || Kdim < 16 || Cout < 32) {
         const long total = (long)B * Tout * Cout;
@@ -262,7 +281,8 @@ extern "C" int nntk_shim_conv1d(const float *d_in, const float *d_wp, const floa
         NNTK_LAUNCH_CHECK("conv1d_valu_kernel");
         return 0;
     }
-    if (p.Cout_p % 128 == 0) return launch_mfma<2, 2, 2, 2>(p);
-    if (p.Cout_p % 64 == 0)  return launch_mfma<4, 1, 1, 2>(p);
-    return launch_mfma<4, 1, 1, 1>(p);
+    const bool a4 = (Cin % 4 == 0) && ((size_t)d_in % 16 == 0);
+    if (p.Cout_p % 128 == 0) return a4 ? launch_mfma<2, 2, 2, 2, true>(p) : launch_mfma<2, 2, 2, 2, false>(p);
+    if (p.Cout_p % 64 == 0)  return a4 ? launch_mfma<4, 1, 1, 2, true>(p) : launch_mfma<4, 1, 1, 2, false>(p);
+    return a4 ? launch_mfma<4, 1, 1, 1, true>(p) : launch_mfma<4, 1, 1, 1, false>(p);
 }

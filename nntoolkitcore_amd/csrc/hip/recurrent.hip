@@ -20,6 +20,7 @@
 // place.  One launch per timestep: the kernel boundary is the grid-wide
 // dependency between steps (every hidden unit of step t needs all of h_{t-1}).
 #include "nntk_common.hpp"
+#include <stdlib.h>
 
 #define REC_KC 32
 #define REC_LS 36      // LDS row stride in floats (16-B aligned rows, skewed banks)
@@ -37,26 +38,56 @@ struct RecParams {
     long out_ld;
     int B, H, Hj_p, Hk_p;
     int a0, a1, a2, a3, a4;   // activation kinds
+    int map;                  // 0: blockIdx.x = batch tile, 1: blockIdx.x = hidden tile
 };
 
-template <int G, bool IS_LSTM>
-__global__ __launch_bounds__(256) void rec_step_kernel(RecParams p) {
-    __shared__ __attribute__((aligned(16))) float As[2][REC_BM * REC_LS];
-    __shared__ __attribute__((aligned(16))) float Bs[2][G * REC_HN * REC_LS];
+// NG = number of intra-workgroup split-K groups (256 threads each).  NG = 2 puts two
+// wavefronts on every SIMD: while one issues its 32 MFMAs of a K-chunk, the other's
+// LDS reads / barrier wait / global prefetch are hidden behind them.  The two partial
+// accumulators are summed through LDS in a fixed order (group 0 + group 1), so results
+// do not depend on scheduling or on how the batch is sharded.
+template <int G, bool IS_LSTM, int NG>
+__global__ __launch_bounds__(256 * NG) void rec_step_kernel(RecParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int A_SZ = REC_BM * REC_LS;
+    constexpr int B_SZ = G * REC_HN * REC_LS;
+    constexpr int BUF = A_SZ + B_SZ;
+    constexpr int RPW = 4 / NG;                  // accumulator rows finished by each wave in the epilogue
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x & 255;
+    const int grp = threadIdx.x >> 8;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = tid >> 6;                   // row slab 0..3
     const int l15 = lane & 15, q = lane >> 4;
-    const int b0 = blockIdx.x * REC_BM;
-    const int j0 = blockIdx.y * REC_HN;
+    // blockIdx.x walks the hidden-unit tiles: blocks are dealt round-robin over the 8
+    // XCDs, so XCD c keeps U^T tiles {c, c+8, ...} (a few hundred KB) resident in its
+    // private L2 for every batch tile, instead of each XCD streaming all of U^T.
+    const int j0 = (p.map ? blockIdx.x : blockIdx.y) * REC_HN;
+    const int b0 = (p.map ? blockIdx.y : blockIdx.x) * REC_BM;
+    const int j = j0 + l15;
     const bool vec4 = (p.H & 3) == 0;
+    float *my = smem + grp * 2 * BUF;
+
+    // ---- epilogue operands do not depend on the GEMM: fetch them first so their
+    //      latency hides behind the K loop ----
+    const int GH = G * p.H;
+    float xwv[RPW][G], prev[RPW], bh[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) bh[g] = (p.bh && j < p.H) ? p.bh[g * p.H + j] : 0.0f;
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int b = b0 + wave * 16 + q * 4 + grp * RPW + rr;
+        const bool ok = b < p.B && j < p.H;
+#pragma unroll
+        for (int g = 0; g < G; ++g) xwv[rr][g] = ok ? p.xw[(size_t)b * GH + g * p.H + j] : 0.0f;
+        prev[rr] = ok ? (IS_LSTM ? p.c[(size_t)b * p.H + j] : p.h_prev[(size_t)b * p.H + j]) : 0.0f;
+    }
 
     f32x4 acc[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // staging: A tile 64 rows x 8 float4, B tile 16G rows x 8 float4
+    // staging: A tile 64 rows x 8 float4, B tile 16G rows x 8 float4 (per group)
     constexpr int A_F4 = REC_BM * (REC_KC / 4);         // 512
     constexpr int B_F4 = G * REC_HN * (REC_KC / 4);     // 384 or 512
     constexpr int A_PT = A_F4 / 256;                    // 2
@@ -96,81 +127,112 @@ __global__ __launch_bounds__(256) void rec_step_kernel(RecParams p) {
         }
     };
     auto store_chunk = [&](int buf) {
+        float *As = my + buf * BUF, *Bs = As + A_SZ;
 #pragma unroll
         for (int s = 0; s < A_PT; ++s) {
             int e = tid + s * 256;
             int r = e >> 3, c4 = e & 7;
-            *reinterpret_cast<float4 *>(&As[buf][r * REC_LS + c4 * 4]) = areg[s];
+            *reinterpret_cast<float4 *>(&As[r * REC_LS + c4 * 4]) = areg[s];
         }
 #pragma unroll
         for (int s = 0; s < B_PT; ++s) {
             int e = tid + s * 256;
             if (e < B_F4) {
                 int r = e >> 3, c4 = e & 7;
-                *reinterpret_cast<float4 *>(&Bs[buf][r * REC_LS + c4 * 4]) = breg[s];
+                *reinterpret_cast<float4 *>(&Bs[r * REC_LS + c4 * 4]) = breg[s];
             }
         }
     };
 
     const int nchunks = p.Hk_p / REC_KC;
-    load_chunk(0);
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int buf = ch & 1;
-        store_chunk(buf);
+    const int iters = (nchunks + NG - 1) / NG;       // same barrier count for every group
+    if (grp < nchunks) load_chunk(grp * REC_KC);
+    for (int it = 0; it < iters; ++it) {
+        const int ch = it * NG + grp;
+        const int buf = it & 1;
+        const bool live = ch < nchunks;
+        if (live) store_chunk(buf);
         __syncthreads();
-        if (ch + 1 < nchunks) load_chunk((ch + 1) * REC_KC);
-        // lane group q owns k = q*8 + s (s = 0..7) of this chunk: any bijection of
-        // k onto (group, step) is a valid MFMA K order as long as A and B agree.
-        const float *arow = &As[buf][(wave * 16 + l15) * REC_LS + q * 8];
-        const float4 a_lo = *reinterpret_cast<const float4 *>(arow);
-        const float4 a_hi = *reinterpret_cast<const float4 *>(arow + 4);
-        const float av[8] = {a_lo.x, a_lo.y, a_lo.z, a_lo.w, a_hi.x, a_hi.y, a_hi.z, a_hi.w};
+        if (ch + NG < nchunks) load_chunk((ch + NG) * REC_KC);
+        if (live) {
+            // lane group q owns k = q*8 + s (s = 0..7) of this chunk: any bijection of
+            // k onto (group, step) is a valid MFMA K order as long as A and B agree.
+            const float *As = my + buf * BUF, *Bs = As + A_SZ;
+            const float *arow = &As[(wave * 16 + l15) * REC_LS + q * 8];
+            const float4 a_lo = *reinterpret_cast<const float4 *>(arow);
+            const float4 a_hi = *reinterpret_cast<const float4 *>(arow + 4);
+            const float av[8] = {a_lo.x, a_lo.y, a_lo.z, a_lo.w, a_hi.x, a_hi.y, a_hi.z, a_hi.w};
+            float bv[G][8];
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const float *brow = &Bs[buf][(g * 16 + l15) * REC_LS + q * 8];
-            const float4 b_lo = *reinterpret_cast<const float4 *>(brow);
-            const float4 b_hi = *reinterpret_cast<const float4 *>(brow + 4);
-            const float bv[8] = {b_lo.x, b_lo.y, b_lo.z, b_lo.w, b_hi.x, b_hi.y, b_hi.z, b_hi.w};
+            for (int g = 0; g < G; ++g) {
+                const float *brow = &Bs[(g * 16 + l15) * REC_LS + q * 8];
+                const float4 b_lo = *reinterpret_cast<const float4 *>(brow);
+                const float4 b_hi = *reinterpret_cast<const float4 *>(brow + 4);
+                bv[g][0] = b_lo.x; bv[g][1] = b_lo.y; bv[g][2] = b_lo.z; bv[g][3] = b_lo.w;
+                bv[g][4] = b_hi.x; bv[g][5] = b_hi.y; bv[g][6] = b_hi.z; bv[g][7] = b_hi.w;
+            }
+            // gates innermost: consecutive MFMAs hit different accumulators, so the
+            // 40-cycle dependent-accumulator latency of 16x16x4 never stalls the pipe
 #pragma unroll
             for (int s = 0; s < 8; ++s)
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[g][s], acc[g], 0, 0, 0);
+        }
+    }
+
+    // ---- split-K reduction: every wave publishes its partial tile, then finishes
+    //      rows [grp*RPW, grp*RPW+RPW) of the sum (fixed order: group 0 + group 1) ----
+    float fin[RPW][G];
+    if (NG == 1) {
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+            for (int g = 0; g < G; ++g) fin[rr][g] = acc[g][rr];
+    } else {
+        __syncthreads();                              // staging buffers are dead
+        float *red = smem;                            // [grp][wave][g][r][lane]
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(((grp * 4 + wave) * G + g) * 4 + r) * 64 + lane] = acc[g][r];
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = grp * RPW + rr;
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                fin[rr][g] = red[(((0 * 4 + wave) * G + g) * 4 + r) * 64 + lane] +
+                             red[(((1 * 4 + wave) * G + g) * 4 + r) * 64 + lane];
         }
     }
 
     // ---- fused gate epilogue: lane holds (b = b0 + 16*wave + 4*q + r, j = j0 + l15) ----
-    const int j = j0 + l15;
     if (j >= p.H) return;
-    const int GH = G * p.H;
-    float bh[G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) bh[g] = p.bh ? p.bh[g * p.H + j] : 0.0f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int b = b0 + wave * 16 + q * 4 + r;
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int b = b0 + wave * 16 + q * 4 + grp * RPW + rr;
         if (b >= p.B) continue;
-        const float *xw = p.xw + (size_t)b * GH + j;
         float hn;
         if (!IS_LSTM) {
             // gru.c:144-186
-            const float hz = acc[0][r] + bh[0], hr = acc[1][r] + bh[1], hh = acc[2][r] + bh[2];
-            const float z = nntk_act(p.a0, xw[0] + hz, 1.0f);
-            const float rg = nntk_act(p.a2, xw[p.H] + hr, 1.0f);
-            const float ht = nntk_act(p.a1, rg * hh + xw[2 * p.H], 1.0f);
-            const float hp = p.h_prev[(size_t)b * p.H + j];
-            hn = (-z + 1.0f) * ht + z * hp;
+            const float hz = fin[rr][0] + bh[0], hr = fin[rr][1] + bh[1], hh = fin[rr][2] + bh[2];
+            const float z = nntk_act(p.a0, xwv[rr][0] + hz, 1.0f);
+            const float rg = nntk_act(p.a2, xwv[rr][1] + hr, 1.0f);
+            const float ht = nntk_act(p.a1, rg * hh + xwv[rr][2], 1.0f);
+            hn = (-z + 1.0f) * ht + z * prev[rr];
         } else {
             // lstm.c:201-238
-            const float zi = xw[0] + (acc[0][r] + bh[0]);
-            const float zf = xw[p.H] + (acc[1][r] + bh[1]);
-            const float zg = xw[2 * p.H] + (acc[2][r] + bh[2]);
-            const float zo = xw[3 * p.H] + (acc[G - 1][r] + bh[G - 1]);
+            const float zi = xwv[rr][0] + (fin[rr][0] + bh[0]);
+            const float zf = xwv[rr][1] + (fin[rr][1] + bh[1]);
+            const float zg = xwv[rr][2] + (fin[rr][2] + bh[2]);
+            const float zo = xwv[rr][G - 1] + (fin[rr][G - 1] + bh[G - 1]);
             const float ig = nntk_act(p.a0, zi, 1.0f);
             const float fg = nntk_act(p.a1, zf, 1.0f);
             const float gg = nntk_act(p.a2, zg, 1.0f);
             const float og = nntk_act(p.a3, zo, 1.0f);
-            const size_t ci = (size_t)b * p.H + j;
-            const float cn = fg * p.c[ci] + ig * gg;
-            p.c[ci] = cn;
+            const float cn = fg * prev[rr] + ig * gg;
+            p.c[(size_t)b * p.H + j] = cn;
             hn = og * nntk_act(p.a4, cn, 1.0f);
         }
         p.h_next[(size_t)b * p.H + j] = hn;
@@ -209,7 +271,23 @@ static int run_recurrent(const float *d_xw, const float *d_ut, const float *d_bh
     p.Hk_p = (H + 31) & ~31;
     p.a0 = acts[0]; p.a1 = acts[1]; p.a2 = acts[2];
     p.a3 = nacts > 3 ? acts[3] : 0; p.a4 = nacts > 4 ? acts[4] : 0;
-    dim3 grid((unsigned)((B + REC_BM - 1) / REC_BM), (unsigned)(p.Hj_p / REC_HN));
+    const char *menv = getenv("NNTK_REC_MAP");
+    p.map = (menv && menv[0] == '1') ? 1 : 0;
+    const unsigned gj = (unsigned)(p.Hj_p / REC_HN), gb = (unsigned)((B + REC_BM - 1) / REC_BM);
+    dim3 grid(p.map ? gj : gb, p.map ? gb : gj);
+    // split-K groups per workgroup: 2 (two waves per SIMD) unless overridden for A/B runs
+    const char *env = getenv("NNTK_REC_GROUPS");
+    const int ng = (env && env[0] == '1') ? 1 : 2;
+    constexpr size_t buf_floats = (size_t)REC_BM * REC_LS + (size_t)G * REC_HN * REC_LS;
+    const size_t lds1 = 2 * buf_floats * sizeof(float);
+    size_t lds2 = 4 * buf_floats * sizeof(float);
+    const size_t red2 = (size_t)8 * G * 4 * 64 * sizeof(float);
+    if (red2 > lds2) lds2 = red2;
+    if (ng == 2 && lds2 > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)rec_step_kernel<G, IS_LSTM, 2>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        if (e != hipSuccess) return nntk_fail("hipFuncSetAttribute(rec_step_kernel)", e);
+    }
     const int span = nntk_prof_span_begin();
     for (int t = 0; t < T; ++t) {
         p.xw = d_xw + (size_t)t * B * G * H;
@@ -218,7 +296,8 @@ static int run_recurrent(const float *d_xw, const float *d_ut, const float *d_bh
         if (return_sequences) { p.out = d_out + (size_t)t * H; p.out_ld = (long)T * H; }
         else if (t == T - 1)  { p.out = d_out; p.out_ld = H; }
         else                  { p.out = nullptr; p.out_ld = 0; }
-        hipLaunchKernelGGL((rec_step_kernel<G, IS_LSTM>), grid, dim3(256), 0, nntk_stream(), p);
+        if (ng == 2) hipLaunchKernelGGL((rec_step_kernel<G, IS_LSTM, 2>), grid, dim3(512), lds2, nntk_stream(), p);
+        else         hipLaunchKernelGGL((rec_step_kernel<G, IS_LSTM, 1>), grid, dim3(256), lds1, nntk_stream(), p);
     }
     nntk_prof_span_end(span, T);
     NNTK_LAUNCH_CHECK("rec_step_kernel");
