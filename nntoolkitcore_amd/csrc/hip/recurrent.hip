@@ -240,8 +240,263 @@ __global__ __launch_bounds__(256 * NG) void rec_step_kernel(RecParams p) {
     }
 }
 
+// ============================================================================
+// Persistent variant: ONE launch runs all T timesteps.
+//
+// Each workgroup owns (batch tile of 64 rows) x (16 hidden units x G gates) for the
+// whole sequence and keeps its U^T tile RESIDENT in LDS (LSTM-512: 64 x 512 f32 =
+// 128 KiB of the CU's 160 KiB), so the only per-step operand traffic is the h tile.
+// The grid-wide dependency between steps is local to a batch tile: the NCT
+// workgroups of one batch tile exchange h through memory each step.  Block ids
+// are dealt so that one batch tile's workgroups share an XCD (bt = id % NBT, with
+// NBT a multiple of 8 at the BASELINE shapes): their h traffic stays in that XCD's
+// L2.  Placement is a speed matter only: the hand-off below is the
+// placement-independent recipe of the CDNA4 guide (Guideline 16, R1 / first row
+// of the sc1 table): payload stored write-through (sc1), every storing wave
+// drains vmcnt, workgroup barrier, ONE lane adds to an agent-scope counter; the
+// consumer polls that counter from one lane (relaxed, s_sleep), joins a
+// workgroup barrier, and EVERY load of handed-off bytes is an sc1 load.
+//
+// MFMA orientation is swapped relative to rec_step_kernel: D[hidden][batch] =
+// U^T tile (A operand) x h^T (B operand), so a lane ends up with consecutive
+// hidden units of ONE batch row: xW loads, h/out stores are contiguous per lane.
+//
+// Residency: the grid is sized to at most one workgroup per CU (LDS use forces
+// that) and never exceeds the CU count; every spin is bounded (1 s of
+// s_memrealtime) and poisons the counter's top bit, which the host checks.
+// ============================================================================
+#define RECP_CNT_STRIDE 64  // uints between arrival counters (256 B)
+#define RECP_CNT_WORDS (256 * RECP_CNT_STRIDE)
+#define RECP_MAXCH 16     // H <= 512 (16 chunks of 32): the whole h tile is held in registers per step
+typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+
+struct RecPParams {
+    const float *xw;      // [T, B, G*H]
+    const float *ut;      // [G, Hj_p, Hk_p]
+    const float *bh;      // [G*H] or NULL
+    float *hbuf;          // [2][B][H] ping-pong state; hbuf[0] holds h_0 on entry, hbuf[T&1] h_T on exit
+    float *c;             // [B][H] LSTM cell state (read at start, written at end)
+    float *out;           // [B, T, H] or [B, H]
+    unsigned *cnt;        // [NBT] arrival counters, zeroed before the launch
+    int B, T, H, Hj_p, Hk_p, NBT, NCT, b_base;
+    int return_sequences;
+    int a0, a1, a2, a3, a4;
+    int dbg_chunks;       // >0: timing experiments only (limits the K loop)
+};
+
+template <bool VEC>
+__device__ __forceinline__ float4 load4_sc1(__amdgpu_buffer_rsrc_t rsrc, int soff, const float *base, size_t idx,
+                                            int n_valid) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n_valid <= 0) return v;
+    if (VEC) {     // H % 4 == 0: k < H implies the whole 16-byte piece is inside the row
+        v4u32 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(idx * 4), soff, 16 /* sc1 */);
+        v.x = __uint_as_float(r.x); v.y = __uint_as_float(r.y); v.z = __uint_as_float(r.z); v.w = __uint_as_float(r.w);
+        return v;
+    }
+    const unsigned *u = reinterpret_cast<const unsigned *>(base + idx);
+    v.x = __uint_as_float(__hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (n_valid > 1) v.y = __uint_as_float(__hip_atomic_load(u + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (n_valid > 2) v.z = __uint_as_float(__hip_atomic_load(u + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (n_valid > 3) v.w = __uint_as_float(__hip_atomic_load(u + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return v;
+}
+
+template <int G, bool IS_LSTM, bool VEC>
+__global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int US = p.Hk_p + 8;                    // U^T row stride: 16-B aligned, conflict-free b128 slots
+    float *Us = smem;                             // [G*16][US]   resident for the whole sequence
+    float *red = smem + G * 16 * US;              // [4 slabs][2 groups][G][2][64] split-K exchange
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w8 = tid >> 6;                      // wavefront 0..7
+    // 8 wavefronts = 4 batch slabs of 16 rows x 2 split-K halves.  (A variant in which every
+    // slab was its own sync domain with per-wave polling was measured 40 % SLOWER: polling
+    // traffic from 2048 waves outweighed the overlap -- one poller per workgroup it is.)
+    const int grp = w8 >> 2;                      // split-K half: k sub-range [16*grp, 16*grp+16) of each chunk
+    const int slab = w8 & 3;
+    const int l15 = lane & 15, q = lane >> 4;
+    const int bt = blockIdx.x % p.NBT;
+    const int ct = blockIdx.x / p.NBT;
+    const int b0 = p.b_base + bt * REC_BM;
+    const int j0 = ct * REC_HN;
+    constexpr bool vec4 = VEC;                    // H % 4 == 0: 16-B sc1 loads, 8-B stores
+    constexpr bool pair8 = VEC;
+    const size_t BH = (size_t)p.B * p.H;
+    const int GH = G * p.H;
+    // one arrival counter per batch tile, each on its own 256-B line: atomics execute at the
+    // memory side, so counters sharing a line serialise on one channel (measured: 3.5x slower)
+    unsigned *cnt = p.cnt + (size_t)bt * RECP_CNT_STRIDE;
+
+    // this lane finishes hidden units j, j+1 of batch row b (after the split-K exchange)
+    const int b = b0 + slab * 16 + l15;
+    const int j = j0 + q * 4 + grp * 2;
+    const bool row_ok = b < p.B;
+    const bool ok0 = row_ok && j < p.H, ok1 = row_ok && j + 1 < p.H;
+
+    // ---- resident U^T tile ----
+    {
+        const int f4_per_row = p.Hk_p / 4;
+        const int total = G * 16 * f4_per_row;
+        for (int e = tid; e < total; e += 512) {
+            const int r = e / f4_per_row, c4 = e % f4_per_row;
+            const int g = r >> 4, jj = r & 15;
+            const float4 v = *reinterpret_cast<const float4 *>(p.ut + ((size_t)g * p.Hj_p + j0 + jj) * p.Hk_p + c4 * 4);
+            *reinterpret_cast<float4 *>(&Us[r * US + c4 * 4]) = v;
+        }
+    }
+    float bh[2][G];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int g = 0; g < G; ++g) bh[e][g] = (p.bh && j + e < p.H) ? p.bh[g * p.H + j + e] : 0.0f;
+    // own previous state: c (LSTM) or h (GRU) for the two elements this lane finishes
+    float prev[2];
+    {
+        const float *src = IS_LSTM ? p.c : p.hbuf;
+        prev[0] = ok0 ? src[(size_t)b * p.H + j] : 0.0f;
+        prev[1] = ok1 ? src[(size_t)b * p.H + j + 1] : 0.0f;
+    }
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.hbuf, 0, (int)(BH * 8), 0x00020000);
+    const int nchunks = p.dbg_chunks > 0 ? p.dbg_chunks : p.Hk_p / REC_KC;
+    float *my_red = red + ((slab * 2 + grp) * G * 2) * 64;
+    const float *peer_red = red + ((slab * 2 + (1 - grp)) * G * 2) * 64;
+    __syncthreads();
+
+    for (int t = 0; t < p.T; ++t) {
+        // xW(+b_i) of this step does not depend on h: fetch before waiting on the peers
+        float xwv[2][G];
+        {
+            const float *xw = p.xw + ((size_t)t * p.B + b) * GH + j;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                xwv[0][g] = ok0 ? xw[g * p.H] : 0.0f;
+                xwv[1][g] = ok1 ? xw[g * p.H + 1] : 0.0f;
+            }
+        }
+        // ---- wait until every workgroup of this batch tile has published h_{t-1}:
+        //      ONE lane polls (relaxed, s_sleep), the workgroup joins a barrier, and every
+        //      load of handed-off bytes below is an sc1 load ----
+        if (t > 0) {
+            if (tid == 0) {
+                const unsigned target = (unsigned)p.NCT * (unsigned)t;
+                const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (__builtin_amdgcn_s_memrealtime() - t_start > 100000000ull) {     // 1 s at 100 MHz
+                        __hip_atomic_fetch_or(cnt, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        const float *hsrc = p.hbuf + (size_t)(t & 1) * BH;
+        const int hoff = (t & 1) ? (int)(BH * 4) : 0;          // byte offset of the read buffer (scalar)
+
+        f32x4 acc[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        // The h operand needs no LDS: in this orientation lane (batch row l15, k-group q)
+        // consumes h[b][32*ch + 16*grp + 4*q .. +3] -- 16 contiguous bytes per chunk that
+        // only this lane uses.  All chunks are requested up front (sc1 loads), so the K
+        // loop below has no barrier and no staging.
+        float4 hreg[RECP_MAXCH];
+#pragma unroll
+        for (int ch = 0; ch < RECP_MAXCH; ++ch) {
+            const int k = ch * REC_KC + grp * 16 + q * 4;
+            hreg[ch] = (ch < nchunks) ? load4_sc1<vec4>(rsrc, hoff, hsrc, (size_t)b * p.H + k, row_ok ? p.H - k : 0)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int ch = 0; ch < RECP_MAXCH; ++ch) {
+            if (ch < nchunks) {
+                const float hv[4] = {hreg[ch].x, hreg[ch].y, hreg[ch].z, hreg[ch].w};
+                float uv[G][4];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const float4 u4 = *reinterpret_cast<const float4 *>(&Us[(g * 16 + l15) * US + ch * REC_KC + grp * 16 + q * 4]);
+                    uv[g][0] = u4.x; uv[g][1] = u4.y; uv[g][2] = u4.z; uv[g][3] = u4.w;
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(uv[g][s], hv[s], acc[g], 0, 0, 0);
+            }
+        }
+
+        // ---- split-K exchange through LDS: send the half the partner wave finishes ----
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) my_red[(g * 2 + e) * 64 + lane] = acc[g][(1 - grp) * 2 + e];
+        __syncthreads();
+        float fin[2][G];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float other = peer_red[(g * 2 + e) * 64 + lane];
+                const float mine = acc[g][grp * 2 + e];
+                fin[e][g] = grp == 0 ? mine + other : other + mine;      // always (group 0) + (group 1)
+            }
+
+        // ---- gates (same formulas as rec_step_kernel) ----
+        float hn[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (!IS_LSTM) {
+                const float hz = fin[e][0] + bh[e][0], hr = fin[e][1] + bh[e][1], hh = fin[e][2] + bh[e][2];
+                const float z = nntk_act(p.a0, xwv[e][0] + hz, 1.0f);
+                const float rg = nntk_act(p.a2, xwv[e][1] + hr, 1.0f);
+                const float ht = nntk_act(p.a1, rg * hh + xwv[e][2], 1.0f);
+                hn[e] = (-z + 1.0f) * ht + z * prev[e];
+                prev[e] = hn[e];
+            } else {
+                const float zi = xwv[e][0] + (fin[e][0] + bh[e][0]);
+                const float zf = xwv[e][1] + (fin[e][1] + bh[e][1]);
+                const float zg = xwv[e][2] + (fin[e][2] + bh[e][2]);
+                const float zo = xwv[e][G - 1] + (fin[e][G - 1] + bh[e][G - 1]);
+                const float ig = nntk_act(p.a0, zi, 1.0f);
+                const float fg = nntk_act(p.a1, zf, 1.0f);
+                const float gg = nntk_act(p.a2, zg, 1.0f);
+                const float og = nntk_act(p.a3, zo, 1.0f);
+                const float cn = fg * prev[e] + ig * gg;
+                prev[e] = cn;
+                hn[e] = og * nntk_act(p.a4, cn, 1.0f);
+            }
+        }
+        // ---- publish h_t (write-through), then this wave's arrival; the layer output
+        //      (never read in this launch) is stored after the arrival ----
+        float *hdst = p.hbuf + (size_t)((t + 1) & 1) * BH + (size_t)b * p.H + j;
+        if (pair8 && ok1) {
+            const unsigned long long pk = ((unsigned long long)__float_as_uint(hn[1]) << 32) | __float_as_uint(hn[0]);
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(hdst), pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (ok0) __hip_atomic_store(reinterpret_cast<unsigned *>(hdst), __float_as_uint(hn[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ok1) __hip_atomic_store(reinterpret_cast<unsigned *>(hdst + 1), __float_as_uint(hn[1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // R1: every storing wave drains ...
+        __syncthreads();                                      // ... the workgroup meets (this also frees `red`) ...
+        if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... ONE lane arrives
+        if (p.return_sequences || t == p.T - 1) {
+            float *o = p.return_sequences ? p.out + ((size_t)b * p.T + t) * p.H + j : p.out + (size_t)b * p.H + j;
+            if (pair8 && ok1) *reinterpret_cast<float2 *>(o) = make_float2(hn[0], hn[1]);
+            else { if (ok0) o[0] = hn[0]; if (ok1) o[1] = hn[1]; }
+        }
+    }
+    if (IS_LSTM) {
+        if (ok0) p.c[(size_t)b * p.H + j] = prev[0];
+        if (ok1) p.c[(size_t)b * p.H + j + 1] = prev[1];
+    }
+}
+
 extern "C" size_t nntk_shim_recurrent_work_floats(int B, int H) {
-    return (size_t)3 * B * H;     // h ping, h pong, c
+    return (size_t)3 * B * H + RECP_CNT_WORDS;     // h ping, h pong, c, arrival counters of the persistent kernel
 }
 
 static int act_ok(int a) {
@@ -275,6 +530,42 @@ static int run_recurrent(const float *d_xw, const float *d_ut, const float *d_bh
     p.map = (menv && menv[0] == '1') ? 1 : 0;
     const unsigned gj = (unsigned)(p.Hj_p / REC_HN), gb = (unsigned)((B + REC_BM - 1) / REC_BM);
     dim3 grid(p.map ? gj : gb, p.map ? gb : gj);
+    // ---- persistent path: one launch for the whole sequence when U^T fits in LDS ----
+    {
+        const char *penv = getenv("NNTK_REC_PERSISTENT");
+        const bool want = !(penv && penv[0] == '0');
+        const int NCT = p.Hj_p / REC_HN;
+        const size_t lds = ((size_t)G * 16 * (p.Hk_p + 8) + (size_t)4 * 2 * G * 2 * 64) * sizeof(float);
+        int dev = 0, cus = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const int tiles_per_launch = NCT > 0 ? cus / NCT : 0;
+        if (want && lds <= 160 * 1024 && p.Hk_p <= RECP_MAXCH * REC_KC && tiles_per_launch >= 1 && BH * 8 < 0x7fffffffULL) {
+            auto kern = (H % 4 == 0) ? rec_persistent_kernel<G, IS_LSTM, true> : rec_persistent_kernel<G, IS_LSTM, false>;
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return nntk_fail("hipFuncSetAttribute(rec_persistent_kernel)", e);
+            unsigned *cnt = reinterpret_cast<unsigned *>(d_work + 3 * BH);
+            RecPParams q;
+            q.xw = d_xw; q.ut = d_ut; q.bh = d_bh; q.hbuf = hbuf[0]; q.c = cbuf; q.out = d_out; q.cnt = cnt;
+            q.B = B; q.T = T; q.H = H; q.Hj_p = p.Hj_p; q.Hk_p = p.Hk_p; q.NCT = NCT;
+            q.return_sequences = return_sequences;
+            { const char *d = getenv("NNTK_REC_DBG_CHUNKS"); q.dbg_chunks = d ? atoi(d) : 0; }
+            q.a0 = p.a0; q.a1 = p.a1; q.a2 = p.a2; q.a3 = p.a3; q.a4 = p.a4;
+            const int nbt_total = (B + REC_BM - 1) / REC_BM;
+            const int span = nntk_prof_span_begin();
+            for (int bt0 = 0; bt0 < nbt_total; bt0 += tiles_per_launch) {
+                const int nbt = nbt_total - bt0 < tiles_per_launch ? nbt_total - bt0 : tiles_per_launch;
+                if (nntk_shim_memset(cnt, 0, (size_t)nbt * RECP_CNT_STRIDE * sizeof(unsigned))) return -1;
+                q.NBT = nbt; q.b_base = bt0 * REC_BM;
+                hipLaunchKernelGGL(kern, dim3((unsigned)(nbt * NCT)), dim3(512), lds, nntk_stream(), q);
+            }
+            nntk_prof_span_end(span, T);
+            NNTK_LAUNCH_CHECK("rec_persistent_kernel");
+            if (d_hT) { if (nntk_shim_copy_d2d(d_hT, hbuf[T & 1], BH * 4)) return -1; }
+            if (IS_LSTM && d_cT) { if (nntk_shim_copy_d2d(d_cT, cbuf, BH * 4)) return -1; }
+            return 0;
+        }
+    }
     // split-K groups per workgroup: 2 (two waves per SIMD) unless overridden for A/B runs
     const char *env = getenv("NNTK_REC_GROUPS");
     const int ng = (env && env[0] == '1') ? 1 : 2;
