@@ -195,18 +195,19 @@ def roofline_for(wl, phase_ms, prof):
                 "algorithmic_flops": flops, "algorithmic_bytes": bytes_,
                 "hbm_frac": bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     # recurrent step kernel: one launch = one timestep of hU = h[B,H] x U[H,G*H] + fused gates
-    if wl.name == "stack":
-        H, G, kern, key = 512, 4, "rec_step_kernel<4,true>", "lstm"
-    else:
-        H, G, kern, key = 256, 3, "rec_step_kernel<3,false>", "gru2"
-    flops = 2.0 * B * H * G * H
-    ms = prof.get("rec_step_ms", None)
+    H, G = (512, 4) if wl.name == "stack" else (256, 3)
+    ms = prof.get("rec_launch_ms", None)
     if ms is None:
         return None
+    tpl = prof["rec_timesteps_per_launch"]
+    persistent = tpl > 1
+    kern = ("rec_persistent_kernel" if persistent else "rec_step_kernel") + ("<4,LSTM>" if G == 4 else "<3,GRU>")
+    flops = 2.0 * B * H * G * H * tpl          # algorithmic flops of ONE launch (tpl timesteps of h[B,H] x U[H,G*H])
     ach = flops / (ms * 1e-3) / 1e12
     return {"kernel": kern, "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None, "ms_per_launch": ms, "algorithmic_flops": flops,
-            "launches_per_step": prof.get("rec_step_launches")}
+            "timesteps_per_launch": tpl, "us_per_timestep": ms * 1e3 / tpl,
+            "launches_per_step": prof.get("rec_launches_per_step")}
 
 
 def cpu_baseline(workload, weights, frames, seed):
@@ -316,10 +317,11 @@ def main():
             phase_ms[n1] = phase_ms.get(n1, 0.0) + e0.elapsed_time(e1) / a.steps
     prof = {}
     ms = C.c_double()
-    cnt = C.c_long()
-    if L.nntk_hip_profile_get(b"rec_step", C.byref(ms), C.byref(cnt)) == 0 and cnt.value > 0:
-        prof["rec_step_ms"] = ms.value / cnt.value
-        prof["rec_step_launches"] = cnt.value // max(1, a.steps + a.warmup)
+    cnt, units = C.c_long(), C.c_long()
+    if L.nntk_hip_profile_get(b"rec_step", C.byref(ms), C.byref(cnt), C.byref(units)) == 0 and cnt.value > 0:
+        prof["rec_launch_ms"] = ms.value / cnt.value                 # average duration of one kernel launch
+        prof["rec_timesteps_per_launch"] = units.value / cnt.value   # 1 = per-step kernels, T = persistent
+        prof["rec_launches_per_step"] = cnt.value / max(1, a.steps + a.warmup)
 
     total_frames = world * B * wl.frames_per_utt * a.steps
     value = total_frames / dt

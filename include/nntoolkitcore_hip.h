@@ -216,10 +216,11 @@ void       *nntk_hip_get_stream(void);
 int         nntk_hip_synchronize(void);               /* waits for the current stream */
 const char *nntk_last_error(void);                    /* "" when the last call succeeded */
 const char *nntk_version(void);
-/* Optional HIP-event spans around the per-timestep recurrent launches (name "rec_step"):
- * enable, run, then read the summed milliseconds and launch count (reading clears them). */
+/* Optional HIP-event spans around the recurrent kernel launches (name "rec_step"): enable,
+ * run, then read the summed milliseconds, the number of kernel launches and the timesteps they
+ * covered (a persistent launch covers all T of a sequence).  Reading clears the spans. */
 void        nntk_hip_profile_enable(int on);
-int         nntk_hip_profile_get(const char *name, double *total_ms, long *launches);
+int         nntk_hip_profile_get(const char *name, double *total_ms, long *launches, long *timesteps);
 
 /* raw device memory helpers for C callers that chain layers on the GPU */
 float *nntk_device_alloc(size_t n_floats);

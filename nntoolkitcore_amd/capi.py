@@ -153,7 +153,7 @@ SIGNATURES = {
     "nntk_last_error": (C.c_char_p, []),
     "nntk_version": (C.c_char_p, []),
     "nntk_hip_profile_enable": (None, [C.c_int]),
-    "nntk_hip_profile_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
+    "nntk_hip_profile_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "nntk_device_alloc": (vp, [C.c_size_t]),
     "nntk_device_free": (None, [vp]),
     "nntk_device_upload": (C.c_int, [vp, fp, C.c_size_t]),

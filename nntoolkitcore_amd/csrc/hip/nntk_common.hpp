@@ -8,7 +8,8 @@ hipStream_t nntk_stream();
 int nntk_fail(const char *what, hipError_t err);
 int nntk_fail_msg(const char *what);
 int nntk_prof_span_begin();                       // -1 when profiling is off
-void nntk_prof_span_end(int idx, long launches);
+void nntk_prof_span_end(int idx, long launches, long units);
+void nntk_set_post_sync_hook(int (*hook)());      // runs after every host-visible stream sync
 
 #define NNTK_HIP_TRY(expr)                                             \
     do {                                                               \

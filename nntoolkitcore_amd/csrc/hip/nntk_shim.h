@@ -37,7 +37,7 @@ void        nntk_shim_clear_error(void);
 
 /* HIP-event spans around the recurrent step launches (off by default) */
 void nntk_shim_profile_enable(int on);
-int  nntk_shim_profile_get(const char *name, double *total_ms, long *launches);
+int  nntk_shim_profile_get(const char *name, double *total_ms, long *launches, long *timesteps);
 
 void *nntk_shim_malloc(size_t bytes);
 void  nntk_shim_free(void *d_ptr);

@@ -495,6 +495,37 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
     }
 }
 
+// ---- host side of the bounded spins: after each persistent launch the arrival counters are
+//      copied (async, same stream) into pinned memory; the next host-visible sync point
+//      checks their poison bit and turns a would-be hang into an ordinary -1 ----
+static unsigned *g_rec_status = nullptr;       // pinned [256]
+static int g_rec_status_n = 0;
+
+static int rec_status_check() {
+    int bad = 0;
+    for (int i = 0; i < g_rec_status_n; ++i) bad |= (g_rec_status[i] & 0x80000000u) != 0;
+    g_rec_status_n = 0;
+    if (bad)
+        return nntk_fail_msg("persistent recurrent kernel: a workgroup timed out waiting for its peers "
+                             "(not all workgroups were resident?); results are invalid. "
+                             "Set NNTK_REC_PERSISTENT=0 to use the per-timestep kernels.");
+    return 0;
+}
+
+static int rec_status_enqueue(const unsigned *d_cnt, int nbt) {
+    if (!g_rec_status) {
+        if (hipHostMalloc((void **)&g_rec_status, 256 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess)
+            return nntk_fail_msg("hipHostMalloc(rec status) failed");
+        nntk_set_post_sync_hook(rec_status_check);
+    }
+    if (g_rec_status_n + nbt > 256) g_rec_status_n = 0;
+    NNTK_HIP_TRY(hipMemcpy2DAsync(g_rec_status + g_rec_status_n, sizeof(unsigned), d_cnt,
+                                  RECP_CNT_STRIDE * sizeof(unsigned), sizeof(unsigned), (size_t)nbt,
+                                  hipMemcpyDeviceToHost, nntk_stream()));
+    g_rec_status_n += nbt;
+    return 0;
+}
+
 extern "C" size_t nntk_shim_recurrent_work_floats(int B, int H) {
     return (size_t)3 * B * H + RECP_CNT_WORDS;     // h ping, h pong, c, arrival counters of the persistent kernel
 }
@@ -558,8 +589,9 @@ static int run_recurrent(const float *d_xw, const float *d_ut, const float *d_bh
                 if (nntk_shim_memset(cnt, 0, (size_t)nbt * RECP_CNT_STRIDE * sizeof(unsigned))) return -1;
                 q.NBT = nbt; q.b_base = bt0 * REC_BM;
                 hipLaunchKernelGGL(kern, dim3((unsigned)(nbt * NCT)), dim3(512), lds, nntk_stream(), q);
+                if (rec_status_enqueue(cnt, nbt)) return -1;
             }
-            nntk_prof_span_end(span, T);
+            nntk_prof_span_end(span, (nbt_total + tiles_per_launch - 1) / tiles_per_launch, T);
             NNTK_LAUNCH_CHECK("rec_persistent_kernel");
             if (d_hT) { if (nntk_shim_copy_d2d(d_hT, hbuf[T & 1], BH * 4)) return -1; }
             if (IS_LSTM && d_cT) { if (nntk_shim_copy_d2d(d_cT, cbuf, BH * 4)) return -1; }
@@ -590,7 +622,7 @@ static int run_recurrent(const float *d_xw, const float *d_ut, const float *d_bh
         if (ng == 2) hipLaunchKernelGGL((rec_step_kernel<G, IS_LSTM, 2>), grid, dim3(512), lds2, nntk_stream(), p);
         else         hipLaunchKernelGGL((rec_step_kernel<G, IS_LSTM, 1>), grid, dim3(256), lds1, nntk_stream(), p);
     }
-    nntk_prof_span_end(span, T);
+    nntk_prof_span_end(span, T, T);
     NNTK_LAUNCH_CHECK("rec_step_kernel");
     if (d_hT) { if (nntk_shim_copy_d2d(d_hT, hbuf[T & 1], BH * 4)) return -1; }
     if (IS_LSTM && d_cT) { if (nntk_shim_copy_d2d(d_cT, cbuf, BH * 4)) return -1; }

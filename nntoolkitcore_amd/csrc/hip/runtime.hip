@@ -10,6 +10,12 @@ static thread_local char g_err[512] = "";
 
 hipStream_t nntk_stream() { return g_stream; }
 
+// Kernels that can only report failure through device memory (the persistent recurrent
+// kernel's bounded spins) register a check that runs after every host-visible sync point.
+static int (*g_post_sync_hook)() = nullptr;
+void nntk_set_post_sync_hook(int (*hook)()) { g_post_sync_hook = hook; }
+static int post_sync() { return g_post_sync_hook ? g_post_sync_hook() : 0; }
+
 int nntk_fail(const char *what, hipError_t err) {
     snprintf(g_err, sizeof(g_err), "HIP error in %s: %s", what, hipGetErrorString(err));
     return -1;
@@ -20,7 +26,7 @@ int nntk_fail_msg(const char *what) {
 }
 
 // ---- optional HIP-event spans around launch sequences (bench.py's live roofline) ----
-struct ProfSpan { hipEvent_t a, b; long launches; };
+struct ProfSpan { hipEvent_t a, b; long launches, units; };
 static std::vector<ProfSpan> g_spans;
 static bool g_prof = false;
 
@@ -28,30 +34,35 @@ int nntk_prof_span_begin() {
     if (!g_prof) return -1;
     ProfSpan s;
     s.launches = 0;
+    s.units = 0;
     if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return -1;
     (void)hipEventRecord(s.a, g_stream);
     g_spans.push_back(s);
     return (int)g_spans.size() - 1;
 }
-void nntk_prof_span_end(int idx, long launches) {
+void nntk_prof_span_end(int idx, long launches, long units) {
     if (idx < 0 || idx >= (int)g_spans.size()) return;
     (void)hipEventRecord(g_spans[idx].b, g_stream);
     g_spans[idx].launches = launches;
+    g_spans[idx].units = units;
 }
 
 extern "C" {
 
 void nntk_shim_profile_enable(int on) { g_prof = on != 0; }
-// Sums and clears the recorded spans ("rec_step": the per-timestep recurrent launches).
-int nntk_shim_profile_get(const char *name, double *total_ms, long *launches) {
+// Sums and clears the recorded spans around the recurrent kernels.  `launches` = kernel
+// launches inside the spans, `units` = timesteps they covered (a persistent launch covers T).
+int nntk_shim_profile_get(const char *name, double *total_ms, long *launches, long *units) {
     (void)name;
     *total_ms = 0.0;
     *launches = 0;
+    *units = 0;
     for (auto &s : g_spans) {
         float ms = 0.f;
         if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
             *total_ms += ms;
             *launches += s.launches;
+            *units += s.units;
         }
         (void)hipEventDestroy(s.a);
         (void)hipEventDestroy(s.b);
@@ -77,7 +88,7 @@ void nntk_shim_set_stream(void *stream) { g_stream = (hipStream_t)stream; }
 void *nntk_shim_get_stream(void) { return (void *)g_stream; }
 int nntk_shim_synchronize(void) {
     NNTK_HIP_TRY(hipStreamSynchronize(g_stream));
-    return 0;
+    return post_sync();
 }
 
 void *nntk_shim_malloc(size_t bytes) {
@@ -109,7 +120,7 @@ int nntk_shim_download(void *h_dst, const void *d_src, size_t bytes) {
     if (!bytes) return 0;
     NNTK_HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, g_stream));
     NNTK_HIP_TRY(hipStreamSynchronize(g_stream));
-    return 0;
+    return post_sync();
 }
 int nntk_shim_copy_d2d(void *d_dst, const void *d_src, size_t bytes) {
     if (!bytes) return 0;

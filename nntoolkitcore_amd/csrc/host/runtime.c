@@ -16,8 +16,8 @@ void *nntk_hip_get_stream(void) { return nntk_shim_get_stream(); }
 int nntk_hip_synchronize(void) { return nntk_shim_synchronize(); }
 const char *nntk_last_error(void) { return nntk_shim_error(); }
 void nntk_hip_profile_enable(int on) { nntk_shim_profile_enable(on); }
-int nntk_hip_profile_get(const char *name, double *total_ms, long *launches) {
-    return nntk_shim_profile_get(name, total_ms, launches);
+int nntk_hip_profile_get(const char *name, double *total_ms, long *launches, long *timesteps) {
+    return nntk_shim_profile_get(name, total_ms, launches, timesteps);
 }
 const char *nntk_version(void) { return "nntoolkitcore_hip 0.1 (gfx950)"; }
 
