@@ -25,148 +25,160 @@ struct SpecParams {
     const float *tw;      // [nfft] interleaved (cos, -sin) = exp(-2*pi*i*m/nfft)
     float *out;           // [B, nts, nfreq]
     long total_frames;    // B * nts
+    int B;
     int input_size, nfft, window_size, step, nfreq, nts;
-    float fft_norm, scale;
+    float fft_norm, scale, inv_scale;
     int mode;
 };
 
-struct cf { float x, y; };
-__device__ __forceinline__ cf cadd(cf a, cf b) { return {a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ cf csub(cf a, cf b) { return {a.x - b.x, a.y - b.y}; }
-__device__ __forceinline__ cf cmul(cf a, cf b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
-__device__ __forceinline__ cf mul_mi(cf a) { return {a.y, -a.x}; }     // a * (-i)
-
-#define BFLY2(a, b) do { cf _t = a; a = cadd(_t, b); b = csub(_t, b); } while (0)
+typedef float f2 __attribute__((ext_vector_type(2)));     // (re, im): adds/subs/muls lower to v_pk_*_f32
+__device__ __forceinline__ f2 cmul2(f2 a, f2 b) { return (f2){a.x, a.x} * b + (f2){-a.y, a.y} * (f2){b.y, b.x}; }
+__device__ __forceinline__ f2 mul_mi2(f2 a) { return (f2){a.y, -a.x}; }     // a * (-i)
+#define BF2(a, b) do { f2 _t = a; a = _t + b; b = _t - b; } while (0)
 
 // forward 8-point DFT, natural-order output, in registers
-__device__ __forceinline__ void fft8(cf v[8]) {
-    BFLY2(v[0], v[4]); BFLY2(v[1], v[5]); BFLY2(v[2], v[6]); BFLY2(v[3], v[7]);
+__device__ __forceinline__ void fft8(f2 v[8]) {
+    BF2(v[0], v[4]); BF2(v[1], v[5]); BF2(v[2], v[6]); BF2(v[3], v[7]);
     const float s = 0.70710678118654752440f;
-    v[5] = cmul(v[5], cf{s, -s});
-    v[6] = mul_mi(v[6]);
-    v[7] = cmul(v[7], cf{-s, -s});
+    v[5] = cmul2(v[5], (f2){s, -s});
+    v[6] = mul_mi2(v[6]);
+    v[7] = cmul2(v[7], (f2){-s, -s});
     // two 4-point DFTs: (v0..v3) -> even outputs, (v4..v7) -> odd outputs
-    BFLY2(v[0], v[2]); BFLY2(v[1], v[3]); v[3] = mul_mi(v[3]); BFLY2(v[0], v[1]); BFLY2(v[2], v[3]);
-    BFLY2(v[4], v[6]); BFLY2(v[5], v[7]); v[7] = mul_mi(v[7]); BFLY2(v[4], v[5]); BFLY2(v[6], v[7]);
-    // registers now hold X0,X4,X2,X6 | X1,X5,X3,X7  (v0=X0, v1=X4, v2=X2, v3=X6, v4=X1, v5=X5, v6=X3, v7=X7)
-    cf x1 = v[4], x2 = v[2], x3 = v[6], x4 = v[1], x5 = v[5], x6 = v[3];
+    BF2(v[0], v[2]); BF2(v[1], v[3]); v[3] = mul_mi2(v[3]); BF2(v[0], v[1]); BF2(v[2], v[3]);
+    BF2(v[4], v[6]); BF2(v[5], v[7]); v[7] = mul_mi2(v[7]); BF2(v[4], v[5]); BF2(v[6], v[7]);
+    // registers now hold X0,X4,X2,X6 | X1,X5,X3,X7
+    f2 x1 = v[4], x2 = v[2], x3 = v[6], x4 = v[1], x5 = v[5], x6 = v[3];
     v[1] = x1; v[2] = x2; v[3] = x3; v[4] = x4; v[5] = x5; v[6] = x6;
 }
 
+// Every wavefront owns its private LDS image and a wave's DS instructions execute in
+// order, so no s_barrier is needed between passes -- only a fence that stops the
+// compiler from reordering the (aliasing) LDS accesses.  Waves of a workgroup drift freely.
+#define WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+                             __builtin_amdgcn_wave_barrier();                        \
+                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #define SPEC_LDS_PER_WAVE 592      // 512 + 8 * 8 padding, rounded to a multiple of 16
 __device__ __forceinline__ int pidx(int i) { return i + ((i >> 6) << 3); }
 
 __device__ __forceinline__ float finish_bin(const SpecParams &p, float re, float im, int k) {
     if (p.fft_norm != 1.0f) { re *= p.fft_norm; im *= p.fft_norm; }
     float m = re * re + im * im;
-    if (p.mode == 0) return sqrtf(m) / p.scale;
-    if (k == 0 || k == p.nfreq - 1) return m / p.scale;
-    return m * (2.0f / p.scale);
+    // p.inv_scale = 1/scale rounded once on the host: one multiply instead of the reference's
+    // divide (spectrogram.c:33) -- differs from it by at most 1 ulp, far inside the stated tolerance
+    if (p.mode == 0) return sqrtf(m) * p.inv_scale;
+    if (k == 0 || k == p.nfreq - 1) return m * p.inv_scale;
+    return m * (2.0f * p.inv_scale);
 }
 
+// The kernel was VALU-bound in its first form (~900 vector instructions per frame pair,
+// a third of them 64-bit address arithmetic, range guards and an integer division), so:
+// grid.y walks utterances (no division), each utterance gets its own buffer descriptor
+// (32-bit offsets, hardware range check instead of per-load guards), complex math is
+// written on 2-vectors so it issues as packed f32, and everything that depends only on
+// the lane (window taps, both twiddle sets) is hoisted out of the frame loop.
 __global__ __launch_bounds__(256) void spectrogram512_kernel(SpecParams p) {
     __shared__ __attribute__((aligned(16))) float lds_re[4][SPEC_LDS_PER_WAVE];
     __shared__ __attribute__((aligned(16))) float lds_im[4][SPEC_LDS_PER_WAVE];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     float *re = lds_re[wave], *im = lds_im[wave];
-    const long npairs = (p.total_frames + 1) / 2;
-    const long wave_stride = (long)gridDim.x * 4;
+    const int ppu = (p.nts + 1) >> 1;                 // frame pairs per utterance
 
-    for (long pair = (long)blockIdx.x * 4 + wave; pair < ((npairs + 3) / 4) * 4; pair += wave_stride) {
-        // all four waves of a workgroup run the same number of iterations (barriers below)
-        const bool active = pair < npairs;
-        const long fa = pair * 2, fb = pair * 2 + 1;
-        const bool has_b = active && fb < p.total_frames;
-        const float *xa = nullptr, *xb = nullptr;
-        if (active) xa = p.in + (fa / p.nts) * (long)p.input_size + (fa % p.nts) * (long)p.step;
-        if (has_b) xb = p.in + (fb / p.nts) * (long)p.input_size + (fb % p.nts) * (long)p.step;
-
-        cf v[8];
-        // ---- pass 1 (Ns = 1): windowed samples from global, no twiddles ----
+    // lane-only constants
+    float wtap[8];
+    bool inwin[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int n = lane + 64 * r;
-            float w = 0.f, a = 0.f, b = 0.f;
-            if (n < p.window_size) {
-                w = p.window[n];
-                if (active) a = xa[n];
-                if (has_b) b = xb[n];
-            }
-            v[r] = cf{w * a, w * b};
-        }
-        fft8(v);
-        {
-            const int base = pidx(lane * 8);     // 8 contiguous, 32-B aligned floats per lane
-            *reinterpret_cast<float4 *>(re + base) = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
-            *reinterpret_cast<float4 *>(re + base + 4) = make_float4(v[4].x, v[5].x, v[6].x, v[7].x);
-            *reinterpret_cast<float4 *>(im + base) = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
-            *reinterpret_cast<float4 *>(im + base + 4) = make_float4(v[4].y, v[5].y, v[6].y, v[7].y);
-        }
-        __syncthreads();
-        // ---- pass 2 (Ns = 8): twiddle exp(-2 pi i (j%8) r / 64) ----
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int i = pidx(lane + 64 * r);
-            v[r] = cf{re[i], im[i]};
-        }
-        {
-            const int jm = lane & 7;
-#pragma unroll
-            for (int r = 1; r < 8; ++r) {
-                const float2 t = reinterpret_cast<const float2 *>(p.tw)[jm * r * 8];
-                v[r] = cmul(v[r], cf{t.x, t.y});
-            }
-        }
-        fft8(v);
-        __syncthreads();
-        {
-            const int base = (lane >> 3) * 64 + (lane & 7);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int i = pidx(base + 8 * r);
-                re[i] = v[r].x; im[i] = v[r].y;
-            }
-        }
-        __syncthreads();
-        // ---- pass 3 (Ns = 64): twiddle exp(-2 pi i j r / 512) ----
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int i = pidx(lane + 64 * r);
-            v[r] = cf{re[i], im[i]};
-        }
+    for (int r = 0; r < 8; ++r) {
+        const int n = lane + 64 * r;
+        inwin[r] = n < p.window_size;
+        wtap[r] = inwin[r] ? p.window[n] : 0.0f;
+    }
+    f2 tw2[8], tw3[8];
+    {
+        const f2 *tw = reinterpret_cast<const f2 *>(p.tw);
 #pragma unroll
         for (int r = 1; r < 8; ++r) {
-            const float2 t = reinterpret_cast<const float2 *>(p.tw)[lane * r];
-            v[r] = cmul(v[r], cf{t.x, t.y});
+            tw2[r] = tw[(lane & 7) * r * 8];          // exp(-2 pi i (j%8) r / 64)
+            tw3[r] = tw[lane * r];                    // exp(-2 pi i j r / 512)
         }
-        fft8(v);
-        __syncthreads();   // LDS image is free for the next pair
-        // lane j now holds Z[j + 64 r], r = 0..7.
-        // ---- split the two real spectra; bins k = j + 64 r for r = 0..3 (+ k = 256 on lane 0) ----
-        const int src = (64 - lane) & 63;
-        cf zc[5];          // Z[N - k] for r = 0..3, and for k = 256
+    }
+    const int i1 = pidx(lane * 8);                    // pass-1 write base (8 contiguous floats)
+    const int i2w = (lane >> 3) * 64 + (lane & 7);    // pass-2 write base
+    const int src = (64 - lane) & 63;
+
+    for (int b = blockIdx.y; b < p.B; b += gridDim.y) {
+        const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(p.in + (size_t)b * p.input_size), 0, p.input_size * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(p.out + (size_t)b * p.nts * p.nfreq), 0, p.nts * p.nfreq * 4, 0x00020000);
+        for (int pr = blockIdx.x * 4 + wave; pr < ppu; pr += gridDim.x * 4) {
+            const int fa = 2 * pr;
+            const bool has_b = fa + 1 < p.nts;        // wave-uniform
+            const int offa = (fa * p.step + lane) * 4;
+            const int offb = has_b ? offa + p.step * 4 : 0x7ffffff0;      // out of range -> loads return 0
+            f2 v[8];
+            // ---- pass 1 (Ns = 1): windowed samples from global, no twiddles ----
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            // lane != 0: partner register 7 - r on lane 64 - j; lane 0: register (8 - r) & 7 of itself
-            const float pr = __shfl(v[7 - r].x, src), pi = __shfl(v[7 - r].y, src);
-            const cf self = v[(8 - r) & 7];
-            zc[r] = lane == 0 ? self : cf{pr, pi};
-        }
-        zc[4] = v[4];      // k = 256 pairs with itself (lane 0 only)
-        if (active) {
-            float *oa = p.out + fa * (long)p.nfreq;
-            float *ob = p.out + fb * (long)p.nfreq;
+            for (int r = 0; r < 8; ++r) {
+                const unsigned ua = __builtin_amdgcn_raw_buffer_load_b32(rin, offa + 256 * r, 0, 0);
+                const unsigned ub = __builtin_amdgcn_raw_buffer_load_b32(rin, offb + 256 * r, 0, 0);
+                const f2 x = (f2){__uint_as_float(ua), __uint_as_float(ub)};
+                v[r] = inwin[r] ? x * wtap[r] : (f2){0.f, 0.f};       // exact zero padding even for inf/nan neighbours
+            }
+            fft8(v);
+            *reinterpret_cast<float4 *>(re + i1) = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
+            *reinterpret_cast<float4 *>(re + i1 + 4) = make_float4(v[4].x, v[5].x, v[6].x, v[7].x);
+            *reinterpret_cast<float4 *>(im + i1) = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
+            *reinterpret_cast<float4 *>(im + i1 + 4) = make_float4(v[4].y, v[5].y, v[6].y, v[7].y);
+            WAVE_LDS_SYNC();
+            // ---- pass 2 (Ns = 8) ----
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int i = pidx(lane + 64 * r);
+                v[r] = (f2){re[i], im[i]};
+            }
+#pragma unroll
+            for (int r = 1; r < 8; ++r) v[r] = cmul2(v[r], tw2[r]);
+            fft8(v);
+            WAVE_LDS_SYNC();
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int i = pidx(i2w + 8 * r);
+                re[i] = v[r].x; im[i] = v[r].y;
+            }
+            WAVE_LDS_SYNC();
+            // ---- pass 3 (Ns = 64) ----
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int i = pidx(lane + 64 * r);
+                v[r] = (f2){re[i], im[i]};
+            }
+#pragma unroll
+            for (int r = 1; r < 8; ++r) v[r] = cmul2(v[r], tw3[r]);
+            fft8(v);
+            WAVE_LDS_SYNC();   // LDS image is free for the next pair
+            // lane j now holds Z[j + 64 r], r = 0..7.
+            // ---- split the two real spectra; bins k = j + 64 r for r = 0..3 (+ k = 256 on lane 0) ----
+            const int oa = fa * p.nfreq * 4 + lane * 4;
+            const int ob = has_b ? oa + p.nfreq * 4 : 0x7ffffff0;          // out of range -> store dropped
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
-                if (r == 4 && lane != 0) break;
-                const int k = lane + 64 * r;
-                const cf z = v[r], c = zc[r];
+                f2 c;
+                if (r < 4) {
+                    // lane != 0: partner register 7 - r on lane 64 - j; lane 0: register (8 - r) & 7 of itself
+                    const f2 pz = (f2){__shfl(v[7 - r].x, src), __shfl(v[7 - r].y, src)};
+                    c = lane == 0 ? v[(8 - r) & 7] : pz;
+                } else {
+                    c = v[4];                        // k = 256 pairs with itself (lane 0 only)
+                }
+                const f2 z = v[r];
                 // X_a = (Z + conj(Zc)) / 2 ; X_b = (Z - conj(Zc)) / (2i)
                 const float ar = 0.5f * (z.x + c.x), ai = 0.5f * (z.y - c.y);
                 const float br = 0.5f * (z.y + c.y), bi = -0.5f * (z.x - c.x);
-                oa[k] = finish_bin(p, ar, ai, k);
-                if (has_b) ob[k] = finish_bin(p, br, bi, k);
+                const int k = lane + 64 * r;
+                const int dead = (r == 4 && lane != 0) ? 0x7ffffff0 : 0;   // only lane 0 owns bin 256
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(finish_bin(p, ar, ai, k)), rout, (oa + 256 * r) | dead, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(finish_bin(p, br, bi, k)), rout, (ob + 256 * r) | dead, 0, 0);
             }
         }
     }
@@ -203,13 +215,18 @@ extern "C" int nntk_shim_spectrogram(const float *d_in, const float *d_window, c
     SpecParams p;
     p.in = d_in; p.window = d_window; p.tw = d_twiddle; p.out = d_out;
     p.total_frames = (long)B * nts;
+    p.B = B;
     p.input_size = input_size; p.nfft = nfft; p.window_size = window_size; p.step = step;
-    p.nfreq = nfreq; p.nts = nts; p.fft_norm = fft_norm; p.scale = scale; p.mode = mode;
+    p.nfreq = nfreq; p.nts = nts; p.fft_norm = fft_norm; p.scale = scale; p.inv_scale = (float)(1.0 / (double)scale); p.mode = mode;
     if (nfft == 512) {
-        long npairs = (p.total_frames + 1) / 2;
-        long g = (npairs + 3) / 4;
-        if (g > 256 * 8 * 4) g = 256 * 8 * 4;
-        hipLaunchKernelGGL(spectrogram512_kernel, dim3((unsigned)g), dim3(256), 0, nntk_stream(), p);
+        if ((long)input_size * 4 >= 0x7ffffff0L || (long)nts * nfreq * 4 >= 0x7ffffff0L)
+            return nntk_fail_msg("spectrogram: one utterance must stay below 2 GiB");
+        const int ppu = (nts + 1) / 2;
+        unsigned gx = (unsigned)((ppu + 3) / 4);
+        unsigned gy = (unsigned)(B < 65535 ? B : 65535);
+        // keep the grid near 8 workgroups per CU; the kernel strides over the rest
+        while ((long)gx * gy > 256L * 8 * 8 && gy > 1) gy = (gy + 1) / 2;
+        hipLaunchKernelGGL(spectrogram512_kernel, dim3(gx, gy), dim3(256), 0, nntk_stream(), p);
         NNTK_LAUNCH_CHECK("spectrogram512_kernel");
     } else {
         long g = p.total_frames < 4096 ? p.total_frames : 4096;
