@@ -41,6 +41,7 @@ struct ConvParams {
     int act_kind;
     int B, T, Cin, Cin_p, Cout, Cout_p, k, stride, Tout;
     int tiles_per_seq;   // ceil(Tout / BM)
+    int m_tiles, n_tiles; // B * tiles_per_seq row tiles x Cout_p / BN column tiles
     int out_mode;        // 0: row b*Tout+x ; 1: row x*B+b
     int rows_a;          // (BM-1)*stride + k window rows per tile
 };
@@ -65,10 +66,17 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, kh = lane >> 5;
 
-    const int tile = blockIdx.x;
+    // XCD-aware tile order (blocks are dealt round-robin over the 8 XCDs): XCD c walks the
+    // row tiles c, c+8, ... and, for each, ALL column tiles back to back, so a row tile's
+    // window is fetched from HBM once and re-read from that XCD's L2 by its other column
+    // tiles.  (x-major order re-streamed the whole input once per column tile: PMC showed
+    // 16x / 8x the algorithmic reads on the LSTM input projection / TDD GEMMs.)
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int tile = (local / p.n_tiles) * 8 + xcd;
+    if (tile >= p.m_tiles) return;
     const int b = tile / p.tiles_per_seq;
     const int x0 = (tile % p.tiles_per_seq) * CONV_BM;
-    const int n0 = blockIdx.y * BN;
+    const int n0 = (local % p.n_tiles) * BN;
     const float *in_b = p.in + (size_t)b * p.T * p.Cin;
     const int t0 = x0 * p.stride;
 
@@ -244,13 +252,19 @@ template <int WM, int WN, int TM, int TN, bool A4>
 static int launch_mfma(const ConvParams &p) {
     constexpr int BN = WN * TN * 32;
     size_t lds = (size_t)(2 * p.rows_a * CONV_AS + 2 * CONV_KC * BN) * sizeof(float);
-    dim3 grid((unsigned)((long)p.B * p.tiles_per_seq), (unsigned)(p.Cout_p / BN));
+    ConvParams q = p;
+    q.m_tiles = p.B * p.tiles_per_seq;
+    q.n_tiles = p.Cout_p / BN;
+    const long blocks = (long)((q.m_tiles + 7) / 8) * 8 * q.n_tiles;
+    if ((long)p.B * p.tiles_per_seq > 0x7fffffffL / 8 || blocks > 0x7fffffffL)
+        return nntk_fail_msg("conv1d: too many tiles for one launch");
+    dim3 grid((unsigned)blocks);
     auto kern = conv1d_mfma_kernel<WM, WN, TM, TN, A4>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return nntk_fail("hipFuncSetAttribute(conv1d)", e);
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, nntk_stream(), p);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, nntk_stream(), q);
     NNTK_LAUNCH_CHECK("conv1d_mfma_kernel");
     return 0;
 }

@@ -76,12 +76,12 @@ __device__ __forceinline__ float finish_bin(const SpecParams &p, float re, float
 // (32-bit offsets, hardware range check instead of per-load guards), complex math is
 // written on 2-vectors so it issues as packed f32, and everything that depends only on
 // the lane (window taps, both twiddle sets) is hoisted out of the frame loop.
+template <int MODE, bool NORM>
 __global__ __launch_bounds__(256) void spectrogram512_kernel(SpecParams p) {
-    __shared__ __attribute__((aligned(16))) float lds_re[4][SPEC_LDS_PER_WAVE];
-    __shared__ __attribute__((aligned(16))) float lds_im[4][SPEC_LDS_PER_WAVE];
+    __shared__ __attribute__((aligned(16))) f2 lds_z[4][SPEC_LDS_PER_WAVE];      // interleaved (re, im)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    float *re = lds_re[wave], *im = lds_im[wave];
+    f2 *z = lds_z[wave];
     const int ppu = (p.nts + 1) >> 1;                 // frame pairs per utterance
 
     // lane-only constants
@@ -102,6 +102,15 @@ __global__ __launch_bounds__(256) void spectrogram512_kernel(SpecParams p) {
             tw3[r] = tw[lane * r];                    // exp(-2 pi i j r / 512)
         }
     }
+    // output scale per bin (magnitude: 1/sum(w); PSD: 2/(fs sum w^2), edges 1/(..): spectrogram.c:41-47),
+    // with fft_normalization_factor folded in AFTER the reference's own rounding points would not be
+    // exact, so the factor still multiplies re/im first (NORM) exactly like spectrogram.c:130-131
+    float osc[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const int k = lane + 64 * r;
+        osc[r] = (MODE == 0 || k == 0 || k == p.nfreq - 1) ? p.inv_scale : 2.0f * p.inv_scale;
+    }
     const int i1 = pidx(lane * 8);                    // pass-1 write base (8 contiguous floats)
     const int i2w = (lane >> 3) * 64 + (lane & 7);    // pass-2 write base
     const int src = (64 - lane) & 63;
@@ -111,48 +120,64 @@ __global__ __launch_bounds__(256) void spectrogram512_kernel(SpecParams p) {
             (void *)(p.in + (size_t)b * p.input_size), 0, p.input_size * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(p.out + (size_t)b * p.nts * p.nfreq), 0, p.nts * p.nfreq * 4, 0x00020000);
-        for (int pr = blockIdx.x * 4 + wave; pr < ppu; pr += gridDim.x * 4) {
+        // software prefetch: the 16 sample loads of this wave's NEXT frame pair are issued
+        // before the current pair is transformed, so HBM latency overlaps the FFT math
+        int pr = blockIdx.x * 4 + wave;
+        unsigned nxa[8], nxb[8];
+        bool nhas_b = false;
+        if (pr < ppu) {
             const int fa = 2 * pr;
-            const bool has_b = fa + 1 < p.nts;        // wave-uniform
+            nhas_b = fa + 1 < p.nts;
             const int offa = (fa * p.step + lane) * 4;
-            const int offb = has_b ? offa + p.step * 4 : 0x7ffffff0;      // out of range -> loads return 0
-            f2 v[8];
-            // ---- pass 1 (Ns = 1): windowed samples from global, no twiddles ----
+            const int offb = nhas_b ? offa + p.step * 4 : 0x7ffffff0;      // out of range -> loads return 0
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const unsigned ua = __builtin_amdgcn_raw_buffer_load_b32(rin, offa + 256 * r, 0, 0);
-                const unsigned ub = __builtin_amdgcn_raw_buffer_load_b32(rin, offb + 256 * r, 0, 0);
-                const f2 x = (f2){__uint_as_float(ua), __uint_as_float(ub)};
+                nxa[r] = __builtin_amdgcn_raw_buffer_load_b32(rin, offa + 256 * r, 0, 0);
+                nxb[r] = __builtin_amdgcn_raw_buffer_load_b32(rin, offb + 256 * r, 0, 0);
+            }
+        }
+        for (; pr < ppu; pr += gridDim.x * 4) {
+            const int fa = 2 * pr;
+            const bool has_b = nhas_b;                // wave-uniform
+            f2 v[8];
+            // ---- pass 1 (Ns = 1): windowed samples, no twiddles ----
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const f2 x = (f2){__uint_as_float(nxa[r]), __uint_as_float(nxb[r])};
                 v[r] = inwin[r] ? x * wtap[r] : (f2){0.f, 0.f};       // exact zero padding even for inf/nan neighbours
             }
+            {
+                const int npr = pr + gridDim.x * 4;
+                if (npr < ppu) {
+                    const int nfa = 2 * npr;
+                    nhas_b = nfa + 1 < p.nts;
+                    const int offa = (nfa * p.step + lane) * 4;
+                    const int offb = nhas_b ? offa + p.step * 4 : 0x7ffffff0;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        nxa[r] = __builtin_amdgcn_raw_buffer_load_b32(rin, offa + 256 * r, 0, 0);
+                        nxb[r] = __builtin_amdgcn_raw_buffer_load_b32(rin, offb + 256 * r, 0, 0);
+                    }
+                }
+            }
             fft8(v);
-            *reinterpret_cast<float4 *>(re + i1) = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
-            *reinterpret_cast<float4 *>(re + i1 + 4) = make_float4(v[4].x, v[5].x, v[6].x, v[7].x);
-            *reinterpret_cast<float4 *>(im + i1) = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
-            *reinterpret_cast<float4 *>(im + i1 + 4) = make_float4(v[4].y, v[5].y, v[6].y, v[7].y);
+#pragma unroll
+            for (int r = 0; r < 8; r += 2)               // 8 contiguous complex per lane: 4 x ds_write_b128
+                *reinterpret_cast<float4 *>(z + i1 + r) = make_float4(v[r].x, v[r].y, v[r + 1].x, v[r + 1].y);
             WAVE_LDS_SYNC();
             // ---- pass 2 (Ns = 8) ----
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int i = pidx(lane + 64 * r);
-                v[r] = (f2){re[i], im[i]};
-            }
+            for (int r = 0; r < 8; ++r) v[r] = z[pidx(lane + 64 * r)];
 #pragma unroll
             for (int r = 1; r < 8; ++r) v[r] = cmul2(v[r], tw2[r]);
             fft8(v);
             WAVE_LDS_SYNC();
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int i = pidx(i2w + 8 * r);
-                re[i] = v[r].x; im[i] = v[r].y;
-            }
+            for (int r = 0; r < 8; ++r) z[pidx(i2w + 8 * r)] = v[r];
             WAVE_LDS_SYNC();
             // ---- pass 3 (Ns = 64) ----
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int i = pidx(lane + 64 * r);
-                v[r] = (f2){re[i], im[i]};
-            }
+            for (int r = 0; r < 8; ++r) v[r] = z[pidx(lane + 64 * r)];
 #pragma unroll
             for (int r = 1; r < 8; ++r) v[r] = cmul2(v[r], tw3[r]);
             fft8(v);
@@ -173,12 +198,14 @@ __global__ __launch_bounds__(256) void spectrogram512_kernel(SpecParams p) {
                 }
                 const f2 z = v[r];
                 // X_a = (Z + conj(Zc)) / 2 ; X_b = (Z - conj(Zc)) / (2i)
-                const float ar = 0.5f * (z.x + c.x), ai = 0.5f * (z.y - c.y);
-                const float br = 0.5f * (z.y + c.y), bi = -0.5f * (z.x - c.x);
-                const int k = lane + 64 * r;
+                f2 xa = (f2){0.5f * (z.x + c.x), 0.5f * (z.y - c.y)};
+                f2 xb = (f2){0.5f * (z.y + c.y), -0.5f * (z.x - c.x)};
+                if (NORM) { xa = xa * p.fft_norm; xb = xb * p.fft_norm; }
+                float ma = xa.x * xa.x + xa.y * xa.y, mb = xb.x * xb.x + xb.y * xb.y;
+                if (MODE == 0) { ma = sqrtf(ma); mb = sqrtf(mb); }
                 const int dead = (r == 4 && lane != 0) ? 0x7ffffff0 : 0;   // only lane 0 owns bin 256
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(finish_bin(p, ar, ai, k)), rout, (oa + 256 * r) | dead, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(finish_bin(p, br, bi, k)), rout, (ob + 256 * r) | dead, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ma * osc[r]), rout, (oa + 256 * r) | dead, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mb * osc[r]), rout, (ob + 256 * r) | dead, 0, 0);
             }
         }
     }
@@ -222,11 +249,14 @@ extern "C" int nntk_shim_spectrogram(const float *d_in, const float *d_window, c
         if ((long)input_size * 4 >= 0x7ffffff0L || (long)nts * nfreq * 4 >= 0x7ffffff0L)
             return nntk_fail_msg("spectrogram: one utterance must stay below 2 GiB");
         const int ppu = (nts + 1) / 2;
-        unsigned gx = (unsigned)((ppu + 3) / 4);
+        unsigned gx = (unsigned)((ppu + 7) / 8);         // ~2 frame pairs per wavefront per utterance (prefetch depth 1)
         unsigned gy = (unsigned)(B < 65535 ? B : 65535);
         // keep the grid near 8 workgroups per CU; the kernel strides over the rest
         while ((long)gx * gy > 256L * 8 * 8 && gy > 1) gy = (gy + 1) / 2;
-        hipLaunchKernelGGL(spectrogram512_kernel, dim3(gx, gy), dim3(256), 0, nntk_stream(), p);
+        const bool norm = fft_norm != 1.0f;
+        auto kern = mode == 0 ? (norm ? spectrogram512_kernel<0, true> : spectrogram512_kernel<0, false>)
+                              : (norm ? spectrogram512_kernel<1, true> : spectrogram512_kernel<1, false>);
+        hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), 0, nntk_stream(), p);
         NNTK_LAUNCH_CHECK("spectrogram512_kernel");
     } else {
         long g = p.total_frames < 4096 ? p.total_frames : 4096;
