@@ -1,0 +1,58 @@
+"""A C application written against the reference's own headers/API, compiled unchanged
+against libnntoolkitcore_hip.so: build check on CPU, end-to-end parity vs the oracle on GPU."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from nntoolkitcore_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "c_api", "dropin_caller.c")
+
+
+def _build(tmp_path, built_lib):
+    exe = str(tmp_path / "dropin_caller")
+    libdir = os.path.dirname(capi.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), SRC,
+                           "-L", libdir, "-lnntoolkitcore_hip", "-Wl,-rpath," + libdir,
+                           "-Wl,--allow-shlib-undefined", "-o", exe])
+    return exe
+
+
+def test_reference_style_c_caller_compiles_and_links(tmp_path, built_lib):
+    assert os.path.exists(_build(tmp_path, built_lib))
+
+
+@pytest.mark.gpu
+def test_reference_style_c_caller_matches_oracle(tmp_path, built_lib, gpu):
+    import oracle as O
+    exe = _build(tmp_path, built_lib)
+    r = np.random.default_rng(21)
+    N, C1, K, H, V, F = 4240, 32, 5, 48, 10, 257
+    u = lambda *s, sc=1.0: r.uniform(-sc, sc, s).astype(np.float32)
+    audio = (0.1 * r.standard_normal(2 * N)).astype(np.float32)
+    Wc, bc = u(C1, F, K, sc=(F * K) ** -0.5), u(C1, sc=0.1)
+    g, be, mu, var = 1 + u(C1, sc=0.5), u(C1, sc=0.5), u(C1, sc=0.1), 1 + u(C1, sc=0.5)
+    gW, gU, gbi, gbh = u(C1, 3 * H, sc=C1 ** -0.5), u(H, 3 * H, sc=H ** -0.5), u(3 * H, sc=0.1), u(3 * H, sc=0.1)
+    dW, db = u(H, V, sc=H ** -0.5), u(V, sc=0.1)
+    for name, arr in dict(audio=audio, conv_W=Wc, conv_b=bc, bn=np.concatenate([g, be, mu, var]), gru_W=gW, gru_U=gU,
+                          gru_bi=gbi, gru_bh=gbh, tdd_W=dW, tdd_b=db).items():
+        arr.tofile(str(tmp_path / (name + ".bin")))
+    env = dict(os.environ)
+    torch_lib = os.path.join(os.path.dirname(__import__("torch").__file__), "lib")
+    env["LD_LIBRARY_PATH"] = torch_lib + ":" + env.get("LD_LIBRARY_PATH", "")     # the HIP runtime that matches this box
+    out = subprocess.run([exe, str(tmp_path)], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    got = np.fromfile(str(tmp_path / "out_y.bin"), np.float32)
+    w = O.window("hann", 400)
+    hstate, ys = None, []
+    for chunk in range(2):
+        s = O.spectrogram(audio[chunk * N:(chunk + 1) * N], w, 512, 240)
+        c = O.activation(O.ACT_RELU, O.batch_norm(O.conv1d(s, Wc, bc, 1), g, be, mu, var, 1e-3))
+        hseq, hstate = O.gru(c, gW, gU, gbi, gbh, h0=hstate)
+        ys.append(O.time_distributed_dense(hseq, dW, db, act=O.ACT_SOFTMAX, softmax_vector_size=V))
+    ref = np.concatenate(ys).ravel()
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 1e-5
