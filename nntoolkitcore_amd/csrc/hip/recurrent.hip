@@ -217,9 +217,9 @@ __global__ __launch_bounds__(256 * NG) void rec_step_kernel(RecParams p) {
         if (!IS_LSTM) {
             // gru.c:144-186
             const float hz = fin[rr][0] + bh[0], hr = fin[rr][1] + bh[1], hh = fin[rr][2] + bh[2];
-            const float z = nntk_act(p.a0, xwv[rr][0] + hz, 1.0f);
-            const float rg = nntk_act(p.a2, xwv[rr][1] + hr, 1.0f);
-            const float ht = nntk_act(p.a1, rg * hh + xwv[rr][2], 1.0f);
+            const float z = nntk_gate_act(p.a0, xwv[rr][0] + hz);
+            const float rg = nntk_gate_act(p.a2, xwv[rr][1] + hr);
+            const float ht = nntk_gate_act(p.a1, rg * hh + xwv[rr][2]);
             hn = (-z + 1.0f) * ht + z * prev[rr];
         } else {
             // lstm.c:201-238
@@ -227,13 +227,13 @@ __global__ __launch_bounds__(256 * NG) void rec_step_kernel(RecParams p) {
             const float zf = xwv[rr][1] + (fin[rr][1] + bh[1]);
             const float zg = xwv[rr][2] + (fin[rr][2] + bh[2]);
             const float zo = xwv[rr][G - 1] + (fin[rr][G - 1] + bh[G - 1]);
-            const float ig = nntk_act(p.a0, zi, 1.0f);
-            const float fg = nntk_act(p.a1, zf, 1.0f);
-            const float gg = nntk_act(p.a2, zg, 1.0f);
-            const float og = nntk_act(p.a3, zo, 1.0f);
+            const float ig = nntk_gate_act(p.a0, zi);
+            const float fg = nntk_gate_act(p.a1, zf);
+            const float gg = nntk_gate_act(p.a2, zg);
+            const float og = nntk_gate_act(p.a3, zo);
             const float cn = fg * prev[rr] + ig * gg;
             p.c[(size_t)b * p.H + j] = cn;
-            hn = og * nntk_act(p.a4, cn, 1.0f);
+            hn = og * nntk_gate_act(p.a4, cn);
         }
         p.h_next[(size_t)b * p.H + j] = hn;
         if (p.out) p.out[(size_t)b * p.out_ld + j] = hn;
@@ -451,9 +451,9 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
         for (int e = 0; e < 2; ++e) {
             if (!IS_LSTM) {
                 const float hz = fin[e][0] + bh[e][0], hr = fin[e][1] + bh[e][1], hh = fin[e][2] + bh[e][2];
-                const float z = nntk_act(p.a0, xwv[e][0] + hz, 1.0f);
-                const float rg = nntk_act(p.a2, xwv[e][1] + hr, 1.0f);
-                const float ht = nntk_act(p.a1, rg * hh + xwv[e][2], 1.0f);
+                const float z = nntk_gate_act(p.a0, xwv[e][0] + hz);
+                const float rg = nntk_gate_act(p.a2, xwv[e][1] + hr);
+                const float ht = nntk_gate_act(p.a1, rg * hh + xwv[e][2]);
                 hn[e] = (-z + 1.0f) * ht + z * prev[e];
                 prev[e] = hn[e];
             } else {
@@ -461,13 +461,13 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
                 const float zf = xwv[e][1] + (fin[e][1] + bh[e][1]);
                 const float zg = xwv[e][2] + (fin[e][2] + bh[e][2]);
                 const float zo = xwv[e][G - 1] + (fin[e][G - 1] + bh[e][G - 1]);
-                const float ig = nntk_act(p.a0, zi, 1.0f);
-                const float fg = nntk_act(p.a1, zf, 1.0f);
-                const float gg = nntk_act(p.a2, zg, 1.0f);
-                const float og = nntk_act(p.a3, zo, 1.0f);
+                const float ig = nntk_gate_act(p.a0, zi);
+                const float fg = nntk_gate_act(p.a1, zf);
+                const float gg = nntk_gate_act(p.a2, zg);
+                const float og = nntk_gate_act(p.a3, zo);
                 const float cn = fg * prev[e] + ig * gg;
                 prev[e] = cn;
-                hn[e] = og * nntk_act(p.a4, cn, 1.0f);
+                hn[e] = og * nntk_gate_act(p.a4, cn);
             }
         }
         // ---- publish h_t (write-through), then this wave's arrival; the layer output
