@@ -401,3 +401,93 @@ def test_sharding_is_bit_identical(gpu):
     b = gru.apply_device(x[3:].contiguous()).clone()
     assert torch.equal(whole, torch.cat([a, b]))
     gru.destroy()
+
+
+# ------------------------------------------------ BASELINE configs at full size ---
+# Utterances are independent on this path, so a full-size batch is checked exactly on a few
+# sampled utterances (first / middle / last: tile and shard edges) against the oracle, which
+# only has to run those rows.
+
+def test_full_size_config3_conv_bn_relu(gpu):
+    import torch
+    r = rng(303)
+    B, T, cin, cout, k = 1024, 1000, 40, 128, 5
+    x = torch.randn(B, T, cin, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    W, b = u(r, cout, cin, k, sc=(cin * k) ** -0.5), u(r, cout, sc=0.1)
+    g, be, mu, var = 1 + u(r, cout, sc=0.5), u(r, cout, sc=0.5), u(r, cout, sc=0.1), 1 + u(r, cout, sc=0.5)
+    conv = NL.Conv1d(cin, cout, k, 1, T)
+    conv.set_weights(W, b)
+    Tc = conv.out_shape[0]
+    bn, relu = NL.BatchNorm(cout, 1e-3, Tc), NL.Activation("relu", Tc * cout, 1.0)
+    bn.set_weights(g, be, mu, var)
+    y = conv.apply_device(x, bn=bn, act=relu)
+    assert y.shape == (B, 996, 128)
+    for i in (0, 511, 1023):
+        ref = O.activation(O.ACT_RELU, O.batch_norm(O.conv1d(x[i].cpu().numpy(), W, b, 1), g, be, mu, var, 1e-3))
+        close(y[i].cpu().numpy(), ref)
+    for o in (conv, bn, relu):
+        o.destroy()
+
+
+def test_full_size_config4_two_layer_gru(gpu):
+    import torch
+    r = rng(404)
+    B, T, I, H = 1024, 1000, 128, 256
+    x = torch.randn(B, T, I, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))
+    W1, U1, bi1, bh1 = gru_weights(r, I, H)
+    W2, U2, bi2, bh2 = gru_weights(r, H, H)
+    g1, g2 = NL.GRU(I, H, True, T), NL.GRU(H, H, True, T)
+    g1.set_weights(W1, U1, bi1, bh1)
+    g2.set_weights(W2, U2, bi2, bh2)
+    y = g2.apply_device(g1.apply_device(x))
+    assert y.shape == (B, T, H)
+    for i in (0, 700, 1023):
+        ref = O.gru(O.gru(x[i:i + 1].cpu().numpy(), W1, U1, bi1, bh1), W2, U2, bi2, bh2)[0]
+        close(y[i].cpu().numpy(), ref, atol=1e-4, rtol=1e-4)
+    g1.destroy()
+    g2.destroy()
+
+
+def test_full_size_config5_stack_one_gpu_shard(gpu):
+    """The bench workload itself: 512 utterances x 1000 frames through the whole stack."""
+    import torch
+    import bench
+    w = bench.make_weights("stack", 3)
+    wl = bench.Workload("stack", 512, 1000, w, torch, NL)
+    wl.step()
+    torch.cuda.synchronize()
+    assert wl.tdd_out.shape == (512, 996, 1000)
+    win = O.window("hann", 400)
+    for i in (0, 511):
+        a = wl.x[i].cpu().numpy()
+        s = O.spectrogram(a, win, 512, 240)
+        close(wl.spec_out[i].cpu().numpy(), s, atol=1e-6 * float(np.abs(s).max()), rtol=2e-5)
+        c = O.activation(O.ACT_RELU, O.batch_norm(O.conv1d(s, w["conv_W"], w["conv_b"], 1), w["bn_gamma"], w["bn_beta"],
+                                                  w["bn_mean"], w["bn_var"], 1e-3))
+        close(wl.conv_out[i].cpu().numpy(), c, atol=1e-5, rtol=1e-4)
+        h, _, _ = O.lstm(c, w["lstm_W"], w["lstm_U"], w["lstm_bi"], w["lstm_bh"], v2=True)
+        close(wl.lstm_out[i].cpu().numpy(), h, atol=1e-4, rtol=1e-4)
+        y = O.time_distributed_dense(h, w["tdd_W"], w["tdd_b"])
+        close(wl.tdd_out[i].cpu().numpy(), y, atol=1e-4, rtol=1e-4)
+    wl.destroy()
+
+
+def test_persistent_and_per_step_recurrent_paths_agree_bitwise_in_sharding(gpu, monkeypatch):
+    """Both recurrent code paths (persistent launch / one launch per timestep) match the oracle, and each
+    is bit-identical between a whole batch and its shards."""
+    import torch
+    r = rng(77)
+    B, T, I, H = 130, 20, 24, 64
+    xs = u(r, B, T, I)
+    x = torch.from_numpy(xs).cuda()
+    W, U, bi, bh = lstm_weights(r, I, H)
+    ref = O.lstm(xs, W, U, bi, bh, v2=True)
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NNTK_REC_PERSISTENT", mode)
+        lstm = NL.LSTM(I, H, True, T, v2=True)
+        lstm.set_weights(W, U, bi, bh)
+        whole = lstm.apply_device(x).clone()
+        close(whole.cpu().numpy(), ref)
+        parts = torch.cat([lstm.apply_device(x[:70].contiguous()).clone(), lstm.apply_device(x[70:].contiguous()).clone()])
+        assert torch.equal(whole, parts)
+        lstm.destroy()
