@@ -12,17 +12,16 @@
 //
 // Tile: BM = 128 output positions x BN in {32, 64, 128} output channels per
 // 256-thread workgroup (4 wavefronts of 64).  K is walked as (channel chunk of
-// KC = 32) x (tap kk); the window chunk is reused by all k taps.  LDS is double
+// KC = 16) x (tap kk); the window chunk is reused by all k taps.  LDS is double
 // buffered and the next chunk's global loads are issued before the MFMA block of
 // the current one (register staging, write-after-barrier).
 //
 // Roofline: exact-f32 MFMA is 64 FLOP/clk/SIMD = 157 TFLOP/s, so config 3
 // (52.2 GFLOP over 686 MB) is MFMA-bound at 332 us, not HBM-bound (86 us).
 #include "nntk_common.hpp"
+#include <stdlib.h>
 
 #define CONV_BM 128
-#define CONV_KC 32
-#define CONV_AS (CONV_KC + 1)   // LDS row stride of the window chunk (odd: conflict-free ds_read_b32)
 
 extern "C" void nntk_shim_conv_pack_sizes(int Cin, int Cout, int k, int *Cin_p, int *Cout_p) {
     (void)k;
@@ -48,16 +47,17 @@ struct ConvParams {
 
 // WM x WN wavefronts, each computing TM x TN MFMA tiles of 32x32.
 // A4 = the window can be fetched with 16-byte loads (Cin % 4 == 0, 16-B aligned base).
-template <int WM, int WN, int TM, int TN, bool A4>
+template <int WM, int WN, int TM, int TN, bool A4, int KC>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
     constexpr int BN = WN * TN * 32;
+    constexpr int AS = KC + 1;                       // LDS row stride of the window chunk (odd: conflict-free ds_read_b32)
     static_assert(WM * WN == 4, "4 wavefronts per workgroup");
     static_assert(WM * TM * 32 == CONV_BM, "BM = 128");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // LDS carve (offsets from the one dynamic array, so every access stays a ds_* op):
     //   window chunk [2][rows_a][AS] | weight chunk [2][KC][BN]
-    const int a_elems = p.rows_a * CONV_AS;
-    constexpr int w_elems = CONV_KC * BN;
+    const int a_elems = p.rows_a * AS;
+    constexpr int w_elems = KC * BN;
     const int w_base = 2 * a_elems;
 
     const int tid = threadIdx.x;
@@ -89,22 +89,23 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     // ---- register staging (global -> VGPR now, VGPR -> LDS after the next barrier) ----
-    constexpr int W_PT = CONV_KC * BN / 4 / 256;     // float4 per thread per weight chunk
-    constexpr int A_PT = A4 ? 6 : 24;                // window: rows_a <= 192 (host checks)
+    constexpr int W_PT = KC * BN / 4 / 256;     // float4 per thread per weight chunk
+    constexpr int A_TPR = A4 ? KC / 4 : KC;          // threads per window row
+    constexpr int AR_STEP = 256 / A_TPR;             // rows covered per pass of the workgroup
+    constexpr int A_PT = 192 / AR_STEP;              // window: rows_a <= 192 (host checks)
     float4 wreg[W_PT];
     float4 areg4[A4 ? A_PT : 1];
     float areg[A4 ? 1 : A_PT];
     // thread -> window element mapping
-    const int ac = A4 ? (tid & 7) * 4 : (tid & 31);  // first channel inside the chunk
-    const int ar = A4 ? (tid >> 3) : (tid >> 5);     // first row; rows advance by 32 (A4) or 8
-    constexpr int AR_STEP = A4 ? 32 : 8;
+    const int ac = A4 ? (tid % A_TPR) * 4 : (tid % A_TPR);   // first channel inside the chunk
+    const int ar = tid / A_TPR;                              // first row; rows advance by AR_STEP
 
-    const int n_cchunks = (p.Cin_p + CONV_KC - 1) / CONV_KC;
+    const int n_cchunks = (p.Cin_p + KC - 1) / KC;
     const int n_chunks = n_cchunks * p.k;
 
     auto load_w = [&](int cc, int kk) {
-        const int i0 = cc * CONV_KC;
-        const int len = min(CONV_KC, p.Cin_p - i0);
+        const int i0 = cc * KC;
+        const int len = min(KC, p.Cin_p - i0);
 #pragma unroll
         for (int q = 0; q < W_PT; ++q) {
             const int e = tid + q * 256;             // float4 index inside [KC, BN/4]
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
         }
     };
     auto load_a = [&](int cc) {
-        const int ch = cc * CONV_KC + ac;
+        const int ch = cc * KC + ac;
 #pragma unroll
         for (int q = 0; q < A_PT; ++q) {
             const int r = ar + q * AR_STEP;
@@ -145,10 +146,10 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
                 const int r = ar + q * AR_STEP;
                 if (r < p.rows_a) {
                     if (A4) {
-                        float *d = As + r * CONV_AS + ac;
+                        float *d = As + r * AS + ac;
                         d[0] = areg4[q].x; d[1] = areg4[q].y; d[2] = areg4[q].z; d[3] = areg4[q].w;
                     } else {
-                        As[r * CONV_AS + ac] = areg[q];
+                        As[r * AS + ac] = areg[q];
                     }
                 }
             }
@@ -166,10 +167,10 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
             load_w(ncc, nkk);
             if (nkk == 0) load_a(ncc);
         }
-        const int len = min(CONV_KC, p.Cin_p - cc * CONV_KC);       // multiple of 8
-        const float *A = smem + abuf * a_elems + ((wm * TM * 32 + l31) * p.stride + kk) * CONV_AS + kh;
+        const int len = min(KC, p.Cin_p - cc * KC);       // multiple of 8
+        const float *A = smem + abuf * a_elems + ((wm * TM * 32 + l31) * p.stride + kk) * AS + kh;
         const float *W = smem + w_base + wbuf * w_elems + kh * BN + wn * TN * 32 + l31;
-        const int a_tile = 32 * p.stride * CONV_AS;
+        const int a_tile = 32 * p.stride * AS;
         for (int s = 0; s < len; s += 8) {
             float a[4][TM], w[4][TN];
 #pragma unroll
@@ -248,10 +249,10 @@ __global__ __launch_bounds__(256) void conv1d_valu_kernel(ConvParams p) {
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool A4>
-static int launch_mfma(const ConvParams &p) {
+template <int WM, int WN, int TM, int TN, bool A4, int KC>
+static int launch_mfma_kc(const ConvParams &p) {
     constexpr int BN = WN * TN * 32;
-    size_t lds = (size_t)(2 * p.rows_a * CONV_AS + 2 * CONV_KC * BN) * sizeof(float);
+    size_t lds = (size_t)(2 * p.rows_a * (KC + 1) + 2 * KC * BN) * sizeof(float);
     ConvParams q = p;
     q.m_tiles = p.B * p.tiles_per_seq;
     q.n_tiles = p.Cout_p / BN;
@@ -259,7 +260,7 @@ static int launch_mfma(const ConvParams &p) {
     if ((long)p.B * p.tiles_per_seq > 0x7fffffffL / 8 || blocks > 0x7fffffffL)
         return nntk_fail_msg("conv1d: too many tiles for one launch");
     dim3 grid((unsigned)blocks);
-    auto kern = conv1d_mfma_kernel<WM, WN, TM, TN, A4>;
+    auto kern = conv1d_mfma_kernel<WM, WN, TM, TN, A4, KC>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return nntk_fail("hipFuncSetAttribute(conv1d)", e);
@@ -267,6 +268,18 @@ static int launch_mfma(const ConvParams &p) {
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, nntk_stream(), q);
     NNTK_LAUNCH_CHECK("conv1d_mfma_kernel");
     return 0;
+}
+
+template <int WM, int WN, int TM, int TN, bool A4>
+static int launch_mfma(const ConvParams &p) {
+    const char *e = getenv("NNTK_CONV_KC");
+    // Chunk depth 16 halves the LDS footprint (33 KB at BN = 128): 3 workgroups per CU instead of
+    // 2, which is what hides the barrier / staging latency.  Measured vs depth 32: config 3
+    // 0.79 -> 0.62 ms, LSTM input projection 3.6 -> 2.6 ms, TDD 5.08 -> 4.67 ms.  NNTK_CONV_KC=32 restores it.
+    if constexpr (WN * TN * 32 >= 64) {
+        if (!(e && e[0] == '3')) return launch_mfma_kc<WM, WN, TM, TN, A4, 16>(p);
+    }
+    return launch_mfma_kc<WM, WN, TM, TN, A4, 32>(p);
 }
 
 extern "C" int nntk_shim_conv1d(const float *d_in, const float *d_wp, const float *d_bias, const float *d_bn,
