@@ -173,6 +173,24 @@ class Workload:
             l.destroy()
 
 
+def pmc_traffic(kernel_prefix, B):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate --pmc runs of this
+    same command and corrected as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from
+    inside a timed run, so this is the profiled value for the same workload shape, or None."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if d.get("utterances_per_gpu") != B:
+        return None
+    for name, v in d.get("kernels", {}).items():
+        if name.startswith(kernel_prefix):
+            return v.get("hbm_bytes_per_launch")
+    return None
+
+
 def roofline_for(wl, phase_ms, prof):
     """Dominant-kernel roofline from live HIP-event timings (ms per launch)."""
     B = wl.B
@@ -204,8 +222,9 @@ def roofline_for(wl, phase_ms, prof):
     kern = ("rec_persistent_kernel" if persistent else "rec_step_kernel") + ("<4,LSTM>" if G == 4 else "<3,GRU>")
     flops = 2.0 * B * H * G * H * tpl          # algorithmic flops of ONE launch (tpl timesteps of h[B,H] x U[H,G*H])
     ach = flops / (ms * 1e-3) / 1e12
+    traffic = pmc_traffic("rec_persistent_kernel<4" if G == 4 else "rec_persistent_kernel<3", B) if (persistent and wl.name == "stack") else None
     return {"kernel": kern, "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None, "ms_per_launch": ms, "algorithmic_flops": flops,
+            "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": traffic, "ms_per_launch": ms, "algorithmic_flops": flops,
             "timesteps_per_launch": tpl, "us_per_timestep": ms * 1e3 / tpl,
             "launches_per_step": prof.get("rec_launches_per_step")}
 

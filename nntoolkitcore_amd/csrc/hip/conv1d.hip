@@ -43,6 +43,7 @@ struct ConvParams {
     int m_tiles, n_tiles; // B * tiles_per_seq row tiles x Cout_p / BN column tiles
     int out_mode;        // 0: row b*Tout+x ; 1: row x*B+b
     int rows_a;          // (BM-1)*stride + k window rows per tile
+    int bn_fast;         // A/B: multiply by 1/sd instead of the reference's divide
 };
 
 // WM x WN wavefronts, each computing TM x TN MFMA tiles of 32x32.
@@ -202,6 +203,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
             g = p.bn[o]; be = p.bn[p.Cout + o]; mu = p.bn[2 * p.Cout + o];
             sd = sqrtf(p.bn[3 * p.Cout + o] + p.bn_eps);
         }
+        const bool fast_bn = p.bn_fast != 0;
+        const float rsd = 1.0f / sd;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
                 const int x = x0 + wm * TM * 32 + i * 32 + row;
                 if (x >= p.Tout) continue;
                 float v = acc[i][j][r] + bias;
-                if (p.bn) v = ((v - mu) / sd) * g + be;
+                if (p.bn) v = fast_bn ? ((v - mu) * rsd) * g + be : ((v - mu) / sd) * g + be;
                 v = nntk_act(p.act_kind, v, p.relu_a);
                 const size_t orow = p.out_mode ? ((size_t)x * p.B + b) : ((size_t)b * p.Tout + x);
                 p.out[orow * p.Cout + o] = v;
@@ -297,6 +300,7 @@ extern "C" int nntk_shim_conv1d(const float *d_in, const float *d_wp, const floa
     p.tiles_per_seq = (Tout + CONV_BM - 1) / CONV_BM;
     p.out_mode = out_mode;
     p.rows_a = (CONV_BM - 1) * stride + k;
+    { const char *e = getenv("NNTK_BN_FAST"); p.bn_fast = (e && e[0] == '1') ? 1 : 0; }
 
     const bool window_fits = p.rows_a <= 192;                          // register staging budget (A_PT)
     const long Kdim = (long)Cin * k;
