@@ -281,7 +281,6 @@ struct RecPParams {
     int B, T, H, Hj_p, Hk_p, NBT, NCT, b_base;
     int return_sequences;
     int a0, a1, a2, a3, a4;
-    int dbg_chunks;       // >0: timing experiments only (limits the K loop)
 };
 
 template <bool VEC>
@@ -302,10 +301,16 @@ __device__ __forceinline__ float4 load4_sc1(__amdgpu_buffer_rsrc_t rsrc, int sof
     return v;
 }
 
-template <int G, bool IS_LSTM, bool VEC>
+// NCH = K chunks of 32 (compile-time: the h loads and the MFMA loop must be straight-line code --
+// a runtime bound made hipcc guard every load with a branch and wait vmcnt(0) for the WHOLE tile
+// before the first MFMA, ~6k cycles per step).  H is padded up to 32*NCH with zero U^T columns
+// and out-of-range (zero-returning) h loads.
+template <int G, bool IS_LSTM, int NCH>
 __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
+    constexpr bool VEC = true;                    // launcher guarantees H % 4 == 0
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int US = p.Hk_p + 8;                    // U^T row stride: 16-B aligned, conflict-free b128 slots
+    constexpr int KP = NCH * REC_KC;              // padded K
+    constexpr int US = KP + 8;                    // U^T row stride: 16-B aligned, conflict-free b128 slots
     float *Us = smem;                             // [G*16][US]   resident for the whole sequence
     float *red = smem + G * 16 * US;              // [4 slabs][2 groups][G][2][64] split-K exchange
 
@@ -322,7 +327,6 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
     const int ct = blockIdx.x / p.NBT;
     const int b0 = p.b_base + bt * REC_BM;
     const int j0 = ct * REC_HN;
-    constexpr bool vec4 = VEC;                    // H % 4 == 0: 16-B sc1 loads, 8-B stores
     constexpr bool pair8 = VEC;
     const size_t BH = (size_t)p.B * p.H;
     const int GH = G * p.H;
@@ -336,14 +340,16 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
     const bool row_ok = b < p.B;
     const bool ok0 = row_ok && j < p.H, ok1 = row_ok && j + 1 < p.H;
 
-    // ---- resident U^T tile ----
+    // ---- resident U^T tile (columns >= Hk_p are zero) ----
     {
-        const int f4_per_row = p.Hk_p / 4;
-        const int total = G * 16 * f4_per_row;
+        constexpr int f4_per_row = KP / 4;
+        constexpr int total = G * 16 * f4_per_row;
         for (int e = tid; e < total; e += 512) {
             const int r = e / f4_per_row, c4 = e % f4_per_row;
             const int g = r >> 4, jj = r & 15;
-            const float4 v = *reinterpret_cast<const float4 *>(p.ut + ((size_t)g * p.Hj_p + j0 + jj) * p.Hk_p + c4 * 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c4 * 4 < p.Hk_p)
+                v = *reinterpret_cast<const float4 *>(p.ut + ((size_t)g * p.Hj_p + j0 + jj) * p.Hk_p + c4 * 4);
             *reinterpret_cast<float4 *>(&Us[r * US + c4 * 4]) = v;
         }
     }
@@ -359,8 +365,14 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
         prev[0] = ok0 ? src[(size_t)b * p.H + j] : 0.0f;
         prev[1] = ok1 ? src[(size_t)b * p.H + j + 1] : 0.0f;
     }
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.hbuf, 0, (int)(BH * 8), 0x00020000);
-    const int nchunks = p.dbg_chunks > 0 ? p.dbg_chunks : p.Hk_p / REC_KC;
+    // per-lane byte offsets of this lane's 16-byte h pieces; rows / columns outside [B, H) get an
+    // out-of-range offset, which the buffer load answers with zeros (no branch around any load)
+    const int row_off = row_ok ? (int)((size_t)(b - p.b_base) * p.H * 4) : 0x3ffffff0;
+    const size_t tile_base = (size_t)p.b_base * p.H * 4;      // buffer descriptor starts at this launch's first row
+    // two descriptors (ping / pong), each covering only [b_base*H, B*H) of its buffer
+    const int rs_bytes = (int)((BH - (size_t)p.b_base * p.H) * 4);
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void *)((char *)p.hbuf + tile_base), 0, rs_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)((char *)(p.hbuf + BH) + tile_base), 0, rs_bytes, 0x00020000);
     float *my_red = red + ((slab * 2 + grp) * G * 2) * 64;
     const float *peer_red = red + ((slab * 2 + (1 - grp)) * G * 2) * 64;
     __syncthreads();
@@ -393,40 +405,51 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
             }
             __syncthreads();
         }
-        const float *hsrc = p.hbuf + (size_t)(t & 1) * BH;
-        const int hoff = (t & 1) ? (int)(BH * 4) : 0;          // byte offset of the read buffer (scalar)
-
         f32x4 acc[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
         // The h operand needs no LDS: in this orientation lane (batch row l15, k-group q)
         // consumes h[b][32*ch + 16*grp + 4*q .. +3] -- 16 contiguous bytes per chunk that
-        // only this lane uses.  All chunks are requested up front (sc1 loads), so the K
-        // loop below has no barrier and no staging.
-        float4 hreg[RECP_MAXCH];
+        // only this lane uses.  All NCH pieces are requested back to back (sc1 loads); the
+        // compiler's counted vmcnt lets chunk c start as soon as piece c has landed.
+        v4u32 hreg[NCH];
+        if (t & 1) {
 #pragma unroll
-        for (int ch = 0; ch < RECP_MAXCH; ++ch) {
-            const int k = ch * REC_KC + grp * 16 + q * 4;
-            hreg[ch] = (ch < nchunks) ? load4_sc1<vec4>(rsrc, hoff, hsrc, (size_t)b * p.H + k, row_ok ? p.H - k : 0)
-                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int k = ch * REC_KC + grp * 16 + q * 4;
+                hreg[ch] = __builtin_amdgcn_raw_buffer_load_b128(rs1, k < p.H ? row_off + k * 4 : 0x3ffffff0, 0, 16 /* sc1 */);
+            }
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int k = ch * REC_KC + grp * 16 + q * 4;
+                hreg[ch] = __builtin_amdgcn_raw_buffer_load_b128(rs0, k < p.H ? row_off + k * 4 : 0x3ffffff0, 0, 16 /* sc1 */);
+            }
         }
+        // U^T fragments: software-pipelined one chunk ahead of the MFMAs that use them
+        const float *ubase = &Us[l15 * US + grp * 16 + q * 4];
+        float4 un[G];
 #pragma unroll
-        for (int ch = 0; ch < RECP_MAXCH; ++ch) {
-            if (ch < nchunks) {
-                const float hv[4] = {hreg[ch].x, hreg[ch].y, hreg[ch].z, hreg[ch].w};
-                float uv[G][4];
+        for (int g = 0; g < G; ++g) un[g] = *reinterpret_cast<const float4 *>(ubase + g * 16 * US);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            float4 uc[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) uc[g] = un[g];
+            if (ch + 1 < NCH) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) un[g] = *reinterpret_cast<const float4 *>(ubase + g * 16 * US + (ch + 1) * REC_KC);
+            }
+            const float hv[4] = {__uint_as_float(hreg[ch].x), __uint_as_float(hreg[ch].y),
+                                 __uint_as_float(hreg[ch].z), __uint_as_float(hreg[ch].w)};
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
-                    const float4 u4 = *reinterpret_cast<const float4 *>(&Us[(g * 16 + l15) * US + ch * REC_KC + grp * 16 + q * 4]);
-                    uv[g][0] = u4.x; uv[g][1] = u4.y; uv[g][2] = u4.z; uv[g][3] = u4.w;
+                    const float u = s == 0 ? uc[g].x : s == 1 ? uc[g].y : s == 2 ? uc[g].z : uc[g].w;
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(u, hv[s], acc[g], 0, 0, 0);
                 }
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int g = 0; g < G; ++g)
-                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(uv[g][s], hv[s], acc[g], 0, 0, 0);
-            }
         }
 
         // ---- split-K exchange through LDS: send the half the partner wave finishes ----
@@ -566,13 +589,20 @@ static int run_recurrent(const float *d_xw, const float *d_ut, const float *d_bh
         const char *penv = getenv("NNTK_REC_PERSISTENT");
         const bool want = !(penv && penv[0] == '0');
         const int NCT = p.Hj_p / REC_HN;
-        const size_t lds = ((size_t)G * 16 * (p.Hk_p + 8) + (size_t)4 * 2 * G * 2 * 64) * sizeof(float);
+        const int nch = p.Hk_p / REC_KC;
+        const int nch_p = nch <= 4 ? 4 : nch <= 8 ? 8 : nch <= 12 ? 12 : 16;      // compiled K depths (x32)
+        const size_t lds = ((size_t)G * 16 * (nch_p * REC_KC + 8) + (size_t)4 * 2 * G * 2 * 64) * sizeof(float);
         int dev = 0, cus = 0;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         const int tiles_per_launch = NCT > 0 ? cus / NCT : 0;
-        if (want && lds <= 160 * 1024 && p.Hk_p <= RECP_MAXCH * REC_KC && tiles_per_launch >= 1 && BH * 8 < 0x7fffffffULL) {
-            auto kern = (H % 4 == 0) ? rec_persistent_kernel<G, IS_LSTM, true> : rec_persistent_kernel<G, IS_LSTM, false>;
+        if (want && (H % 4) == 0 && lds <= 160 * 1024 && p.Hk_p <= RECP_MAXCH * REC_KC && tiles_per_launch >= 1 &&
+            BH * 4 < 0x3ffffff0ULL) {
+            void (*kern)(RecPParams);
+            if (nch_p == 4)       kern = rec_persistent_kernel<G, IS_LSTM, 4>;
+            else if (nch_p == 8)  kern = rec_persistent_kernel<G, IS_LSTM, 8>;
+            else if (nch_p == 12) kern = rec_persistent_kernel<G, IS_LSTM, 12>;
+            else                  kern = rec_persistent_kernel<G, IS_LSTM, 16>;
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return nntk_fail("hipFuncSetAttribute(rec_persistent_kernel)", e);
             unsigned *cnt = reinterpret_cast<unsigned *>(d_work + 3 * BH);
@@ -580,7 +610,6 @@ static int run_recurrent(const float *d_xw, const float *d_ut, const float *d_bh
             q.xw = d_xw; q.ut = d_ut; q.bh = d_bh; q.hbuf = hbuf[0]; q.c = cbuf; q.out = d_out; q.cnt = cnt;
             q.B = B; q.T = T; q.H = H; q.Hj_p = p.Hj_p; q.Hk_p = p.Hk_p; q.NCT = NCT;
             q.return_sequences = return_sequences;
-            { const char *d = getenv("NNTK_REC_DBG_CHUNKS"); q.dbg_chunks = d ? atoi(d) : 0; }
             q.a0 = p.a0; q.a1 = p.a1; q.a2 = p.a2; q.a3 = p.a3; q.a4 = p.a4;
             const int nbt_total = (B + REC_BM - 1) / REC_BM;
             const int span = nntk_prof_span_begin();
