@@ -282,12 +282,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
+    # one process per GPU.  (NNTK_BENCH_BACKEND=gloo is a rehearsal mode for a 1-GPU box: several ranks share
+    # the card and the collectives run on the CPU; never used by the driver.)
+    backend = os.environ.get("NNTK_BENCH_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)     # "nccl" is RCCL on ROCm
+        dist.init_process_group(backend, rank=rank, world_size=world)     # "nccl" is RCCL on ROCm
     assert a.gpus == world, "--gpus must equal WORLD_SIZE (launch N>1 with torch.distributed.run)"
 
     from nntoolkitcore_amd import capi, layers as NL
@@ -325,7 +329,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
