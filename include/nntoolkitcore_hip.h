@@ -204,6 +204,26 @@ void SpectrogramSetScaleFactor(Spectrogram filter, float factor);
 void SpectrogramApply(Spectrogram filter, const float *input, float *output);  /* host; errors via nntk_last_error() */
 void SpectrogramDestroy(Spectrogram filter);
 
+/* ---- nntoolkitcore/signal/mel_filterbank.h:14-41, log_mel_spectrogram.h:12-18 ----
+ * (the first "next" row: 257 spectrogram bins -> n_mels features) */
+typedef struct {
+    int n_mels;
+    int n_fft;
+    int sample_rate;
+    float lower_hz;
+    float upper_hz;
+} MelFilterBankConfig;
+typedef struct MelFilterBankStruct *MelFilterBank;
+typedef struct LogMelSpectrogramStruct *LogMelSpectrogram;
+
+MelFilterBankConfig MelFilterBankConfigCreate(int n_mels, int n_fft, int sample_rate, float lower_hz, float upper_hz);
+MelFilterBank MelFilterBankCreate(MelFilterBankConfig config);
+void MelFilterBankApply(MelFilterBank filter_bank, const float *spectrogram, float *mel_spectrogram, int timesteps);
+void MelFilterBankDestroy(MelFilterBank filter_bank);
+LogMelSpectrogram LogMelSpectrogramCreate(Spectrogram spectrogram, MelFilterBankConfig mel_filter_bank_config);
+void LogMelSpectrogramApply(LogMelSpectrogram filter, const float *input, float *output);   /* log(mel + 1.5849e-13) */
+void LogMelSpectrogramDestroy(LogMelSpectrogram filter);
+
 /* ======================================================================= */
 /* PART 2 -- additive MI355X entry points                                    */
 /* ======================================================================= */
@@ -247,11 +267,16 @@ int GRUApplyInferenceBatch(GRU filter, const float *input, float *output, int ba
 int LSTMApplyInferenceBatch(LSTM filter, const float *input, float *output, int batch);
 int TimeDistributedDenseApplyInferenceBatch(TimeDistributedDense filter, const float *input, float *output, int batch);
 int SpectrogramApplyBatch(Spectrogram filter, const float *input, float *output, int batch);
+int LogMelSpectrogramApplyBatch(LogMelSpectrogram filter, const float *input, float *output, int batch);
 
 /* ---- device-pointer forms (all pointers are device addresses; asynchronous
  *      on the current stream; 0 ok, -1 error) ------------------------------ */
 int SpectrogramApplyDevice(Spectrogram filter, const float *d_input /*[batch,input_size]*/,
                            float *d_output /*[batch,ntime_series,nfreq]*/, int batch);
+int MelFilterBankApplyDevice(MelFilterBank filter_bank, const float *d_spectrogram /*[rows,nbins]*/,
+                             float *d_mel /*[rows,n_mels]*/, int rows);
+int LogMelSpectrogramApplyDevice(LogMelSpectrogram filter, const float *d_input /*[batch,input_size]*/,
+                                 float *d_output /*[batch,ntime_series,n_mels]*/, int batch);
 int Conv1dApplyDevice(Conv1d filter, const float *d_input /*[batch,T,Cin]*/,
                       float *d_output /*[batch,Tout,Cout]*/, int batch);
 /* fused Conv1d -> BatchNorm(inference) -> activation in one kernel; bn and/or act may be NULL */

@@ -73,6 +73,11 @@ class SpectrogramConfig(C.Structure):
                 ("fft_normalization_factor", C.c_float)]
 
 
+class MelFilterBankConfig(C.Structure):
+    _fields_ = [("n_mels", C.c_int), ("n_fft", C.c_int), ("sample_rate", C.c_int), ("lower_hz", C.c_float),
+                ("upper_hz", C.c_float)]
+
+
 WINDOW_FN = C.CFUNCTYPE(None, fp, C.c_int)
 ACT_IMPL_FN = C.CFUNCTYPE(None, vp, fp, fp, C.c_int)
 
@@ -144,6 +149,14 @@ SIGNATURES = {
     "SpectrogramSetScaleFactor": (None, [vp, C.c_float]),
     "SpectrogramApply": (None, [vp, fp, fp]),
     "SpectrogramDestroy": (None, [vp]),
+    # mel_filterbank.h / log_mel_spectrogram.h
+    "MelFilterBankConfigCreate": (MelFilterBankConfig, [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]),
+    "MelFilterBankCreate": (vp, [MelFilterBankConfig]),
+    "MelFilterBankApply": (None, [vp, fp, fp, C.c_int]),
+    "MelFilterBankDestroy": (None, [vp]),
+    "LogMelSpectrogramCreate": (vp, [vp, MelFilterBankConfig]),
+    "LogMelSpectrogramApply": (None, [vp, fp, fp]),
+    "LogMelSpectrogramDestroy": (None, [vp]),
     # ---- additive API
     "nntk_hip_device_count": (C.c_int, []),
     "nntk_hip_set_device": (C.c_int, [C.c_int]),
@@ -169,6 +182,9 @@ SIGNATURES = {
     "LSTMApplyInferenceBatch": (C.c_int, [vp, fp, fp, C.c_int]),
     "TimeDistributedDenseApplyInferenceBatch": (C.c_int, [vp, fp, fp, C.c_int]),
     "SpectrogramApplyBatch": (C.c_int, [vp, fp, fp, C.c_int]),
+    "LogMelSpectrogramApplyBatch": (C.c_int, [vp, fp, fp, C.c_int]),
+    "MelFilterBankApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
+    "LogMelSpectrogramApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
     "SpectrogramApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
     "Conv1dApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
     "Conv1dBatchNormActivationApplyDevice": (C.c_int, [vp, vp, vp, vp, vp, C.c_int]),

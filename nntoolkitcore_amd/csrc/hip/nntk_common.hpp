@@ -39,6 +39,7 @@ __device__ __forceinline__ float nntk_act(int kind, float x, float relu_a) {
         float y = fmaxf(x, 0.0f);
         return relu_a != 1.0f ? y * relu_a : y;
     }
+    case NNTK_ACT_LOG_EPS: return logf(x + relu_a);
     default: return x;
     }
 }

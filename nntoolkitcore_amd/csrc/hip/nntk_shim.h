@@ -22,6 +22,7 @@ enum {
     NNTK_ACT_TANH     = 2,
     NNTK_ACT_RELU     = 3,
     NNTK_ACT_SOFTMAX  = 4,
+    NNTK_ACT_LOG_EPS  = 5,    /* log(x + a): log-mel epilogue (log_mel_spectrogram.c:34-35); a rides in relu_a */
     NNTK_ACT_CUSTOM   = 100   /* host callback: not runnable on the device */
 };
 

@@ -60,6 +60,8 @@ const float *nntk_batch_norm_device_block(BatchNorm bn, int check_edits);   /* g
 int   nntk_batch_norm_channels(BatchNorm bn);
 float nntk_batch_norm_epsilon(BatchNorm bn);
 
+const float *nntk_mel_weights(MelFilterBank bank);   /* host [nbins, n_mels] */
+
 void nntk_set_error(const char *msg);
 #define NNTK_FAIL(msg) do { nntk_set_error(msg); return -1; } while (0)
 

@@ -31,6 +31,7 @@
 #include "nntoolkitcore/layers/dense.h"
 #include "nntoolkitcore/layers/time_distributed_dense.h"
 #include "nntoolkitcore/layers/activation_default.h"
+#include "nntoolkitcore/signal/mel_filterbank.h"
 
 static void *lib;
 #define SYM(type, name) type name##_p = (type)dlsym(lib, #name); \
@@ -107,6 +108,8 @@ int main(int argc, char **argv) {
     SZ(LSTMConfig); OFF(LSTMConfig, base); OFF(LSTMConfig, v2); OFF(LSTMConfig, activations);
     SZ(DenseConfig); OFF(DenseConfig, input_size); OFF(DenseConfig, output_size); OFF(DenseConfig, activation);
     SZ(TimeDistributedDenseConfig); OFF(TimeDistributedDenseConfig, dense); OFF(TimeDistributedDenseConfig, ts);
+    SZ(MelFilterBankConfig); OFF(MelFilterBankConfig, n_mels); OFF(MelFilterBankConfig, n_fft); OFF(MelFilterBankConfig, sample_rate);
+    OFF(MelFilterBankConfig, lower_hz); OFF(MelFilterBankConfig, upper_hz);
     SZ(DefaultWeights); SZ(RecurrentWeights); SZ(BatchNormWeights);
     printf("    \"end\": 0\n  },\n");
 

@@ -22,7 +22,7 @@ STRUCTS = {
     "LSTMActivations": capi.LSTMActivations, "LSTMConfig": capi.LSTMConfig,
     "DenseConfig": capi.DenseConfig, "TimeDistributedDenseConfig": capi.TimeDistributedDenseConfig,
     "DefaultWeights": capi.DefaultWeights, "RecurrentWeights": capi.RecurrentWeights,
-    "BatchNormWeights": capi.BatchNormWeights,
+    "BatchNormWeights": capi.BatchNormWeights, "MelFilterBankConfig": capi.MelFilterBankConfig,
 }
 
 
@@ -119,3 +119,18 @@ def test_product_never_references_the_oracle():
                 assert "oracle" not in text.lower() or f == "__init__.py" and False, os.path.join(dirpath, f)
     syms = subprocess.check_output(["nm", "-D", capi.LIB_PATH], text=True)
     assert "ref_" not in syms
+
+
+def test_mel_filterbank_weights_match_oracle_restatement(built_lib):
+    """MelFilterBankCreate is pure host setup (no device): its matrix must equal the oracle's restatement of
+    signal/mel_filterbank.c:43-102 bit for bit (same formulas, same libm)."""
+    import oracle as O
+    built_lib.nntk_mel_weights.restype = capi.fp
+    built_lib.nntk_mel_weights.argtypes = [C.c_void_p]
+    for (n_mels, n_fft, sr, lo, hi) in [(40, 512, 16000, 20.0, 8000.0), (13, 256, 8000, 0.0, 4000.0), (64, 1024, 44100, 50.0, 20000.0)]:
+        bank = built_lib.MelFilterBankCreate(built_lib.MelFilterBankConfigCreate(n_mels, n_fft, sr, lo, hi))
+        nb = n_fft // 2 + 1
+        w = np.ctypeslib.as_array(built_lib.nntk_mel_weights(bank), shape=(nb, n_mels)).copy()
+        assert np.array_equal(w, O.mel_filterbank_weights(n_mels, n_fft, sr, lo, hi))
+        assert (w[0] == 0).all() and (w >= 0).all()
+        built_lib.MelFilterBankDestroy(bank)

@@ -491,3 +491,37 @@ def test_persistent_and_per_step_recurrent_paths_agree_bitwise_in_sharding(gpu, 
         parts = torch.cat([lstm.apply_device(x[:70].contiguous()).clone(), lstm.apply_device(x[70:].contiguous()).clone()])
         assert torch.equal(whole, parts)
         lstm.destroy()
+
+
+# ------------------------------------------------ next row: mel filterbank / log-mel ---
+
+def test_mel_filterbank_and_log_mel_spectrogram(gpu):
+    import ctypes as C
+    L = capi.load()
+    r = rng(88)
+    B, N = 3, 8240
+    x = (0.1 * r.standard_normal((B, N))).astype(np.float32)
+    sp = NL.Spectrogram(512, 400, 240, N)
+    T, F = sp.out_shape
+    cfg = L.MelFilterBankConfigCreate(40, 512, 16000, 20.0, 8000.0)
+    w = O.mel_filterbank_weights(40, 512, 16000, 20.0, 8000.0)
+    spec = O.spectrogram(x, O.window("hann", 400), 512, 240)
+    # MelFilterBankApply: spec[T,257] x W[257,40]
+    bank = L.MelFilterBankCreate(cfg)
+    mel = np.full((T, 40), np.nan, np.float32)
+    L.MelFilterBankApply(bank, spec[0].ctypes.data_as(capi.fp), mel.ctypes.data_as(capi.fp), T)
+    assert capi.last_error() == ""
+    close(mel, (spec[0].astype(np.float64) @ w.astype(np.float64)).astype(np.float32), atol=1e-6, rtol=1e-5)
+    L.MelFilterBankDestroy(bank)
+    # LogMelSpectrogramApply (one utterance) and the batched form
+    lm = L.LogMelSpectrogramCreate(sp.h, cfg)
+    out1 = np.full((T, 40), np.nan, np.float32)
+    L.LogMelSpectrogramApply(lm, x[0].ctypes.data_as(capi.fp), out1.ctypes.data_as(capi.fp))
+    ref = np.stack([O.log_mel(spec[i], w) for i in range(B)])
+    close(out1, ref[0], atol=2e-5, rtol=1e-5)
+    outb = np.empty((B, T, 40), np.float32)
+    check = L.LogMelSpectrogramApplyBatch(lm, x.ctypes.data_as(capi.fp), outb.ctypes.data_as(capi.fp), B)
+    assert check == 0, capi.last_error()
+    close(outb, ref, atol=2e-5, rtol=1e-5)
+    L.LogMelSpectrogramDestroy(lm)
+    sp.destroy()
