@@ -525,3 +525,52 @@ def test_mel_filterbank_and_log_mel_spectrogram(gpu):
     close(outb, ref, atol=2e-5, rtol=1e-5)
     L.LogMelSpectrogramDestroy(lm)
     sp.destroy()
+
+
+# ------------------------------------------------------ randomized shape sweeps ---
+# Seeded sweeps over ragged shapes: they reach every kernel variant (MFMA tiles of 32/64/128
+# columns, the VALU conv, padded K, H not a multiple of 4 or 16, batch tails, both recurrent paths).
+
+def test_random_conv_shapes(gpu):
+    r = rng(2024)
+    for _ in range(24):
+        cin, cout = int(r.integers(1, 70)), int(r.integers(1, 140))
+        k, stride = int(r.integers(1, 8)), int(r.integers(1, 4))
+        T = int(r.integers(k, 300))
+        B = int(r.integers(1, 4))
+        x, W, b = u(r, B, T, cin), u(r, cout, cin, k, sc=(cin * k) ** -0.5), u(r, cout, sc=0.2)
+        conv = NL.Conv1d(cin, cout, k, stride, T)
+        conv.set_weights(W, b)
+        close(conv.apply(x), O.conv1d(x, W, b, stride))
+        conv.destroy()
+
+
+def test_random_recurrent_shapes(gpu, monkeypatch):
+    r = rng(4048)
+    for i in range(16):
+        I, H = int(r.integers(1, 40)), int(r.integers(1, 90))
+        T, B = int(r.integers(1, 12)), int(r.integers(1, 80))
+        seq, v2 = bool(r.integers(0, 2)), bool(r.integers(0, 2))
+        monkeypatch.setenv("NNTK_REC_PERSISTENT", "1" if i % 2 else "0")
+        x = u(r, B, T, I)
+        W, U, bi, bh = gru_weights(r, I, H)
+        g = NL.GRU(I, H, seq, T)
+        g.set_weights(W, U, bi, bh)
+        close(g.apply(x), O.gru(x, W, U, bi, bh, return_sequences=seq))
+        g.destroy()
+        W, U, bi, bh = lstm_weights(r, I, H)
+        l = NL.LSTM(I, H, seq, T, v2=v2)
+        l.set_weights(W, U, bi, bh)
+        close(l.apply(x), O.lstm(x, W, U, bi, bh, return_sequences=seq, v2=v2))
+        l.destroy()
+
+
+def test_random_dense_shapes(gpu):
+    r = rng(777)
+    for _ in range(12):
+        ts, I, Ov = int(r.integers(1, 50)), int(r.integers(1, 100)), int(r.integers(1, 130))
+        W, b, x = u(r, I, Ov, sc=I ** -0.5), u(r, Ov, sc=0.2), u(r, 2, ts, I)
+        tdd = NL.TimeDistributedDense(ts, I, Ov)
+        tdd.set_weights(W, b)
+        close(tdd.apply(x), O.time_distributed_dense(x, W, b))
+        tdd.destroy()
