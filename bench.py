@@ -319,15 +319,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def check_device_status(where):
+        # surfaces asynchronous kernel-side failures (e.g. a timed-out hand-off of the persistent recurrent
+        # kernel): a number measured on invalid results must never be printed
+        if L.nntk_hip_synchronize() != 0:
+            raise SystemExit("bench.py: device error %s: %s" % (where, capi.last_error()))
+
     for _ in range(a.warmup):
         wl.step()
     barrier()
+    check_device_status("after warm-up")
     t0 = time.perf_counter()
     events = []
     for i in range(a.steps):
         events.append(wl.step(timed=True))
     barrier()
     dt = time.perf_counter() - t0
+    check_device_status("after the timed steps")
     if dist is not None:
         t = torch.tensor([dt], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -38,7 +38,6 @@ struct RecParams {
     long out_ld;
     int B, H, Hj_p, Hk_p;
     int a0, a1, a2, a3, a4;   // activation kinds
-    int map;                  // 0: blockIdx.x = batch tile, 1: blockIdx.x = hidden tile
 };
 
 // NG = number of intra-workgroup split-K groups (256 threads each).  NG = 2 puts two
@@ -62,8 +61,10 @@ __global__ __launch_bounds__(256 * NG) void rec_step_kernel(RecParams p) {
     // blockIdx.x walks the hidden-unit tiles: blocks are dealt round-robin over the 8
     // XCDs, so XCD c keeps U^T tiles {c, c+8, ...} (a few hundred KB) resident in its
     // private L2 for every batch tile, instead of each XCD streaming all of U^T.
-    const int j0 = (p.map ? blockIdx.x : blockIdx.y) * REC_HN;
-    const int b0 = (p.map ? blockIdx.y : blockIdx.x) * REC_BM;
+    // blockIdx.x = batch tile: blocks are dealt round-robin over the XCDs, so a batch tile's
+    // workgroups share an XCD and its h rows stay in that L2 (hidden-tile-major was 7 % slower)
+    const int j0 = blockIdx.y * REC_HN;
+    const int b0 = blockIdx.x * REC_BM;
     const int j = j0 + l15;
     const bool vec4 = (p.H & 3) == 0;
     float *my = smem + grp * 2 * BUF;
@@ -580,10 +581,7 @@ static int run_recurrent(const float *d_xw, const float *d_ut, const float *d_bh
     p.Hk_p = (H + 31) & ~31;
     p.a0 = acts[0]; p.a1 = acts[1]; p.a2 = acts[2];
     p.a3 = nacts > 3 ? acts[3] : 0; p.a4 = nacts > 4 ? acts[4] : 0;
-    const char *menv = getenv("NNTK_REC_MAP");
-    p.map = (menv && menv[0] == '1') ? 1 : 0;
-    const unsigned gj = (unsigned)(p.Hj_p / REC_HN), gb = (unsigned)((B + REC_BM - 1) / REC_BM);
-    dim3 grid(p.map ? gj : gb, p.map ? gb : gj);
+    dim3 grid((unsigned)((B + REC_BM - 1) / REC_BM), (unsigned)(p.Hj_p / REC_HN));
     // ---- persistent path: one launch for the whole sequence when U^T fits in LDS ----
     {
         const char *penv = getenv("NNTK_REC_PERSISTENT");

@@ -116,7 +116,7 @@ def test_product_never_references_the_oracle():
         for f in files:
             if f.endswith((".py", ".c", ".h", ".hip", ".hpp")):
                 text = open(os.path.join(dirpath, f)).read()
-                assert "oracle" not in text.lower() or f == "__init__.py" and False, os.path.join(dirpath, f)
+                assert "oracle" not in text.lower(), os.path.join(dirpath, f)
     syms = subprocess.check_output(["nm", "-D", capi.LIB_PATH], text=True)
     assert "ref_" not in syms
 
