@@ -306,7 +306,14 @@ __device__ __forceinline__ float4 load4_sc1(__amdgpu_buffer_rsrc_t rsrc, int sof
 // a runtime bound made hipcc guard every load with a branch and wait vmcnt(0) for the WHOLE tile
 // before the first MFMA, ~6k cycles per step).  H is padded up to 32*NCH with zero U^T columns
 // and out-of-range (zero-returning) h loads.
-template <int G, bool IS_LSTM, int NCH>
+// XW = where this step's xW loads and the previous step's output store are issued:
+//   0 before the poll (prefetch), 1 right after the h loads, 2 a quarter into the K loop.
+// Vector-memory results return in issue order, so with XW = 0 the poll's load waits behind HBM
+// loads / stores: global timestamps showed the poll passing 0.2 .. 2.6 us after the last arrival
+// (the workgroup that signalled last stays last) against 0.3 .. 1.0 us with XW = 1.  XW = 1 wins
+// when the K loop is long enough to cover the xW latency afterwards (LSTM-512: -3 %), XW = 0
+// when it is short (GRU-256: 3 % faster than XW = 1); XW = 2 loses on both.
+template <int G, bool IS_LSTM, int NCH, int XW>
 __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
     constexpr bool VEC = true;                    // launcher guarantees H % 4 == 0
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -378,17 +385,22 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
     const float *peer_red = red + ((slab * 2 + (1 - grp)) * G * 2) * 64;
     __syncthreads();
 
+    float hn_prev[2] = {0.f, 0.f};
     for (int t = 0; t < p.T; ++t) {
-        // xW(+b_i) of this step does not depend on h: fetch before waiting on the peers
         float xwv[2][G];
-        {
-            const float *xw = p.xw + ((size_t)t * p.B + b) * GH + j;
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                xwv[0][g] = ok0 ? xw[g * p.H] : 0.0f;
-                xwv[1][g] = ok1 ? xw[g * p.H + 1] : 0.0f;
-            }
-        }
+#define REC_XW_ISSUE() do {                                                                          \
+            const float *xw = p.xw + ((size_t)t * p.B + b) * GH + j;                                   \
+            _Pragma("unroll") for (int g = 0; g < G; ++g) {                                            \
+                xwv[0][g] = ok0 ? xw[g * p.H] : 0.0f;                                                  \
+                xwv[1][g] = ok1 ? xw[g * p.H + 1] : 0.0f;                                              \
+            }                                                                                          \
+            if (XW != 0 && t > 0 && p.return_sequences) {                                              \
+                float *o = p.out + ((size_t)b * p.T + (t - 1)) * p.H + j;                              \
+                if (pair8 && ok1) *reinterpret_cast<float2 *>(o) = make_float2(hn_prev[0], hn_prev[1]); \
+                else { if (ok0) o[0] = hn_prev[0]; if (ok1) o[1] = hn_prev[1]; }                       \
+            }                                                                                          \
+        } while (0)
+        if (XW == 0) REC_XW_ISSUE();
         // ---- wait until every workgroup of this batch tile has published h_{t-1}:
         //      ONE lane polls (relaxed, s_sleep), the workgroup joins a barrier, and every
         //      load of handed-off bytes below is an sc1 load ----
@@ -428,6 +440,7 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
                 hreg[ch] = __builtin_amdgcn_raw_buffer_load_b128(rs0, k < p.H ? row_off + k * 4 : 0x3ffffff0, 0, 16 /* sc1 */);
             }
         }
+        if (XW == 1) REC_XW_ISSUE();
         // U^T fragments: software-pipelined one chunk ahead of the MFMAs that use them
         const float *ubase = &Us[l15 * US + grp * 16 + q * 4];
         float4 un[G];
@@ -438,6 +451,7 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
             float4 uc[G];
 #pragma unroll
             for (int g = 0; g < G; ++g) uc[g] = un[g];
+            if (XW == 2 && ch == NCH / 4) REC_XW_ISSUE();
             if (ch + 1 < NCH) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) un[g] = *reinterpret_cast<const float4 *>(ubase + g * 16 * US + (ch + 1) * REC_KC);
@@ -507,11 +521,19 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // R1: every storing wave drains ...
         __syncthreads();                                      // ... the workgroup meets (this also frees `red`) ...
         if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... ONE lane arrives
-        if (p.return_sequences || t == p.T - 1) {
-            float *o = p.return_sequences ? p.out + ((size_t)b * p.T + t) * p.H + j : p.out + (size_t)b * p.H + j;
-            if (pair8 && ok1) *reinterpret_cast<float2 *>(o) = make_float2(hn[0], hn[1]);
-            else { if (ok0) o[0] = hn[0]; if (ok1) o[1] = hn[1]; }
+        if (XW == 0) {
+            if (p.return_sequences || t == p.T - 1) {
+                float *o = p.return_sequences ? p.out + ((size_t)b * p.T + t) * p.H + j : p.out + (size_t)b * p.H + j;
+                if (pair8 && ok1) *reinterpret_cast<float2 *>(o) = make_float2(hn[0], hn[1]);
+                else { if (ok0) o[0] = hn[0]; if (ok1) o[1] = hn[1]; }
+            }
         }
+        hn_prev[0] = hn[0]; hn_prev[1] = hn[1];
+    }
+    if (XW != 0) {   // output of the last step (the only one when !return_sequences)
+        float *o = p.return_sequences ? p.out + ((size_t)b * p.T + (p.T - 1)) * p.H + j : p.out + (size_t)b * p.H + j;
+        if (pair8 && ok1) *reinterpret_cast<float2 *>(o) = make_float2(hn_prev[0], hn_prev[1]);
+        else { if (ok0) o[0] = hn_prev[0]; if (ok1) o[1] = hn_prev[1]; }
     }
     if (IS_LSTM) {
         if (ok0) p.c[(size_t)b * p.H + j] = prev[0];
@@ -597,10 +619,13 @@ static int run_recurrent(const float *d_xw, const float *d_ut, const float *d_bh
         if (want && (H % 4) == 0 && lds <= 160 * 1024 && p.Hk_p <= RECP_MAXCH * REC_KC && tiles_per_launch >= 1 &&
             BH * 4 < 0x3ffffff0ULL) {
             void (*kern)(RecPParams);
-            if (nch_p == 4)       kern = rec_persistent_kernel<G, IS_LSTM, 4>;
-            else if (nch_p == 8)  kern = rec_persistent_kernel<G, IS_LSTM, 8>;
-            else if (nch_p == 12) kern = rec_persistent_kernel<G, IS_LSTM, 12>;
-            else                  kern = rec_persistent_kernel<G, IS_LSTM, 16>;
+            const char *xenv = getenv("NNTK_REC_XW");
+            const int xwm = xenv ? atoi(xenv) : (nch_p >= 12 ? 1 : 0);
+#define REC_PICK(N) (xwm == 1 ? rec_persistent_kernel<G, IS_LSTM, N, 1> : xwm == 2 ? rec_persistent_kernel<G, IS_LSTM, N, 2> : rec_persistent_kernel<G, IS_LSTM, N, 0>)
+            if (nch_p == 4)       kern = REC_PICK(4);
+            else if (nch_p == 8)  kern = REC_PICK(8);
+            else if (nch_p == 12) kern = REC_PICK(12);
+            else                  kern = REC_PICK(16);
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return nntk_fail("hipFuncSetAttribute(rec_persistent_kernel)", e);
             unsigned *cnt = reinterpret_cast<unsigned *>(d_work + 3 * BH);
