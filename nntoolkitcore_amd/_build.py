@@ -56,7 +56,8 @@ def build(force=False, verbose=False):
         objs.append(obj)
         if force or _newer([src] + headers, obj):
             out = _run([HIPCC, "-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-Wall",
-                        "-Wno-unused-function", "-c", src, "-o", obj])
+                        "-Wno-unused-function"] + os.environ.get("NNTK_EXTRA_HIPFLAGS", "").split() +
+                       ["-c", src, "-o", obj])
             if verbose and out:
                 print(out)
     if force or _newer(objs, LIB):

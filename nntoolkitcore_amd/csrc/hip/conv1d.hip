@@ -90,10 +90,11 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     // ---- register staging (global -> VGPR now, VGPR -> LDS after the next barrier) ----
-    constexpr int W_PT = KC * BN / 4 / 256;     // float4 per thread per weight chunk
+    constexpr int W_F4 = KC * BN / 4;                // float4 per weight chunk
+    constexpr int W_PT = (W_F4 + 255) / 256;         // float4 per thread per weight chunk
     constexpr int A_TPR = A4 ? KC / 4 : KC;          // threads per window row
     constexpr int AR_STEP = 256 / A_TPR;             // rows covered per pass of the workgroup
-    constexpr int A_PT = 192 / AR_STEP;              // window: rows_a <= 192 (host checks)
+    constexpr int A_PT = (192 + AR_STEP - 1) / AR_STEP;   // window: rows_a <= 192 (host checks)
     float4 wreg[W_PT];
     float4 areg4[A4 ? A_PT : 1];
     float areg[A4 ? 1 : A_PT];
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
             const int e = tid + q * 256;             // float4 index inside [KC, BN/4]
             const int r = e / (BN / 4), c4 = e % (BN / 4);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < len)
+            if (r < len && (W_F4 % 256 == 0 || e < W_F4))
                 v = *reinterpret_cast<const float4 *>(p.wp + (size_t)(kk * p.Cin_p + i0 + r) * p.Cout_p + n0 + c4 * 4);
             wreg[q] = v;
         }
@@ -158,7 +159,9 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
         {
             float *Ws = smem + w_base + wbuf * w_elems;
 #pragma unroll
-            for (int q = 0; q < W_PT; ++q) *reinterpret_cast<float4 *>(Ws + (size_t)(tid + q * 256) * 4) = wreg[q];
+            for (int q = 0; q < W_PT; ++q)
+                if (W_F4 % 256 == 0 || tid + q * 256 < W_F4)
+                    *reinterpret_cast<float4 *>(Ws + (size_t)(tid + q * 256) * 4) = wreg[q];
         }
         __syncthreads();
         // next chunk's coordinates; prefetch it while this one is multiplied
@@ -313,6 +316,8 @@ extern "C" int nntk_shim_conv1d(const float *d_in, const float *d_wp, const floa
         return 0;
     }
     const bool a4 = (Cin % 4 == 0) && ((size_t)d_in % 16 == 0);
+    { const char *e = getenv("NNTK_CONV_LOWLDS");
+      if (e && e[0] == '1' && a4 && p.Cout_p % 64 == 0 && k == 1) return launch_mfma_kc<4, 1, 1, 2, true, 8>(p); }
     if (p.Cout_p % 128 == 0) return a4 ? launch_mfma<2, 2, 2, 2, true>(p) : launch_mfma<2, 2, 2, 2, false>(p);
     if (p.Cout_p % 64 == 0)  return a4 ? launch_mfma<4, 1, 1, 2, true>(p) : launch_mfma<4, 1, 1, 2, false>(p);
     return a4 ? launch_mfma<4, 1, 1, 1, true>(p) : launch_mfma<4, 1, 1, 1, false>(p);

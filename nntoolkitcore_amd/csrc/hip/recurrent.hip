@@ -20,6 +20,7 @@
 // place.  One launch per timestep: the kernel boundary is the grid-wide
 // dependency between steps (every hidden unit of step t needs all of h_{t-1}).
 #include "nntk_common.hpp"
+#include <stdio.h>
 #include <stdlib.h>
 
 #define REC_KC 32
@@ -275,14 +276,35 @@ struct RecPParams {
     const float *xw;      // [T, B, G*H]
     const float *ut;      // [G, Hj_p, Hk_p]
     const float *bh;      // [G*H] or NULL
-    float *hbuf;          // [2][B][H] ping-pong state; hbuf[0] holds h_0 on entry, hbuf[T&1] h_T on exit
+    float *hbuf;          // [2][hb_floats] ping-pong h in the TILED hand-off layout (see below); parity 0 holds h_0
+    const float *h0;      // [B][H] initial state in the caller's layout, or NULL (zeros): GRU's own-h term
+    float *hT;            // [B][H] final state in the caller's layout, or NULL
+    size_t hb_floats;     // floats per parity: B rounded up to 64, times the padded K
     float *c;             // [B][H] LSTM cell state (read at start, written at end)
     float *out;           // [B, T, H] or [B, H]
     unsigned *cnt;        // [NBT] arrival counters, zeroed before the launch
     int B, T, H, Hj_p, Hk_p, NBT, NCT, b_base;
     int return_sequences;
     int a0, a1, a2, a3, a4;
+#ifdef NNTK_REC_STAMPS
+    unsigned long long *stamp;   // [2 halves][T][8] s_memtime of workgroup 0's leader waves (diagnostics build only)
+#endif
 };
+#ifdef NNTK_REC_STAMPS
+#define REC_STAMP(i) do { if (p.stamp && blockIdx.x == 0 && lane == 0 && (PP ? wih == 0 : (w8 & 3) == 0)) \
+        p.stamp[((size_t)(PP ? half : (w8 >> 2)) * p.T + t) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define REC_STAMP(i) do {} while (0)
+#endif
+
+// LDS spin on a monotonic word written by another wavefront of the same workgroup.  Relaxed
+// loads only: an acquire at workgroup scope would make hipcc drain vmcnt, i.e. wait for the
+// h / xW loads in flight.  LDS operations of one wave execute in order, so "data, then flag"
+// on the producer side and "flag, then data" on the consumer side is enough.
+__device__ __forceinline__ void recp_lds_wait_ge(const unsigned *w, unsigned target) {
+    while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
 
 template <bool VEC>
 __device__ __forceinline__ float4 load4_sc1(__amdgpu_buffer_rsrc_t rsrc, int soff, const float *base, size_t idx,
@@ -307,20 +329,53 @@ __device__ __forceinline__ float4 load4_sc1(__amdgpu_buffer_rsrc_t rsrc, int sof
 // before the first MFMA, ~6k cycles per step).  H is padded up to 32*NCH with zero U^T columns
 // and out-of-range (zero-returning) h loads.
 // XW = where this step's xW loads and the previous step's output store are issued:
-//   0 before the poll (prefetch), 1 right after the h loads, 2 a quarter into the K loop.
+//   0 before the poll (prefetch), 1 right after the h loads.
 // Vector-memory results return in issue order, so with XW = 0 the poll's load waits behind HBM
 // loads / stores: global timestamps showed the poll passing 0.2 .. 2.6 us after the last arrival
-// (the workgroup that signalled last stays last) against 0.3 .. 1.0 us with XW = 1.  XW = 1 wins
-// when the K loop is long enough to cover the xW latency afterwards (LSTM-512: -3 %), XW = 0
-// when it is short (GRU-256: 3 % faster than XW = 1); XW = 2 loses on both.
-template <int G, bool IS_LSTM, int NCH, int XW>
+// (the workgroup that signalled last stays last) against 0.3 .. 1.0 us with XW = 1.  That was with
+// eight 4-byte xW loads per wave; with one 16-byte load per gate the two are within 2 % of each other
+// in the classic kernel (default XW = 1) and XW = 0 is 10 % faster in the ping-pong kernel, where the
+// poll is off the critical path; NNTK_REC_XW overrides.
+// Hand-off layout of h (hbuf): [16-row slab][16-float k block][k group q = 0..3][row n = 0..15][4 floats],
+//   i.e. exactly the order in which the 64 lanes (lane = 16 q + n) of one wavefront consume a
+//   (slab, k block) as the MFMA B operand -- one b128 load instruction reads 1 KB CONTIGUOUS.
+//   With h in the caller's row-major [B][H] layout the same instruction touched 16 rows x 64 B
+//   with neighbouring lanes 2 KB apart; a microbenchmark of just these loads (tools/micro/
+//   hload_bench.hip) delivers the 128 KB tile in 3.6 us that way and in 1.15 us contiguously,
+//   and the in-kernel stamps showed the second split-K wave receiving its data 9k cycles late.
+//   Padding (rows >= B, k >= H) stays zero: the buffers are cleared before the launch and only
+//   valid elements are ever written.
+// PP = ping-pong: the workgroup's 64 batch rows are two independent 32-row halves, each with its
+//   own arrival counter and hand-off chain, worked by one wavefront per SIMD (2 slabs x 2 split-K
+//   halves: wavefronts 0-3 and 4-7) in strict alternation: half A multiplies, half A runs its
+//   exchange + gates and publishes, half B multiplies, ... so one half's drain / arrival /
+//   propagation / poll / first-bytes latency (about 7k cycles of a 27k-cycle step) hides behind
+//   the other half's MFMA phase.  The token passes only AFTER the gate phase: a wave issuing
+//   back-to-back f32 MFMAs starves the VALU of the other wave on its SIMD completely, whatever
+//   s_setprio says (tools/micro/coissue_bench.hip: 410k + 81k cycles alone, 490k together), so
+//   gates that overlap the other half's K loop simply wait for its end (measured: +9k cycles).
+//   There is no workgroup barrier in the step loop; wavefronts meet through monotonic LDS words.
+//   LSTM-512: 27.2k -> 21.7k cycles per step.  Not for short K loops (GRU-256: the hand-off
+//   chain, not the SIMD, is the bound there and the extra sync costs 5 %).
+// STD = the gate activations are the standard ones (GRU: sigmoid / tanh / sigmoid, LSTM: sigmoid x3 +
+//   tanh x2): the kinds become compile-time constants and the gate phase -- pure VALU work that
+//   cannot overlap the MFMAs -- loses its 10 scalar branch ladders.
+template <int G, bool IS_LSTM, int NCH, int XW, bool PP, bool STD>
 __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
+    const int A0 = STD ? NNTK_ACT_SIGMOID : p.a0;
+    const int A1 = STD ? (IS_LSTM ? NNTK_ACT_SIGMOID : NNTK_ACT_TANH) : p.a1;
+    const int A2 = STD ? (IS_LSTM ? NNTK_ACT_TANH : NNTK_ACT_SIGMOID) : p.a2;
+    const int A3 = STD ? NNTK_ACT_SIGMOID : p.a3;
+    const int A4 = STD ? NNTK_ACT_TANH : p.a4;
     constexpr bool VEC = true;                    // launcher guarantees H % 4 == 0
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KP = NCH * REC_KC;              // padded K
     constexpr int US = KP + 8;                    // U^T row stride: 16-B aligned, conflict-free b128 slots
     float *Us = smem;                             // [G*16][US]   resident for the whole sequence
     float *red = smem + G * 16 * US;              // [4 slabs][2 groups][G][2][64] split-K exchange
+    // ping-pong sync words (monotonic): [0..1] poll passed (step) | [2..3] waves drained (4 per step)
+    //   | [4..5] waves past their gate phase (4 per step) | [8..15] split-K partials written (step+1), per (slab, K half)
+    unsigned *syncw = reinterpret_cast<unsigned *>(red + 4 * 2 * G * 2 * 64);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -328,19 +383,22 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
     // 8 wavefronts = 4 batch slabs of 16 rows x 2 split-K halves.  (A variant in which every
     // slab was its own sync domain with per-wave polling was measured 40 % SLOWER: polling
     // traffic from 2048 waves outweighed the overlap -- one poller per workgroup it is.)
-    const int grp = w8 >> 2;                      // split-K half: k sub-range [16*grp, 16*grp+16) of each chunk
-    const int slab = w8 & 3;
+    // ping-pong: half = which 32-row half this wave works on; one wave of each half per SIMD
+    const int half = PP ? (w8 >> 2) : 0;
+    const int wih = PP ? (w8 & 3) : w8;           // wave index inside the half, 0..3
+    const int grp = PP ? (wih >> 1) : (w8 >> 2);  // split-K half: k sub-range [16*grp, 16*grp+16) of each chunk
+    const int slab = PP ? (half * 2 + (wih & 1)) : (w8 & 3);
+    const bool leader = PP ? (wih == 0) : (w8 == 0);
     const int l15 = lane & 15, q = lane >> 4;
     const int bt = blockIdx.x % p.NBT;
     const int ct = blockIdx.x / p.NBT;
     const int b0 = p.b_base + bt * REC_BM;
     const int j0 = ct * REC_HN;
     constexpr bool pair8 = VEC;
-    const size_t BH = (size_t)p.B * p.H;
     const int GH = G * p.H;
     // one arrival counter per batch tile, each on its own 256-B line: atomics execute at the
     // memory side, so counters sharing a line serialise on one channel (measured: 3.5x slower)
-    unsigned *cnt = p.cnt + (size_t)bt * RECP_CNT_STRIDE;
+    unsigned *cnt = p.cnt + ((size_t)bt * (PP ? 2 : 1) + half) * RECP_CNT_STRIDE;
 
     // this lane finishes hidden units j, j+1 of batch row b (after the split-K exchange)
     const int b = b0 + slab * 16 + l15;
@@ -369,30 +427,37 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
     // own previous state: c (LSTM) or h (GRU) for the two elements this lane finishes
     float prev[2];
     {
-        const float *src = IS_LSTM ? p.c : p.hbuf;
-        prev[0] = ok0 ? src[(size_t)b * p.H + j] : 0.0f;
-        prev[1] = ok1 ? src[(size_t)b * p.H + j + 1] : 0.0f;
+        const float *src = IS_LSTM ? p.c : p.h0;
+        prev[0] = (ok0 && src) ? src[(size_t)b * p.H + j] : 0.0f;
+        prev[1] = (ok1 && src) ? src[(size_t)b * p.H + j + 1] : 0.0f;
     }
-    // per-lane byte offsets of this lane's 16-byte h pieces; rows / columns outside [B, H) get an
-    // out-of-range offset, which the buffer load answers with zeros (no branch around any load)
-    const int row_off = row_ok ? (int)((size_t)(b - p.b_base) * p.H * 4) : 0x3ffffff0;
-    const size_t tile_base = (size_t)p.b_base * p.H * 4;      // buffer descriptor starts at this launch's first row
-    // two descriptors (ping / pong), each covering only [b_base*H, B*H) of its buffer
-    const int rs_bytes = (int)((BH - (size_t)p.b_base * p.H) * 4);
-    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void *)((char *)p.hbuf + tile_base), 0, rs_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)((char *)(p.hbuf + BH) + tile_base), 0, rs_bytes, 0x00020000);
+    // tiled hand-off buffers (ping / pong): this wave's (slab, k block) pieces are 1 KB apart
+    constexpr int KB = KP / 16;                   // 16-float k blocks per row
+    const int slab_abs = (b0 >> 4) + slab;
+    const int hb_bytes = (int)(p.hb_floats * 4);
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void *)p.hbuf, 0, hb_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.hbuf + p.hb_floats), 0, hb_bytes, 0x00020000);
+    const int h_lane_off = lane * 16;
+    const int h_wave_off = (slab_abs * KB + grp) * 1024;      // + ch * 2048
+    // where this lane publishes its two finished elements (k = j, j + 1) of row b
+    const size_t h_pub_off = ((((size_t)slab_abs * KB + ct) * 4 + q) * 16 + l15) * 4 + grp * 2;
     float *my_red = red + ((slab * 2 + grp) * G * 2) * 64;
     const float *peer_red = red + ((slab * 2 + (1 - grp)) * G * 2) * 64;
+    if (PP && tid < 16) syncw[tid] = 0u;
     __syncthreads();
 
     float hn_prev[2] = {0.f, 0.f};
     for (int t = 0; t < p.T; ++t) {
         float xwv[2][G];
 #define REC_XW_ISSUE() do {                                                                          \
-            const float *xw = p.xw + ((size_t)t * p.B + b) * GH + j;                                   \
+            /* one 16-byte load per gate: the 4 hidden units of this lane's quad (both split-K waves  */ \
+            /* fetch the quad, each keeps its two) -- a quarter of the VMEM instructions of 2 x b32   */ \
+            const float *xw = p.xw + ((size_t)t * p.B + b) * GH + (j & ~3);                            \
             _Pragma("unroll") for (int g = 0; g < G; ++g) {                                            \
-                xwv[0][g] = ok0 ? xw[g * p.H] : 0.0f;                                                  \
-                xwv[1][g] = ok1 ? xw[g * p.H + 1] : 0.0f;                                              \
+                float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);                                           \
+                if (ok0) x4 = *reinterpret_cast<const float4 *>(xw + g * p.H);                         \
+                xwv[0][g] = grp ? x4.z : x4.x;                                                         \
+                xwv[1][g] = grp ? x4.w : x4.y;                                                         \
             }                                                                                          \
             if (XW != 0 && t > 0 && p.return_sequences) {                                              \
                 float *o = p.out + ((size_t)b * p.T + (t - 1)) * p.H + j;                              \
@@ -400,12 +465,13 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
                 else { if (ok0) o[0] = hn_prev[0]; if (ok1) o[1] = hn_prev[1]; }                       \
             }                                                                                          \
         } while (0)
+        REC_STAMP(0);
         if (XW == 0) REC_XW_ISSUE();
         // ---- wait until every workgroup of this batch tile has published h_{t-1}:
         //      ONE lane polls (relaxed, s_sleep), the workgroup joins a barrier, and every
         //      load of handed-off bytes below is an sc1 load ----
         if (t > 0) {
-            if (tid == 0) {
+            if (leader && lane == 0) {
                 const unsigned target = (unsigned)p.NCT * (unsigned)t;
                 const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
                 while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
@@ -415,9 +481,12 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
                         break;
                     }
                 }
+                if (PP) __hip_atomic_store(&syncw[half], (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            __syncthreads();
+            if (PP) { if (!leader) recp_lds_wait_ge(&syncw[half], (unsigned)t); }
+            else __syncthreads();
         }
+        REC_STAMP(1);
         f32x4 acc[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -429,18 +498,17 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
         v4u32 hreg[NCH];
         if (t & 1) {
 #pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-                const int k = ch * REC_KC + grp * 16 + q * 4;
-                hreg[ch] = __builtin_amdgcn_raw_buffer_load_b128(rs1, k < p.H ? row_off + k * 4 : 0x3ffffff0, 0, 16 /* sc1 */);
-            }
+            for (int ch = 0; ch < NCH; ++ch)
+                hreg[ch] = __builtin_amdgcn_raw_buffer_load_b128(rs1, h_lane_off, h_wave_off + ch * 2048, 16 /* sc1 */);
         } else {
 #pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-                const int k = ch * REC_KC + grp * 16 + q * 4;
-                hreg[ch] = __builtin_amdgcn_raw_buffer_load_b128(rs0, k < p.H ? row_off + k * 4 : 0x3ffffff0, 0, 16 /* sc1 */);
-            }
+            for (int ch = 0; ch < NCH; ++ch)
+                hreg[ch] = __builtin_amdgcn_raw_buffer_load_b128(rs0, h_lane_off, h_wave_off + ch * 2048, 16 /* sc1 */);
         }
         if (XW == 1) REC_XW_ISSUE();
+        // token: half 0 multiplies step t after half 1 has finished the gates of step t-1, half 1 after half 0's of step t
+        if (PP) recp_lds_wait_ge(&syncw[4 + (1 - half)], 4u * (unsigned)(t + half));
+        REC_STAMP(2);
         // U^T fragments: software-pipelined one chunk ahead of the MFMAs that use them
         const float *ubase = &Us[l15 * US + grp * 16 + q * 4];
         float4 un[G];
@@ -451,7 +519,6 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
             float4 uc[G];
 #pragma unroll
             for (int g = 0; g < G; ++g) uc[g] = un[g];
-            if (XW == 2 && ch == NCH / 4) REC_XW_ISSUE();
             if (ch + 1 < NCH) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) un[g] = *reinterpret_cast<const float4 *>(ubase + g * 16 * US + (ch + 1) * REC_KC);
@@ -467,19 +534,29 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
                 }
         }
 
+        REC_STAMP(3);
         // ---- split-K exchange through LDS: send the half the partner wave finishes ----
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int e = 0; e < 2; ++e) my_red[(g * 2 + e) * 64 + lane] = acc[g][(1 - grp) * 2 + e];
-        __syncthreads();
+            for (int e = 0; e < 2; ++e) my_red[(g * 2 + e) * 64 + lane] = grp ? acc[g][e] : acc[g][2 + e];
+        if (PP) {
+            asm volatile("" ::: "memory");
+            if (lane == 0) {
+                __hip_atomic_store(&syncw[8 + slab * 2 + grp], (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            recp_lds_wait_ge(&syncw[8 + slab * 2 + (1 - grp)], (unsigned)(t + 1));
+        } else {
+            __syncthreads();
+        }
+        REC_STAMP(4);
         float fin[2][G];
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const float other = peer_red[(g * 2 + e) * 64 + lane];
-                const float mine = acc[g][grp * 2 + e];
+                const float mine = grp ? acc[g][2 + e] : acc[g][e];
                 fin[e][g] = grp == 0 ? mine + other : other + mine;      // always (group 0) + (group 1)
             }
 
@@ -489,9 +566,9 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
         for (int e = 0; e < 2; ++e) {
             if (!IS_LSTM) {
                 const float hz = fin[e][0] + bh[e][0], hr = fin[e][1] + bh[e][1], hh = fin[e][2] + bh[e][2];
-                const float z = nntk_gate_act(p.a0, xwv[e][0] + hz);
-                const float rg = nntk_gate_act(p.a2, xwv[e][1] + hr);
-                const float ht = nntk_gate_act(p.a1, rg * hh + xwv[e][2]);
+                const float z = nntk_gate_act(A0, xwv[e][0] + hz);
+                const float rg = nntk_gate_act(A2, xwv[e][1] + hr);
+                const float ht = nntk_gate_act(A1, rg * hh + xwv[e][2]);
                 hn[e] = (-z + 1.0f) * ht + z * prev[e];
                 prev[e] = hn[e];
             } else {
@@ -499,18 +576,18 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
                 const float zf = xwv[e][1] + (fin[e][1] + bh[e][1]);
                 const float zg = xwv[e][2] + (fin[e][2] + bh[e][2]);
                 const float zo = xwv[e][G - 1] + (fin[e][G - 1] + bh[e][G - 1]);
-                const float ig = nntk_gate_act(p.a0, zi);
-                const float fg = nntk_gate_act(p.a1, zf);
-                const float gg = nntk_gate_act(p.a2, zg);
-                const float og = nntk_gate_act(p.a3, zo);
+                const float ig = nntk_gate_act(A0, zi);
+                const float fg = nntk_gate_act(A1, zf);
+                const float gg = nntk_gate_act(A2, zg);
+                const float og = nntk_gate_act(A3, zo);
                 const float cn = fg * prev[e] + ig * gg;
                 prev[e] = cn;
-                hn[e] = og * nntk_gate_act(p.a4, cn);
+                hn[e] = og * nntk_gate_act(A4, cn);
             }
         }
         // ---- publish h_t (write-through), then this wave's arrival; the layer output
         //      (never read in this launch) is stored after the arrival ----
-        float *hdst = p.hbuf + (size_t)((t + 1) & 1) * BH + (size_t)b * p.H + j;
+        float *hdst = p.hbuf + (size_t)((t + 1) & 1) * p.hb_floats + h_pub_off;
         if (pair8 && ok1) {
             const unsigned long long pk = ((unsigned long long)__float_as_uint(hn[1]) << 32) | __float_as_uint(hn[0]);
             __hip_atomic_store(reinterpret_cast<unsigned long long *>(hdst), pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -518,9 +595,26 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
             if (ok0) __hip_atomic_store(reinterpret_cast<unsigned *>(hdst), __float_as_uint(hn[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (ok1) __hip_atomic_store(reinterpret_cast<unsigned *>(hdst + 1), __float_as_uint(hn[1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        // the other half may start multiplying now (not earlier: its MFMAs would starve these gates)
+        if (PP && lane == 0) __hip_atomic_fetch_add(&syncw[4 + half], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        REC_STAMP(5);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // R1: every storing wave drains ...
-        __syncthreads();                                      // ... the workgroup meets (this also frees `red`) ...
-        if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... ONE lane arrives
+        REC_STAMP(6);
+        if (PP) {
+            // ... the half's four waves meet on an LDS word (`red` is not rewritten before the next
+            // step's poll has passed, i.e. after the partner has drained too) ...
+            if (lane == 0) {
+                __hip_atomic_fetch_add(&syncw[2 + half], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (leader) {
+                    while (__hip_atomic_load(&syncw[2 + half], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u * (unsigned)(t + 1)) {}
+                    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ... ONE lane arrives
+                }
+            }
+        } else {
+            __syncthreads();                                  // ... the workgroup meets (this also frees `red`) ...
+            if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... ONE lane arrives
+        }
+        REC_STAMP(7);
         if (XW == 0) {
             if (p.return_sequences || t == p.T - 1) {
                 float *o = p.return_sequences ? p.out + ((size_t)b * p.T + t) * p.H + j : p.out + (size_t)b * p.H + j;
@@ -538,6 +632,19 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
     if (IS_LSTM) {
         if (ok0) p.c[(size_t)b * p.H + j] = prev[0];
         if (ok1) p.c[(size_t)b * p.H + j + 1] = prev[1];
+    }
+    if (p.hT) {
+        if (ok0) p.hT[(size_t)b * p.H + j] = hn_prev[0];
+        if (ok1) p.hT[(size_t)b * p.H + j + 1] = hn_prev[1];
+    }
+}
+
+// h_0 from the caller's [B][H] layout into the tiled hand-off layout (parity 0)
+__global__ __launch_bounds__(256) void rec_tile_h0_kernel(const float *src, float *dst, int B, int H, int KB) {
+    const long total = (long)B * H;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(e / H), k = (int)(e % H);
+        dst[(((size_t)(b >> 4) * KB + (k >> 4)) * 4 + ((k >> 2) & 3)) * 64 + (b & 15) * 4 + (k & 3)] = src[e];
     }
 }
 
@@ -572,8 +679,15 @@ static int rec_status_enqueue(const unsigned *d_cnt, int nbt) {
     return 0;
 }
 
+// floats per parity of the h ping-pong area: the persistent kernel's tiled layout pads rows to 64
+// and k to a multiple of 128 (4 chunks); the per-step kernels use the first B*H floats of each half
+static size_t rec_hb_floats(int B, int H) {
+    return (size_t)((B + 63) & ~63) * (size_t)((H + 127) & ~127);
+}
+
 extern "C" size_t nntk_shim_recurrent_work_floats(int B, int H) {
-    return (size_t)3 * B * H + RECP_CNT_WORDS;     // h ping, h pong, c, arrival counters of the persistent kernel
+    // h ping | h pong | c | arrival counters of the persistent kernel
+    return 2 * rec_hb_floats(B, H) + (size_t)B * H + RECP_CNT_WORDS;
 }
 
 static int act_ok(int a) {
@@ -588,10 +702,9 @@ static int run_recurrent(const float *d_xw, const float *d_ut, const float *d_bh
         if (!act_ok(acts[i]))
             return nntk_fail_msg("recurrent: gate activation must be one of the built-in identity/sigmoid/tanh/relu");
     const size_t BH = (size_t)B * H;
-    float *hbuf[2] = {d_work, d_work + BH};
-    float *cbuf = d_work + 2 * BH;
-    if (d_h0) { if (nntk_shim_copy_d2d(hbuf[0], d_h0, BH * 4)) return -1; }
-    else      { if (nntk_shim_memset(hbuf[0], 0, BH * 4)) return -1; }
+    const size_t hbmax = rec_hb_floats(B, H);
+    float *hbuf[2] = {d_work, d_work + hbmax};
+    float *cbuf = d_work + 2 * hbmax;
     if (IS_LSTM) {
         if (d_c0) { if (nntk_shim_copy_d2d(cbuf, d_c0, BH * 4)) return -1; }
         else      { if (nntk_shim_memset(cbuf, 0, BH * 4)) return -1; }
@@ -611,45 +724,84 @@ static int run_recurrent(const float *d_xw, const float *d_ut, const float *d_bh
         const int NCT = p.Hj_p / REC_HN;
         const int nch = p.Hk_p / REC_KC;
         const int nch_p = nch <= 4 ? 4 : nch <= 8 ? 8 : nch <= 12 ? 12 : 16;      // compiled K depths (x32)
-        const size_t lds = ((size_t)G * 16 * (nch_p * REC_KC + 8) + (size_t)4 * 2 * G * 2 * 64) * sizeof(float);
+        const size_t lds = ((size_t)G * 16 * (nch_p * REC_KC + 8) + (size_t)4 * 2 * G * 2 * 64 + 16) * sizeof(float);
         int dev = 0, cus = 0;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         const int tiles_per_launch = NCT > 0 ? cus / NCT : 0;
+        const size_t hb_floats = (size_t)((B + 63) & ~63) * (size_t)(nch_p * REC_KC);      // <= hbmax
         if (want && (H % 4) == 0 && lds <= 160 * 1024 && p.Hk_p <= RECP_MAXCH * REC_KC && tiles_per_launch >= 1 &&
-            BH * 4 < 0x3ffffff0ULL) {
+            hb_floats * 4 < 0x3ffffff0ULL) {
             void (*kern)(RecPParams);
             const char *xenv = getenv("NNTK_REC_XW");
-            const int xwm = xenv ? atoi(xenv) : (nch_p >= 12 ? 1 : 0);
-#define REC_PICK(N) (xwm == 1 ? rec_persistent_kernel<G, IS_LSTM, N, 1> : xwm == 2 ? rec_persistent_kernel<G, IS_LSTM, N, 2> : rec_persistent_kernel<G, IS_LSTM, N, 0>)
-            if (nch_p == 4)       kern = REC_PICK(4);
+            int xwm = xenv ? atoi(xenv) : -1;
+const bool std_acts = IS_LSTM ? (p.a0 == NNTK_ACT_SIGMOID && p.a1 == NNTK_ACT_SIGMOID && p.a2 == NNTK_ACT_TANH &&
+                                              p.a3 == NNTK_ACT_SIGMOID && p.a4 == NNTK_ACT_TANH)
+                                           : (p.a0 == NNTK_ACT_SIGMOID && p.a1 == NNTK_ACT_TANH && p.a2 == NNTK_ACT_SIGMOID);
+            // ping-pong halves pay when the K loop is long (see the kernel's header); NNTK_REC_PINGPONG=0/1 overrides
+            const char *ppenv = getenv("NNTK_REC_PINGPONG");
+            const bool pp = std_acts && nch_p == 16 && (ppenv ? ppenv[0] != '0' : true);
+            if (xwm < 0) xwm = pp ? 0 : 1;      // measured: ping-pong LSTM-512 11.8 (XW 0) vs 13.1 ms; classic GRU-256 7.82 vs 7.63 (XW 1)
+#define REC_PICK(N) (!std_acts ? rec_persistent_kernel<G, IS_LSTM, N, 0, false, false> \
+                     : xwm == 1 ? rec_persistent_kernel<G, IS_LSTM, N, 1, false, true> : rec_persistent_kernel<G, IS_LSTM, N, 0, false, true>)
+            if (pp)               kern = xwm == 1 ? rec_persistent_kernel<G, IS_LSTM, 16, 1, true, true> : rec_persistent_kernel<G, IS_LSTM, 16, 0, true, true>;
+            else if (nch_p == 4)  kern = REC_PICK(4);
             else if (nch_p == 8)  kern = REC_PICK(8);
             else if (nch_p == 12) kern = REC_PICK(12);
             else                  kern = REC_PICK(16);
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return nntk_fail("hipFuncSetAttribute(rec_persistent_kernel)", e);
-            unsigned *cnt = reinterpret_cast<unsigned *>(d_work + 3 * BH);
+            unsigned *cnt = reinterpret_cast<unsigned *>(d_work + 2 * hbmax + BH);
+            // tiled hand-off buffers: both parities cleared (the padding must stay zero), h_0 tiled into parity 0
+            if (nntk_shim_memset(d_work, 0, 2 * hbmax * 4)) return -1;
+            if (d_h0) {
+                long g = (long)((BH + 255) / 256);
+                if (g > 2048) g = 2048;
+                hipLaunchKernelGGL(rec_tile_h0_kernel, dim3((unsigned)g), dim3(256), 0, nntk_stream(), d_h0, d_work, B, H,
+                                   nch_p * REC_KC / 16);
+            }
             RecPParams q;
-            q.xw = d_xw; q.ut = d_ut; q.bh = d_bh; q.hbuf = hbuf[0]; q.c = cbuf; q.out = d_out; q.cnt = cnt;
+            q.xw = d_xw; q.ut = d_ut; q.bh = d_bh; q.hbuf = d_work; q.c = cbuf; q.out = d_out; q.cnt = cnt;
+            q.h0 = d_h0; q.hT = d_hT; q.hb_floats = hb_floats;
             q.B = B; q.T = T; q.H = H; q.Hj_p = p.Hj_p; q.Hk_p = p.Hk_p; q.NCT = NCT;
             q.return_sequences = return_sequences;
             q.a0 = p.a0; q.a1 = p.a1; q.a2 = p.a2; q.a3 = p.a3; q.a4 = p.a4;
+            const int ncnt = pp ? 2 : 1;      // arrival counters per batch tile
+#ifdef NNTK_REC_STAMPS
+            q.stamp = nullptr;
+            const char *stamp_path = getenv("NNTK_REC_STAMP_FILE");
+            if (stamp_path) {
+                if (hipMalloc((void **)&q.stamp, (size_t)2 * T * 8 * 8) != hipSuccess) return nntk_fail_msg("stamp alloc");
+                (void)hipMemset(q.stamp, 0, (size_t)2 * T * 8 * 8);
+            }
+#endif
             const int nbt_total = (B + REC_BM - 1) / REC_BM;
             const int span = nntk_prof_span_begin();
             for (int bt0 = 0; bt0 < nbt_total; bt0 += tiles_per_launch) {
                 const int nbt = nbt_total - bt0 < tiles_per_launch ? nbt_total - bt0 : tiles_per_launch;
-                if (nntk_shim_memset(cnt, 0, (size_t)nbt * RECP_CNT_STRIDE * sizeof(unsigned))) return -1;
+                if (nntk_shim_memset(cnt, 0, (size_t)nbt * ncnt * RECP_CNT_STRIDE * sizeof(unsigned))) return -1;
                 q.NBT = nbt; q.b_base = bt0 * REC_BM;
                 hipLaunchKernelGGL(kern, dim3((unsigned)(nbt * NCT)), dim3(512), lds, nntk_stream(), q);
-                if (rec_status_enqueue(cnt, nbt)) return -1;
+                if (rec_status_enqueue(cnt, nbt * ncnt)) return -1;
             }
             nntk_prof_span_end(span, (nbt_total + tiles_per_launch - 1) / tiles_per_launch, T);
+#ifdef NNTK_REC_STAMPS
+            if (q.stamp) {
+                (void)hipStreamSynchronize(nntk_stream());
+                unsigned long long *hs = (unsigned long long *)malloc((size_t)2 * T * 8 * 8);
+                (void)hipMemcpy(hs, q.stamp, (size_t)2 * T * 8 * 8, hipMemcpyDeviceToHost);
+                FILE *f = fopen(stamp_path, "wb");
+                if (f) { fwrite(hs, 8, (size_t)2 * T * 8, f); fclose(f); }
+                free(hs); (void)hipFree(q.stamp);
+            }
+#endif
             NNTK_LAUNCH_CHECK("rec_persistent_kernel");
-            if (d_hT) { if (nntk_shim_copy_d2d(d_hT, hbuf[T & 1], BH * 4)) return -1; }
             if (IS_LSTM && d_cT) { if (nntk_shim_copy_d2d(d_cT, cbuf, BH * 4)) return -1; }
             return 0;
         }
     }
+    if (d_h0) { if (nntk_shim_copy_d2d(hbuf[0], d_h0, BH * 4)) return -1; }
+    else      { if (nntk_shim_memset(hbuf[0], 0, BH * 4)) return -1; }
     // split-K groups per workgroup: 2 (two waves per SIMD) unless overridden for A/B runs
     const char *env = getenv("NNTK_REC_GROUPS");
     const int ng = (env && env[0] == '1') ? 1 : 2;

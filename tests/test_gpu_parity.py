@@ -493,6 +493,62 @@ def test_persistent_and_per_step_recurrent_paths_agree_bitwise_in_sharding(gpu, 
         lstm.destroy()
 
 
+def test_lstm512_pingpong_and_classic_kernels_agree_bitwise(gpu, monkeypatch):
+    """LSTM-512 runs the ping-pong variant of the persistent kernel by default (two 32-row halves per
+    workgroup in alternation); it must equal the classic variant bit for bit -- ragged batch (a tile whose
+    second half is empty, a tile with a partial half), carried state, last-step-only output."""
+    import torch
+    r = rng(512)
+    I, H, T = 24, 512, 7
+    W, U, bi, bh = lstm_weights(r, I, H)
+    for B, seq in ((1, True), (33, True), (130, True), (97, False)):
+        xs = u(r, B, T, I)
+        x = torch.from_numpy(xs).cuda()
+        ref = O.lstm(xs, W, U, bi, bh, return_sequences=seq, v2=True)
+        outs = []
+        for mode in ("1", "0"):
+            monkeypatch.setenv("NNTK_REC_PINGPONG", mode)
+            lstm = NL.LSTM(I, H, seq, T, v2=True)
+            lstm.set_weights(W, U, bi, bh)
+            o = lstm.apply_device(x).clone()
+            close(o.cpu().numpy(), ref)
+            outs.append(o)
+            lstm.destroy()
+        assert torch.equal(outs[0], outs[1])
+    # single-sequence API with carried (h, c): the second call starts from a non-zero tiled h_0
+    x1, x2 = u(r, T, I), u(r, T, I)
+    o1, h1, c1 = O.lstm(x1, W, U, bi, bh, v2=True)
+    o2, h2, c2 = O.lstm(x2, W, U, bi, bh, h0=h1, c0=c1, v2=True)
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NNTK_REC_PINGPONG", mode)
+        lstm = NL.LSTM(I, H, True, T, v2=True)
+        lstm.set_weights(W, U, bi, bh)
+        close(lstm.apply(x1), o1)
+        close(lstm.apply(x2), o2)
+        h, c = lstm.state()
+        close(h, h2)
+        close(c, c2)
+        lstm.destroy()
+
+
+def test_lstm512_nondefault_gate_activations(gpu):
+    """Non-standard gate activations take the generic (run-time dispatched) gate code of the persistent kernel."""
+    L = capi.load()
+    I, H, T = 8, 512, 5
+    r = rng(5512)
+    W, U, bi, bh = lstm_weights(r, I, H)
+    x = u(r, T, I)
+    # LSTMActivationsCreate argument order: input gate, forget gate, candidate, output gate, output (lstm.c:246-258)
+    acts = L.LSTMActivationsCreate(L.ActivationFunctionCreateSigmoid(H), L.ActivationFunctionCreateSigmoid(H),
+                                   L.ActivationFunctionCreateReLU(H, 1.0), L.ActivationFunctionCreateSigmoid(H),
+                                   L.ActivationFunctionCreateTanh(H))
+    lstm = NL.LSTM(I, H, True, T, v2=True, acts=acts)
+    lstm.set_weights(W, U, bi, bh)
+    ref, _, _ = O.lstm(x, W, U, bi, bh, v2=True, acts=(O.ACT_SIGMOID, O.ACT_SIGMOID, O.ACT_RELU, O.ACT_SIGMOID, O.ACT_TANH))
+    close(lstm.apply(x), ref)
+    lstm.destroy()
+
+
 # ------------------------------------------------ next row: mel filterbank / log-mel ---
 
 def test_mel_filterbank_and_log_mel_spectrogram(gpu):
