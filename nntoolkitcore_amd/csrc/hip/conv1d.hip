@@ -16,22 +16,41 @@
 // buffered and the next chunk's global loads are issued before the MFMA block of
 // the current one (register staging, write-after-barrier).
 //
+// Everything around the MFMAs is written to need (almost) no VALU instructions, because on
+// gfx950 an f32 MFMA and a VALU instruction never overlap -- not inside a wave, not between
+// the waves of a SIMD (tools/micro/coissue_bench.hip: 3200 MFMAs = 205k cycles alone, + 4.1
+// cycles for every v_fma added in their shadow).  Every VALU instruction is therefore paid
+// in full out of the 157 TFLOP/s:
+//   * both LDS tiles are K-contiguous ([row][KC + 4]; the weights are packed [Cout_p][k * Cin_p]
+//     in HBM for that) and the K order inside an 8-deep block is permuted so that a lane's four
+//     operands are ONE ds_read_b128 (lane half kh takes k = 4 kh .. 4 kh + 3): 4 LDS reads and
+//     no address arithmetic per 16 MFMAs (was 8 ds_read2_b32 + 6 v_add);
+//   * global -> register staging uses buffer loads whose per-thread offset never changes; the
+//     chunk advance moves the descriptor's base (scalar ALU), the tensor's end is its range check
+//     (only the VECTOR offset is range-checked, so nothing that must be clipped rides in soffset);
+//   * the epilogue stores through a buffer descriptor with the row advance in the scalar offset;
+//     padded columns get an out-of-range vector offset, and only the last row tile of a sequence
+//     takes a compare-per-element path.
+//
 // Roofline: exact-f32 MFMA is 64 FLOP/clk/SIMD = 157 TFLOP/s, so config 3
 // (52.2 GFLOP over 686 MB) is MFMA-bound at 332 us, not HBM-bound (86 us).
 #include "nntk_common.hpp"
 #include <stdlib.h>
+#include <type_traits>
 
 #define CONV_BM 128
+#define CONV_KC 16
+#define CONV_LS (CONV_KC + 4)     // LDS row stride in floats: 16-B aligned rows, conflict-free b128 reads
 
 extern "C" void nntk_shim_conv_pack_sizes(int Cin, int Cout, int k, int *Cin_p, int *Cout_p) {
     (void)k;
-    *Cin_p = (Cin + 7) & ~7;          // the MFMA loop consumes 8 channels (4 K-steps of 2) per trip
-    *Cout_p = (Cout + 31) & ~31;      // whole 32-wide MFMA column tiles
+    *Cin_p = (Cin + CONV_KC - 1) & ~(CONV_KC - 1);   // whole K chunks: no guard in the weight staging
+    *Cout_p = (Cout + 31) & ~31;                     // whole 32-wide MFMA column tiles
 }
 
 struct ConvParams {
     const float *in;     // [B, T, Cin]
-    const float *wp;     // [k * Cin_p, Cout_p]
+    const float *wp;     // [Cout_p][k * Cin_p]   (K-contiguous)
     const float *bias;   // [Cout]
     const float *bn;     // NULL or gamma|beta|mean|var, each [Cout]
     float *out;
@@ -44,26 +63,40 @@ struct ConvParams {
     int out_mode;        // 0: row b*Tout+x ; 1: row x*B+b
     int rows_a;          // (BM-1)*stride + k window rows per tile
     int bn_fast;         // A/B: multiply by 1/sd instead of the reference's divide
+#ifdef NNTK_CONV_DBG
+    int dbg;             // timing experiments only: 1 no stores, 2 no MFMAs, 4 no global loads in the loop
+#endif
 };
+#ifdef NNTK_CONV_DBG
+#define CONV_DBG(bit) (p.dbg & (bit))
+#else
+#define CONV_DBG(bit) 0
+#endif
+
+typedef unsigned v4u32_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t conv_rsrc(const void *base, size_t bytes) {
+    const unsigned n = bytes > 0xfffffff0ull ? 0xfffffff0u : (unsigned)bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)n, 0x00020000);
+}
 
 // WM x WN wavefronts, each computing TM x TN MFMA tiles of 32x32.
 // A4 = the window can be fetched with 16-byte loads (Cin % 4 == 0, 16-B aligned base).
-template <int WM, int WN, int TM, int TN, bool A4, int KC>
+template <int WM, int WN, int TM, int TN, bool A4>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
     constexpr int BN = WN * TN * 32;
-    constexpr int AS = KC + 1;                       // LDS row stride of the window chunk (odd: conflict-free ds_read_b32)
+    constexpr int KC = CONV_KC, LS = CONV_LS;
     static_assert(WM * WN == 4, "4 wavefronts per workgroup");
     static_assert(WM * TM * 32 == CONV_BM, "BM = 128");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // LDS carve (offsets from the one dynamic array, so every access stays a ds_* op):
-    //   window chunk [2][rows_a][AS] | weight chunk [2][KC][BN]
-    const int a_elems = p.rows_a * AS;
-    constexpr int w_elems = KC * BN;
+    // LDS carve: window chunk [2][rows_a][LS] | weight chunk [2][BN][LS]
+    const int a_elems = p.rows_a * LS;
+    constexpr int w_elems = BN * LS;
     const int w_base = 2 * a_elems;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, kh = lane >> 5;
 
@@ -78,65 +111,87 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
     const int b = tile / p.tiles_per_seq;
     const int x0 = (tile % p.tiles_per_seq) * CONV_BM;
     const int n0 = (local % p.n_tiles) * BN;
-    const float *in_b = p.in + (size_t)b * p.T * p.Cin;
-    const int t0 = x0 * p.stride;
+    const int Ktot = p.k * p.Cin_p;
+
+    // (Measured and NOT kept, see DESIGN.md: persistent workgroups with the next tile's first chunk in
+    // flight during the epilogue, an LDS-transposed epilogue with 16-byte stores, a start stagger of the
+    // co-resident workgroups -- each within +-3 % of this simpler form on the stack's GEMMs.)
 
     f32x16 acc[TM][TN];
+
+    // ---- global -> register staging through buffer descriptors ----
+    constexpr int A_TPR = A4 ? KC / 4 : KC;          // threads per window row
+    constexpr int AR_STEP = 256 / A_TPR;             // rows covered per pass of the workgroup
+    constexpr int A_PT = (192 + AR_STEP - 1) / AR_STEP;   // window: rows_a <= 192 (host checks)
+    constexpr int W_PT = (BN * (KC / 4) + 255) / 256;     // 16-byte pieces per thread per weight chunk
+    constexpr bool W_ALL = (BN * (KC / 4)) % 256 == 0;
+    const int ac = A4 ? (tid % A_TPR) * 4 : (tid % A_TPR);   // first channel inside the chunk
+    const int ar = tid / A_TPR;                              // first row; rows advance by AR_STEP
+    const int wr = tid >> 2, wc4 = tid & 3;                  // weight row (output channel) / 16-byte piece
+    v4u32_t areg4[A4 ? A_PT : 1];
+    unsigned areg[A4 ? 1 : A_PT];
+    v4u32_t wreg[W_PT];
+    int a_voff[A_PT], w_voff[W_PT];
+#pragma unroll
+    for (int q = 0; q < A_PT; ++q) a_voff[q] = ((ar + q * AR_STEP) * p.Cin + ac) * 4;
+#pragma unroll
+    for (int q = 0; q < W_PT; ++q) w_voff[q] = ((wr + q * 64) * Ktot + wc4 * 4) * 4;
+    const bool cin_ragged = (p.Cin % KC) != 0;       // the last channel chunk runs past the row: mask it
+
+    const int n_cchunks = p.Cin_p / KC;
+    const int n_chunks = n_cchunks * p.k;
+    const int last_blocks = (((p.Cin + 7) & ~7) - (n_cchunks - 1) * KC + 7) / 8;      // 1 or 2
+
+    // weights: ONE descriptor for the kernel; tile column block and chunk ride in the scalar offset
+    // (always in range: the packed matrix is whole chunks x whole column tiles)
+    const __amdgpu_buffer_rsrc_t rs_w = conv_rsrc(p.wp, (size_t)p.Cout_p * Ktot * 4);
+    auto load_w = [&](int tn0, int cc, int kk) {
+        const int soff = (tn0 * Ktot + kk * p.Cin_p + cc * KC) * 4;
+#pragma unroll
+        for (int q = 0; q < W_PT; ++q)
+            if (W_ALL || tid + q * 256 < BN * (KC / 4))
+                wreg[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_voff[q], soff, 0);
+    };
+    // window: the descriptor starts at the tile's first window row and ends with the tensor, so the
+    // (range-checked) per-thread row offset drops rows past the tensor's end; rows past this
+    // sequence's end read the next sequence and only feed outputs x >= Tout, which are never stored.
+    // The chunk's channel offset rides in the unchecked scalar offset: a row that exists contains all
+    // its chunks -- except the ragged last chunk, whose out-of-row lanes get an out-of-range offset.
+    const size_t in_total = (size_t)p.B * p.T * p.Cin;
+    auto load_a = [&](int tb, int tx0, int cc) {
+        const size_t in_off = ((size_t)tb * p.T + (size_t)tx0 * p.stride) * p.Cin;
+        const __amdgpu_buffer_rsrc_t rs_in = conv_rsrc(p.in + in_off, (in_total - in_off) * 4);
+        const int soff = cc * KC * 4;
+        if (cin_ragged && cc == n_cchunks - 1) {     // uniform branch, last chunk only
+            const bool ch_ok = cc * KC + ac < p.Cin;
+#pragma unroll
+            for (int q = 0; q < A_PT; ++q) {
+                const int vo = ch_ok ? a_voff[q] : 0x7ffffff0;
+                if (A4) areg4[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, soff, 0);
+                else    areg[q] = __builtin_amdgcn_raw_buffer_load_b32(rs_in, vo, soff, 0);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < A_PT; ++q) {
+                if (A4) areg4[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, a_voff[q], soff, 0);
+                else    areg[q] = __builtin_amdgcn_raw_buffer_load_b32(rs_in, a_voff[q], soff, 0);
+            }
+        }
+    };
+
+    // per-lane LDS read bases (floats): row l31 of the wave's first tile, k offset 4*kh
+    const int a_rd = ((wm * TM * 32 + l31) * p.stride) * LS + 4 * kh;
+    const int w_rd = w_base + (wn * TN * 32 + l31) * LS + 4 * kh;
+    const int a_tile = 32 * p.stride * LS;
+
+    load_a(b, x0, 0);
+    load_w(n0, 0, 0);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    // ---- register staging (global -> VGPR now, VGPR -> LDS after the next barrier) ----
-    constexpr int W_F4 = KC * BN / 4;                // float4 per weight chunk
-    constexpr int W_PT = (W_F4 + 255) / 256;         // float4 per thread per weight chunk
-    constexpr int A_TPR = A4 ? KC / 4 : KC;          // threads per window row
-    constexpr int AR_STEP = 256 / A_TPR;             // rows covered per pass of the workgroup
-    constexpr int A_PT = (192 + AR_STEP - 1) / AR_STEP;   // window: rows_a <= 192 (host checks)
-    float4 wreg[W_PT];
-    float4 areg4[A4 ? A_PT : 1];
-    float areg[A4 ? 1 : A_PT];
-    // thread -> window element mapping
-    const int ac = A4 ? (tid % A_TPR) * 4 : (tid % A_TPR);   // first channel inside the chunk
-    const int ar = tid / A_TPR;                              // first row; rows advance by AR_STEP
-
-    const int n_cchunks = (p.Cin_p + KC - 1) / KC;
-    const int n_chunks = n_cchunks * p.k;
-
-    auto load_w = [&](int cc, int kk) {
-        const int i0 = cc * KC;
-        const int len = min(KC, p.Cin_p - i0);
-#pragma unroll
-        for (int q = 0; q < W_PT; ++q) {
-            const int e = tid + q * 256;             // float4 index inside [KC, BN/4]
-            const int r = e / (BN / 4), c4 = e % (BN / 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < len && (W_F4 % 256 == 0 || e < W_F4))
-                v = *reinterpret_cast<const float4 *>(p.wp + (size_t)(kk * p.Cin_p + i0 + r) * p.Cout_p + n0 + c4 * 4);
-            wreg[q] = v;
-        }
-    };
-    auto load_a = [&](int cc) {
-        const int ch = cc * KC + ac;
-#pragma unroll
-        for (int q = 0; q < A_PT; ++q) {
-            const int r = ar + q * AR_STEP;
-            const int t = t0 + r;
-            const bool ok = r < p.rows_a && t < p.T && ch < p.Cin;
-            if (A4) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) v = *reinterpret_cast<const float4 *>(in_b + (size_t)t * p.Cin + ch);
-                areg4[q] = v;
-            } else {
-                areg[q] = ok ? in_b[(size_t)t * p.Cin + ch] : 0.0f;
-            }
-        }
-    };
-
-    load_a(0);
-    load_w(0, 0);
     int cc = 0, kk = 0;
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         const int wbuf = chunk & 1;
@@ -147,12 +202,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
             for (int q = 0; q < A_PT; ++q) {
                 const int r = ar + q * AR_STEP;
                 if (r < p.rows_a) {
-                    if (A4) {
-                        float *d = As + r * AS + ac;
-                        d[0] = areg4[q].x; d[1] = areg4[q].y; d[2] = areg4[q].z; d[3] = areg4[q].w;
-                    } else {
-                        As[r * AS + ac] = areg[q];
-                    }
+                    if (A4) *reinterpret_cast<v4u32_t *>(As + r * LS + ac) = areg4[q];
+                    else    *reinterpret_cast<unsigned *>(As + r * LS + ac) = areg[q];
                 }
             }
         }
@@ -160,68 +211,119 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
             float *Ws = smem + w_base + wbuf * w_elems;
 #pragma unroll
             for (int q = 0; q < W_PT; ++q)
-                if (W_F4 % 256 == 0 || tid + q * 256 < W_F4)
-                    *reinterpret_cast<float4 *>(Ws + (size_t)(tid + q * 256) * 4) = wreg[q];
+                if (W_ALL || tid + q * 256 < BN * (KC / 4))
+                    *reinterpret_cast<v4u32_t *>(Ws + (wr + q * 64) * LS + wc4 * 4) = wreg[q];
         }
         __syncthreads();
         // next chunk's coordinates; prefetch it while this one is multiplied
         int ncc = cc, nkk = kk + 1;
         if (nkk == p.k) { nkk = 0; ncc = cc + 1; }
-        if (chunk + 1 < n_chunks) {
-            load_w(ncc, nkk);
-            if (nkk == 0) load_a(ncc);
+        if (chunk + 1 < n_chunks && !CONV_DBG(4)) {
+            load_w(n0, ncc, nkk);
+            if (nkk == 0) load_a(b, x0, ncc);
         }
-        const int len = min(KC, p.Cin_p - cc * KC);       // multiple of 8
-        const float *A = smem + abuf * a_elems + ((wm * TM * 32 + l31) * p.stride + kk) * AS + kh;
-        const float *W = smem + w_base + wbuf * w_elems + kh * BN + wn * TN * 32 + l31;
-        const int a_tile = 32 * p.stride * AS;
-        for (int s = 0; s < len; s += 8) {
-            float a[4][TM], w[4][TN];
+        const float *A = smem + abuf * a_elems + kk * LS + a_rd;
+        const float *W = smem + wbuf * w_elems + w_rd;
+        auto block8 = [&](int s) {
+            float4 a[TM], w[TN];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4 *>(A + i * a_tile + s);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[u][i] = A[i * a_tile + s + 2 * u];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) w[u][j] = W[(s + 2 * u) * BN + j * 32];
-            }
+            for (int j = 0; j < TN; ++j) w[j] = *reinterpret_cast<const float4 *>(W + j * 32 * LS + s);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], w[u][j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) {
+                        const float av = u == 0 ? a[i].x : u == 1 ? a[i].y : u == 2 ? a[i].z : a[i].w;
+                        const float wv = u == 0 ? w[j].x : u == 1 ? w[j].y : u == 2 ? w[j].z : w[j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wv, acc[i][j], 0, 0, 0);
+                    }
+        };
+        if (!CONV_DBG(2)) {
+        block8(0);
+        // the last channel chunk may hold only one 8-deep block of real channels (the rest is zero padding)
+        if (cc != n_cchunks - 1 || last_blocks > 1) block8(8);
         }
         cc = ncc; kk = nkk;
     }
 
-    // ---- epilogue: bias, BatchNorm (batch_norm.c:140-163 op order), activation ----
+    // ---- epilogue: bias, BatchNorm (batch_norm.c:140-163 op order), activation, buffer stores ----
+    // descriptor = this sequence's output rows (mode 0) or the whole time-major tensor from column
+    // block b (mode 1).  Interior row tiles store with the row advance in the (unchecked) scalar
+    // offset and the padded columns on an out-of-range vector offset; the last row tile of a
+    // sequence compares every element's row instead.  The uniform choices (BatchNorm or not,
+    // which activation, which store path) are taken ONCE, outside the 64-element loops: inside
+    // them every instruction is VALU time taken from the MFMAs.
+    const size_t row_bytes = (size_t)(p.out_mode ? p.B : 1) * p.Cout * 4;      // distance between output rows x, x+1
+    const size_t obase = p.out_mode ? (size_t)b * p.Cout : (size_t)b * p.Tout * p.Cout;
+    const size_t olen = p.out_mode ? ((size_t)p.Tout * p.B * p.Cout - obase) : (size_t)p.Tout * p.Cout;
+    const __amdgpu_buffer_rsrc_t rs_out = conv_rsrc(p.out + obase, olen * 4);
+    const bool fast_store = x0 + CONV_BM <= p.Tout &&                              // every row of the tile exists
+                            row_bytes * (size_t)(x0 + CONV_BM) < 0x7fffffffull;    // and is reachable by 32-bit offsets
+    const int rb = (int)row_bytes;
+
+    auto epilogue = [&](auto bn_tag, auto act_tag, auto fast_tag) {
+        constexpr bool HAS_BN = decltype(bn_tag)::value;
+        constexpr int ACT = decltype(act_tag)::value;            // -1: run-time kind
+        constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int o = n0 + wn * TN * 32 + j * 32 + l31;
-        if (o >= p.Cout) continue;
-        const float bias = p.bias ? p.bias[o] : 0.0f;
-        float g = 1.f, be = 0.f, mu = 0.f, sd = 1.f;
-        if (p.bn) {
-            g = p.bn[o]; be = p.bn[p.Cout + o]; mu = p.bn[2 * p.Cout + o];
-            sd = sqrtf(p.bn[3 * p.Cout + o] + p.bn_eps);
-        }
-        const bool fast_bn = p.bn_fast != 0;
-        const float rsd = 1.0f / sd;
+        for (int j = 0; j < TN; ++j) {
+            const int o = n0 + wn * TN * 32 + j * 32 + l31;
+            const bool col_ok = o < p.Cout;
+            const float bias = (p.bias && col_ok) ? p.bias[o] : 0.0f;
+            float g = 1.f, be = 0.f, mu = 0.f, sd = 1.f;
+            if (HAS_BN && col_ok) {
+                g = p.bn[o]; be = p.bn[p.Cout + o]; mu = p.bn[2 * p.Cout + o];
+                sd = sqrtf(p.bn[3 * p.Cout + o] + p.bn_eps);
+            }
+            const float rsd = 1.0f / sd;
+            // per-lane part of the address: column, and the +4 rows of the upper lane half
+            const int voff = col_ok ? o * 4 + kh * 4 * rb : 0x7ffffff0;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const int x = x0 + wm * TM * 32 + i * 32 + row;
-                if (x >= p.Tout) continue;
-                float v = acc[i][j][r] + bias;
-                if (p.bn) v = fast_bn ? ((v - mu) * rsd) * g + be : ((v - mu) / sd) * g + be;
-                v = nntk_act(p.act_kind, v, p.relu_a);
-                const size_t orow = p.out_mode ? ((size_t)x * p.B + b) : ((size_t)b * p.Tout + x);
-                p.out[orow * p.Cout + o] = v;
+                for (int r = 0; r < 16; ++r) {
+                    const int xs = x0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2);     // wave-uniform
+                    float v = acc[i][j][r] + bias;
+                    if (HAS_BN) {
+                        // (v - mu) / sd with the quotient refined by one FMA step: the correctly rounded
+                        // quotient without the 11-instruction IEEE division sequence
+                        const float d = v - mu;
+                        float qn = d * rsd;
+                        qn = fmaf(fmaf(-qn, sd, d), rsd, qn);
+                        v = p.bn_fast ? (d * rsd) * g + be : qn * g + be;
+                    }
+                    v = ACT == -1 ? nntk_act(p.act_kind, v, p.relu_a)
+                      : ACT == NNTK_ACT_RELU ? nntk_act(NNTK_ACT_RELU, v, p.relu_a)
+                      : v;
+                    if (FAST) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, voff, xs * rb, 0);
+                    } else {
+                        const int x = xs + 4 * kh;
+                        if (x < p.Tout && col_ok) {
+                            const size_t orow = p.out_mode ? ((size_t)x * p.B + b) : ((size_t)b * p.Tout + x);
+                            p.out[orow * p.Cout + o] = v;
+                        }
+                    }
+                }
             }
         }
+    };
+    using T_ = std::true_type; using F_ = std::false_type;
+    using AId = std::integral_constant<int, NNTK_ACT_IDENTITY>;
+    using ARelu = std::integral_constant<int, NNTK_ACT_RELU>;
+    using AAny = std::integral_constant<int, -1>;
+    if (CONV_DBG(1) && acc[0][0][0] != 12345.678f) {
+    } else if (fast_store) {
+        if (!p.bn && p.act_kind == NNTK_ACT_IDENTITY) epilogue(F_{}, AId{}, T_{});
+        else if (p.bn && p.act_kind == NNTK_ACT_RELU) epilogue(T_{}, ARelu{}, T_{});
+        else if (p.bn)                                epilogue(T_{}, AAny{}, T_{});
+        else                                          epilogue(F_{}, AAny{}, T_{});
+    } else {
+        if (p.bn) epilogue(T_{}, AAny{}, F_{});
+        else      epilogue(F_{}, AAny{}, F_{});
     }
 }
 
@@ -241,7 +343,7 @@ __global__ __launch_bounds__(256) void conv1d_valu_kernel(ConvParams p) {
         for (int i = 0; i < p.Cin; ++i) {
             float dot = 0.0f;
             for (int kk = 0; kk < p.k; ++kk)
-                dot += in_b[(size_t)kk * p.Cin + i] * p.wp[(size_t)(kk * p.Cin_p + i) * p.Cout_p + o];
+                dot += in_b[(size_t)kk * p.Cin + i] * p.wp[(size_t)o * p.k * p.Cin_p + (size_t)kk * p.Cin_p + i];
             result += dot;
         }
         if (p.bias) result += p.bias[o];
@@ -255,37 +357,26 @@ __global__ __launch_bounds__(256) void conv1d_valu_kernel(ConvParams p) {
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool A4, int KC>
-static int launch_mfma_kc(const ConvParams &p) {
+template <int WM, int WN, int TM, int TN, bool A4>
+static int launch_mfma(const ConvParams &p) {
     constexpr int BN = WN * TN * 32;
-    size_t lds = (size_t)(2 * p.rows_a * (KC + 1) + 2 * KC * BN) * sizeof(float);
+    // 41 KB at BN = 128: three workgroups per CU, which is what hides the barrier / staging latency
+    size_t lds = (size_t)(2 * p.rows_a * CONV_LS + 2 * BN * CONV_LS) * sizeof(float);
     ConvParams q = p;
     q.m_tiles = p.B * p.tiles_per_seq;
     q.n_tiles = p.Cout_p / BN;
     const long blocks = (long)((q.m_tiles + 7) / 8) * 8 * q.n_tiles;
     if ((long)p.B * p.tiles_per_seq > 0x7fffffffL / 8 || blocks > 0x7fffffffL)
         return nntk_fail_msg("conv1d: too many tiles for one launch");
-    dim3 grid((unsigned)blocks);
-    auto kern = conv1d_mfma_kernel<WM, WN, TM, TN, A4, KC>;
+    auto kern = conv1d_mfma_kernel<WM, WN, TM, TN, A4>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return nntk_fail("hipFuncSetAttribute(conv1d)", e);
     }
+    dim3 grid((unsigned)blocks);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, nntk_stream(), q);
     NNTK_LAUNCH_CHECK("conv1d_mfma_kernel");
     return 0;
-}
-
-template <int WM, int WN, int TM, int TN, bool A4>
-static int launch_mfma(const ConvParams &p) {
-    const char *e = getenv("NNTK_CONV_KC");
-    // Chunk depth 16 halves the LDS footprint (33 KB at BN = 128): 3 workgroups per CU instead of
-    // 2, which is what hides the barrier / staging latency.  Measured vs depth 32: config 3
-    // 0.79 -> 0.62 ms, LSTM input projection 3.6 -> 2.6 ms, TDD 5.08 -> 4.67 ms.  NNTK_CONV_KC=32 restores it.
-    if constexpr (WN * TN * 32 >= 64) {
-        if (!(e && e[0] == '3')) return launch_mfma_kc<WM, WN, TM, TN, A4, 16>(p);
-    }
-    return launch_mfma_kc<WM, WN, TM, TN, A4, 32>(p);
 }
 
 extern "C" int nntk_shim_conv1d(const float *d_in, const float *d_wp, const float *d_bias, const float *d_bn,
@@ -304,6 +395,9 @@ extern "C" int nntk_shim_conv1d(const float *d_in, const float *d_wp, const floa
     p.out_mode = out_mode;
     p.rows_a = (CONV_BM - 1) * stride + k;
     { const char *e = getenv("NNTK_BN_FAST"); p.bn_fast = (e && e[0] == '1') ? 1 : 0; }
+#ifdef NNTK_CONV_DBG
+    { const char *e = getenv("NNTK_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }
+#endif
 
     const bool window_fits = p.rows_a <= 192;                          // register staging budget (A_PT)
     const long Kdim = (long)Cin * k;
@@ -316,8 +410,6 @@ extern "C" int nntk_shim_conv1d(const float *d_in, const float *d_wp, const floa
         return 0;
     }
     const bool a4 = (Cin % 4 == 0) && ((size_t)d_in % 16 == 0);
-    { const char *e = getenv("NNTK_CONV_LOWLDS");
-      if (e && e[0] == '1' && a4 && p.Cout_p % 64 == 0 && k == 1) return launch_mfma_kc<4, 1, 1, 2, true, 8>(p); }
     if (p.Cout_p % 128 == 0) return a4 ? launch_mfma<2, 2, 2, 2, true>(p) : launch_mfma<2, 2, 2, 2, false>(p);
     if (p.Cout_p % 64 == 0)  return a4 ? launch_mfma<4, 1, 1, 2, true>(p) : launch_mfma<4, 1, 1, 2, false>(p);
     return a4 ? launch_mfma<4, 1, 1, 1, true>(p) : launch_mfma<4, 1, 1, 1, false>(p);

@@ -52,7 +52,7 @@ int   nntk_shim_memset(void *d_ptr, int value, size_t bytes);             /* asy
 /* ---- K2/K3: implicit-GEMM conv1d / dense on f32 MFMA with fused epilogue ----
  * out[b, x, o] = act( bn( bias[o] + sum_{kk,i} in[b, x*stride+kk, i] * Wp[(kk*Cin_p + i), o] ) )
  *   d_in   [B, T, Cin]           channels-last
- *   d_wp   packed weights [k*Cin_p, Cout_p] (see nntk_shim_conv_pack_sizes)
+ *   d_wp   packed weights [Cout_p][k*Cin_p], K-contiguous, zero padded (see nntk_shim_conv_pack_sizes)
  *   d_bias [Cout]
  *   d_bn   NULL or 4*Cout floats: gamma | beta | mean | variance (batch_norm.c:79-84 order)
  *   out_mode 0: out[b, x, :] at row b*Tout + x;  1: time-major row x*B + b (for recurrent input projections)

@@ -379,7 +379,9 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int w8 = tid >> 6;                      // wavefront 0..7
+    // wavefront 0..7, as a SCALAR: everything derived from it (slab, split-K half, buffer soffsets) stays
+    // in SGPRs -- with a VGPR-derived index hipcc wrapped each of the 16 h loads in a waterfall loop
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     // 8 wavefronts = 4 batch slabs of 16 rows x 2 split-K halves.  (A variant in which every
     // slab was its own sync domain with per-wave polling was measured 40 % SLOWER: polling
     // traffic from 2048 waves outweighed the overlap -- one poller per workgroup it is.)
@@ -509,11 +511,17 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
         // token: half 0 multiplies step t after half 1 has finished the gates of step t-1, half 1 after half 0's of step t
         if (PP) recp_lds_wait_ge(&syncw[4 + (1 - half)], 4u * (unsigned)(t + half));
         REC_STAMP(2);
-        // U^T fragments: software-pipelined one chunk ahead of the MFMAs that use them
-        const float *ubase = &Us[l15 * US + grp * 16 + q * 4];
+        // U^T fragments: software-pipelined one chunk ahead of the MFMAs that use them.  (Pinning that
+        // order with sched_barrier cost 12 %, a sched_group_barrier interleave serialised the gates'
+        // accumulators: the scheduler's own placement is the best measured.)
+        // two base addresses so that every fragment read is base + immediate (ds offsets stop at 64 KB)
+        const int uoff01 = l15 * US + grp * 16 + q * 4;
+        int uoff23 = uoff01 + 2 * 16 * US;
+        asm volatile("" : "+v"(uoff23));        // opaque: otherwise hipcc folds it back into uoff01 + (too large an) immediate
+#define REC_UFRAG(g, ch) (*reinterpret_cast<const float4 *>(&Us[((g) < 2 ? uoff01 + (g) * 16 * US : uoff23 + ((g) - 2) * 16 * US) + (ch) * REC_KC]))
         float4 un[G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) un[g] = *reinterpret_cast<const float4 *>(ubase + g * 16 * US);
+        for (int g = 0; g < G; ++g) un[g] = REC_UFRAG(g, 0);
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             float4 uc[G];
@@ -521,8 +529,10 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
             for (int g = 0; g < G; ++g) uc[g] = un[g];
             if (ch + 1 < NCH) {
 #pragma unroll
-                for (int g = 0; g < G; ++g) un[g] = *reinterpret_cast<const float4 *>(ubase + g * 16 * US + (ch + 1) * REC_KC);
+                for (int g = 0; g < G; ++g) un[g] = REC_UFRAG(g, ch + 1);
             }
+            // keep the next chunk's LDS reads ABOVE this chunk's 4 G MFMAs: left alone, the scheduler
+            // sinks each read to just before its first use and every chunk eats the LDS latency
             const float hv[4] = {__uint_as_float(hreg[ch].x), __uint_as_float(hreg[ch].y),
                                  __uint_as_float(hreg[ch].z), __uint_as_float(hreg[ch].w)};
 #pragma unroll

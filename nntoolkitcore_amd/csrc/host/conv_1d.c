@@ -59,7 +59,7 @@ void Conv1dDestroy(Conv1d filter) {
     free(filter);
 }
 
-/* W [Cout][Cin][k] (conv_1d.c:129-139 indexing) -> Wp [(kk*Cin_p + i), Cout_p] */
+/* W [Cout][Cin][k] (conv_1d.c:129-139 indexing) -> Wp [Cout_p][kk*Cin_p + i] (K-contiguous, zero padded) */
 static int conv_upload(Conv1d f) {
     const Conv1dConfig *c = &f->config;
     int Cin = c->input_feature_channels, Cout = c->output_feature_channels, k = c->kernel_size;
@@ -72,7 +72,7 @@ static int conv_upload(Conv1d f) {
     for (int o = 0; o < Cout; ++o)
         for (int i = 0; i < Cin; ++i)
             for (int kk = 0; kk < k; ++kk)
-                tmp[((size_t)kk * Cin_p + i) * Cout_p + o] = W[((size_t)o * Cin + i) * k + kk];
+                tmp[((size_t)o * k + kk) * Cin_p + i] = W[((size_t)o * Cin + i) * k + kk];
     int rc = nntk_upload_floats(&f->d_wp, tmp, n);
     free(tmp);
     if (rc) return rc;

@@ -35,7 +35,7 @@ void   nntk_devbuf_free(nntk_devbuf *b);
 /* upload a host array into a fresh/reused device buffer */
 int nntk_upload_floats(float **d_dst, const float *h_src, size_t n);
 
-/* pack a row-major [K, N] matrix into the conv/GEMM kernel's [K_p, N_p] layout and upload */
+/* pack a row-major [K, N] matrix into the conv/GEMM kernel's [N_p][K_p] (K-contiguous) layout and upload */
 int nntk_upload_gemm_weights(float **d_wp, const float *W, int K, int N);
 
 struct ActivationFunctionStruct {

@@ -86,7 +86,8 @@ int nntk_upload_gemm_weights(float **d_wp, const float *W, int K, int N) {
     size_t n = (size_t)K_p * N_p;
     float *tmp = (float *)calloc(n, sizeof(float));
     if (!tmp) NNTK_FAIL("out of host memory while packing weights");
-    for (int k = 0; k < K; ++k) memcpy(tmp + (size_t)k * N_p, W + (size_t)k * N, (size_t)N * sizeof(float));
+    for (int k = 0; k < K; ++k)                 /* [K, N] row-major -> [N_p][K_p], K-contiguous */
+        for (int j = 0; j < N; ++j) tmp[(size_t)j * K_p + k] = W[(size_t)k * N + j];
     int rc = nntk_upload_floats(d_wp, tmp, n);
     free(tmp);
     return rc;

@@ -49,6 +49,87 @@ __global__ __launch_bounds__(512) void coissue(float *sink, unsigned long long *
     if (r == 1234.5678f) sink[threadIdx.x] = r;
 }
 
+// one wave per SIMD pair... every wave: K MFMAs (32x32x2, 64 cycles each), each followed by NV independent VALU ops
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int NV, bool LDS>
+__global__ __launch_bounds__(256) void intrawave(float *sink, unsigned long long *cyc, int iters) {
+    __shared__ float lds[4096];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = i;
+    __syncthreads();
+    f32x16 a0, a1;
+    for (int r = 0; r < 16; ++r) { a0[r] = 0; a1[r] = 0; }
+    float x = lane * 0.001f, y = 1.0f + lane * 0.002f;
+    float v[8];
+    for (int k = 0; k < 8; ++k) v[k] = lane * 0.1f + k;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) v[(u + k) & 7] = __builtin_fmaf(v[(u + k) & 7], 1.0001f, 0.5f);
+            if (LDS) x += lds[(lane + u * 64 + i) & 4095];
+            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) v[(u + k + 4) & 7] = __builtin_fmaf(v[(u + k + 4) & 7], 0.9999f, 0.25f);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && blockIdx.x == 0) cyc[w] = t1 - t0;
+    float r = a0[0] + a1[5];
+    for (int k = 0; k < 8; ++k) r += v[k];
+    if (r == 1234.5678f) sink[threadIdx.x] = r;
+}
+// each 32x32x2 MFMA followed by ND independent ds_read_b128 (results never consumed) and NG global loads
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int ND, int NG>
+__global__ __launch_bounds__(256) void intrawave_mem(float *sink, unsigned long long *cyc, const float *gsrc, int iters) {
+    __shared__ __attribute__((aligned(16))) float lds[8192];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 8192; i += 256) lds[i] = i;
+    __syncthreads();
+    f32x16 a0, a1;
+    for (int r = 0; r < 16; ++r) { a0[r] = 0; a1[r] = 0; }
+    float x = lane * 0.001f, y = 1.0f + lane * 0.002f;
+    const unsigned laddr = (unsigned)(size_t)(lds) + (threadIdx.x & 255) * 16;
+    const float *gp = gsrc + (blockIdx.x * 256 + threadIdx.x) * 4;
+    f32x4v t0v, t1v;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < ND; ++k) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t0v) : "v"(laddr), "n"(k * 4096));
+#pragma unroll
+            for (int k = 0; k < NG; ++k) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(t1v) : "v"(gp));
+            if (ND + NG > 0 && (u & 3) == 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && blockIdx.x == 0) cyc[w] = t1 - t0;
+    float r = a0[0] + a1[5];
+    if (r == 1234.5678f) sink[threadIdx.x] = r + t0v[0] + t1v[0];
+}
+template <int ND, int NG>
+static void run_mem(const char *name, float *sink, unsigned long long *d_cyc, const float *gsrc) {
+    unsigned long long h[8];
+    intrawave_mem<ND, NG><<<256, 256>>>(sink, d_cyc, gsrc, 200);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(h, d_cyc, 64, hipMemcpyDeviceToHost);
+    printf("%-60s %7llu cycles  (MFMA alone = %d)\n", name, h[0], 200 * 16 * 64);
+}
+
+template <int NV, bool LDS>
+static void run_intra(const char *name, float *sink, unsigned long long *d_cyc) {
+    unsigned long long h[8];
+    intrawave<NV, LDS><<<256, 256>>>(sink, d_cyc, 200);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(h, d_cyc, 64, hipMemcpyDeviceToHost);
+    printf("%-60s %7llu cycles  (MFMA alone = %d)\n", name, h[0], 200 * 16 * 64);
+}
+
 template <int MODE, int PRIO>
 static void run(const char *name, float *sink, unsigned long long *d_cyc) {
     unsigned long long h[8];
@@ -69,5 +150,15 @@ int main() {
     run<0, 1>("MFMA (0-3) prio0 + VALU (4-7) prio3", sink, cyc);
     run<3, 0>("VALU (0-3) + MFMA (4-7)", sink, cyc);
     run<3, 1>("VALU (0-3) prio3 + MFMA (4-7) prio0", sink, cyc);
+    run_intra<0, false>("1 wave/SIMD: 32x32x2 MFMAs only", sink, cyc);
+    run_intra<2, false>("1 wave/SIMD: each MFMA + 2 independent v_fma", sink, cyc);
+    run_intra<4, false>("1 wave/SIMD: each MFMA + 4 independent v_fma", sink, cyc);
+    run_intra<8, false>("1 wave/SIMD: each MFMA + 8 independent v_fma", sink, cyc);
+    float *gsrc; (void)hipMalloc(&gsrc, 256 * 256 * 16); (void)hipMemset(gsrc, 0, 256 * 256 * 16);
+    run_mem<0, 0>("1 wave/SIMD: 3200 MFMAs (asm harness)", sink, cyc, gsrc);
+    run_mem<1, 0>("1 wave/SIMD: each MFMA + 1 ds_read_b128", sink, cyc, gsrc);
+    run_mem<2, 0>("1 wave/SIMD: each MFMA + 2 ds_read_b128", sink, cyc, gsrc);
+    run_mem<0, 1>("1 wave/SIMD: each MFMA + 1 global_load_dwordx4", sink, cyc, gsrc);
+    run_mem<1, 1>("1 wave/SIMD: each MFMA + 1 ds_read_b128 + 1 global load", sink, cyc, gsrc);
     return 0;
 }
