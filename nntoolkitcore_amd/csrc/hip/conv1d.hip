@@ -49,7 +49,8 @@ extern "C" void nntk_shim_conv_pack_sizes(int Cin, int Cout, int k, int *Cin_p, 
 }
 
 struct ConvParams {
-    const float *in;     // [B, T, Cin]
+    const float *in;     // [B, T, Cin]: row t of sequence b at in + b * in_seq + t * in_row
+    long in_seq, in_row; // element strides (T * Cin, Cin for the plain layout)
     const float *wp;     // [Cout_p][k * Cin_p]   (K-contiguous)
     const float *bias;   // [Cout]
     const float *bn;     // NULL or gamma|beta|mean|var, each [Cout]
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
     v4u32_t wreg[W_PT];
     int a_voff[A_PT], w_voff[W_PT];
 #pragma unroll
-    for (int q = 0; q < A_PT; ++q) a_voff[q] = ((ar + q * AR_STEP) * p.Cin + ac) * 4;
+    for (int q = 0; q < A_PT; ++q) a_voff[q] = (int)(((long)(ar + q * AR_STEP) * p.in_row + ac) * 4);
 #pragma unroll
     for (int q = 0; q < W_PT; ++q) w_voff[q] = ((wr + q * 64) * Ktot + wc4 * 4) * 4;
     const bool cin_ragged = (p.Cin % KC) != 0;       // the last channel chunk runs past the row: mask it
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
     // its chunks -- except the ragged last chunk, whose out-of-row lanes get an out-of-range offset.
     const size_t in_total = (size_t)p.B * p.T * p.Cin;
     auto load_a = [&](int tb, int tx0, int cc) {
-        const size_t in_off = ((size_t)tb * p.T + (size_t)tx0 * p.stride) * p.Cin;
+        const size_t in_off = (size_t)tb * p.in_seq + (size_t)tx0 * p.stride * p.in_row;
         const __amdgpu_buffer_rsrc_t rs_in = conv_rsrc(p.in + in_off, (in_total - in_off) * 4);
         const int soff = cc * KC * 4;
         if (cin_ragged && cc == n_cchunks - 1) {     // uniform branch, last chunk only
@@ -390,6 +391,7 @@ extern "C" int nntk_shim_conv1d(const float *d_in, const float *d_wp, const floa
     p.in = d_in; p.wp = d_wp; p.bias = d_bias; p.bn = d_bn; p.out = d_out;
     p.bn_eps = bn_eps; p.relu_a = relu_a; p.act_kind = act_kind;
     p.B = B; p.T = T; p.Cin = Cin; p.Cout = Cout; p.k = k; p.stride = stride; p.Tout = Tout;
+    p.in_seq = (long)T * Cin; p.in_row = Cin;
     nntk_shim_conv_pack_sizes(Cin, Cout, k, &p.Cin_p, &p.Cout_p);
     p.tiles_per_seq = (Tout + CONV_BM - 1) / CONV_BM;
     p.out_mode = out_mode;
@@ -410,6 +412,19 @@ extern "C" int nntk_shim_conv1d(const float *d_in, const float *d_wp, const floa
         return 0;
     }
     const bool a4 = (Cin % 4 == 0) && ((size_t)d_in % 16 == 0);
+    // Time-major output of a dense GEMM (the recurrent input projection): tile over the BATCH at a
+    // fixed timestep instead of over time within a sequence.  A tile then writes 128 rows of one
+    // [B, Cout] slab (8 KB apart for LSTM-512) instead of 128 rows that are B * Cout * 4 bytes = 4 MB
+    // apart; its input rows become the strided side (T * Cin apart, each still Cin contiguous floats).
+    // Same arithmetic per output element, so the results are bit-identical.
+    const char *tme = getenv("NNTK_GEMM_TM_BATCH");
+    if (out_mode == 1 && k == 1 && stride == 1 && !(tme && tme[0] == '0') &&
+        (long)(CONV_BM + 64) * T * Cin * 4 < 0x7fffffffL) {
+        p.B = T; p.T = B; p.Tout = B;                 // "sequences" = timesteps, "rows" = batch entries
+        p.in_seq = Cin; p.in_row = (long)T * Cin;
+        p.out_mode = 0;                               // row (t, b) -> t * B + b: exactly the time-major layout
+        p.tiles_per_seq = (p.Tout + CONV_BM - 1) / CONV_BM;
+    }
     if (p.Cout_p % 128 == 0) return a4 ? launch_mfma<2, 2, 2, 2, true>(p) : launch_mfma<2, 2, 2, 2, false>(p);
     if (p.Cout_p % 64 == 0)  return a4 ? launch_mfma<4, 1, 1, 2, true>(p) : launch_mfma<4, 1, 1, 2, false>(p);
     return a4 ? launch_mfma<4, 1, 1, 1, true>(p) : launch_mfma<4, 1, 1, 1, false>(p);
