@@ -151,6 +151,34 @@ LSTM LSTMCreateForInference(LSTMConfig config);
 int  LSTMApplyInference(LSTM filter, const float *input, float *output); /* host, one sequence, STATEFUL */
 void LSTMDestroy(LSTM filter);
 
+/* ---- nntoolkitcore/layers/rnn.h:15-52 ------------ */
+/* One-gate recurrent cell (rnn.c:144-166): h' = act((x W + b_i) + (h U [+ b_h if v2])).
+ * W [in,out], U [out,out], b_i [out], b_h [out] in one block (rnn.c:36-46). */
+typedef RecurrentWeights RNNWeights;
+typedef struct { RecurrentConfig base; bool v2; ActivationFunction activation; } RNNConfig;
+typedef struct RNNStruct *RNN;
+
+RNNConfig RNNConfigCreate(int input_feature_channels, int output_feature_channels, bool return_sequences,
+                          int timesteps, bool v2, ActivationFunction activation);
+RNNWeights *RNNGetWeights(RNN filter);
+RNN  RNNCreateForInference(RNNConfig config);
+/* host, one sequence, STATEFUL: T cells from the handle's h, output [T,out] or the last [out].  The
+ * reference's loop (rnn.c:228-247) addresses its output at i * (i * out) and reloads h from the wrong row;
+ * this is the layer its own batch forward pass (rnn.c:249-291) computes, not that indexing slip. */
+int  RNNApplyInference(RNN filter, const float *input, float *output);
+void RNNDestroy(RNN filter);
+
+/* ---- nntoolkitcore/layers/bidirectional.h:15-46 (forward helpers) ------- */
+/* host pointers, like the reference; the *_device forms below take device pointers */
+void bd_reverse_input_batch(const float *input, float *output, RecurrentConfig config, int batch);    /* [B,T,in]  rows in reverse time order */
+void bd_reverse_backward_batch(const float *input, float *output, RecurrentConfig config, int batch); /* [B,T,out] likewise */
+int  bd_merge_concat_buffer_size(RecurrentConfig config);
+/* output [B, rows, 2*out] = forward row | backward row (rows = timesteps if return_sequences else 1); buffer unused */
+void bd_merge_concat(const float *forward_result, const float *backward_result, float *output,
+                     RecurrentConfig config, int batch, float *buffer);
+void bd_merge_sum(const float *forward_result, const float *backward_result, float *output,
+                  RecurrentConfig config, int batch);
+
 /* ---- nntoolkitcore/layers/dense.h:21-55 -------------------------------- */
 typedef DefaultWeights DenseWeights;
 typedef struct { int input_size; int output_size; ActivationFunction activation; } DenseConfig;
@@ -255,6 +283,7 @@ int Conv1dSyncWeights(Conv1d filter);
 int BatchNormSyncWeights(BatchNorm filter);
 int GRUSyncWeights(GRU filter);
 int LSTMSyncWeights(LSTM filter);
+int RNNSyncWeights(RNN filter);
 int DenseSyncWeights(Dense filter);
 int TimeDistributedDenseSyncWeights(TimeDistributedDense filter);
 
@@ -265,6 +294,7 @@ int TimeDistributedDenseSyncWeights(TimeDistributedDense filter);
 int Conv1dApplyInferenceBatch(Conv1d filter, const float *input, float *output, int batch);
 int GRUApplyInferenceBatch(GRU filter, const float *input, float *output, int batch);
 int LSTMApplyInferenceBatch(LSTM filter, const float *input, float *output, int batch);
+int RNNApplyInferenceBatch(RNN filter, const float *input, float *output, int batch);   /* rnn.c:249-291 forward */
 int TimeDistributedDenseApplyInferenceBatch(TimeDistributedDense filter, const float *input, float *output, int batch);
 int SpectrogramApplyBatch(Spectrogram filter, const float *input, float *output, int batch);
 int LogMelSpectrogramApplyBatch(LogMelSpectrogram filter, const float *input, float *output, int batch);
@@ -286,13 +316,20 @@ int BatchNormApplyDevice(BatchNorm filter, const float *d_input, float *d_output
 int ActivationFunctionApplyDevice(ActivationFunction filter, const float *d_input, float *d_output, int size);
 int GRUApplyDevice(GRU filter, const float *d_input /*[batch,T,in]*/, float *d_output, int batch);
 int LSTMApplyDevice(LSTM filter, const float *d_input /*[batch,T,in]*/, float *d_output, int batch);
+int RNNApplyDevice(RNN filter, const float *d_input /*[batch,T,in]*/, float *d_output, int batch);
+int bd_reverse_input_batch_device(const float *d_input, float *d_output, RecurrentConfig config, int batch);
+int bd_reverse_backward_batch_device(const float *d_input, float *d_output, RecurrentConfig config, int batch);
+int bd_merge_concat_device(const float *d_forward, const float *d_backward, float *d_output, RecurrentConfig config, int batch);
+int bd_merge_sum_device(const float *d_forward, const float *d_backward, float *d_output, RecurrentConfig config, int batch);
 int DenseApplyDevice(Dense filter, const float *d_input /*[rows,in]*/, float *d_output /*[rows,out]*/, int rows);
 int TimeDistributedDenseApplyDevice(TimeDistributedDense filter, const float *d_input, float *d_output, int batch);
 
 /* recurrent state of the stateful single-sequence API (gru.c:201, lstm.c:264-265) */
 int GRUResetState(GRU filter);
 int LSTMResetState(LSTM filter);
+int RNNResetState(RNN filter);
 int GRUGetState(GRU filter, float *h_host);
+int RNNGetState(RNN filter, float *h_host);
 int LSTMGetState(LSTM filter, float *h_host, float *c_host);
 
 #ifdef __cplusplus

@@ -59,6 +59,10 @@ class LSTMConfig(C.Structure):
     _fields_ = [("base", RecurrentConfig), ("v2", C.c_bool), ("activations", LSTMActivations)]
 
 
+class RNNConfig(C.Structure):
+    _fields_ = [("base", RecurrentConfig), ("v2", C.c_bool), ("activation", C.c_void_p)]
+
+
 class DenseConfig(C.Structure):
     _fields_ = [("input_size", C.c_int), ("output_size", C.c_int), ("activation", vp)]
 
@@ -114,6 +118,18 @@ SIGNATURES = {
     "GRUCreateForInference": (vp, [GRUConfig]),
     "GRUApplyInference": (C.c_int, [vp, fp, fp]),
     "GRUDestroy": (None, [vp]),
+    # rnn.h
+    "RNNConfigCreate": (RNNConfig, [C.c_int, C.c_int, C.c_bool, C.c_int, C.c_bool, vp]),
+    "RNNGetWeights": (C.POINTER(RecurrentWeights), [vp]),
+    "RNNCreateForInference": (vp, [RNNConfig]),
+    "RNNApplyInference": (C.c_int, [vp, fp, fp]),
+    "RNNDestroy": (None, [vp]),
+    # bidirectional.h (forward helpers)
+    "bd_reverse_input_batch": (None, [fp, fp, RecurrentConfig, C.c_int]),
+    "bd_reverse_backward_batch": (None, [fp, fp, RecurrentConfig, C.c_int]),
+    "bd_merge_concat_buffer_size": (C.c_int, [RecurrentConfig]),
+    "bd_merge_concat": (None, [fp, fp, fp, RecurrentConfig, C.c_int, fp]),
+    "bd_merge_sum": (None, [fp, fp, fp, RecurrentConfig, C.c_int]),
     # lstm.h
     "LSTMActivationsCreate": (LSTMActivations, [vp] * 5),
     "LSTMActivationsCreateDefault": (LSTMActivations, [C.c_int]),
@@ -175,11 +191,13 @@ SIGNATURES = {
     "BatchNormSyncWeights": (C.c_int, [vp]),
     "GRUSyncWeights": (C.c_int, [vp]),
     "LSTMSyncWeights": (C.c_int, [vp]),
+    "RNNSyncWeights": (C.c_int, [vp]),
     "DenseSyncWeights": (C.c_int, [vp]),
     "TimeDistributedDenseSyncWeights": (C.c_int, [vp]),
     "Conv1dApplyInferenceBatch": (C.c_int, [vp, fp, fp, C.c_int]),
     "GRUApplyInferenceBatch": (C.c_int, [vp, fp, fp, C.c_int]),
     "LSTMApplyInferenceBatch": (C.c_int, [vp, fp, fp, C.c_int]),
+    "RNNApplyInferenceBatch": (C.c_int, [vp, fp, fp, C.c_int]),
     "TimeDistributedDenseApplyInferenceBatch": (C.c_int, [vp, fp, fp, C.c_int]),
     "SpectrogramApplyBatch": (C.c_int, [vp, fp, fp, C.c_int]),
     "LogMelSpectrogramApplyBatch": (C.c_int, [vp, fp, fp, C.c_int]),
@@ -192,10 +210,17 @@ SIGNATURES = {
     "ActivationFunctionApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
     "GRUApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
     "LSTMApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
+    "RNNApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
+    "bd_reverse_input_batch_device": (C.c_int, [vp, vp, RecurrentConfig, C.c_int]),
+    "bd_reverse_backward_batch_device": (C.c_int, [vp, vp, RecurrentConfig, C.c_int]),
+    "bd_merge_concat_device": (C.c_int, [vp, vp, vp, RecurrentConfig, C.c_int]),
+    "bd_merge_sum_device": (C.c_int, [vp, vp, vp, RecurrentConfig, C.c_int]),
     "DenseApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
     "TimeDistributedDenseApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
     "GRUResetState": (C.c_int, [vp]),
     "LSTMResetState": (C.c_int, [vp]),
+    "RNNResetState": (C.c_int, [vp]),
+    "RNNGetState": (C.c_int, [vp, fp]),
     "GRUGetState": (C.c_int, [vp, fp]),
     "LSTMGetState": (C.c_int, [vp, fp, fp]),
 }

@@ -69,6 +69,12 @@ int nntk_shim_batch_norm(const float *d_in, const float *d_bn /*gamma|beta|mean|
 int nntk_shim_activation(int kind, float relu_a, int softmax_vector_size,
                          const float *d_in, float *d_out, long n_elems);
 
+/* ---- bidirectional helpers (layers/bidirectional.c): rows of [B, T, F] in reverse time order; row-wise
+ *      concatenation [rows, C] | [rows, C] -> [rows, 2C]; elementwise sum */
+int nntk_shim_reverse_time(const float *d_in, float *d_out, long B, int T, int F);
+int nntk_shim_concat2(const float *d_a, const float *d_b, float *d_out, long rows, int C);
+int nntk_shim_add2(const float *d_a, const float *d_b, float *d_out, long n);
+
 /* ---- K4: recurrent layers -------------------------------------------------
  * d_xw   [T, B, G*H] time-major input projections INCLUDING b_i (from nntk_shim_conv1d out_mode 1)
  * d_ut   packed recurrent weights U^T: [G*H, H] (row n = column n of U)
@@ -79,6 +85,10 @@ int nntk_shim_activation(int kind, float relu_a, int softmax_vector_size,
  * d_work scratch >= nntk_shim_recurrent_work_floats(B, H) floats
  * acts   GRU: {z, h, r};  LSTM: {i, f, g, o, out}
  */
+/* simple RNN cell (rnn.c:144-166): one gate, h' = act(xW + hU + b); same buffers as nntk_shim_gru */
+int nntk_shim_rnn(const float *d_xw, const float *d_ut, const float *d_bh, const float *d_h0,
+                  float *d_out, float *d_hT, float *d_work, int B, int T, int H,
+                  int return_sequences, int act);
 size_t nntk_shim_recurrent_work_floats(int B, int H);
 int nntk_shim_gru(const float *d_xw, const float *d_ut, const float *d_bh,
                   const float *d_h0, float *d_out, float *d_hT, float *d_work,

@@ -216,7 +216,10 @@ __global__ __launch_bounds__(256 * NG) void rec_step_kernel(RecParams p) {
         const int b = b0 + wave * 16 + q * 4 + grp * RPW + rr;
         if (b >= p.B) continue;
         float hn;
-        if (!IS_LSTM) {
+        if constexpr (G == 1) {
+            // rnn.c:144-166: gate = (h U [+ b_h]) + (x W + b_i); h' = act(gate)
+            hn = nntk_gate_act(p.a0, xwv[rr][0] + (fin[rr][0] + bh[0]));
+        } else if constexpr (!IS_LSTM) {
             // gru.c:144-186
             const float hz = fin[rr][0] + bh[0], hr = fin[rr][1] + bh[1], hh = fin[rr][2] + bh[2];
             const float z = nntk_gate_act(p.a0, xwv[rr][0] + hz);
@@ -362,7 +365,7 @@ __device__ __forceinline__ float4 load4_sc1(__amdgpu_buffer_rsrc_t rsrc, int sof
 //   cannot overlap the MFMAs -- loses its 10 scalar branch ladders.
 template <int G, bool IS_LSTM, int NCH, int XW, bool PP, bool STD>
 __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
-    const int A0 = STD ? NNTK_ACT_SIGMOID : p.a0;
+    const int A0 = STD ? (G == 1 ? NNTK_ACT_TANH : NNTK_ACT_SIGMOID) : p.a0;
     const int A1 = STD ? (IS_LSTM ? NNTK_ACT_SIGMOID : NNTK_ACT_TANH) : p.a1;
     const int A2 = STD ? (IS_LSTM ? NNTK_ACT_TANH : NNTK_ACT_SIGMOID) : p.a2;
     const int A3 = STD ? NNTK_ACT_SIGMOID : p.a3;
@@ -574,7 +577,9 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
         float hn[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            if (!IS_LSTM) {
+            if constexpr (G == 1) {
+                hn[e] = nntk_gate_act(A0, xwv[e][0] + (fin[e][0] + bh[e][0]));      // rnn.c:144-166
+            } else if constexpr (!IS_LSTM) {
                 const float hz = fin[e][0] + bh[e][0], hr = fin[e][1] + bh[e][1], hh = fin[e][2] + bh[e][2];
                 const float z = nntk_gate_act(A0, xwv[e][0] + hz);
                 const float rg = nntk_gate_act(A2, xwv[e][1] + hr);
@@ -724,7 +729,7 @@ static int run_recurrent(const float *d_xw, const float *d_ut, const float *d_bh
     p.B = B; p.H = H;
     p.Hj_p = (H + 15) & ~15;
     p.Hk_p = (H + 31) & ~31;
-    p.a0 = acts[0]; p.a1 = acts[1]; p.a2 = acts[2];
+    p.a0 = acts[0]; p.a1 = nacts > 1 ? acts[1] : 0; p.a2 = nacts > 2 ? acts[2] : 0;
     p.a3 = nacts > 3 ? acts[3] : 0; p.a4 = nacts > 4 ? acts[4] : 0;
     dim3 grid((unsigned)((B + REC_BM - 1) / REC_BM), (unsigned)(p.Hj_p / REC_HN));
     // ---- persistent path: one launch for the whole sequence when U^T fits in LDS ----
@@ -745,7 +750,8 @@ static int run_recurrent(const float *d_xw, const float *d_ut, const float *d_bh
             void (*kern)(RecPParams);
             const char *xenv = getenv("NNTK_REC_XW");
             int xwm = xenv ? atoi(xenv) : -1;
-const bool std_acts = IS_LSTM ? (p.a0 == NNTK_ACT_SIGMOID && p.a1 == NNTK_ACT_SIGMOID && p.a2 == NNTK_ACT_TANH &&
+const bool std_acts = G == 1 ? p.a0 == NNTK_ACT_TANH
+                                 : IS_LSTM ? (p.a0 == NNTK_ACT_SIGMOID && p.a1 == NNTK_ACT_SIGMOID && p.a2 == NNTK_ACT_TANH &&
                                               p.a3 == NNTK_ACT_SIGMOID && p.a4 == NNTK_ACT_TANH)
                                            : (p.a0 == NNTK_ACT_SIGMOID && p.a1 == NNTK_ACT_TANH && p.a2 == NNTK_ACT_SIGMOID);
             // ping-pong halves pay when the K loop is long (see the kernel's header); NNTK_REC_PINGPONG=0/1 overrides
@@ -849,6 +855,15 @@ extern "C" int nntk_shim_gru(const float *d_xw, const float *d_ut, const float *
     if (B <= 0 || T <= 0) return 0;
     return run_recurrent<3, false>(d_xw, d_ut, d_bh, d_h0, nullptr, d_out, d_hT, nullptr, d_work, B, T, H,
                                    return_sequences, acts, 3);
+}
+
+extern "C" int nntk_shim_rnn(const float *d_xw, const float *d_ut, const float *d_bh, const float *d_h0,
+                             float *d_out, float *d_hT, float *d_work, int B, int T, int H,
+                             int return_sequences, int act) {
+    if (B <= 0 || T <= 0) return 0;
+    const int acts[1] = {act};
+    return run_recurrent<1, false>(d_xw, d_ut, d_bh, d_h0, nullptr, d_out, d_hT, nullptr, d_work, B, T, H,
+                                   return_sequences, acts, 1);
 }
 
 extern "C" int nntk_shim_lstm(const float *d_xw, const float *d_ut, const float *d_bh, const float *d_h0,

@@ -212,6 +212,34 @@ __global__ __launch_bounds__(256) void softmax_kernel(const float *in, float *ou
     }
 }
 
+// Bidirectional helpers (layers/bidirectional.c): time reversal of [B, T, F] rows, and the two merges.
+// HBM-bound row copies; one thread per element, rows are contiguous so neighbouring lanes are too.
+__global__ __launch_bounds__(256) void reverse_time_kernel(const float *in, float *out, long B, int T, int F) {
+    const long total = B * (long)T * F;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int f = (int)(e % F);
+        const long bt = e / F;
+        const int t = (int)(bt % T);
+        const long b = bt / T;
+        out[e] = in[(b * T + (T - 1 - t)) * F + f];          // bidirectional.c:11-15
+    }
+}
+
+// out[r][0:C] = a[r][:], out[r][C:2C] = b[r][:]   (bd_merge_concat, bidirectional.c:40-56, without its transposes)
+__global__ __launch_bounds__(256) void concat2_kernel(const float *a, const float *b, float *out, long rows, int C) {
+    const long total = rows * 2L * C;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % (2 * C));
+        const long r = e / (2 * C);
+        out[e] = c < C ? a[r * C + c] : b[r * C + (c - C)];
+    }
+}
+
+__global__ __launch_bounds__(256) void add2_kernel(const float *a, const float *b, float *out, long n) {
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+        out[e] = a[e] + b[e];                                  // bd_merge_sum: op_vec_add (bidirectional.c:76-85)
+}
+
 static int grid_for(long work_items, int block) {
     long g = (work_items + block - 1) / block;
     if (g < 1) g = 1;
@@ -232,6 +260,28 @@ int nntk_shim_batch_norm(const float *d_in, const float *d_bn, float eps, float 
         hipLaunchKernelGGL(bn_kernel, dim3(grid_for(n, 256)), dim3(256), 0, nntk_stream(), d_in, d_bn, eps, d_out, n, C);
     }
     NNTK_LAUNCH_CHECK("bn_kernel");
+    return 0;
+}
+
+int nntk_shim_reverse_time(const float *d_in, float *d_out, long B, int T, int F) {
+    if (B <= 0 || T <= 0 || F <= 0) return 0;
+    if (d_in == d_out) return nntk_fail_msg("reverse_time: in-place reversal is not supported");
+    hipLaunchKernelGGL(reverse_time_kernel, dim3(grid_for(B * T * F, 256)), dim3(256), 0, nntk_stream(), d_in, d_out, B, T, F);
+    NNTK_LAUNCH_CHECK("reverse_time_kernel");
+    return 0;
+}
+
+int nntk_shim_concat2(const float *d_a, const float *d_b, float *d_out, long rows, int C) {
+    if (rows <= 0 || C <= 0) return 0;
+    hipLaunchKernelGGL(concat2_kernel, dim3(grid_for(rows * 2 * C, 256)), dim3(256), 0, nntk_stream(), d_a, d_b, d_out, rows, C);
+    NNTK_LAUNCH_CHECK("concat2_kernel");
+    return 0;
+}
+
+int nntk_shim_add2(const float *d_a, const float *d_b, float *d_out, long n) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(add2_kernel, dim3(grid_for(n, 256)), dim3(256), 0, nntk_stream(), d_a, d_b, d_out, n);
+    NNTK_LAUNCH_CHECK("add2_kernel");
     return 0;
 }
 

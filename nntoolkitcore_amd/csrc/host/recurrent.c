@@ -29,7 +29,7 @@ RecurrentConfig RecurrentConfigCreate(int input_feature_channels, int output_fea
 
 /* shared core of both layers */
 typedef struct {
-    int G;                      /* 3 (GRU) or 4 (LSTM) */
+    int G;                      /* 1 (RNN), 3 (GRU) or 4 (LSTM) */
     int in, H, T;
     bool return_sequences;
     RecurrentWeights *weights;
@@ -111,6 +111,9 @@ static int core_apply_device(rec_core *c, int is_lstm, int use_bh, const int *ac
                          B, T, c->in, G * H, 1, 1, T, 1))
         return -1;
     const float *bh = use_bh ? c->d_bh : NULL;
+    if (G == 1)
+        return nntk_shim_rnn(d_xw, c->d_ut, bh, stateful ? c->d_h : NULL, d_out, stateful ? c->d_h : NULL, d_work,
+                             B, T, H, c->return_sequences, acts[0]);
     if (is_lstm)
         return nntk_shim_lstm(d_xw, c->d_ut, bh, stateful ? c->d_h : NULL, stateful ? c->d_c : NULL, d_out,
                               stateful ? c->d_h : NULL, stateful ? c->d_c : NULL, d_work, B, T, H,
@@ -360,4 +363,152 @@ int LSTMGetState(LSTM filter, float *h_host, float *c_host) {
     if (h_host && nntk_shim_download(h_host, filter->core.d_h, (size_t)filter->core.H * sizeof(float))) return -1;
     if (c_host && nntk_shim_download(c_host, filter->core.d_c, (size_t)filter->core.H * sizeof(float))) return -1;
     return 0;
+}
+
+/* ================================= RNN ==================================== */
+/* layers/rnn.c forward.  One gate; the activation is the layer's single
+ * ActivationFunction (rnn.h:20-24), which must be one of the built-ins to run inside the step kernel. */
+
+struct RNNStruct {
+    RNNConfig config;
+    rec_core core;
+};
+
+/* rnn.c:48-61 */
+RNNConfig RNNConfigCreate(int input_feature_channels, int output_feature_channels, bool return_sequences,
+                          int timesteps, bool v2, ActivationFunction activation) {
+    RNNConfig c;
+    memset(&c, 0, sizeof(c));
+    c.base = RecurrentConfigCreate(input_feature_channels, output_feature_channels, return_sequences, timesteps);
+    c.v2 = v2;
+    c.activation = activation;
+    return c;
+}
+
+RNN RNNCreateForInference(RNNConfig config) {
+    nntk_shim_clear_error();
+    RNN f = (RNN)calloc(1, sizeof(struct RNNStruct));
+    if (!f) return NULL;
+    f->config = config;
+    if (core_init(&f->core, 1, config.base)) { free(f); return NULL; }
+    return f;
+}
+RNNWeights *RNNGetWeights(RNN filter) { return filter->core.weights; }
+void RNNDestroy(RNN filter) {
+    if (!filter) return;
+    core_free(&filter->core);   /* the activation stays with the caller, as in GRU/LSTM */
+    free(filter);
+}
+
+int RNNSyncWeights(RNN filter) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("RNNSyncWeights: NULL handle");
+    nntk_shim_synchronize();
+    return core_upload(&filter->core);
+}
+
+/* rnn.c:228-247 (intended semantics, see the header) */
+int RNNApplyInference(RNN filter, const float *input, float *output) {
+    nntk_shim_clear_error();
+    int act;
+    if (!filter) NNTK_FAIL("RNNApplyInference: NULL handle");
+    if (gate_kind(filter->config.activation, &act)) return -1;
+    return core_apply_host(&filter->core, 0, filter->config.v2, &act, input, output, 1, 1);
+}
+/* rnn.c:249-291 forward semantics */
+int RNNApplyInferenceBatch(RNN filter, const float *input, float *output, int batch) {
+    nntk_shim_clear_error();
+    int act;
+    if (!filter) NNTK_FAIL("RNNApplyInferenceBatch: NULL handle");
+    if (gate_kind(filter->config.activation, &act)) return -1;
+    return core_apply_host(&filter->core, 0, filter->config.v2, &act, input, output, batch, 0);
+}
+int RNNApplyDevice(RNN filter, const float *d_input, float *d_output, int batch) {
+    nntk_shim_clear_error();
+    int act;
+    if (!filter) NNTK_FAIL("RNNApplyDevice: NULL handle");
+    if (gate_kind(filter->config.activation, &act)) return -1;
+    if (core_ensure(&filter->core, 0)) return -1;
+    return core_apply_device(&filter->core, 0, filter->config.v2, &act, d_input, d_output, batch, 0);
+}
+int RNNResetState(RNN filter) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("RNNResetState: NULL handle");
+    return nntk_shim_memset(filter->core.d_h, 0, (size_t)filter->core.H * sizeof(float));
+}
+int RNNGetState(RNN filter, float *h_host) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("RNNGetState: NULL handle");
+    return nntk_shim_download(h_host, filter->core.d_h, (size_t)filter->core.H * sizeof(float));
+}
+
+/* ============================ bidirectional helpers ======================== */
+/* layers/bidirectional.c forward helpers.  The device forms are the product; the host-pointer forms keep the
+ * reference's signatures (void, caller-owned host buffers) and stage through device scratch. */
+
+static nntk_devbuf g_bd_a, g_bd_b, g_bd_out;
+
+int bd_reverse_input_batch_device(const float *d_input, float *d_output, RecurrentConfig config, int batch) {
+    nntk_shim_clear_error();
+    return nntk_shim_reverse_time(d_input, d_output, batch, config.timesteps, config.input_feature_channels);
+}
+int bd_reverse_backward_batch_device(const float *d_input, float *d_output, RecurrentConfig config, int batch) {
+    nntk_shim_clear_error();
+    return nntk_shim_reverse_time(d_input, d_output, batch, config.timesteps, config.output_feature_channels);
+}
+int bd_merge_concat_device(const float *d_forward, const float *d_backward, float *d_output, RecurrentConfig config, int batch) {
+    nntk_shim_clear_error();
+    long rows = (long)batch * (config.return_sequences ? config.timesteps : 1);
+    return nntk_shim_concat2(d_forward, d_backward, d_output, rows, config.output_feature_channels);
+}
+int bd_merge_sum_device(const float *d_forward, const float *d_backward, float *d_output, RecurrentConfig config, int batch) {
+    nntk_shim_clear_error();
+    long rows = (long)batch * (config.return_sequences ? config.timesteps : 1);
+    return nntk_shim_add2(d_forward, d_backward, d_output, rows * config.output_feature_channels);
+}
+
+static void bd_reverse_host(const float *input, float *output, int batch, int T, int F) {
+    nntk_shim_clear_error();
+    size_t n = (size_t)batch * T * F;
+    if (!n) return;
+    float *d_in = nntk_devbuf_reserve(&g_bd_a, n), *d_out = nntk_devbuf_reserve(&g_bd_out, n);
+    if (!d_in || !d_out) return;
+    if (nntk_shim_upload(d_in, input, n * sizeof(float))) return;
+    if (nntk_shim_reverse_time(d_in, d_out, batch, T, F)) return;
+    (void)nntk_shim_download(output, d_out, n * sizeof(float));
+}
+/* bidirectional.c:25-35 */
+void bd_reverse_input_batch(const float *input, float *output, RecurrentConfig config, int batch) {
+    bd_reverse_host(input, output, batch, config.timesteps, config.input_feature_channels);
+}
+void bd_reverse_backward_batch(const float *input, float *output, RecurrentConfig config, int batch) {
+    bd_reverse_host(input, output, batch, config.timesteps, config.output_feature_channels);
+}
+/* bidirectional.c:37-40 */
+int bd_merge_concat_buffer_size(RecurrentConfig config) {
+    int rows = config.return_sequences ? config.timesteps : 1;
+    return 2 * rows * config.output_feature_channels;
+}
+static void bd_merge_host(const float *fwd, const float *bwd, float *output, RecurrentConfig config, int batch, int concat) {
+    nntk_shim_clear_error();
+    size_t n = (size_t)batch * (config.return_sequences ? config.timesteps : 1) * config.output_feature_channels;
+    if (!n) return;
+    float *d_a = nntk_devbuf_reserve(&g_bd_a, n), *d_b = nntk_devbuf_reserve(&g_bd_b, n);
+    float *d_out = nntk_devbuf_reserve(&g_bd_out, concat ? 2 * n : n);
+    if (!d_a || !d_b || !d_out) return;
+    if (nntk_shim_upload(d_a, fwd, n * sizeof(float)) || nntk_shim_upload(d_b, bwd, n * sizeof(float))) return;
+    int rc = concat ? bd_merge_concat_device(d_a, d_b, d_out, config, batch) : bd_merge_sum_device(d_a, d_b, d_out, config, batch);
+    if (rc) return;
+    (void)nntk_shim_download(output, d_out, (concat ? 2 * n : n) * sizeof(float));
+}
+/* bidirectional.c:42-58: per sequence, [rows, out] | [rows, out] -> [rows, 2*out] (the reference does it with three transposes) */
+void bd_merge_concat(const float *forward_result, const float *backward_result, float *output,
+                     RecurrentConfig config, int batch, float *buffer) {
+    (void)buffer;
+    bd_merge_host(forward_result, backward_result, output, config, batch, 1);
+}
+/* bidirectional.c:76-85 */
+void bd_merge_sum(const float *forward_result, const float *backward_result, float *output,
+                  RecurrentConfig config, int batch) {
+    bd_merge_host(forward_result, backward_result, output, config, batch, 0);
 }

@@ -218,6 +218,56 @@ class GRU(_Recurrent):
         return h
 
 
+class RNN(_Recurrent):
+    """One-gate recurrent layer (rnn.h); `act` is an ActivationFunction handle (default tanh over H)."""
+
+    def __init__(self, in_features, hidden, return_sequences, timesteps, v2=True, act=None):
+        L = capi.load()
+        self.act = L.ActivationFunctionCreateTanh(hidden) if act is None else act
+        self.cfg = L.RNNConfigCreate(in_features, hidden, return_sequences, timesteps, v2, self.act)
+        self.h = L.RNNCreateForInference(self.cfg)
+        self._get_weights, self._apply, self._apply_batch = L.RNNGetWeights, L.RNNApplyInference, L.RNNApplyInferenceBatch
+        self._apply_device, self._sync, self._reset = L.RNNApplyDevice, L.RNNSyncWeights, L.RNNResetState
+        self._destroy = L.RNNDestroy
+        self.acts = self.act
+        self._acts_destroy = L.ActivationFunctionDestroy
+
+    def state(self):
+        H = self.cfg.base.output_feature_channels
+        h = np.empty(H, np.float32)
+        check(capi.load().RNNGetState(self.h, _p(h)), "RNNGetState")
+        return h
+
+
+def bd_reverse_device(x, kind="input"):
+    """[B,T,F] device tensor with every sequence's rows in reverse time order (bidirectional.h)."""
+    import torch
+    L = capi.load()
+    B, T, F = x.shape
+    cfg = capi.RecurrentConfig(F, F, True, T)
+    out = torch.empty_like(x)
+    fn = L.bd_reverse_input_batch_device if kind == "input" else L.bd_reverse_backward_batch_device
+    check(fn(_dp(x), _dp(out), cfg, B), "bd_reverse_*_device")
+    return out
+
+
+def bd_merge_device(fwd, bwd, mode="concat"):
+    """fwd, bwd: [B,rows,C] (or [B,C]) device tensors -> concat along features or sum."""
+    import torch
+    L = capi.load()
+    seq = fwd.dim() == 3
+    B, Cc = fwd.shape[0], fwd.shape[-1]
+    rows = fwd.shape[1] if seq else 1
+    cfg = capi.RecurrentConfig(Cc, Cc, seq, rows)
+    if mode == "concat":
+        out = torch.empty(fwd.shape[:-1] + (2 * Cc,), device=fwd.device)
+        check(L.bd_merge_concat_device(_dp(fwd), _dp(bwd), _dp(out), cfg, B), "bd_merge_concat_device")
+    else:
+        out = torch.empty_like(fwd)
+        check(L.bd_merge_sum_device(_dp(fwd), _dp(bwd), _dp(out), cfg, B), "bd_merge_sum_device")
+    return out
+
+
 class LSTM(_Recurrent):
     def __init__(self, in_features, hidden, return_sequences, timesteps, v2=True, acts=None):
         L = capi.load()

@@ -108,6 +108,18 @@ void ref_gru_batch(const float *x, const float *W, const float *U,
                    int B, int T, int in, int H, int return_sequences,
                    int act_z, int act_h, int act_r);
 
+/* RNN (one gate): W [in,H], U [H,H], b_i[H], b_h[H] (b_h used only if v2) */
+void ref_rnn_sequence(const float *x, const float *W, const float *U,
+                      const float *b_i, const float *b_h, float *h_state, float *out,
+                      int T, int in, int H, int return_sequences, int v2, int act);
+void ref_rnn_batch(const float *x, const float *W, const float *U,
+                   const float *b_i, const float *b_h, float *out,
+                   int B, int T, int in, int H, int return_sequences, int v2, int act);
+/* bidirectional forward helpers */
+void ref_bd_reverse_batch(const float *in, float *out, int B, int T, int F);
+void ref_bd_merge_concat(const float *fwd, const float *bwd, float *out, int B, int rows, int C);
+void ref_bd_merge_sum(const float *fwd, const float *bwd, float *out, int B, int rows, int C);
+
 /* LSTM: W [in,4H], U [H,4H], b_i[4H], b_h[4H] (b_h used only if v2); gate order i,f,g,o */
 void ref_lstm_sequence(const float *x, const float *W, const float *U,
                        const float *b_i, const float *b_h, float *h_state, float *c_state,

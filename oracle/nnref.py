@@ -183,6 +183,46 @@ def gru(x, W, U, b_i, b_h, h0=None, return_sequences=True, acts=(ACT_SIGMOID, AC
     return out
 
 
+def rnn(x, W, U, b_i, b_h, h0=None, return_sequences=True, v2=True, act=ACT_TANH):
+    """One-gate RNN.  x: [T,in] (stateful single sequence; returns (out, h_final)) or [B,T,in] (zero state)."""
+    x, W, U, b_i, b_h = _f32(x), _f32(W), _f32(U), _f32(b_i), _f32(b_h)
+    H = U.shape[0]
+    if x.ndim == 2:
+        T, in_ = x.shape
+        h = np.zeros(H, np.float32) if h0 is None else _f32(h0).copy()
+        out = np.empty((T, H) if return_sequences else (H,), np.float32)
+        lib().ref_rnn_sequence(_p(x), _p(W), _p(U), _p(b_i), _p(b_h), _p(h), _p(out), T, in_, H,
+                               int(return_sequences), int(v2), int(act))
+        return out, h
+    B, T, in_ = x.shape
+    out = np.empty((B, T, H) if return_sequences else (B, H), np.float32)
+    lib().ref_rnn_batch(_p(x), _p(W), _p(U), _p(b_i), _p(b_h), _p(out), B, T, in_, H,
+                        int(return_sequences), int(v2), int(act))
+    return out
+
+
+def bd_reverse(x):
+    """[B,T,F] with the rows of every sequence in reverse time order (bd_reverse_input_batch / _backward_batch)."""
+    x = _f32(x)
+    B, T, F = x.shape
+    out = np.empty_like(x)
+    lib().ref_bd_reverse_batch(_p(x), _p(out), B, T, F)
+    return out
+
+
+def bd_merge(fwd, bwd, mode="concat"):
+    """fwd, bwd: [B,rows,C] -> [B,rows,2C] (concat) or [B,rows,C] (sum)."""
+    fwd, bwd = _f32(fwd), _f32(bwd)
+    B, rows, Cc = fwd.shape
+    if mode == "concat":
+        out = np.empty((B, rows, 2 * Cc), np.float32)
+        lib().ref_bd_merge_concat(_p(fwd), _p(bwd), _p(out), B, rows, Cc)
+    else:
+        out = np.empty((B, rows, Cc), np.float32)
+        lib().ref_bd_merge_sum(_p(fwd), _p(bwd), _p(out), B, rows, Cc)
+    return out
+
+
 def lstm(x, W, U, b_i, b_h, h0=None, c0=None, return_sequences=True, v2=True,
          acts=(ACT_SIGMOID, ACT_SIGMOID, ACT_TANH, ACT_SIGMOID, ACT_TANH)):
     """acts = (input, forget, candidate, output_gate, output)."""

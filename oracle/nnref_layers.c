@@ -240,6 +240,76 @@ void ref_lstm_batch(const float *x, const float *W, const float *U,
     free(h); free(c);
 }
 
+/* ------------------------------------------------------------------- RNN --- */
+
+/* layers/rnn.c:144-166 (RNNCellForward): x_W = x W + b_i; h_U = h U (+ b_h if v2); gate = h_U + x_W; h' = act(gate).
+ * buf needs 3*H floats. */
+static void rnn_cell(const float *x, const float *W, const float *U, const float *b_i, const float *b_h,
+                     const float *h_prev, float *h, float *buf, int in, int H, int v2, int act) {
+    float *x_W = buf, *h_U = buf + H, *gate = buf + 2 * H;
+    ref_op_mat_mul(x, W, x_W, 1, H, in);
+    vec_add(x_W, b_i, x_W, H);
+    ref_op_mat_mul(h_prev, U, h_U, 1, H, H);
+    if (v2) vec_add(h_U, b_h, h_U, H);
+    vec_add(h_U, x_W, gate, H);
+    ref_activation(act, 1.0f, 0, gate, h, H);
+}
+
+/* The layer that layers/rnn.c:249-291 (the batch forward pass) computes, one sequence, state carried in
+ * h_state.  RNNApplyInference itself (rnn.c:228-247) writes cell i's output at output + i*(i*out) and then
+ * reloads h from output + i*out -- an indexing slip ("note and do not replicate"). */
+void ref_rnn_sequence(const float *x, const float *W, const float *U,
+                      const float *b_i, const float *b_h, float *h_state, float *out,
+                      int T, int in, int H, int return_sequences, int v2, int act) {
+    float *buf = (float *)calloc((size_t)3 * H, sizeof(float));
+    for (int t = 0; t < T; ++t) {
+        float *o = out + (return_sequences ? (size_t)t * H : 0);
+        rnn_cell(x + (size_t)t * in, W, U, b_i, b_h, h_state, o, buf, in, H, v2, act);
+        memcpy(h_state, o, sizeof(float) * (size_t)H);
+    }
+    free(buf);
+}
+
+/* layers/rnn.c:249-291 forward semantics: zero state per sequence (:260) */
+void ref_rnn_batch(const float *x, const float *W, const float *U,
+                   const float *b_i, const float *b_h, float *out,
+                   int B, int T, int in, int H, int return_sequences, int v2, int act) {
+    float *h = (float *)malloc(sizeof(float) * (size_t)H);
+    for (int n = 0; n < B; ++n) {
+        memset(h, 0, sizeof(float) * (size_t)H);
+        float *o = out + (return_sequences ? (size_t)n * T * H : (size_t)n * H);
+        ref_rnn_sequence(x + (size_t)n * T * in, W, U, b_i, b_h, h, o, T, in, H, return_sequences, v2, act);
+    }
+    free(h);
+}
+
+/* --------------------------------------------------------- bidirectional --- */
+
+/* layers/bidirectional.c:11-23 (reverse / reverse_batch): rows of each [T, F] sequence in reverse order */
+void ref_bd_reverse_batch(const float *in, float *out, int B, int T, int F) {
+    for (int b = 0; b < B; ++b)
+        for (int t = 0; t < T; ++t)
+            memcpy(out + ((size_t)b * T + t) * F, in + ((size_t)b * T + (T - 1 - t)) * F, sizeof(float) * (size_t)F);
+}
+
+/* layers/bidirectional.c:42-58 (bd_merge_concat): transpose both results into one [2C, rows] buffer and
+ * transpose that back, i.e. out[b][r] = forward[b][r] | backward[b][r] */
+void ref_bd_merge_concat(const float *fwd, const float *bwd, float *out, int B, int rows, int C) {
+    float *buffer = (float *)malloc(sizeof(float) * (size_t)2 * rows * C);
+    size_t size = (size_t)rows * C;
+    for (int b = 0; b < B; ++b) {
+        ref_op_mat_transp(fwd + b * size, buffer, C, rows);
+        ref_op_mat_transp(bwd + b * size, buffer + size, C, rows);
+        ref_op_mat_transp(buffer, out + 2 * b * size, rows, 2 * C);
+    }
+    free(buffer);
+}
+
+/* layers/bidirectional.c:76-85 (bd_merge_sum) */
+void ref_bd_merge_sum(const float *fwd, const float *bwd, float *out, int B, int rows, int C) {
+    vec_add(fwd, bwd, out, B * rows * C);
+}
+
 /* ----------------------------------------------------------------- dense --- */
 
 /* layers/dense.c:122-142: z = x*W + b ; a = activation(z) (or copy if none).

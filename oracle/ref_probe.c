@@ -28,6 +28,8 @@
 #include "nntoolkitcore/layers/batch_norm.h"
 #include "nntoolkitcore/layers/gru.h"
 #include "nntoolkitcore/layers/lstm.h"
+#include "nntoolkitcore/layers/rnn.h"
+#include "nntoolkitcore/layers/bidirectional.h"
 #include "nntoolkitcore/layers/dense.h"
 #include "nntoolkitcore/layers/time_distributed_dense.h"
 #include "nntoolkitcore/layers/activation_default.h"
@@ -75,6 +77,14 @@ int main(int argc, char **argv) {
     SYM(lstm_act_fn, LSTMActivationsCreateDefault) SYM(lstm_cfg_fn, LSTMConfigCreate)
     SYM(lstm_create_fn, LSTMCreateForInference) SYM(lstm_w_fn, LSTMGetWeights)
 
+    typedef RNNConfig (*rnn_cfg_fn)(int, int, bool, int, bool, ActivationFunction);
+    typedef RNN (*rnn_create_fn)(RNNConfig);
+    typedef RNNWeights *(*rnn_w_fn)(RNN);
+    typedef void (*bd_rev_fn)(const float *, float *, RecurrentConfig, int);
+    typedef int (*bd_size_fn)(RecurrentConfig);
+    SYM(rnn_cfg_fn, RNNConfigCreate) SYM(rnn_create_fn, RNNCreateForInference) SYM(rnn_w_fn, RNNGetWeights)
+    SYM(bd_rev_fn, bd_reverse_input_batch) SYM(bd_rev_fn, bd_reverse_backward_batch) SYM(bd_size_fn, bd_merge_concat_buffer_size)
+
     typedef BatchNormConfig (*bn_cfg_fn)(int, float, int);
     typedef BatchNorm (*bn_create_fn)(BatchNormConfig);
     typedef BatchNormWeights *(*bn_w_fn)(BatchNorm);
@@ -106,6 +116,7 @@ int main(int argc, char **argv) {
     SZ(LSTMActivations); OFF(LSTMActivations, candidate_gate_activation); OFF(LSTMActivations, input_gate_activation);
     OFF(LSTMActivations, forget_gate_activation); OFF(LSTMActivations, output_gate_activation); OFF(LSTMActivations, output_activation);
     SZ(LSTMConfig); OFF(LSTMConfig, base); OFF(LSTMConfig, v2); OFF(LSTMConfig, activations);
+    SZ(RNNConfig); OFF(RNNConfig, base); OFF(RNNConfig, v2); OFF(RNNConfig, activation);
     SZ(DenseConfig); OFF(DenseConfig, input_size); OFF(DenseConfig, output_size); OFF(DenseConfig, activation);
     SZ(TimeDistributedDenseConfig); OFF(TimeDistributedDenseConfig, dense); OFF(TimeDistributedDenseConfig, ts);
     SZ(MelFilterBankConfig); OFF(MelFilterBankConfig, n_mels); OFF(MelFilterBankConfig, n_fft); OFF(MelFilterBankConfig, sample_rate);
@@ -174,6 +185,28 @@ int main(int argc, char **argv) {
             TimeDistributedDenseConfigCreate_p(9, DenseConfigCreate_p(5, 7, NULL)));
         DenseWeights *w = TimeDistributedDenseGetWeights_p(t);
         printf("  \"tdd_weights\": {\"in\": 5, \"out\": 7, \"b_offset\": %td},\n", w->b - w->W);
+    }
+
+    /* ---- RNN weight block layout and the op-free bidirectional helpers ---- */
+    {
+        RNN r = RNNCreateForInference_p(RNNConfigCreate_p(5, 7, true, 11, true, NULL));
+        RNNWeights *w = RNNGetWeights_p(r);
+        printf("  \"rnn_weights\": {\"in\": 5, \"out\": 7, \"U_offset\": %td, \"b_i_offset\": %td, \"b_h_offset\": %td},\n",
+               w->U - w->W, w->b_i - w->W, w->b_h - w->W);
+        /* batch 2, 3 timesteps, 2 input / 3 output channels, values 0, 1, 2, ... */
+        RecurrentConfig rc = {2, 3, true, 3};
+        float in[12], out_in[12], bw[18], out_bw[18];
+        for (int i = 0; i < 12; ++i) in[i] = (float)i;
+        for (int i = 0; i < 18; ++i) bw[i] = (float)i;
+        bd_reverse_input_batch_p(in, out_in, rc, 2);
+        bd_reverse_backward_batch_p(bw, out_bw, rc, 2);
+        printf("  \"bidirectional\": {\n  ");
+        print_floats("reverse_input_B2_T3_F2", out_in, 12, 0);
+        printf("  ");
+        print_floats("reverse_backward_B2_T3_F3", out_bw, 18, 0);
+        RecurrentConfig last = {2, 3, false, 3};
+        printf("    \"concat_buffer_size_seq\": %d, \"concat_buffer_size_last\": %d\n  },\n",
+               bd_merge_concat_buffer_size_p(rc), bd_merge_concat_buffer_size_p(last));
     }
 
     /* ---- windows (size 16 and the first/last 8 taps of size 400) ---- */

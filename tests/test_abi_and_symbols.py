@@ -20,6 +20,7 @@ STRUCTS = {
     "BatchNormConfig": capi.BatchNormConfig, "RecurrentConfig": capi.RecurrentConfig,
     "GRUActivations": capi.GRUActivations, "GRUConfig": capi.GRUConfig,
     "LSTMActivations": capi.LSTMActivations, "LSTMConfig": capi.LSTMConfig,
+    "RNNConfig": capi.RNNConfig,
     "DenseConfig": capi.DenseConfig, "TimeDistributedDenseConfig": capi.TimeDistributedDenseConfig,
     "DefaultWeights": capi.DefaultWeights, "RecurrentWeights": capi.RecurrentWeights,
     "BatchNormWeights": capi.BatchNormWeights, "MelFilterBankConfig": capi.MelFilterBankConfig,

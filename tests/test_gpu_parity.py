@@ -549,6 +549,87 @@ def test_lstm512_nondefault_gate_activations(gpu):
     lstm.destroy()
 
 
+# ------------------------------------------- next row: RNN cell and bidirectional helpers ---
+
+def rnn_weights(r, I, H):
+    return u(r, I, H, sc=I ** -0.5), u(r, H, H, sc=H ** -0.5), u(r, H, sc=0.1), u(r, H, sc=0.1)
+
+
+@pytest.mark.parametrize("I,H,T,seq,v2", [(5, 7, 11, True, True), (24, 40, 13, False, False), (64, 256, 9, True, True),
+                                          (16, 512, 6, True, True)])
+def test_rnn_single_sequence_stateful_and_batch(gpu, I, H, T, seq, v2):
+    """layers/rnn.c forward: stateful single-sequence call, carried state, zero-state batch."""
+    r = rng(I + H)
+    W, U, bi, bh = rnn_weights(r, I, H)
+    x1, x2 = u(r, T, I), u(r, T, I)
+    rnn = NL.RNN(I, H, seq, T, v2=v2)
+    rnn.set_weights(W, U, bi, bh)
+    o1, h1 = O.rnn(x1, W, U, bi, bh, return_sequences=seq, v2=v2)
+    o2, h2 = O.rnn(x2, W, U, bi, bh, h0=h1, return_sequences=seq, v2=v2)
+    close(rnn.apply(x1), o1)
+    close(rnn.state(), h1)
+    close(rnn.apply(x2), o2)
+    rnn.reset_state()
+    close(rnn.apply(x1), o1)
+    xb = u(r, 70, T, I)
+    close(rnn.apply(xb), O.rnn(xb, W, U, bi, bh, return_sequences=seq, v2=v2))
+    rnn.destroy()
+
+
+def test_rnn_relu_and_both_recurrent_paths(gpu, monkeypatch):
+    L = capi.load()
+    r = rng(31)
+    B, T, I, H = 9, 12, 10, 48
+    W, U, bi, bh = rnn_weights(r, I, H)
+    x = u(r, B, T, I)
+    ref = O.rnn(x, W, U, bi, bh, act=O.ACT_RELU)
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NNTK_REC_PERSISTENT", mode)
+        rnn = NL.RNN(I, H, True, T, act=L.ActivationFunctionCreateReLU(H, 1.0))
+        rnn.set_weights(W, U, bi, bh)
+        close(rnn.apply(x), ref)
+        rnn.destroy()
+
+
+def test_bidirectional_helpers_and_a_bidirectional_gru(gpu):
+    """bidirectional.h forward helpers on host and device pointers, then the composition they exist for:
+    forward GRU + backward GRU on the time-reversed input, backward output reversed back, concat / sum."""
+    import torch
+    import ctypes as C
+    L = capi.load()
+    r = rng(77)
+    B, T, I, H = 5, 9, 6, 20
+    x = u(r, B, T, I)
+    cfg_in = capi.RecurrentConfig(I, H, True, T)
+    out = np.empty_like(x)
+    L.bd_reverse_input_batch(NL._p(x), NL._p(out), cfg_in, B)
+    assert np.array_equal(out, O.bd_reverse(x))
+    Wf, Uf, bif, bhf = gru_weights(r, I, H)
+    Wb, Ub, bib, bhb = gru_weights(r, I, H)
+    fwd_ref = O.gru(x, Wf, Uf, bif, bhf)
+    bwd_ref = O.bd_reverse(O.gru(O.bd_reverse(x), Wb, Ub, bib, bhb))
+    gf, gb = NL.GRU(I, H, True, T), NL.GRU(I, H, True, T)
+    gf.set_weights(Wf, Uf, bif, bhf)
+    gb.set_weights(Wb, Ub, bib, bhb)
+    xd = torch.from_numpy(x).cuda()
+    f = gf.apply_device(xd)
+    bw = NL.bd_reverse_device(gb.apply_device(NL.bd_reverse_device(xd, "input")), "backward")
+    close(NL.bd_merge_device(f, bw, "concat").cpu().numpy(), O.bd_merge(fwd_ref, bwd_ref, "concat"))
+    close(NL.bd_merge_device(f, bw, "sum").cpu().numpy(), O.bd_merge(fwd_ref, bwd_ref, "sum"))
+    # host-pointer merges (reference signatures), last-step-only layout
+    cfg_last = capi.RecurrentConfig(I, H, False, T)
+    a, b2 = fwd_ref[:, -1].copy(), bwd_ref[:, 0].copy()
+    outc = np.empty((B, 2 * H), np.float32)
+    buf = np.empty(L.bd_merge_concat_buffer_size(cfg_last), np.float32)
+    L.bd_merge_concat(NL._p(a), NL._p(b2), NL._p(outc), cfg_last, B, NL._p(buf))
+    assert np.array_equal(outc, np.concatenate([a, b2], axis=1))
+    outs = np.empty((B, H), np.float32)
+    L.bd_merge_sum(NL._p(a), NL._p(b2), NL._p(outs), cfg_last, B)
+    assert np.array_equal(outs, a + b2)
+    assert L.bd_merge_concat_buffer_size(cfg_in) == 2 * T * H
+    gf.destroy(); gb.destroy()
+
+
 # ------------------------------------------------ next row: mel filterbank / log-mel ---
 
 def test_mel_filterbank_and_log_mel_spectrogram(gpu):

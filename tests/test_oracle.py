@@ -107,6 +107,52 @@ def test_gru_vs_torch_including_T1000():
         assert np.abs(last - want[:, -1]).max() < 5e-6
 
 
+@pytest.mark.parametrize("nonlin,act", [("tanh", O.ACT_TANH), ("relu", O.ACT_RELU)])
+def test_rnn_vs_torch_and_reference_layout(nonlin, act):
+    """the one-gate cell of layers/rnn.c equals torch.nn.RNN; the weight block layout the
+    real reference returns (W | U | b_i | b_h) is the one the C API reproduces."""
+    import torch
+    r = rng(6)
+    B, T, I, H = 3, 40, 5, 7
+    x = r.standard_normal((B, T, I)).astype(np.float32)
+    W = (r.standard_normal((I, H)) * I ** -0.5).astype(np.float32)
+    U = (r.standard_normal((H, H)) * H ** -0.5).astype(np.float32)
+    bi, bh = (0.1 * r.standard_normal(H)).astype(np.float32), (0.1 * r.standard_normal(H)).astype(np.float32)
+    m = torch.nn.RNN(I, H, batch_first=True, nonlinearity=nonlin)
+    with torch.no_grad():
+        m.weight_ih_l0.copy_(torch.tensor(W.T)); m.weight_hh_l0.copy_(torch.tensor(U.T))
+        m.bias_ih_l0.copy_(torch.tensor(bi)); m.bias_hh_l0.copy_(torch.tensor(bh))
+        want = m(torch.tensor(x))[0].numpy()
+    assert np.abs(O.rnn(x, W, U, bi, bh, act=act) - want).max() < 5e-6
+    assert np.abs(O.rnn(x, W, U, bi, bh, act=act, return_sequences=False) - want[:, -1]).max() < 5e-6
+    # v2 = False drops b_h (rnn.c:158-160)
+    with torch.no_grad():
+        m.bias_hh_l0.zero_()
+        want1 = m(torch.tensor(x))[0].numpy()
+    assert np.abs(O.rnn(x, W, U, bi, bh, act=act, v2=False) - want1).max() < 5e-6
+    # stateful single-sequence form = one long call
+    o1, h1 = O.rnn(x[0, :15], W, U, bi, bh, act=act)
+    o2, _ = O.rnn(x[0, 15:], W, U, bi, bh, h0=h1, act=act)
+    assert np.array_equal(np.concatenate([o1, o2]), O.rnn(x[0], W, U, bi, bh, act=act)[0])
+    g = GOLD["rnn_weights"]
+    assert (g["U_offset"], g["b_i_offset"], g["b_h_offset"]) == (5 * 7, 5 * 7 + 7 * 7, 5 * 7 + 7 * 7 + 7)
+
+
+def test_bidirectional_helpers_vs_reference_outputs():
+    """bd_reverse_*_batch are op-free in the reference, so the REAL functions were run (oracle/ref_probe.c);
+    the restatement must reproduce their output bit for bit.  The merges are checked against numpy."""
+    g = GOLD["bidirectional"]
+    x_in = np.arange(12, dtype=np.float32).reshape(2, 3, 2)
+    x_bw = np.arange(18, dtype=np.float32).reshape(2, 3, 3)
+    assert O.bd_reverse(x_in).ravel().tolist() == g["reverse_input_B2_T3_F2"]
+    assert O.bd_reverse(x_bw).ravel().tolist() == g["reverse_backward_B2_T3_F3"]
+    r = rng(9)
+    f, b = r.standard_normal((3, 5, 4)).astype(np.float32), r.standard_normal((3, 5, 4)).astype(np.float32)
+    assert np.array_equal(O.bd_merge(f, b, "concat"), np.concatenate([f, b], axis=2))
+    assert np.array_equal(O.bd_merge(f, b, "sum"), f + b)
+    assert (g["concat_buffer_size_seq"], g["concat_buffer_size_last"]) == (2 * 3 * 3, 2 * 1 * 3)
+
+
 @pytest.mark.parametrize("v2", [True, False])
 def test_lstm_vs_torch(v2):
     import torch
