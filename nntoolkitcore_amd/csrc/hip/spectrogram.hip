@@ -18,6 +18,7 @@
 // frame with a precomputed twiddle table -- correct for every configuration the
 // reference accepts, not tuned.
 #include "nntk_common.hpp"
+#include <stdlib.h>
 
 struct SpecParams {
     const float *in;      // [B, input_size]
@@ -80,18 +81,21 @@ template <int MODE, bool NORM>
 __global__ __launch_bounds__(256) void spectrogram512_kernel(SpecParams p) {
     __shared__ __attribute__((aligned(16))) f2 lds_z[4][SPEC_LDS_PER_WAVE];      // interleaved (re, im)
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // scalar: frame offsets stay in SGPRs
     f2 *z = lds_z[wave];
     const int ppu = (p.nts + 1) >> 1;                 // frame pairs per utterance
 
     // lane-only constants
+    // window taps, and the per-lane sample offset: taps beyond the window get an out-of-range offset,
+    // so the load itself returns the exact zero padding (no select, even next to inf/nan samples)
     float wtap[8];
-    bool inwin[8];
+    int loff[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int n = lane + 64 * r;
-        inwin[r] = n < p.window_size;
-        wtap[r] = inwin[r] ? p.window[n] : 0.0f;
+        const bool inwin = n < p.window_size;
+        wtap[r] = inwin ? p.window[n] : 0.0f;
+        loff[r] = inwin ? n * 4 : 0x7ffffff0;
     }
     f2 tw2[8], tw3[8];
     {
@@ -112,7 +116,8 @@ __global__ __launch_bounds__(256) void spectrogram512_kernel(SpecParams p) {
         osc[r] = (MODE == 0 || k == 0 || k == p.nfreq - 1) ? p.inv_scale : 2.0f * p.inv_scale;
     }
     const int i1 = pidx(lane * 8);                    // pass-1 write base (8 contiguous floats)
-    const int i2w = (lane >> 3) * 64 + (lane & 7);    // pass-2 write base
+    // pass-2 write base, already padded: pidx(i2w + 8 r) = i2w + 8 r + 8 (lane >> 3) for r < 8
+    const int i2w = (lane >> 3) * 64 + (lane & 7) + 8 * (lane >> 3);
     const int src = (64 - lane) & 63;
 
     for (int b = blockIdx.y; b < p.B; b += gridDim.y) {
@@ -125,15 +130,17 @@ __global__ __launch_bounds__(256) void spectrogram512_kernel(SpecParams p) {
         int pr = blockIdx.x * 4 + wave;
         unsigned nxa[8], nxb[8];
         bool nhas_b = false;
+        // the frame's start is wave-uniform: it rides in the scalar offset, the vector offset is the
+        // lane-only loff[] (a missing frame B re-reads frame A; its outputs are never stored)
         if (pr < ppu) {
             const int fa = 2 * pr;
             nhas_b = fa + 1 < p.nts;
-            const int offa = (fa * p.step + lane) * 4;
-            const int offb = nhas_b ? offa + p.step * 4 : 0x7ffffff0;      // out of range -> loads return 0
+            const int soa = fa * p.step * 4;
+            const int sob = nhas_b ? soa + p.step * 4 : soa;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                nxa[r] = __builtin_amdgcn_raw_buffer_load_b32(rin, offa + 256 * r, 0, 0);
-                nxb[r] = __builtin_amdgcn_raw_buffer_load_b32(rin, offb + 256 * r, 0, 0);
+                nxa[r] = __builtin_amdgcn_raw_buffer_load_b32(rin, loff[r], soa, 0);
+                nxb[r] = __builtin_amdgcn_raw_buffer_load_b32(rin, loff[r], sob, 0);
             }
         }
         for (; pr < ppu; pr += gridDim.x * 4) {
@@ -144,19 +151,19 @@ __global__ __launch_bounds__(256) void spectrogram512_kernel(SpecParams p) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const f2 x = (f2){__uint_as_float(nxa[r]), __uint_as_float(nxb[r])};
-                v[r] = inwin[r] ? x * wtap[r] : (f2){0.f, 0.f};       // exact zero padding even for inf/nan neighbours
+                v[r] = x * wtap[r];                                   // taps beyond the window were loaded as 0
             }
             {
                 const int npr = pr + gridDim.x * 4;
                 if (npr < ppu) {
                     const int nfa = 2 * npr;
                     nhas_b = nfa + 1 < p.nts;
-                    const int offa = (nfa * p.step + lane) * 4;
-                    const int offb = nhas_b ? offa + p.step * 4 : 0x7ffffff0;
+                    const int soa = nfa * p.step * 4;
+                    const int sob = nhas_b ? soa + p.step * 4 : soa;
 #pragma unroll
                     for (int r = 0; r < 8; ++r) {
-                        nxa[r] = __builtin_amdgcn_raw_buffer_load_b32(rin, offa + 256 * r, 0, 0);
-                        nxb[r] = __builtin_amdgcn_raw_buffer_load_b32(rin, offb + 256 * r, 0, 0);
+                        nxa[r] = __builtin_amdgcn_raw_buffer_load_b32(rin, loff[r], soa, 0);
+                        nxb[r] = __builtin_amdgcn_raw_buffer_load_b32(rin, loff[r], sob, 0);
                     }
                 }
             }
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(256) void spectrogram512_kernel(SpecParams p) {
             fft8(v);
             WAVE_LDS_SYNC();
 #pragma unroll
-            for (int r = 0; r < 8; ++r) z[pidx(i2w + 8 * r)] = v[r];
+            for (int r = 0; r < 8; ++r) z[i2w + 8 * r] = v[r];
             WAVE_LDS_SYNC();
             // ---- pass 3 (Ns = 64) ----
 #pragma unroll
@@ -184,8 +191,10 @@ __global__ __launch_bounds__(256) void spectrogram512_kernel(SpecParams p) {
             WAVE_LDS_SYNC();   // LDS image is free for the next pair
             // lane j now holds Z[j + 64 r], r = 0..7.
             // ---- split the two real spectra; bins k = j + 64 r for r = 0..3 (+ k = 256 on lane 0) ----
-            const int oa = fa * p.nfreq * 4 + lane * 4;
-            const int ob = has_b ? oa + p.nfreq * 4 : 0x7ffffff0;          // out of range -> store dropped
+            // output rows: frame offset in the scalar offset, lane offset in the vector offset; a missing
+            // frame B (wave-uniform) is simply not stored
+            const int soa = fa * p.nfreq * 4, sob = soa + p.nfreq * 4;
+            const int vo = lane * 4, vo4 = lane == 0 ? 0 : 0x7ffffff0;     // only lane 0 owns bin 256
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
                 f2 c;
@@ -202,10 +211,11 @@ __global__ __launch_bounds__(256) void spectrogram512_kernel(SpecParams p) {
                 f2 xb = (f2){0.5f * (z.y + c.y), -0.5f * (z.x - c.x)};
                 if (NORM) { xa = xa * p.fft_norm; xb = xb * p.fft_norm; }
                 float ma = xa.x * xa.x + xa.y * xa.y, mb = xb.x * xb.x + xb.y * xb.y;
-                if (MODE == 0) { ma = sqrtf(ma); mb = sqrtf(mb); }
-                const int dead = (r == 4 && lane != 0) ? 0x7ffffff0 : 0;   // only lane 0 owns bin 256
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ma * osc[r]), rout, (oa + 256 * r) | dead, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mb * osc[r]), rout, (ob + 256 * r) | dead, 0, 0);
+                // hardware square root (<= 1 ulp; libm's correctly rounded sqrtf costs 12 instructions a bin)
+                if (MODE == 0) { ma = __builtin_amdgcn_sqrtf(ma); mb = __builtin_amdgcn_sqrtf(mb); }
+                const int vor = r == 4 ? vo4 : vo;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ma * osc[r]), rout, vor, soa + 256 * r, 0);
+                if (has_b) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mb * osc[r]), rout, vor, sob + 256 * r, 0);
             }
         }
     }
@@ -249,7 +259,13 @@ extern "C" int nntk_shim_spectrogram(const float *d_in, const float *d_window, c
         if ((long)input_size * 4 >= 0x7ffffff0L || (long)nts * nfreq * 4 >= 0x7ffffff0L)
             return nntk_fail_msg("spectrogram: one utterance must stay below 2 GiB");
         const int ppu = (nts + 1) / 2;
-        unsigned gx = (unsigned)((ppu + 7) / 8);         // ~2 frame pairs per wavefront per utterance (prefetch depth 1)
+        // frame pairs per wavefront per utterance: long runs amortise the per-utterance prologue (descriptor +
+        // un-overlapped first prefetch) as long as the chip stays full.  Measured at the stack's size (256 k pairs):
+        // 1 / 2 / 4 / 8 / 16 pairs = 0.245 / 0.225 / 0.220 / 0.207 / 0.199 ms; config 2 (12.5 k pairs): 4 is best.
+        long ppw_l = (long)B * ppu / 4096;
+        int ppw = ppw_l < 4 ? 4 : ppw_l > 16 ? 16 : (int)ppw_l;
+        { const char *e = getenv("NNTK_SPEC_PPW"); if (e && atoi(e) > 0) ppw = atoi(e); }
+        unsigned gx = (unsigned)((ppu + 4 * ppw - 1) / (4 * ppw));
         unsigned gy = (unsigned)(B < 65535 ? B : 65535);
         // keep the grid near 8 workgroups per CU; the kernel strides over the rest
         while ((long)gx * gy > 256L * 8 * 8 && gy > 1) gy = (gy + 1) / 2;
