@@ -549,6 +549,26 @@ def test_lstm512_nondefault_gate_activations(gpu):
     lstm.destroy()
 
 
+def test_time_major_projection_tiled_over_batch_is_bit_identical(gpu, monkeypatch):
+    """The recurrent input projection writes a time-major tensor; by default its GEMM is tiled over the batch at a
+    fixed timestep instead of over time within a sequence.  Same arithmetic per element: bit-identical layers."""
+    import torch
+    r = rng(2048)
+    for (B, T, I, H) in ((130, 9, 24, 64), (3, 140, 20, 32), (257, 2, 36, 48)):
+        xs = u(r, B, T, I)
+        x = torch.from_numpy(xs).cuda()
+        W, U, bi, bh = gru_weights(r, I, H)
+        outs = []
+        for mode in ("1", "0"):
+            monkeypatch.setenv("NNTK_GEMM_TM_BATCH", mode)
+            g = NL.GRU(I, H, True, T)
+            g.set_weights(W, U, bi, bh)
+            outs.append(g.apply_device(x).clone())
+            g.destroy()
+        close(outs[0].cpu().numpy(), O.gru(xs, W, U, bi, bh))
+        assert torch.equal(outs[0], outs[1])
+
+
 # ------------------------------------------- next row: RNN cell and bidirectional helpers ---
 
 def rnn_weights(r, I, H):
