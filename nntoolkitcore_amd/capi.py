@@ -10,6 +10,8 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libnntoolkitcore_hip.so")
+if os.environ.get("NNTK_LIB"):      # A/B of two builds on one box (tools/ab_lib.sh)
+    LIB_PATH = os.path.abspath(os.environ["NNTK_LIB"])
 
 fp = C.POINTER(C.c_float)
 vp = C.c_void_p
