@@ -401,6 +401,8 @@ extern "C" int nntk_shim_conv1d(const float *d_in, const float *d_wp, const floa
     { const char *e = getenv("NNTK_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }
 #endif
 
+    if ((long)p.Cout_p * k * p.Cin_p * 4 >= 0x7fffffffL)
+        return nntk_fail_msg("conv1d: packed weights must stay below 2 GiB (32-bit buffer offsets)");
     const bool window_fits = p.rows_a <= 192;                          // register staging budget (A_PT)
     const long Kdim = (long)Cin * k;
     if (!window_fits || Kdim < 16 || Cout < 32) {
