@@ -112,6 +112,62 @@ __global__ __launch_bounds__(256) void intrawave_mem(float *sink, unsigned long 
     float r = a0[0] + a1[5];
     if (r == 1234.5678f) sink[threadIdx.x] = r + t0v[0] + t1v[0];
 }
+// The recurrent K loop in isolation: 16 chunks x (4 ds_read_b128 of the NEXT chunk's fragments, 16 dependent-free
+// v_mfma_f32_16x16x4 on the current ones), one wave per SIMD, B operand in registers.
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+template <int AHEAD>
+__global__ __launch_bounds__(256) void kloop(float *sink, unsigned long long *cyc, int iters) {
+    extern __shared__ __attribute__((aligned(16))) float U[];          // [64][520]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 64 * 520; i += 256) U[i] = (float)(i & 255) * 0.001f;
+    __syncthreads();
+    const int l15 = lane & 15, q = lane >> 4;
+    const float *ub = &U[l15 * 520 + q * 4];
+    float hv[16][4];
+    for (int c = 0; c < 16; ++c) for (int k = 0; k < 4; ++k) hv[c][k] = lane * 0.01f + c + k;
+    f32x4m acc[4];
+    for (int g = 0; g < 4; ++g) acc[g] = (f32x4m){0, 0, 0, 0};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        float4 un[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) un[g] = *reinterpret_cast<const float4 *>(ub + g * 16 * 520);
+#pragma unroll
+        for (int ch = 0; ch < 16; ++ch) {
+            float4 uc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) uc[g] = un[g];
+            if (ch + 1 < 16) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) un[g] = *reinterpret_cast<const float4 *>(ub + g * 16 * 520 + (ch + 1) * 32);
+            }
+            if (AHEAD) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float u = s2 == 0 ? uc[g].x : s2 == 1 ? uc[g].y : s2 == 2 ? uc[g].z : uc[g].w;
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(u, hv[ch][s2], acc[g], 0, 0, 0);
+                }
+            if (AHEAD) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && blockIdx.x == 0) cyc[w] = t1 - t0;
+    float r = 0;
+    for (int g = 0; g < 4; ++g) r += acc[g][0] + acc[g][3];
+    if (r == 1234.5678f) sink[threadIdx.x] = r;
+}
+template <int AHEAD>
+static void run_kloop(const char *name, float *sink, unsigned long long *d_cyc) {
+    unsigned long long h[8];
+    (void)hipFuncSetAttribute((const void *)kloop<AHEAD>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 520 * 4);
+    kloop<AHEAD><<<256, 256, 64 * 520 * 4>>>(sink, d_cyc, 100);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(h, d_cyc, 64, hipMemcpyDeviceToHost);
+    printf("%-60s %7.0f cycles per 256-MFMA K loop (pure MFMA = 8192)\n", name, h[0] / 100.0);
+}
+
 template <int ND, int NG>
 static void run_mem(const char *name, float *sink, unsigned long long *d_cyc, const float *gsrc) {
     unsigned long long h[8];
@@ -160,5 +216,7 @@ int main() {
     run_mem<2, 0>("1 wave/SIMD: each MFMA + 2 ds_read_b128", sink, cyc, gsrc);
     run_mem<0, 1>("1 wave/SIMD: each MFMA + 1 global_load_dwordx4", sink, cyc, gsrc);
     run_mem<1, 1>("1 wave/SIMD: each MFMA + 1 ds_read_b128 + 1 global load", sink, cyc, gsrc);
+    run_kloop<0>("K loop, 1 wave/SIMD, scheduler's placement", sink, cyc);
+    run_kloop<1>("K loop, 1 wave/SIMD, LDS reads pinned one chunk ahead", sink, cyc);
     return 0;
 }
