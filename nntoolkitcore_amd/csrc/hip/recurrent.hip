@@ -756,11 +756,15 @@ const bool std_acts = G == 1 ? p.a0 == NNTK_ACT_TANH
                                            : (p.a0 == NNTK_ACT_SIGMOID && p.a1 == NNTK_ACT_TANH && p.a2 == NNTK_ACT_SIGMOID);
             // ping-pong halves pay when the K loop is long (see the kernel's header); NNTK_REC_PINGPONG=0/1 overrides
             const char *ppenv = getenv("NNTK_REC_PINGPONG");
-            const bool pp = std_acts && nch_p == 16 && (ppenv ? ppenv[0] != '0' : true);
+            // measured (ms, classic -> ping-pong): LSTM H=320/384/448/512 5.5->4.3 / 5.8->4.5 / 6.1->5.5 / 14.1->11.8,
+            // GRU H=320/384/512 4.7->4.4 / 9.0->8.2 / 5.8->4.5; LSTM-256 +-0, GRU-256 +5..20 %, RNN-512 +24 %: the K loop
+            // must carry >= 36 groups of 4 MFMAs per wave for the alternation to pay
+            const bool pp = std_acts && nch_p >= 12 && G * nch_p >= 36 && (ppenv ? ppenv[0] != '0' : true);
             if (xwm < 0) xwm = pp ? 0 : 1;      // measured: ping-pong LSTM-512 11.8 (XW 0) vs 13.1 ms; classic GRU-256 7.82 vs 7.63 (XW 1)
 #define REC_PICK(N) (!std_acts ? rec_persistent_kernel<G, IS_LSTM, N, 0, false, false> \
                      : xwm == 1 ? rec_persistent_kernel<G, IS_LSTM, N, 1, false, true> : rec_persistent_kernel<G, IS_LSTM, N, 0, false, true>)
-            if (pp)               kern = xwm == 1 ? rec_persistent_kernel<G, IS_LSTM, 16, 1, true, true> : rec_persistent_kernel<G, IS_LSTM, 16, 0, true, true>;
+            if (pp && nch_p == 12) kern = xwm == 1 ? rec_persistent_kernel<G, IS_LSTM, 12, 1, true, true> : rec_persistent_kernel<G, IS_LSTM, 12, 0, true, true>;
+            else if (pp)          kern = xwm == 1 ? rec_persistent_kernel<G, IS_LSTM, 16, 1, true, true> : rec_persistent_kernel<G, IS_LSTM, 16, 0, true, true>;
             else if (nch_p == 4)  kern = REC_PICK(4);
             else if (nch_p == 8)  kern = REC_PICK(8);
             else if (nch_p == 12) kern = REC_PICK(12);

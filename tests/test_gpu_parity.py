@@ -532,6 +532,32 @@ def test_lstm512_pingpong_and_classic_kernels_agree_bitwise(gpu, monkeypatch):
         lstm.destroy()
 
 
+@pytest.mark.parametrize("cell,H", [("gru", 384), ("gru", 512), ("lstm", 320), ("lstm", 448)])
+def test_pingpong_default_shapes_match_classic_bitwise(gpu, monkeypatch, cell, H):
+    """The ping-pong variant is selected wherever the K loop is long enough (LSTM H > 256, GRU H > 256);
+    every such selection must equal the classic kernel bit for bit and the oracle within tolerance."""
+    import torch
+    r = rng(H + len(cell))
+    B, T, I = 70, 5, 12
+    xs = u(r, B, T, I)
+    x = torch.from_numpy(xs).cuda()
+    if cell == "gru":
+        W, U, bi, bh = gru_weights(r, I, H)
+        ref = O.gru(xs, W, U, bi, bh)
+    else:
+        W, U, bi, bh = lstm_weights(r, I, H)
+        ref = O.lstm(xs, W, U, bi, bh, v2=True)
+    outs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NNTK_REC_PINGPONG", mode)
+        l = NL.GRU(I, H, True, T) if cell == "gru" else NL.LSTM(I, H, True, T, v2=True)
+        l.set_weights(W, U, bi, bh)
+        outs.append(l.apply_device(x).clone())
+        l.destroy()
+    close(outs[0].cpu().numpy(), ref)
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_lstm512_nondefault_gate_activations(gpu):
     """Non-standard gate activations take the generic (run-time dispatched) gate code of the persistent kernel."""
     L = capi.load()
