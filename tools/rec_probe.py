@@ -13,11 +13,12 @@ def main():
     torch.cuda.set_device(0); capi.load(); NL.use_torch_stream()
     G = {"lstm": 4, "gru": 3, "rnn": 1}[kind]
     r = np.random.default_rng(0)
-    mk = {"lstm": lambda: NL.LSTM(128, H, True, T), "gru": lambda: NL.GRU(128, H, True, T), "rnn": lambda: NL.RNN(128, H, True, T)}[kind]
+    seq = os.environ.get("REC_PROBE_SEQ", "1") == "1"      # REC_PROBE_SEQ=0: return_sequences = false (no per-step output store)
+    mk = {"lstm": lambda: NL.LSTM(128, H, seq, T), "gru": lambda: NL.GRU(128, H, seq, T), "rnn": lambda: NL.RNN(128, H, seq, T)}[kind]
     l = mk()
     l.set_weights(r.standard_normal((128, G * H)).astype(np.float32) * 0.05, r.standard_normal((H, G * H)).astype(np.float32) * H ** -0.5,
                   np.zeros(G * H, np.float32), np.zeros(G * H, np.float32))
-    x = torch.randn(B, T, 128, device="cuda"); out = torch.empty(B, T, H, device="cuda")
+    x = torch.randn(B, T, 128, device="cuda"); out = torch.empty((B, T, H) if seq else (B, H), device="cuda")
     res = {v: [] for v in vals}
     for v in vals:
         os.environ[var] = v; l.apply_device(x, out=out)
