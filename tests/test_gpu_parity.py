@@ -558,6 +558,23 @@ def test_pingpong_default_shapes_match_classic_bitwise(gpu, monkeypatch, cell, H
     assert torch.equal(outs[0], outs[1])
 
 
+def test_hidden_sizes_beyond_the_persistent_kernel(gpu):
+    """H > 512 does not fit the LDS-resident kernel: the per-timestep kernels take over (also for H % 4 != 0)."""
+    r = rng(600)
+    for (I, H, B, T) in ((20, 600, 5, 4), (8, 1024, 3, 3), (6, 258, 4, 5)):
+        x = u(r, B, T, I)
+        W, U, bi, bh = lstm_weights(r, I, H)
+        l = NL.LSTM(I, H, True, T, v2=True)
+        l.set_weights(W, U, bi, bh)
+        close(l.apply(x), O.lstm(x, W, U, bi, bh, v2=True))
+        l.destroy()
+        W, U, bi, bh = gru_weights(r, I, H)
+        g = NL.GRU(I, H, False, T)
+        g.set_weights(W, U, bi, bh)
+        close(g.apply(x), O.gru(x, W, U, bi, bh, return_sequences=False))
+        g.destroy()
+
+
 def test_lstm512_nondefault_gate_activations(gpu):
     """Non-standard gate activations take the generic (run-time dispatched) gate code of the persistent kernel."""
     L = capi.load()
