@@ -294,8 +294,12 @@ struct RecPParams {
 #endif
 };
 #ifdef NNTK_REC_STAMPS
-#define REC_STAMP(i) do { if (p.stamp && blockIdx.x == 0 && lane == 0 && (PP ? wih == 0 : (w8 & 3) == 0)) \
-        p.stamp[((size_t)(PP ? half : (w8 >> 2)) * p.T + t) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define REC_STAMP(i) do { if (p.stamp && blockIdx.x == 0 && lane == 0) {                                               \
+        if (PP ? wih == 0 : (w8 & 3) == 0)                                                                            \
+            p.stamp[((size_t)(PP ? half : (w8 >> 2)) * p.T + t) * 8 + (i)] = __builtin_amdgcn_s_memtime();           \
+        if ((i) == 2 || (i) == 3)      /* K-loop start / end of EVERY wave, after the leaders' block */              \
+            p.stamp[(size_t)2 * p.T * 8 + ((size_t)w8 * p.T + t) * 2 + ((i) - 2)] = __builtin_amdgcn_s_memtime();    \
+    } } while (0)
 #else
 #define REC_STAMP(i) do {} while (0)
 #endif
@@ -791,8 +795,8 @@ const bool std_acts = G == 1 ? p.a0 == NNTK_ACT_TANH
             q.stamp = nullptr;
             const char *stamp_path = getenv("NNTK_REC_STAMP_FILE");
             if (stamp_path) {
-                if (hipMalloc((void **)&q.stamp, (size_t)2 * T * 8 * 8) != hipSuccess) return nntk_fail_msg("stamp alloc");
-                (void)hipMemset(q.stamp, 0, (size_t)2 * T * 8 * 8);
+                if (hipMalloc((void **)&q.stamp, (size_t)(2 * T * 8 + 8 * T * 2) * 8) != hipSuccess) return nntk_fail_msg("stamp alloc");
+                (void)hipMemset(q.stamp, 0, (size_t)(2 * T * 8 + 8 * T * 2) * 8);
             }
 #endif
             const int nbt_total = (B + REC_BM - 1) / REC_BM;
@@ -808,10 +812,10 @@ const bool std_acts = G == 1 ? p.a0 == NNTK_ACT_TANH
 #ifdef NNTK_REC_STAMPS
             if (q.stamp) {
                 (void)hipStreamSynchronize(nntk_stream());
-                unsigned long long *hs = (unsigned long long *)malloc((size_t)2 * T * 8 * 8);
-                (void)hipMemcpy(hs, q.stamp, (size_t)2 * T * 8 * 8, hipMemcpyDeviceToHost);
+                unsigned long long *hs = (unsigned long long *)malloc((size_t)(2 * T * 8 + 8 * T * 2) * 8);
+                (void)hipMemcpy(hs, q.stamp, (size_t)(2 * T * 8 + 8 * T * 2) * 8, hipMemcpyDeviceToHost);
                 FILE *f = fopen(stamp_path, "wb");
-                if (f) { fwrite(hs, 8, (size_t)2 * T * 8, f); fclose(f); }
+                if (f) { fwrite(hs, 8, (size_t)(2 * T * 8 + 8 * T * 2), f); fclose(f); }
                 free(hs); (void)hipFree(q.stamp);
             }
 #endif

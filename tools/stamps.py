@@ -22,7 +22,16 @@ def main():
     os.environ["NNTK_REC_STAMP_FILE"] = path
     lstm.apply_device(x, out=h); torch.cuda.synchronize()
     del os.environ["NNTK_REC_STAMP_FILE"]
-    s = np.fromfile(path, dtype=np.uint64).reshape(2, T, 8).astype(np.int64)
+    raw = np.fromfile(path, dtype=np.uint64).astype(np.int64)
+    s = raw[:2 * T * 8].reshape(2, T, 8)
+    if raw.size >= 2 * T * 8 + 8 * T * 2:
+        kw = raw[2 * T * 8:2 * T * 8 + 8 * T * 2].reshape(8, T, 2)[:, 100:900]
+        base = kw[0, :, 0]
+        print("per-wave K loop (start offset vs wave 0's start, duration), mean over steps:")
+        for w in range(8):
+            print("  wave %d: start %+7.0f  dur %6.0f  (min %6.0f max %6.0f)" % (
+                w, (kw[w, :, 0] - base).mean(), (kw[w, :, 1] - kw[w, :, 0]).mean(),
+                (kw[w, :, 1] - kw[w, :, 0]).min(), (kw[w, :, 1] - kw[w, :, 0]).max()))
     names = ["top", "poll", "kstart", "kend", "xchg", "gates+st", "drain", "arrive"]
     for half in range(2):
         d = s[half, 100:900]
