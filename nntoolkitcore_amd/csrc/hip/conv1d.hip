@@ -420,7 +420,10 @@ extern "C" int nntk_shim_conv1d(const float *d_in, const float *d_wp, const floa
     // apart; its input rows become the strided side (T * Cin apart, each still Cin contiguous floats).
     // Same arithmetic per output element, so the results are bit-identical.
     const char *tme = getenv("NNTK_GEMM_TM_BATCH");
-    if (out_mode == 1 && k == 1 && stride == 1 && !(tme && tme[0] == '0') &&
+    // (small batches keep the time tiling: a batch tile would be mostly padding -- one sequence of 1000 steps is
+    // 8 time tiles but 1000 batch tiles of one valid row each)
+    const bool tm_batch = tme ? tme[0] != '0' : B >= 64;
+    if (out_mode == 1 && k == 1 && stride == 1 && tm_batch &&
         (long)(CONV_BM + 64) * T * Cin * 4 < 0x7fffffffL) {
         p.B = T; p.T = B; p.Tout = B;                 // "sequences" = timesteps, "rows" = batch entries
         p.in_seq = Cin; p.in_row = (long)T * Cin;
