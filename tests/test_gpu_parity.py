@@ -317,7 +317,12 @@ def test_spectrogram_512_all_windows(gpu, wname, mode):
 
 @pytest.mark.parametrize("nfft,win,nov,N,B", [(512, 400, 240, 16000, 5), (512, 512, 0, 5120, 2), (512, 400, 399, 900, 3),
                                               (256, 200, 120, 8000, 2), (64, 48, 16, 1000, 3), (60, 45, 15, 777, 2),
-                                              (16, 16, 8, 40, 1)])
+                                              (16, 16, 8, 40, 1),
+                                              # every count of 64-sample blocks the 512-point kernel is specialised for
+                                              (512, 40, 8, 2000, 2), (512, 64, 0, 1300, 1), (512, 100, 20, 3000, 3),
+                                              (512, 192, 64, 2500, 2), (512, 256, 128, 3000, 2), (512, 300, 37, 4000, 2),
+                                              (512, 384, 100, 5000, 2), (512, 385, 0, 5000, 3), (512, 448, 200, 6000, 2),
+                                              (512, 449, 10, 6000, 2)])
 def test_spectrogram_batch_geometries(gpu, nfft, win, nov, N, B):
     r = rng(nfft + N)
     x = (0.1 * r.standard_normal((B, N))).astype(np.float32)
