@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Random-shape soak of the conv / dense / recurrent kernels against the oracle (370 cases, ~20 s on the GPU):
+"""Random-shape soak of the conv / dense / recurrent kernels against the oracle (440 cases incl. spectrogram geometries and the RNN, ~30 s on the GPU):
 python tools/soak.py [seed]"""
 import os, sys
 import numpy as np
@@ -37,4 +37,22 @@ for _ in range(60):
     W, U, bi, bh = u(I, 4 * H, sc=I ** -0.5), u(H, 4 * H, sc=H ** -0.5), u(4 * H, sc=0.1), u(4 * H, sc=0.1)
     l = NL.LSTM(I, H, False, T); l.set_weights(W, U, bi, bh)
     close(l.apply(x), O.lstm(x, W, U, bi, bh, return_sequences=False), 1e-4); l.destroy(); n += 2
+for _ in range(40):
+    win = int(r.integers(8, 513)); nov = int(r.integers(0, win)); nfft = 512
+    N = int(r.integers(win, 6000)); B = int(r.integers(1, 5))
+    x = u(B, N, sc=0.1)
+    mode = "psd" if r.integers(0, 2) else "magnitude"
+    sp = NL.Spectrogram(nfft, win, nov, N, mode=mode, fs=16000, window_name="hamming_window")
+    ref = O.spectrogram(x, O.window("hamming", win), nfft, nov, mode=mode, fs=16000)
+    got = sp.apply(x)
+    assert got.shape == ref.shape and np.abs(got - ref).max() <= 2e-5 * (1e-6 + np.abs(ref).max()), (win, nov, N)
+    sp.destroy(); n += 1
+for _ in range(30):
+    I, H = int(r.integers(1, 100)), int(r.integers(1, 140)) * 4
+    T, B = int(r.integers(1, 8)), int(r.integers(1, 150))
+    x = u(B, T, I)
+    W, U, bi, bh = u(I, H, sc=I ** -0.5), u(H, H, sc=H ** -0.5), u(H, sc=0.1), u(H, sc=0.1)
+    v2 = bool(r.integers(0, 2))
+    m = NL.RNN(I, H, True, T, v2=v2); m.set_weights(W, U, bi, bh)
+    close(m.apply(x), O.rnn(x, W, U, bi, bh, v2=v2), 1e-4); m.destroy(); n += 1
 print("soak ok:", n, "cases")
