@@ -16,11 +16,22 @@ Inputs are resident in HBM before the timed region.  `value` = whole-job frames/
 `roofline` describes the dominant kernel from HIP-event timings taken inside this run;
 `cpu_baseline` times the CPU oracle (oracle/, a restatement of the reference's
 single-threaded scalar path) on a bounded sample of the same workload, rank 0, N=1 only.
+
+Multi-GPU: one process per GPU.  Under a launcher (torch.distributed.run sets RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_*) this file is a rank.  Run bare as `python bench.py --gpus N` with N > 1 it
+is its own launcher: the parent -- before importing torch or touching the GPU in any way --
+starts N fresh rank processes of this same file, waits for them, and exits non-zero if any of them
+failed; rank 0's JSON line is the output.  No data-path collective: utterances are sharded, the only
+RCCL traffic is one weight broadcast, an all_gather of the rank ids (`config.ranks_seen`) and the
+barrier / MAX-reduce of the timing contract.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -43,7 +54,60 @@ def parse():
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher rehearsal on the CPU (gloo): rendezvous + all_gather of the rank ids, no GPU work, "
+                         "prints {\"dry_run\": true, ...} and NO metric")
     return ap.parse_args()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` (N > 1) with no launcher around it: become the launcher.  Runs before torch is
+    imported and before anything touches the GPU; children are fresh processes (never os.exec*), one per GPU."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # only rank 0 prints the JSON line; the other ranks' stdout goes to our stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+
+    def relay(stream):                   # rank 0: JSON lines to stdout, any library chatter to stderr
+        for line in stream:
+            (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+            sys.stdout.flush()
+
+    import threading
+    pump = threading.Thread(target=relay, args=(procs[0].stdout,), daemon=True)
+    pump.start()
+    deadline = time.time() + float(os.environ.get("NNTK_BENCH_LAUNCH_TIMEOUT", "1500"))
+    rc = 0
+    live = set(range(a.gpus))
+    while live and rc == 0:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is not None:
+                live.discard(r)
+                if code != 0:
+                    sys.stderr.write("bench.py: rank %d exited with code %d\n" % (r, code))
+                    rc = code if code > 0 else 1
+        if time.time() > deadline:
+            sys.stderr.write("bench.py: ranks still running at the launch timeout\n")
+            rc = 124
+        if live and rc == 0:
+            time.sleep(0.05)
+    for r in live:                       # a rank failed or timed out: stop exactly the processes started here
+        procs[r].terminate()
+    for r in live:
+        try:
+            procs[r].wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            procs[r].kill()
+    pump.join(timeout=10)
+    return rc
 
 
 # ------------------------------------------------------------------ weights ---
@@ -174,21 +238,25 @@ class Workload:
 
 
 def pmc_traffic(kernel_prefix, B):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate --pmc runs of this
-    same command and corrected as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from
-    inside a timed run, so this is the profiled value for the same workload shape, or None."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        d = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    if d.get("utterances_per_gpu") != B:
-        return None
-    for name, v in d.get("kernels", {}).items():
-        if name.startswith(kernel_prefix):
-            return v.get("hbm_bytes_per_launch")
-    return None
+    """HBM bytes per launch of the dominant kernel from a committed rocprofv3 PMC summary (profiles/*_pmc_traffic.json:
+    FETCH_SIZE / WRITE_SIZE collected in separate --pmc runs of this same command and corrected as
+    MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside a timed run, so this is a profiled
+    value -- returned ONLY when the profile is stamped with the hash of the sources this library was built from
+    and the same utterances per GPU; otherwise (None, why)."""
+    import glob
+    from nntoolkitcore_amd._build import source_hash
+    want = source_hash()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if d.get("source_hash") != want or d.get("utterances_per_gpu") != B:
+            continue
+        for name, v in d.get("kernels", {}).items():
+            if name.startswith(kernel_prefix):
+                return v.get("hbm_bytes_per_launch"), "%s (source_hash %s)" % (os.path.relpath(path, ROOT), want)
+    return None, "no profiles/*_pmc_traffic.json stamped with this library's source_hash %s at %d utterances/GPU" % (want, B)
 
 
 def roofline_for(wl, phase_ms, prof):
@@ -222,9 +290,11 @@ def roofline_for(wl, phase_ms, prof):
     kern = ("rec_persistent_kernel" if persistent else "rec_step_kernel") + ("<4,LSTM>" if G == 4 else "<3,GRU>")
     flops = 2.0 * B * H * G * H * tpl          # algorithmic flops of ONE launch (tpl timesteps of h[B,H] x U[H,G*H])
     ach = flops / (ms * 1e-3) / 1e12
-    traffic = pmc_traffic("rec_persistent_kernel<4" if G == 4 else "rec_persistent_kernel<3", B) if (persistent and wl.name == "stack") else None
+    traffic, traffic_source = (pmc_traffic("rec_persistent_kernel<4" if G == 4 else "rec_persistent_kernel<3", B)
+                               if (persistent and wl.name == "stack") else (None, "not profiled for this workload"))
     return {"kernel": kern, "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": traffic, "ms_per_launch": ms, "algorithmic_flops": flops,
+            "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
+            "ms_per_launch": ms, "algorithmic_flops": flops,
             "timesteps_per_launch": tpl, "us_per_timestep": ms * 1e3 / tpl,
             "launches_per_step": prof.get("rec_launches_per_step")}
 
@@ -272,7 +342,7 @@ def cpu_baseline(workload, weights, frames, seed):
         sample = "%d utterances x %d frames of the same stack" % (n_utt, fr)
     dt = time.perf_counter() - t0
     res = {"value": nframes / dt, "unit": "frames/s", "cores": 1, "kind": "port", "sample": sample,
-           "seconds": round(dt, 2)}
+           "seconds": round(dt, 2), "host_nproc": os.cpu_count()}
     if workload == "stack":
         # N independent workers, one utterance each (the reference's Linux build is serial --
         # core/loop.h:23 -- so the 1-thread figure above stays the faithful one; this is its embarrassingly
@@ -297,24 +367,63 @@ def cpu_baseline(workload, weights, frames, seed):
     return res
 
 
+def dry_run(a, world, rank):
+    """Launcher rehearsal (tests, CPU): rendezvous over gloo, all_gather of the rank ids, one barrier.  Prints no metric."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    seen = [rank]
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([rank], dtype=torch.int32)
+        parts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        seen = [int(p.item()) for p in parts]
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": seen, "backend": "gloo"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
-    import torch
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))          # parent: nothing below runs here, the GPU is never touched
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (run `python bench.py --gpus N` bare, or under "
+                         "torch.distributed.run with --nproc-per-node N)" % (a.gpus, world))
+    if a.dry_run:
+        return dry_run(a, world, rank)
+    import torch
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
     # one process per GPU.  (NNTK_BENCH_BACKEND=gloo is a rehearsal mode for a 1-GPU box: several ranks share
     # the card and the collectives run on the CPU; never used by the driver.)
     backend = os.environ.get("NNTK_BENCH_BACKEND", "nccl")
-    local = local % torch.cuda.device_count() if backend != "nccl" else local
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        raise SystemExit("bench.py: %d ranks but only %d GPU(s) visible; RCCL needs one GPU per rank "
+                         "(NNTK_BENCH_BACKEND=gloo rehearses several ranks on one card)" % (world, ndev))
+    local = local % ndev
     torch.cuda.set_device(local)
     dist = None
+    ranks_seen = [0]
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend, rank=rank, world_size=world)     # "nccl" is RCCL on ROCm
-    assert a.gpus == world, "--gpus must equal WORLD_SIZE (launch N>1 with torch.distributed.run)"
+        if backend == "nccl":             # "nccl" is RCCL on ROCm; bind the communicator to this rank's GPU
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        # every rank reports in through the communicator the bench uses: N distinct ids = N ranks really joined
+        t = torch.tensor([rank], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+        parts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        ranks_seen = [int(p.item()) for p in parts]
+        assert sorted(ranks_seen) == list(range(world)), ranks_seen
 
     from nntoolkitcore_amd import capi, layers as NL
     from nntoolkitcore_amd.sharding import broadcast_weights
@@ -332,13 +441,17 @@ def main():
     flat = pack(parts) if rank == 0 else np.zeros_like(pack(parts))
     flat = broadcast_weights(flat, torch, dist)
     weights = unpack(flat, parts)
+    weights_crc = int(hashlib.sha256(flat.tobytes()).hexdigest()[:8], 16)
 
     wl = Workload(a.workload, B, frames, weights, torch, NL)
 
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            if backend == "nccl":
+                dist.barrier(device_ids=[local])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     def check_device_status(where):
@@ -358,10 +471,18 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     check_device_status("after the timed steps")
+    crcs = [weights_crc]
     if dist is not None:
-        t = torch.tensor([dt], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        on_gpu = dist.get_backend() == "nccl"
+        t = torch.tensor([dt], device="cuda" if on_gpu else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # the broadcast really delivered rank 0's weights everywhere
+        c = torch.tensor([weights_crc], device="cuda" if on_gpu else "cpu", dtype=torch.int64)
+        cs = [torch.zeros_like(c) for _ in range(world)]
+        dist.all_gather(cs, c)
+        crcs = [int(x.item()) for x in cs]
+        assert len(set(crcs)) == 1, "weight broadcast mismatch across ranks: %r" % crcs
 
     # per-phase HIP-event times (ms), averaged over the timed steps
     phase_ms = {}
@@ -375,6 +496,8 @@ def main():
         prof["rec_launch_ms"] = ms.value / cnt.value                 # average duration of one kernel launch
         prof["rec_timesteps_per_launch"] = units.value / cnt.value   # 1 = per-step kernels, T = persistent
         prof["rec_launches_per_step"] = cnt.value / max(1, a.steps + a.warmup)
+    if L.nntk_hip_profile_get(b"spectrogram", C.byref(ms), C.byref(cnt), C.byref(units)) == 0 and cnt.value > 0:
+        prof["spec_launch_ms"] = ms.value / cnt.value
 
     total_frames = world * B * wl.frames_per_utt * a.steps
     value = total_frames / dt
@@ -388,7 +511,9 @@ def main():
             "conv": "BASELINE configs[2]: Conv1d(40->128,k=5)+BN+ReLU on batch x frames x 40",
             "gru": "BASELINE configs[3]: 2-layer GRU(128->256->256) on batch x frames x 128"}[a.workload],
             "utterances_per_gpu": B, "frames_per_utterance": wl.frames_per_utt, "global_batch": B * world,
-            "parallelism": "utterance shards, dp%d, no data-path collective" % world},
+            "parallelism": "utterance shards, dp%d, no data-path collective" % world,
+            "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
+            "ranks_seen": ranks_seen},
         "phase_ms": {k: round(v, 4) for k, v in phase_ms.items()},
     }
     if rank == 0:

@@ -19,6 +19,21 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel + host sources the library is built from: the identity a
+    profile (profiles/*_pmc_traffic.json) is stamped with, so bench.py never prints another library's counters."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, "host", f) for f in HOST_SRC] + [os.path.join(CSRC, "hip", f) for f in HIP_SRC]
+    files += [os.path.join(CSRC, "hip", "nntk_shim.h"), os.path.join(CSRC, "hip", "nntk_common.hpp"),
+              os.path.join(CSRC, "host", "nntk_internal.h"), os.path.join(ROOT, "include", "nntoolkitcore_hip.h")]
+    for f in sorted(files):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _newer(src_list, target):
     if not os.path.exists(target):
         return True
