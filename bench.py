@@ -464,10 +464,20 @@ def main():
         wl.step()
     barrier()
     check_device_status("after warm-up")
+    # per-phase HIP events on the launch stream.  A one-kernel workload is bracketed ONCE around all K launches (an event
+    # pair around each 15-us launch costs about as much as the launch); the multi-kernel ones get per-phase events.
+    single = {"spectrogram": "spectrogram", "conv": "conv_bn_relu"}.get(a.workload)
     t0 = time.perf_counter()
     events = []
-    for i in range(a.steps):
-        events.append(wl.step(timed=True))
+    if single:
+        r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        r0.record()
+        for i in range(a.steps):
+            wl.step()
+        r1.record()
+    else:
+        for i in range(a.steps):
+            events.append(wl.step(timed=True))
     barrier()
     dt = time.perf_counter() - t0
     check_device_status("after the timed steps")
@@ -486,6 +496,8 @@ def main():
 
     # per-phase HIP-event times (ms), averaged over the timed steps
     phase_ms = {}
+    if single:
+        phase_ms[single] = r0.elapsed_time(r1) / a.steps
     for ev in events:
         for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):
             phase_ms[n1] = phase_ms.get(n1, 0.0) + e0.elapsed_time(e1) / a.steps
@@ -496,8 +508,6 @@ def main():
         prof["rec_launch_ms"] = ms.value / cnt.value                 # average duration of one kernel launch
         prof["rec_timesteps_per_launch"] = units.value / cnt.value   # 1 = per-step kernels, T = persistent
         prof["rec_launches_per_step"] = cnt.value / max(1, a.steps + a.warmup)
-    if L.nntk_hip_profile_get(b"spectrogram", C.byref(ms), C.byref(cnt), C.byref(units)) == 0 and cnt.value > 0:
-        prof["spec_launch_ms"] = ms.value / cnt.value
 
     total_frames = world * B * wl.frames_per_utt * a.steps
     value = total_frames / dt

@@ -259,11 +259,31 @@ void LogMelSpectrogramDestroy(LogMelSpectrogram filter);
 /* ---- runtime ----------------------------------------------------------- */
 int         nntk_hip_device_count(void);
 int         nntk_hip_set_device(int device);          /* 0 ok, -1 error */
-void        nntk_hip_set_stream(void *hip_stream);    /* all later launches use it; NULL = default stream */
+void        nntk_hip_set_stream(void *hip_stream);    /* all later launches OF THE CALLING THREAD use it; NULL = default stream */
 void       *nntk_hip_get_stream(void);
-int         nntk_hip_synchronize(void);               /* waits for the current stream */
+int         nntk_hip_synchronize(void);               /* waits for the calling thread's current stream; -1 if a recurrent
+                                                         launch faulted since the last check (see below) */
 const char *nntk_last_error(void);                    /* "" when the last call succeeded */
 const char *nntk_version(void);
+/* Threading (as the reference: distinct handles are independent, a handle is not re-entrant -- conv_1d.c:41,
+ * gru.c:86, lstm.c:97): the current stream and the error string are per host thread; two threads may drive two
+ * handles on two streams at the same time.  One handle is used by one thread and on one stream at a time
+ * (nntk_hip_synchronize() before moving it to another stream).
+ *
+ * Tuning / diagnostics knobs by name; environment variables NNTK_<NAME> give the initial values (read once).
+ *   "rec_persistent" 0 = per-timestep recurrent kernels only     "rec_pingpong" 0/1 = ping-pong halves off/on
+ *   "rec_spin_us"    budget of the persistent kernel's spins     "gemm_tm_batch" 0/1
+ *   "weights_check"  2 = host-pointer Apply compares the whole weight block with the uploaded copy each call,
+ *                    1 = sampled probes (default), 0 = never (use <Layer>SyncWeights)
+ * value "auto" restores the default.  0 ok, -1 unknown option. */
+int         nntk_hip_set_option(const char *name, const char *value);
+int         nntk_hip_get_option(const char *name, int *value);
+/* The persistent GRU/LSTM kernel needs all its workgroups resident; if another process's kernel holds the CUs its
+ * bounded spins give up and raise a sticky fault word.  Host-pointer recurrent calls notice it themselves and repeat
+ * the call on the per-timestep kernels (same bits); device-pointer callers see it as -1 from nntk_hip_synchronize(),
+ * or poll it without blocking here (0 healthy, 1 a completed recurrent launch of this thread has faulted).  After a
+ * fault the process keeps to the per-timestep kernels. */
+int         nntk_hip_device_status(void);
 /* Optional HIP-event spans around the recurrent kernel launches (name "rec_step"): enable,
  * run, then read the summed milliseconds, the number of kernel launches and the timesteps they
  * covered (a persistent launch covers all T of a sequence).  Reading clears the spans. */

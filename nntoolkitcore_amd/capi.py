@@ -183,6 +183,9 @@ SIGNATURES = {
     "nntk_hip_synchronize": (C.c_int, []),
     "nntk_last_error": (C.c_char_p, []),
     "nntk_version": (C.c_char_p, []),
+    "nntk_hip_set_option": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "nntk_hip_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
+    "nntk_hip_device_status": (C.c_int, []),
     "nntk_hip_profile_enable": (None, [C.c_int]),
     "nntk_hip_profile_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "nntk_device_alloc": (vp, [C.c_size_t]),
@@ -260,6 +263,20 @@ def load():
 
 def last_error():
     return load().nntk_last_error().decode()
+
+
+def set_option(name, value):
+    """nntk_hip_set_option: tuning / diagnostics knob by name; value "auto" restores the default."""
+    rc = load().nntk_hip_set_option(name.encode(), str(value).encode())
+    if rc != 0:
+        raise NNTKError("nntk_hip_set_option(%s): %s" % (name, last_error()))
+
+
+def get_option(name):
+    v = C.c_int()
+    if load().nntk_hip_get_option(name.encode(), C.byref(v)) != 0:
+        raise NNTKError("nntk_hip_get_option(%s): %s" % (name, last_error()))
+    return v.value
 
 
 class NNTKError(RuntimeError):

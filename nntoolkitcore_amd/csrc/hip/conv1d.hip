@@ -76,8 +76,13 @@ struct ConvParams {
 
 typedef unsigned v4u32_t __attribute__((ext_vector_type(4)));
 
+// Out-of-range sentinel for a lane's VECTOR offset (the only part of a buffer address the hardware range-checks).
+// Every descriptor here is clamped to at most CONV_OOB bytes, so the sentinel is out of range whatever the
+// tensor's size: a load returns 0, a store is dropped.  Legitimate vector offsets stay far below it: descriptors
+// are based at the tile (or weight matrix) they serve, and the host rejects shapes whose in-tile offsets would not fit.
+#define CONV_OOB 0x7ffffff0
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t conv_rsrc(const void *base, size_t bytes) {
-    const unsigned n = bytes > 0xfffffff0ull ? 0xfffffff0u : (unsigned)bytes;
+    const unsigned n = bytes > (size_t)CONV_OOB ? (unsigned)CONV_OOB : (unsigned)bytes;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)n, 0x00020000);
 }
 
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
             const bool ch_ok = cc * KC + ac < p.Cin;
 #pragma unroll
             for (int q = 0; q < A_PT; ++q) {
-                const int vo = ch_ok ? a_voff[q] : 0x7ffffff0;
+                const int vo = ch_ok ? a_voff[q] : CONV_OOB;
                 if (A4) areg4[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, soff, 0);
                 else    areg[q] = __builtin_amdgcn_raw_buffer_load_b32(rs_in, vo, soff, 0);
             }
@@ -251,18 +256,20 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
     }
 
     // ---- epilogue: bias, BatchNorm (batch_norm.c:140-163 op order), activation, buffer stores ----
-    // descriptor = this sequence's output rows (mode 0) or the whole time-major tensor from column
-    // block b (mode 1).  Interior row tiles store with the row advance in the (unchecked) scalar
-    // offset and the padded columns on an out-of-range vector offset; the last row tile of a
-    // sequence compares every element's row instead.  The uniform choices (BatchNorm or not,
-    // which activation, which store path) are taken ONCE, outside the 64-element loops: inside
-    // them every instruction is VALU time taken from the MFMAs.
-    const size_t row_bytes = (size_t)(p.out_mode ? p.B : 1) * p.Cout * 4;      // distance between output rows x, x+1
-    const size_t obase = p.out_mode ? (size_t)b * p.Cout : (size_t)b * p.Tout * p.Cout;
-    const size_t olen = p.out_mode ? ((size_t)p.Tout * p.B * p.Cout - obase) : (size_t)p.Tout * p.Cout;
-    const __amdgpu_buffer_rsrc_t rs_out = conv_rsrc(p.out + obase, olen * 4);
+    // descriptor = THIS TILE's output rows: based at the tile's first row (so offsets inside it stay small however
+    // large the tensor is -- a TimeDistributedDense output passes 2 GiB at ~540 k rows of 1000) and never longer than
+    // CONV_OOB bytes (so the padded columns' sentinel offset is out of range by construction).  Interior row tiles
+    // store with the row advance in the (unchecked) scalar offset and the padded columns on the out-of-range vector
+    // offset; the last row tile of a sequence compares every element's row instead.  The uniform choices (BatchNorm
+    // or not, which activation, which store path) are taken ONCE, outside the 64-element loops: inside them every
+    // instruction is VALU time taken from the MFMAs.
+    const size_t row_elems = (size_t)(p.out_mode ? p.B : 1) * p.Cout;           // distance between output rows x, x+1
+    const size_t row_bytes = row_elems * 4;
+    const size_t obase = (p.out_mode ? (size_t)b * p.Cout : (size_t)b * p.Tout * p.Cout) + (size_t)x0 * row_elems;
+    const size_t oend = p.out_mode ? (size_t)p.Tout * p.B * p.Cout : ((size_t)b + 1) * p.Tout * p.Cout;
+    const __amdgpu_buffer_rsrc_t rs_out = conv_rsrc(p.out + obase, (oend - obase) * 4);
     const bool fast_store = x0 + CONV_BM <= p.Tout &&                              // every row of the tile exists
-                            row_bytes * (size_t)(x0 + CONV_BM) < 0x7fffffffull;    // and is reachable by 32-bit offsets
+                            row_bytes * (size_t)(CONV_BM + 4) < (size_t)CONV_OOB;  // and is reachable by 32-bit offsets
     const int rb = (int)row_bytes;
 
     auto epilogue = [&](auto bn_tag, auto act_tag, auto fast_tag) {
@@ -281,12 +288,13 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
             }
             const float rsd = 1.0f / sd;
             // per-lane part of the address: column, and the +4 rows of the upper lane half
-            const int voff = col_ok ? o * 4 + kh * 4 * rb : 0x7ffffff0;
+            const int voff = col_ok ? o * 4 + kh * 4 * rb : CONV_OOB;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int xs = x0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2);     // wave-uniform
+                    const int xr = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2);          // row inside the tile, wave-uniform
+                    const int xs = x0 + xr;
                     float v = acc[i][j][r] + bias;
                     if (HAS_BN) {
                         // (v - mu) / sd with the quotient refined by one FMA step: the correctly rounded
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
                       : ACT == NNTK_ACT_RELU ? nntk_act(NNTK_ACT_RELU, v, p.relu_a)
                       : v;
                     if (FAST) {
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, voff, xs * rb, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, voff, xr * rb, 0);
                     } else {
                         const int x = xs + 4 * kh;
                         if (x < p.Tout && col_ok) {
@@ -371,8 +379,7 @@ static int launch_mfma(const ConvParams &p) {
         return nntk_fail_msg("conv1d: too many tiles for one launch");
     auto kern = conv1d_mfma_kernel<WM, WN, TM, TN, A4>;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return nntk_fail("hipFuncSetAttribute(conv1d)", e);
+        if (nntk_set_max_dynamic_lds((const void *)kern, lds)) return -1;
     }
     dim3 grid((unsigned)blocks);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, nntk_stream(), q);
@@ -396,13 +403,16 @@ extern "C" int nntk_shim_conv1d(const float *d_in, const float *d_wp, const floa
     p.tiles_per_seq = (Tout + CONV_BM - 1) / CONV_BM;
     p.out_mode = out_mode;
     p.rows_a = (CONV_BM - 1) * stride + k;
-    { const char *e = getenv("NNTK_BN_FAST"); p.bn_fast = (e && e[0] == '1') ? 1 : 0; }
+    const NntkOptions &opt = nntk_options();
+    p.bn_fast = opt.bn_fast == 1 ? 1 : 0;
 #ifdef NNTK_CONV_DBG
-    { const char *e = getenv("NNTK_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }
+    p.dbg = opt.conv_dbg;
 #endif
 
-    if ((long)p.Cout_p * k * p.Cin_p * 4 >= 0x7fffffffL)
+    if ((long)p.Cout_p * k * p.Cin_p * 4 >= (long)CONV_OOB)
         return nntk_fail_msg("conv1d: packed weights must stay below 2 GiB (32-bit buffer offsets)");
+    if ((long)(192 + 1) * Cin * 4 >= (long)CONV_OOB)
+        return nntk_fail_msg("conv1d: a window of 192 input rows must stay below 2 GiB (32-bit buffer offsets)");
     const bool window_fits = p.rows_a <= 192;                          // register staging budget (A_PT)
     const long Kdim = (long)Cin * k;
     if (!window_fits || Kdim < 16 || Cout < 32) {
@@ -419,12 +429,11 @@ extern "C" int nntk_shim_conv1d(const float *d_in, const float *d_wp, const floa
     // [B, Cout] slab (8 KB apart for LSTM-512) instead of 128 rows that are B * Cout * 4 bytes = 4 MB
     // apart; its input rows become the strided side (T * Cin apart, each still Cin contiguous floats).
     // Same arithmetic per output element, so the results are bit-identical.
-    const char *tme = getenv("NNTK_GEMM_TM_BATCH");
     // (small batches keep the time tiling: a batch tile would be mostly padding -- one sequence of 1000 steps is
     // 8 time tiles but 1000 batch tiles of one valid row each)
-    const bool tm_batch = tme ? tme[0] != '0' : B >= 64;
+    const bool tm_batch = opt.gemm_tm_batch >= 0 ? opt.gemm_tm_batch != 0 : B >= 64;
     if (out_mode == 1 && k == 1 && stride == 1 && tm_batch &&
-        (long)(CONV_BM + 64) * T * Cin * 4 < 0x7fffffffL) {
+        (long)(CONV_BM + 64) * T * Cin * 4 < (long)CONV_OOB) {
         p.B = T; p.T = B; p.Tout = B;                 // "sequences" = timesteps, "rows" = batch entries
         p.in_seq = Cin; p.in_row = (long)T * Cin;
         p.out_mode = 0;                               // row (t, b) -> t * B + b: exactly the time-major layout

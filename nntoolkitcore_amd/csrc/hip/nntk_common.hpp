@@ -4,12 +4,41 @@
 #include <math.h>
 #include "nntk_shim.h"
 
-hipStream_t nntk_stream();
+hipStream_t nntk_stream();                        // the calling THREAD's current stream
 int nntk_fail(const char *what, hipError_t err);
 int nntk_fail_msg(const char *what);
-int nntk_prof_span_begin();                       // -1 when profiling is off
+enum { NNTK_SPAN_REC = 0, NNTK_SPAN_SPEC = 1 };
+int nntk_prof_span_begin(int kind);               // -1 when profiling is off
 void nntk_prof_span_end(int idx, long launches, long units);
-void nntk_set_post_sync_hook(int (*hook)());      // runs after every host-visible stream sync
+
+// Tuning / diagnostics knobs (runtime.hip): environment defaults read once, nntk_hip_set_option() at run time.
+// -1 = "auto" (the launcher's own measured choice).
+struct NntkOptions {
+    int rec_persistent = -1;     // 0: always the per-timestep recurrent kernels
+    int rec_xw = -1;             // where the persistent kernel issues its xW loads (see recurrent.hip)
+    int rec_pingpong = -1;       // ping-pong halves in the persistent kernel
+    int rec_groups = 2;          // split-K groups of the per-timestep kernel
+    int rec_spin_us = 1000000;   // budget of every in-kernel spin before it gives up and raises the fault word
+    int rec_stream = -1;         // small-batch streaming kernel (0 off)
+    int rec_fused2 = -1;         // fused two-layer GRU kernel (0 off)
+    int spec_ppw = 0;            // frame pairs per wavefront in K1 (0 = auto)
+    int spec_variant = -1;       // K1 kernel variant (A/B runs)
+    int bn_fast = 0;             // reciprocal-multiply BatchNorm (not the reference's divide)
+    int gemm_tm_batch = -1;      // tile time-major GEMM outputs over the batch
+    int gemm_split_bf16 = 0;     // opt-in 3-way split-bf16 contraction for conv / dense / xW (NOT exact f32)
+    int conv_dbg = 0;            // diagnostics build only
+    int weights_check = -1;      // host-pointer Apply: 1 compare the whole weight block with its shadow each call (default),
+                                 // 0 trust *SyncWeights
+};
+const NntkOptions &nntk_options();
+
+unsigned *nntk_fault_word();                      // device word the persistent kernel ORs into on a spin timeout
+int nntk_fault_enqueue_copy();                    // async copy of the word to its pinned mirror on the current stream
+int nntk_persistent_disabled();                   // set after a fault: take the per-timestep kernels
+void nntk_persistent_launch_begin();              // orders persistent launches across the process's streams (holds a mutex)
+void nntk_persistent_launch_end();
+int nntk_cu_count();                              // cached per device
+int nntk_set_max_dynamic_lds(const void *kernel, size_t bytes);   // hipFuncSetAttribute once per (kernel, device)
 
 #define NNTK_HIP_TRY(expr)                                             \
     do {                                                               \
@@ -58,11 +87,15 @@ __device__ __forceinline__ float nntk_fast_tanh(float x) {
     const float r = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
     return copysignf(r, x);
 }
-__device__ __forceinline__ float nntk_gate_act(int kind, float x) {
+// `a` = ReLU's output scale (activation_default.c:123-129: max(x, 0), then * a when a != 1); ignored by the other kinds
+__device__ __forceinline__ float nntk_gate_act(int kind, float x, float a = 1.0f) {
     switch (kind) {
     case NNTK_ACT_SIGMOID: return nntk_fast_sigmoid(x);
     case NNTK_ACT_TANH:    return nntk_fast_tanh(x);
-    case NNTK_ACT_RELU:    return fmaxf(x, 0.0f);
+    case NNTK_ACT_RELU: {
+        const float y = fmaxf(x, 0.0f);
+        return a != 1.0f ? y * a : y;
+    }
     default: return x;
     }
 }

@@ -36,6 +36,15 @@ const char *nntk_shim_error(void);
 void        nntk_shim_set_error(const char *msg);
 void        nntk_shim_clear_error(void);
 
+/* tuning / diagnostics knobs by name ("rec_persistent", "rec_pingpong", "gemm_tm_batch", ...; value "auto" restores
+ * the default).  Environment variables NNTK_<NAME> give the initial values, read once. */
+int nntk_shim_set_option(const char *name, const char *value);
+int nntk_shim_get_option(const char *name, int *value);
+/* sticky fault word of the persistent recurrent kernel (see runtime.hip) */
+int nntk_shim_take_fault(void);            /* after a stream sync: 1 = a launch faulted (cleared, per-step kernels from now on) */
+int nntk_shim_persistent_disabled(void);
+int nntk_shim_device_status(void);         /* non-blocking: 1 = a completed recurrent launch has faulted */
+
 /* HIP-event spans around the recurrent step launches (off by default) */
 void nntk_shim_profile_enable(int on);
 int  nntk_shim_profile_get(const char *name, double *total_ms, long *launches, long *timesteps);
@@ -45,7 +54,9 @@ void  nntk_shim_free(void *d_ptr);
 void *nntk_shim_host_alloc(size_t bytes);              /* pinned, zero-filled */
 void  nntk_shim_host_free(void *ptr);
 int   nntk_shim_upload(void *d_dst, const void *h_src, size_t bytes);     /* blocking */
-int   nntk_shim_download(void *h_dst, const void *d_src, size_t bytes);   /* blocking */
+int   nntk_shim_upload_async(void *d_dst, const void *h_src, size_t bytes);        /* async on stream (pinned source) */
+int   nntk_shim_download(void *h_dst, const void *d_src, size_t bytes);   /* blocking; -1 if a recurrent launch faulted */
+int   nntk_shim_download_nocheck(void *h_dst, const void *d_src, size_t bytes);    /* blocking; leaves a fault for nntk_shim_take_fault */
 int   nntk_shim_copy_d2d(void *d_dst, const void *d_src, size_t bytes);   /* async on stream */
 int   nntk_shim_memset(void *d_ptr, int value, size_t bytes);             /* async on stream */
 
@@ -84,18 +95,19 @@ int nntk_shim_add2(const float *d_a, const float *d_b, float *d_out, long n);
  * d_hT / d_cT  [B, H] final state (may be NULL)
  * d_work scratch >= nntk_shim_recurrent_work_floats(B, H) floats
  * acts   GRU: {z, h, r};  LSTM: {i, f, g, o, out}
+ * act_scales  parallel to acts: ReLU's output scale `a` (activation_default.c:123-129), ignored for other kinds; NULL = 1
  */
 /* simple RNN cell (rnn.c:144-166): one gate, h' = act(xW + hU + b); same buffers as nntk_shim_gru */
 int nntk_shim_rnn(const float *d_xw, const float *d_ut, const float *d_bh, const float *d_h0,
                   float *d_out, float *d_hT, float *d_work, int B, int T, int H,
-                  int return_sequences, int act);
+                  int return_sequences, int act, float act_scale);
 size_t nntk_shim_recurrent_work_floats(int B, int H);
 int nntk_shim_gru(const float *d_xw, const float *d_ut, const float *d_bh,
                   const float *d_h0, float *d_out, float *d_hT, float *d_work,
-                  int B, int T, int H, int return_sequences, const int acts[3]);
+                  int B, int T, int H, int return_sequences, const int acts[3], const float act_scales[3]);
 int nntk_shim_lstm(const float *d_xw, const float *d_ut, const float *d_bh,
                    const float *d_h0, const float *d_c0, float *d_out, float *d_hT, float *d_cT,
-                   float *d_work, int B, int T, int H, int return_sequences, const int acts[5]);
+                   float *d_work, int B, int T, int H, int return_sequences, const int acts[5], const float act_scales[5]);
 
 /* ---- K1: framed STFT magnitude / PSD ---------------------------------------
  * d_in [B, input_size], d_window [window_size], d_out [B, nts, nfreq]

@@ -39,6 +39,7 @@ struct RecParams {
     long out_ld;
     int B, H, Hj_p, Hk_p;
     int a0, a1, a2, a3, a4;   // activation kinds
+    float s0, s1, s2, s3, s4; // ReLU output scales of those activations (activation_default.c:123-129), 1 otherwise
 };
 
 // NG = number of intra-workgroup split-K groups (256 threads each).  NG = 2 puts two
@@ -218,13 +219,13 @@ __global__ __launch_bounds__(256 * NG) void rec_step_kernel(RecParams p) {
         float hn;
         if constexpr (G == 1) {
             // rnn.c:144-166: gate = (h U [+ b_h]) + (x W + b_i); h' = act(gate)
-            hn = nntk_gate_act(p.a0, xwv[rr][0] + (fin[rr][0] + bh[0]));
+            hn = nntk_gate_act(p.a0, xwv[rr][0] + (fin[rr][0] + bh[0]), p.s0);
         } else if constexpr (!IS_LSTM) {
             // gru.c:144-186
             const float hz = fin[rr][0] + bh[0], hr = fin[rr][1] + bh[1], hh = fin[rr][2] + bh[2];
-            const float z = nntk_gate_act(p.a0, xwv[rr][0] + hz);
-            const float rg = nntk_gate_act(p.a2, xwv[rr][1] + hr);
-            const float ht = nntk_gate_act(p.a1, rg * hh + xwv[rr][2]);
+            const float z = nntk_gate_act(p.a0, xwv[rr][0] + hz, p.s0);
+            const float rg = nntk_gate_act(p.a2, xwv[rr][1] + hr, p.s2);
+            const float ht = nntk_gate_act(p.a1, rg * hh + xwv[rr][2], p.s1);
             hn = (-z + 1.0f) * ht + z * prev[rr];
         } else {
             // lstm.c:201-238
@@ -232,13 +233,13 @@ __global__ __launch_bounds__(256 * NG) void rec_step_kernel(RecParams p) {
             const float zf = xwv[rr][1] + (fin[rr][1] + bh[1]);
             const float zg = xwv[rr][2] + (fin[rr][2] + bh[2]);
             const float zo = xwv[rr][G - 1] + (fin[rr][G - 1] + bh[G - 1]);
-            const float ig = nntk_gate_act(p.a0, zi);
-            const float fg = nntk_gate_act(p.a1, zf);
-            const float gg = nntk_gate_act(p.a2, zg);
-            const float og = nntk_gate_act(p.a3, zo);
+            const float ig = nntk_gate_act(p.a0, zi, p.s0);
+            const float fg = nntk_gate_act(p.a1, zf, p.s1);
+            const float gg = nntk_gate_act(p.a2, zg, p.s2);
+            const float og = nntk_gate_act(p.a3, zo, p.s3);
             const float cn = fg * prev[rr] + ig * gg;
             p.c[(size_t)b * p.H + j] = cn;
-            hn = og * nntk_gate_act(p.a4, cn);
+            hn = og * nntk_gate_act(p.a4, cn, p.s4);
         }
         p.h_next[(size_t)b * p.H + j] = hn;
         if (p.out) p.out[(size_t)b * p.out_ld + j] = hn;
@@ -271,7 +272,6 @@ __global__ __launch_bounds__(256 * NG) void rec_step_kernel(RecParams p) {
 // s_memrealtime) and poisons the counter's top bit, which the host checks.
 // ============================================================================
 #define RECP_CNT_STRIDE 64  // uints between arrival counters (256 B)
-#define RECP_CNT_WORDS (256 * RECP_CNT_STRIDE)
 #define RECP_MAXCH 16     // H <= 512 (16 chunks of 32): the whole h tile is held in registers per step
 typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
 
@@ -289,6 +289,9 @@ struct RecPParams {
     int B, T, H, Hj_p, Hk_p, NBT, NCT, b_base;
     int return_sequences;
     int a0, a1, a2, a3, a4;
+    float s0, s1, s2, s3, s4;       // ReLU output scales (generic-activation variant only)
+    unsigned *fault;                // sticky device fault word (runtime.hip): OR-ed on a spin timeout, never reset per launch
+    unsigned long long spin_ticks;  // budget of every spin in s_memrealtime ticks (100 MHz)
 #ifdef NNTK_REC_STAMPS
     unsigned long long *stamp;   // [2 halves][T][8] s_memtime of workgroup 0's leader waves (diagnostics build only)
 #endif
@@ -374,6 +377,8 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
     const int A2 = STD ? (IS_LSTM ? NNTK_ACT_TANH : NNTK_ACT_SIGMOID) : p.a2;
     const int A3 = STD ? NNTK_ACT_SIGMOID : p.a3;
     const int A4 = STD ? NNTK_ACT_TANH : p.a4;
+    const float S0 = STD ? 1.0f : p.s0, S1 = STD ? 1.0f : p.s1, S2 = STD ? 1.0f : p.s2, S3 = STD ? 1.0f : p.s3,
+                S4 = STD ? 1.0f : p.s4;
     constexpr bool VEC = true;                    // launcher guarantees H % 4 == 0
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KP = NCH * REC_KC;              // padded K
@@ -483,12 +488,17 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
             if (leader && lane == 0) {
                 const unsigned target = (unsigned)p.NCT * (unsigned)t;
                 const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                // spin_ticks == 0 is fault injection (tests): behave as if the first poll had run out of budget
+                bool expired = p.spin_ticks == 0;
+                while (!expired && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (__builtin_amdgcn_s_memrealtime() - t_start > 100000000ull) {     // 1 s at 100 MHz
-                        __hip_atomic_fetch_or(cnt, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
+                    expired = __builtin_amdgcn_s_memrealtime() - t_start > p.spin_ticks;     // default 1 s at 100 MHz
+                }
+                if (expired) {
+                    // give up: raise the sticky fault word for the host, and poison the counter so that
+                    // every other poller of this batch tile falls through as well (all spins stay bounded)
+                    __hip_atomic_fetch_or(p.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_or(cnt, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if (PP) __hip_atomic_store(&syncw[half], (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
@@ -582,12 +592,12 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             if constexpr (G == 1) {
-                hn[e] = nntk_gate_act(A0, xwv[e][0] + (fin[e][0] + bh[e][0]));      // rnn.c:144-166
+                hn[e] = nntk_gate_act(A0, xwv[e][0] + (fin[e][0] + bh[e][0]), S0);      // rnn.c:144-166
             } else if constexpr (!IS_LSTM) {
                 const float hz = fin[e][0] + bh[e][0], hr = fin[e][1] + bh[e][1], hh = fin[e][2] + bh[e][2];
-                const float z = nntk_gate_act(A0, xwv[e][0] + hz);
-                const float rg = nntk_gate_act(A2, xwv[e][1] + hr);
-                const float ht = nntk_gate_act(A1, rg * hh + xwv[e][2]);
+                const float z = nntk_gate_act(A0, xwv[e][0] + hz, S0);
+                const float rg = nntk_gate_act(A2, xwv[e][1] + hr, S2);
+                const float ht = nntk_gate_act(A1, rg * hh + xwv[e][2], S1);
                 hn[e] = (-z + 1.0f) * ht + z * prev[e];
                 prev[e] = hn[e];
             } else {
@@ -595,13 +605,13 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
                 const float zf = xwv[e][1] + (fin[e][1] + bh[e][1]);
                 const float zg = xwv[e][2] + (fin[e][2] + bh[e][2]);
                 const float zo = xwv[e][G - 1] + (fin[e][G - 1] + bh[e][G - 1]);
-                const float ig = nntk_gate_act(A0, zi);
-                const float fg = nntk_gate_act(A1, zf);
-                const float gg = nntk_gate_act(A2, zg);
-                const float og = nntk_gate_act(A3, zo);
+                const float ig = nntk_gate_act(A0, zi, S0);
+                const float fg = nntk_gate_act(A1, zf, S1);
+                const float gg = nntk_gate_act(A2, zg, S2);
+                const float og = nntk_gate_act(A3, zo, S3);
                 const float cn = fg * prev[e] + ig * gg;
                 prev[e] = cn;
-                hn[e] = og * nntk_gate_act(A4, cn);
+                hn[e] = og * nntk_gate_act(A4, cn, S4);
             }
         }
         // ---- publish h_t (write-through), then this wave's arrival; the layer output
@@ -667,46 +677,21 @@ __global__ __launch_bounds__(256) void rec_tile_h0_kernel(const float *src, floa
     }
 }
 
-// ---- host side of the bounded spins: after each persistent launch the arrival counters are
-//      copied (async, same stream) into pinned memory; the next host-visible sync point
-//      checks their poison bit and turns a would-be hang into an ordinary -1 ----
-static unsigned *g_rec_status = nullptr;       // pinned [256]
-static int g_rec_status_n = 0;
-
-static int rec_status_check() {
-    int bad = 0;
-    for (int i = 0; i < g_rec_status_n; ++i) bad |= (g_rec_status[i] & 0x80000000u) != 0;
-    g_rec_status_n = 0;
-    if (bad)
-        return nntk_fail_msg("persistent recurrent kernel: a workgroup timed out waiting for its peers "
-                             "(not all workgroups were resident?); results are invalid. "
-                             "Set NNTK_REC_PERSISTENT=0 to use the per-timestep kernels.");
-    return 0;
-}
-
-static int rec_status_enqueue(const unsigned *d_cnt, int nbt) {
-    if (!g_rec_status) {
-        if (hipHostMalloc((void **)&g_rec_status, 256 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess)
-            return nntk_fail_msg("hipHostMalloc(rec status) failed");
-        nntk_set_post_sync_hook(rec_status_check);
-    }
-    if (g_rec_status_n + nbt > 256) g_rec_status_n = 0;
-    NNTK_HIP_TRY(hipMemcpy2DAsync(g_rec_status + g_rec_status_n, sizeof(unsigned), d_cnt,
-                                  RECP_CNT_STRIDE * sizeof(unsigned), sizeof(unsigned), (size_t)nbt,
-                                  hipMemcpyDeviceToHost, nntk_stream()));
-    g_rec_status_n += nbt;
-    return 0;
-}
-
 // floats per parity of the h ping-pong area: the persistent kernel's tiled layout pads rows to 64
 // and k to a multiple of 128 (4 chunks); the per-step kernels use the first B*H floats of each half
 static size_t rec_hb_floats(int B, int H) {
     return (size_t)((B + 63) & ~63) * (size_t)((H + 127) & ~127);
 }
 
+// arrival counters: up to two per batch tile (ping-pong halves), each on its own 256-B line
+static size_t rec_cnt_words(int B) {
+    const size_t nbt = (size_t)(B + REC_BM - 1) / REC_BM;
+    return (2 * nbt < 256 ? 256 : 2 * nbt) * RECP_CNT_STRIDE;
+}
+
 extern "C" size_t nntk_shim_recurrent_work_floats(int B, int H) {
     // h ping | h pong | c | arrival counters of the persistent kernel
-    return 2 * rec_hb_floats(B, H) + (size_t)B * H + RECP_CNT_WORDS;
+    return 2 * rec_hb_floats(B, H) + (size_t)B * H + rec_cnt_words(B);
 }
 
 static int act_ok(int a) {
@@ -716,10 +701,11 @@ static int act_ok(int a) {
 template <int G, bool IS_LSTM>
 static int run_recurrent(const float *d_xw, const float *d_ut, const float *d_bh, const float *d_h0,
                          const float *d_c0, float *d_out, float *d_hT, float *d_cT, float *d_work,
-                         int B, int T, int H, int return_sequences, const int *acts, int nacts) {
+                         int B, int T, int H, int return_sequences, const int *acts, const float *scales, int nacts) {
     for (int i = 0; i < nacts; ++i)
         if (!act_ok(acts[i]))
             return nntk_fail_msg("recurrent: gate activation must be one of the built-in identity/sigmoid/tanh/relu");
+    const NntkOptions &opt = nntk_options();
     const size_t BH = (size_t)B * H;
     const size_t hbmax = rec_hb_floats(B, H);
     float *hbuf[2] = {d_work, d_work + hbmax};
@@ -735,35 +721,33 @@ static int run_recurrent(const float *d_xw, const float *d_ut, const float *d_bh
     p.Hk_p = (H + 31) & ~31;
     p.a0 = acts[0]; p.a1 = nacts > 1 ? acts[1] : 0; p.a2 = nacts > 2 ? acts[2] : 0;
     p.a3 = nacts > 3 ? acts[3] : 0; p.a4 = nacts > 4 ? acts[4] : 0;
+    auto sc = [&](int i) { return (scales && i < nacts && acts[i] == NNTK_ACT_RELU) ? scales[i] : 1.0f; };
+    p.s0 = sc(0); p.s1 = sc(1); p.s2 = sc(2); p.s3 = sc(3); p.s4 = sc(4);
     dim3 grid((unsigned)((B + REC_BM - 1) / REC_BM), (unsigned)(p.Hj_p / REC_HN));
     // ---- persistent path: one launch for the whole sequence when U^T fits in LDS ----
     {
-        const char *penv = getenv("NNTK_REC_PERSISTENT");
-        const bool want = !(penv && penv[0] == '0');
+        const bool want = opt.rec_persistent != 0 && !nntk_persistent_disabled();
         const int NCT = p.Hj_p / REC_HN;
         const int nch = p.Hk_p / REC_KC;
         const int nch_p = nch <= 4 ? 4 : nch <= 8 ? 8 : nch <= 12 ? 12 : 16;      // compiled K depths (x32)
         const size_t lds = ((size_t)G * 16 * (nch_p * REC_KC + 8) + (size_t)4 * 2 * G * 2 * 64 + 16) * sizeof(float);
-        int dev = 0, cus = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const int cus = nntk_cu_count();
         const int tiles_per_launch = NCT > 0 ? cus / NCT : 0;
         const size_t hb_floats = (size_t)((B + 63) & ~63) * (size_t)(nch_p * REC_KC);      // <= hbmax
-        if (want && (H % 4) == 0 && lds <= 160 * 1024 && p.Hk_p <= RECP_MAXCH * REC_KC && tiles_per_launch >= 1 &&
+        unsigned *fault = want ? nntk_fault_word() : nullptr;
+        if (want && fault && (H % 4) == 0 && lds <= 160 * 1024 && p.Hk_p <= RECP_MAXCH * REC_KC && tiles_per_launch >= 1 &&
             hb_floats * 4 < 0x3ffffff0ULL) {
             void (*kern)(RecPParams);
-            const char *xenv = getenv("NNTK_REC_XW");
-            int xwm = xenv ? atoi(xenv) : -1;
-const bool std_acts = G == 1 ? p.a0 == NNTK_ACT_TANH
+            int xwm = opt.rec_xw;
+            const bool std_acts = G == 1 ? p.a0 == NNTK_ACT_TANH
                                  : IS_LSTM ? (p.a0 == NNTK_ACT_SIGMOID && p.a1 == NNTK_ACT_SIGMOID && p.a2 == NNTK_ACT_TANH &&
                                               p.a3 == NNTK_ACT_SIGMOID && p.a4 == NNTK_ACT_TANH)
                                            : (p.a0 == NNTK_ACT_SIGMOID && p.a1 == NNTK_ACT_TANH && p.a2 == NNTK_ACT_SIGMOID);
-            // ping-pong halves pay when the K loop is long (see the kernel's header); NNTK_REC_PINGPONG=0/1 overrides
-            const char *ppenv = getenv("NNTK_REC_PINGPONG");
+            // ping-pong halves pay when the K loop is long (see the kernel's header); option rec_pingpong = 0/1 overrides
             // measured (ms, classic -> ping-pong): LSTM H=320/384/448/512 5.5->4.3 / 5.8->4.5 / 6.1->5.5 / 14.1->11.8,
             // GRU H=320/384/512 4.7->4.4 / 9.0->8.2 / 5.8->4.5; LSTM-256 +-0, GRU-256 +5..20 %, RNN-512 +24 %: the K loop
             // must carry >= 36 groups of 4 MFMAs per wave for the alternation to pay
-            const bool pp = std_acts && nch_p >= 12 && G * nch_p >= 36 && (ppenv ? ppenv[0] != '0' : true);
+            const bool pp = std_acts && nch_p >= 12 && G * nch_p >= 36 && opt.rec_pingpong != 0;
             if (xwm < 0) xwm = pp ? 0 : 1;      // measured: ping-pong LSTM-512 11.8 (XW 0) vs 13.1 ms; classic GRU-256 7.82 vs 7.63 (XW 1)
 #define REC_PICK(N) (!std_acts ? rec_persistent_kernel<G, IS_LSTM, N, 0, false, false> \
                      : xwm == 1 ? rec_persistent_kernel<G, IS_LSTM, N, 1, false, true> : rec_persistent_kernel<G, IS_LSTM, N, 0, false, true>)
@@ -773,8 +757,7 @@ const bool std_acts = G == 1 ? p.a0 == NNTK_ACT_TANH
             else if (nch_p == 8)  kern = REC_PICK(8);
             else if (nch_p == 12) kern = REC_PICK(12);
             else                  kern = REC_PICK(16);
-            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return nntk_fail("hipFuncSetAttribute(rec_persistent_kernel)", e);
+            if (nntk_set_max_dynamic_lds((const void *)kern, lds)) return -1;
             unsigned *cnt = reinterpret_cast<unsigned *>(d_work + 2 * hbmax + BH);
             // tiled hand-off buffers: both parities cleared (the padding must stay zero), h_0 tiled into parity 0
             if (nntk_shim_memset(d_work, 0, 2 * hbmax * 4)) return -1;
@@ -790,6 +773,9 @@ const bool std_acts = G == 1 ? p.a0 == NNTK_ACT_TANH
             q.B = B; q.T = T; q.H = H; q.Hj_p = p.Hj_p; q.Hk_p = p.Hk_p; q.NCT = NCT;
             q.return_sequences = return_sequences;
             q.a0 = p.a0; q.a1 = p.a1; q.a2 = p.a2; q.a3 = p.a3; q.a4 = p.a4;
+            q.s0 = p.s0; q.s1 = p.s1; q.s2 = p.s2; q.s3 = p.s3; q.s4 = p.s4;
+            q.fault = fault;
+            q.spin_ticks = (unsigned long long)(opt.rec_spin_us > 0 ? opt.rec_spin_us : 0) * 100ull;     // s_memrealtime: 100 MHz; 0 = inject a fault
             const int ncnt = pp ? 2 : 1;      // arrival counters per batch tile
 #ifdef NNTK_REC_STAMPS
             q.stamp = nullptr;
@@ -800,14 +786,19 @@ const bool std_acts = G == 1 ? p.a0 == NNTK_ACT_TANH
             }
 #endif
             const int nbt_total = (B + REC_BM - 1) / REC_BM;
-            const int span = nntk_prof_span_begin();
+            const int span = nntk_prof_span_begin(NNTK_SPAN_REC);
+            // all arrival counters of all launches are cleared by ONE memset (each launch gets its own slice)
+            if (nntk_shim_memset(cnt, 0, (size_t)nbt_total * ncnt * RECP_CNT_STRIDE * sizeof(unsigned))) return -1;
+            nntk_persistent_launch_begin();
             for (int bt0 = 0; bt0 < nbt_total; bt0 += tiles_per_launch) {
                 const int nbt = nbt_total - bt0 < tiles_per_launch ? nbt_total - bt0 : tiles_per_launch;
-                if (nntk_shim_memset(cnt, 0, (size_t)nbt * ncnt * RECP_CNT_STRIDE * sizeof(unsigned))) return -1;
                 q.NBT = nbt; q.b_base = bt0 * REC_BM;
+                q.cnt = cnt + (size_t)bt0 * ncnt * RECP_CNT_STRIDE;
                 hipLaunchKernelGGL(kern, dim3((unsigned)(nbt * NCT)), dim3(512), lds, nntk_stream(), q);
-                if (rec_status_enqueue(cnt, nbt * ncnt)) return -1;
             }
+            const int copy_rc = nntk_fault_enqueue_copy();
+            nntk_persistent_launch_end();
+            if (copy_rc) return -1;
             nntk_prof_span_end(span, (nbt_total + tiles_per_launch - 1) / tiles_per_launch, T);
 #ifdef NNTK_REC_STAMPS
             if (q.stamp) {
@@ -827,19 +818,16 @@ const bool std_acts = G == 1 ? p.a0 == NNTK_ACT_TANH
     if (d_h0) { if (nntk_shim_copy_d2d(hbuf[0], d_h0, BH * 4)) return -1; }
     else      { if (nntk_shim_memset(hbuf[0], 0, BH * 4)) return -1; }
     // split-K groups per workgroup: 2 (two waves per SIMD) unless overridden for A/B runs
-    const char *env = getenv("NNTK_REC_GROUPS");
-    const int ng = (env && env[0] == '1') ? 1 : 2;
+    const int ng = opt.rec_groups == 1 ? 1 : 2;
     constexpr size_t buf_floats = (size_t)REC_BM * REC_LS + (size_t)G * REC_HN * REC_LS;
     const size_t lds1 = 2 * buf_floats * sizeof(float);
     size_t lds2 = 4 * buf_floats * sizeof(float);
     const size_t red2 = (size_t)8 * G * 4 * 64 * sizeof(float);
     if (red2 > lds2) lds2 = red2;
     if (ng == 2 && lds2 > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)rec_step_kernel<G, IS_LSTM, 2>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-        if (e != hipSuccess) return nntk_fail("hipFuncSetAttribute(rec_step_kernel)", e);
+        if (nntk_set_max_dynamic_lds((const void *)rec_step_kernel<G, IS_LSTM, 2>, lds2)) return -1;
     }
-    const int span = nntk_prof_span_begin();
+    const int span = nntk_prof_span_begin(NNTK_SPAN_REC);
     for (int t = 0; t < T; ++t) {
         p.xw = d_xw + (size_t)t * B * G * H;
         p.h_prev = hbuf[t & 1];
@@ -859,25 +847,26 @@ const bool std_acts = G == 1 ? p.a0 == NNTK_ACT_TANH
 
 extern "C" int nntk_shim_gru(const float *d_xw, const float *d_ut, const float *d_bh, const float *d_h0,
                              float *d_out, float *d_hT, float *d_work, int B, int T, int H,
-                             int return_sequences, const int acts[3]) {
+                             int return_sequences, const int acts[3], const float act_scales[3]) {
     if (B <= 0 || T <= 0) return 0;
     return run_recurrent<3, false>(d_xw, d_ut, d_bh, d_h0, nullptr, d_out, d_hT, nullptr, d_work, B, T, H,
-                                   return_sequences, acts, 3);
+                                   return_sequences, acts, act_scales, 3);
 }
 
 extern "C" int nntk_shim_rnn(const float *d_xw, const float *d_ut, const float *d_bh, const float *d_h0,
                              float *d_out, float *d_hT, float *d_work, int B, int T, int H,
-                             int return_sequences, int act) {
+                             int return_sequences, int act, float act_scale) {
     if (B <= 0 || T <= 0) return 0;
     const int acts[1] = {act};
+    const float scales[1] = {act_scale};
     return run_recurrent<1, false>(d_xw, d_ut, d_bh, d_h0, nullptr, d_out, d_hT, nullptr, d_work, B, T, H,
-                                   return_sequences, acts, 1);
+                                   return_sequences, acts, scales, 1);
 }
 
 extern "C" int nntk_shim_lstm(const float *d_xw, const float *d_ut, const float *d_bh, const float *d_h0,
                               const float *d_c0, float *d_out, float *d_hT, float *d_cT, float *d_work,
-                              int B, int T, int H, int return_sequences, const int acts[5]) {
+                              int B, int T, int H, int return_sequences, const int acts[5], const float act_scales[5]) {
     if (B <= 0 || T <= 0) return 0;
     return run_recurrent<4, true>(d_xw, d_ut, d_bh, d_h0, d_c0, d_out, d_hT, d_cT, d_work, B, T, H,
-                                  return_sequences, acts, 5);
+                                  return_sequences, acts, act_scales, 5);
 }

@@ -5,16 +5,19 @@
 #include <string.h>
 #include <vector>
 
-static hipStream_t g_stream = nullptr;
+#include <atomic>
+#include <mutex>
+#include <stdlib.h>
+
+// ---- threading contract (SURVEY 8(b) "Threading": distinct handles are independent) ----
+// The CURRENT STREAM and the error string are per host thread; options, the profiling switch and the
+// device fault word are process-wide and either atomic or mutex-guarded.  A handle is not re-entrant
+// (it owns scratch and recurrent state, like the reference's: conv_1d.c:41, gru.c:86, lstm.c:97), and is
+// used on one stream at a time; two threads may drive two handles on two streams concurrently.
+static thread_local hipStream_t t_stream = nullptr;
 static thread_local char g_err[512] = "";
 
-hipStream_t nntk_stream() { return g_stream; }
-
-// Kernels that can only report failure through device memory (the persistent recurrent
-// kernel's bounded spins) register a check that runs after every host-visible sync point.
-static int (*g_post_sync_hook)() = nullptr;
-void nntk_set_post_sync_hook(int (*hook)()) { g_post_sync_hook = hook; }
-static int post_sync() { return g_post_sync_hook ? g_post_sync_hook() : 0; }
+hipStream_t nntk_stream() { return t_stream; }
 
 int nntk_fail(const char *what, hipError_t err) {
     snprintf(g_err, sizeof(g_err), "HIP error in %s: %s", what, hipGetErrorString(err));
@@ -25,39 +28,202 @@ int nntk_fail_msg(const char *what) {
     return -1;
 }
 
-// ---- optional HIP-event spans around launch sequences (bench.py's live roofline) ----
-struct ProfSpan { hipEvent_t a, b; long launches, units; };
-static std::vector<ProfSpan> g_spans;
-static bool g_prof = false;
+// ---- options: tuning / diagnostics knobs.  Defaults come from the environment (NNTK_<NAME>) ONCE, at first
+//      use; nntk_hip_set_option() changes them at run time.  Nothing on an Apply path calls getenv(). ----
+static NntkOptions g_opt;
+static std::once_flag g_opt_once;
+static std::mutex g_opt_mutex;
 
-int nntk_prof_span_begin() {
-    if (!g_prof) return -1;
+struct OptDesc { const char *name; const char *env; int NntkOptions::*field; };
+static const OptDesc g_opt_table[] = {
+    {"rec_persistent", "NNTK_REC_PERSISTENT", &NntkOptions::rec_persistent},
+    {"rec_xw", "NNTK_REC_XW", &NntkOptions::rec_xw},
+    {"rec_pingpong", "NNTK_REC_PINGPONG", &NntkOptions::rec_pingpong},
+    {"rec_groups", "NNTK_REC_GROUPS", &NntkOptions::rec_groups},
+    {"rec_spin_us", "NNTK_REC_SPIN_US", &NntkOptions::rec_spin_us},
+    {"rec_stream", "NNTK_REC_STREAM", &NntkOptions::rec_stream},
+    {"rec_fused2", "NNTK_REC_FUSED2", &NntkOptions::rec_fused2},
+    {"spec_ppw", "NNTK_SPEC_PPW", &NntkOptions::spec_ppw},
+    {"spec_variant", "NNTK_SPEC_VARIANT", &NntkOptions::spec_variant},
+    {"bn_fast", "NNTK_BN_FAST", &NntkOptions::bn_fast},
+    {"gemm_tm_batch", "NNTK_GEMM_TM_BATCH", &NntkOptions::gemm_tm_batch},
+    {"gemm_split_bf16", "NNTK_GEMM_SPLIT_BF16", &NntkOptions::gemm_split_bf16},
+    {"conv_dbg", "NNTK_CONV_DBG", &NntkOptions::conv_dbg},
+    {"weights_check", "NNTK_WEIGHTS_CHECK", &NntkOptions::weights_check},
+};
+static void opt_init() {
+    for (const OptDesc &d : g_opt_table) {
+        const char *e = getenv(d.env);
+        if (e && *e) g_opt.*(d.field) = atoi(e);
+    }
+}
+const NntkOptions &nntk_options() {
+    std::call_once(g_opt_once, opt_init);
+    return g_opt;
+}
+
+// ---- optional HIP-event spans around launch sequences (bench.py's live roofline) ----
+struct ProfSpan { hipEvent_t a, b; long launches, units; int kind; hipStream_t stream; };
+static std::vector<ProfSpan> g_spans;
+static std::mutex g_span_mutex;
+static std::atomic<bool> g_prof{false};
+
+int nntk_prof_span_begin(int kind) {
+    if (!g_prof.load(std::memory_order_relaxed)) return -1;
     ProfSpan s;
     s.launches = 0;
     s.units = 0;
+    s.kind = kind;
+    s.stream = t_stream;
     if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return -1;
-    (void)hipEventRecord(s.a, g_stream);
+    (void)hipEventRecord(s.a, t_stream);
+    std::lock_guard<std::mutex> lk(g_span_mutex);
     g_spans.push_back(s);
     return (int)g_spans.size() - 1;
 }
 void nntk_prof_span_end(int idx, long launches, long units) {
+    std::lock_guard<std::mutex> lk(g_span_mutex);
     if (idx < 0 || idx >= (int)g_spans.size()) return;
-    (void)hipEventRecord(g_spans[idx].b, g_stream);
+    (void)hipEventRecord(g_spans[idx].b, g_spans[idx].stream);
     g_spans[idx].launches = launches;
     g_spans[idx].units = units;
 }
 
+// ---- device fault word: the persistent recurrent kernel's bounded spins cannot return an error, they OR a bit
+//      into ONE sticky word in device memory (never reset per launch).  After each such launch the word is copied
+//      (async, same stream) to pinned memory; every host-visible sync point looks at the copy.  Nothing is lost when
+//      many launches go by without a sync, and device-pointer callers can poll nntk_hip_device_status().
+//      The word (and its mirror) belong to the launching THREAD, so one thread's check never consumes another's fault.
+static thread_local unsigned *t_fault_dev = nullptr;              // device word
+static thread_local volatile unsigned *t_fault_host = nullptr;    // pinned copy
+static std::atomic<int> g_persistent_off{0};         // set after a fault: later recurrent calls take the per-step kernels
+
+unsigned *nntk_fault_word() {
+    if (!t_fault_dev) {
+        unsigned *d = nullptr, *h = nullptr;
+        if (hipMalloc((void **)&d, 256) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipHostMalloc((void **)&h, 256, hipHostMallocDefault) != hipSuccess) { (void)hipFree(d); (void)hipGetLastError(); return nullptr; }
+        (void)hipMemset(d, 0, 256);
+        h[0] = 0;
+        t_fault_host = h;
+        t_fault_dev = d;
+    }
+    return t_fault_dev;
+}
+int nntk_fault_enqueue_copy() {
+    if (!t_fault_dev) return 0;
+    NNTK_HIP_TRY(hipMemcpyAsync((void *)t_fault_host, t_fault_dev, sizeof(unsigned), hipMemcpyDeviceToHost, t_stream));
+    return 0;
+}
+int nntk_persistent_disabled() { return g_persistent_off.load(std::memory_order_relaxed); }
+
+// Looks at the pinned copy (valid after the calling thread synchronised its stream).  On a fault: clears the
+// device word, switches the process to the per-step recurrent kernels (bit-compatible, no co-residency needed)
+// and reports it ONCE on stderr.  Returns the fault bits seen (0 = healthy).
+static unsigned fault_take() {
+    if (!t_fault_host || t_fault_host[0] == 0) return 0;
+    const unsigned bits = t_fault_host[0];
+    (void)hipMemsetAsync(t_fault_dev, 0, sizeof(unsigned), t_stream);
+    (void)hipStreamSynchronize(t_stream);
+    t_fault_host[0] = 0;
+    if (!g_persistent_off.exchange(1))
+        fprintf(stderr, "nntoolkitcore_hip: a persistent recurrent launch timed out waiting for its peer workgroups "
+                        "(another kernel held the CUs?); switching this process to the per-timestep recurrent kernels\n");
+    return bits;
+}
+static int post_sync() {
+    if (fault_take())
+        return nntk_fail_msg("persistent recurrent kernel: a workgroup timed out waiting for its peers; results of the "
+                             "recurrent calls since the last successful synchronisation are invalid. Later calls use "
+                             "the per-timestep kernels.");
+    return 0;
+}
+
+// ---- persistent launches are co-residency-critical (grid <= CU count, one workgroup per CU): two of them running
+//      at once on two streams could each hold CUs the other is waiting for.  Inside one process they are therefore
+//      ordered across streams with an event chain (no host blocking); other processes are covered by the bounded
+//      spins + fault word above. ----
+static std::mutex g_persist_mutex;
+static hipStream_t g_persist_last = nullptr;
+static bool g_persist_any = false;
+static hipEvent_t g_persist_ev = nullptr;
+void nntk_persistent_launch_begin() {
+    g_persist_mutex.lock();
+    if (g_persist_any && g_persist_last != t_stream) {
+        if (!g_persist_ev && hipEventCreateWithFlags(&g_persist_ev, hipEventDisableTiming) != hipSuccess) g_persist_ev = nullptr;
+        if (g_persist_ev && hipEventRecord(g_persist_ev, g_persist_last) == hipSuccess)
+            (void)hipStreamWaitEvent(t_stream, g_persist_ev, 0);
+        (void)hipGetLastError();      // a destroyed previous stream is not this call's error
+    }
+}
+void nntk_persistent_launch_end() {
+    g_persist_last = t_stream;
+    g_persist_any = true;
+    g_persist_mutex.unlock();
+}
+
+// ---- per-device facts and per-kernel attributes, looked up once ----
+int nntk_cu_count() {
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int c = cus[dev].load(std::memory_order_relaxed);
+    if (c == 0) {
+        (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
+        cus[dev].store(c, std::memory_order_relaxed);
+    }
+    return c;
+}
+int nntk_set_max_dynamic_lds(const void *kernel, size_t bytes) {
+    struct Seen { const void *k; size_t bytes; int dev; };
+    static std::vector<Seen> seen;
+    static std::mutex m;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(m);
+    for (const Seen &s : seen)
+        if (s.k == kernel && s.dev == dev && s.bytes >= bytes) return 0;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return nntk_fail("hipFuncSetAttribute(MaxDynamicSharedMemorySize)", e);
+    seen.push_back({kernel, bytes, dev});
+    return 0;
+}
+
 extern "C" {
 
-void nntk_shim_profile_enable(int on) { g_prof = on != 0; }
-// Sums and clears the recorded spans around the recurrent kernels.  `launches` = kernel
-// launches inside the spans, `units` = timesteps they covered (a persistent launch covers T).
+int nntk_shim_set_option(const char *name, const char *value) {
+    if (!name || !value) return nntk_fail_msg("nntk_hip_set_option: NULL name or value");
+    (void)nntk_options();
+    std::lock_guard<std::mutex> lk(g_opt_mutex);
+    for (const OptDesc &d : g_opt_table)
+        if (strcmp(d.name, name) == 0) {
+            g_opt.*(d.field) = (strcmp(value, "auto") == 0 || strcmp(value, "default") == 0) ? NntkOptions().*(d.field) : atoi(value);
+            // asking for the persistent kernel again re-arms it after a fault had switched the process away from it
+            if (d.field == &NntkOptions::rec_persistent && g_opt.rec_persistent != 0) g_persistent_off.store(0);
+            return 0;
+        }
+    return nntk_fail_msg("nntk_hip_set_option: unknown option");
+}
+int nntk_shim_get_option(const char *name, int *value) {
+    if (!name || !value) return nntk_fail_msg("nntk_hip_get_option: NULL argument");
+    const NntkOptions &o = nntk_options();
+    for (const OptDesc &d : g_opt_table)
+        if (strcmp(d.name, name) == 0) { *value = o.*(d.field); return 0; }
+    return nntk_fail_msg("nntk_hip_get_option: unknown option");
+}
+
+void nntk_shim_profile_enable(int on) { g_prof.store(on != 0); }
+// Sums and clears the recorded spans of one kind ("rec_step": recurrent kernels, "spectrogram": K1).  `launches` =
+// kernel launches inside the spans, `units` = timesteps (or frames) they covered.
 int nntk_shim_profile_get(const char *name, double *total_ms, long *launches, long *units) {
-    (void)name;
+    const int kind = (name && strcmp(name, "spectrogram") == 0) ? NNTK_SPAN_SPEC : NNTK_SPAN_REC;
     *total_ms = 0.0;
     *launches = 0;
     *units = 0;
+    std::lock_guard<std::mutex> lk(g_span_mutex);
+    std::vector<ProfSpan> keep;
     for (auto &s : g_spans) {
+        if (s.kind != kind) { keep.push_back(s); continue; }
         float ms = 0.f;
         if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
             *total_ms += ms;
@@ -67,7 +233,7 @@ int nntk_shim_profile_get(const char *name, double *total_ms, long *launches, lo
         (void)hipEventDestroy(s.a);
         (void)hipEventDestroy(s.b);
     }
-    g_spans.clear();
+    g_spans.swap(keep);
     return 0;
 }
 
@@ -84,12 +250,19 @@ int nntk_shim_set_device(int device) {
     NNTK_HIP_TRY(hipSetDevice(device));
     return 0;
 }
-void nntk_shim_set_stream(void *stream) { g_stream = (hipStream_t)stream; }
-void *nntk_shim_get_stream(void) { return (void *)g_stream; }
+void nntk_shim_set_stream(void *stream) { t_stream = (hipStream_t)stream; }
+void *nntk_shim_get_stream(void) { return (void *)t_stream; }
 int nntk_shim_synchronize(void) {
-    NNTK_HIP_TRY(hipStreamSynchronize(g_stream));
+    NNTK_HIP_TRY(hipStreamSynchronize(t_stream));
     return post_sync();
 }
+// After a stream sync: 1 if a persistent recurrent launch faulted since the last call (and clears it), else 0.
+// Used by the host-pointer recurrent Apply calls, which then simply repeat the call on the per-step kernels.
+int nntk_shim_take_fault(void) { return fault_take() ? 1 : 0; }
+int nntk_shim_persistent_disabled(void) { return nntk_persistent_disabled(); }
+// Non-blocking health query for device-pointer callers that synchronise by their own means: 0 healthy,
+// 1 a recurrent launch completed so far has faulted (sticky until nntk_hip_synchronize() reports it).
+int nntk_shim_device_status(void) { return (t_fault_host && t_fault_host[0]) ? 1 : 0; }
 
 void *nntk_shim_malloc(size_t bytes) {
     void *p = nullptr;
@@ -112,24 +285,35 @@ void nntk_shim_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 int nntk_shim_upload(void *d_dst, const void *h_src, size_t bytes) {
     if (!bytes) return 0;
-    NNTK_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, g_stream));
-    NNTK_HIP_TRY(hipStreamSynchronize(g_stream));
+    NNTK_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, t_stream));
+    NNTK_HIP_TRY(hipStreamSynchronize(t_stream));
+    return 0;
+}
+int nntk_shim_upload_async(void *d_dst, const void *h_src, size_t bytes) {
+    if (!bytes) return 0;
+    NNTK_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, t_stream));
     return 0;
 }
 int nntk_shim_download(void *h_dst, const void *d_src, size_t bytes) {
     if (!bytes) return 0;
-    NNTK_HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, g_stream));
-    NNTK_HIP_TRY(hipStreamSynchronize(g_stream));
+    NNTK_HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, t_stream));
+    NNTK_HIP_TRY(hipStreamSynchronize(t_stream));
     return post_sync();
+}
+// like nntk_shim_download but leaves a recurrent fault for the caller to take (nntk_shim_take_fault)
+int nntk_shim_download_nocheck(void *h_dst, const void *d_src, size_t bytes) {
+    if (bytes) NNTK_HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, t_stream));
+    NNTK_HIP_TRY(hipStreamSynchronize(t_stream));
+    return 0;
 }
 int nntk_shim_copy_d2d(void *d_dst, const void *d_src, size_t bytes) {
     if (!bytes) return 0;
-    NNTK_HIP_TRY(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, g_stream));
+    NNTK_HIP_TRY(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, t_stream));
     return 0;
 }
 int nntk_shim_memset(void *d_ptr, int value, size_t bytes) {
     if (!bytes) return 0;
-    NNTK_HIP_TRY(hipMemsetAsync(d_ptr, value, bytes, g_stream));
+    NNTK_HIP_TRY(hipMemsetAsync(d_ptr, value, bytes, t_stream));
     return 0;
 }
 

@@ -30,26 +30,98 @@ struct SpecParams {
     int input_size, nfft, window_size, step, nfreq, nts;
     float fft_norm, scale, inv_scale;
     int mode;
+    int ppw;              // frame pairs per wavefront (consecutive-run variant)
+#ifdef NNTK_SPEC_DBG
+    int dbg;              // timing experiments only: 1 no stores, 2 no sample loads, 4 no LDS passes (wrong results), 8 no split / shuffles
+#endif
 };
+#ifdef NNTK_SPEC_DBG
+#define SPEC_DBG(bit) (p.dbg & (bit))
+#else
+#define SPEC_DBG(bit) 0
+#endif
 
-typedef float f2 __attribute__((ext_vector_type(2)));     // (re, im): adds/subs/muls lower to v_pk_*_f32
-__device__ __forceinline__ f2 cmul2(f2 a, f2 b) { return (f2){a.x, a.x} * b + (f2){-a.y, a.y} * (f2){b.y, b.x}; }
-__device__ __forceinline__ f2 mul_mi2(f2 a) { return (f2){a.y, -a.x}; }     // a * (-i)
-#define BF2(a, b) do { f2 _t = a; a = _t + b; b = _t - b; } while (0)
+typedef float f2 __attribute__((ext_vector_type(2)));     // (re, im)
+typedef unsigned v4u32x __attribute__((ext_vector_type(4)));
+typedef unsigned v2u32x __attribute__((ext_vector_type(2)));
 
-// forward 8-point DFT, natural-order output, in registers
-__device__ __forceinline__ void fft8(f2 v[8]) {
-    BF2(v[0], v[4]); BF2(v[1], v[5]); BF2(v[2], v[6]); BF2(v[3], v[7]);
-    const float s = 0.70710678118654752440f;
-    v[5] = cmul2(v[5], (f2){s, -s});
-    v[6] = mul_mi2(v[6]);
-    v[7] = cmul2(v[7], (f2){-s, -s});
-    // two 4-point DFTs: (v0..v3) -> even outputs, (v4..v7) -> odd outputs
-    BF2(v[0], v[2]); BF2(v[1], v[3]); v[3] = mul_mi2(v[3]); BF2(v[0], v[1]); BF2(v[2], v[3]);
-    BF2(v[4], v[6]); BF2(v[5], v[7]); v[7] = mul_mi2(v[7]); BF2(v[4], v[5]); BF2(v[6], v[7]);
-    // registers now hold X0,X4,X2,X6 | X1,X5,X3,X7
-    f2 x1 = v[4], x2 = v[2], x3 = v[6], x4 = v[1], x5 = v[5], x6 = v[3];
-    v[1] = x1; v[2] = x2; v[3] = x3; v[4] = x4; v[5] = x5; v[6] = x6;
+// ---- packed-f32 complex arithmetic -------------------------------------------------------------------------
+// K1 is VALU-bound (measured, DESIGN.md: with loads, stores and LDS passes all removed the loop still takes 3/4 of
+// its time), and on gfx950 EVERY vector instruction of a wave costs one 4-cycle issue slot, packed or not -- the
+// f32 peak is reached only by v_pk_* instructions, which do two lanes' worth of work in that slot.  So the count of
+// vector instructions is the cost model, and the complex arithmetic is written directly in v_pk_*_f32 with their
+// operand modifiers: op_sel / op_sel_hi pick which half of each 64-bit source feeds the low / high result, neg_lo /
+// neg_hi negate it.  A multiplication by -i, a conjugation or a (re, re) broadcast then costs nothing -- hipcc
+// (ROCm 7.2) folds whole-vector negations and some swaps, but emitted v_xor / v_mov pairs for per-half signs:
+// 277 vector instructions per frame pair before, 17x after.  The statements are plain (non-volatile) asm on register
+// operands only: the compiler still schedules and interleaves them freely.
+#define SPEC_PK2(name, text) \
+    __device__ __forceinline__ f2 name(f2 a, f2 b) { f2 d; asm(text : "=v"(d) : "v"(a), "v"(b)); return d; }
+#define SPEC_PK1(name, text) \
+    __device__ __forceinline__ f2 name(f2 a) { f2 d; asm(text : "=v"(d) : "v"(a)); return d; }
+#define SPEC_PK3(name, text) \
+    __device__ __forceinline__ f2 name(f2 a, f2 b, f2 c) { f2 d; asm(text : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+SPEC_PK2(add_mi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")        // a + (-i) b
+SPEC_PK2(sub_mi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")        // a - (-i) b
+SPEC_PK1(rot_w1, "v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")        // a (1 - i)  = sqrt2 a w8^1
+SPEC_PK1(rot_w3, "v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[1,1]")   // a (-1 - i) = sqrt2 a w8^3
+SPEC_PK3(fma_mi, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]")   // c + b (-i) a   (b real pair)
+SPEC_PK3(fms_mi, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]")   // c - b (-i) a
+SPEC_PK2(cmul_lo, "v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]")                          // (a.x b.x, a.x b.y)
+SPEC_PK3(cmul_hi, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]")   // (c.x - a.y b.y, c.y + a.y b.x)
+SPEC_PK2(split_p, "v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]")       // (a.x + b.x, a.x - b.x)
+SPEC_PK2(split_q, "v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1] neg_lo:[0,1]")       // (a.y - b.y, a.y + b.y)
+SPEC_PK2(mul_blo, "v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]")                                 // a * (b.x, b.x)
+SPEC_PK2(mul_bhi, "v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]")                                    // a * (b.y, b.y)
+SPEC_PK3(fma_bhi, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]")                              // a * (b.y, b.y) + c
+__device__ __forceinline__ f2 cmul2(f2 a, f2 b) { return cmul_hi(a, b, cmul_lo(a, b)); }   // complex a * b: 2 instructions
+// S = (1/sqrt2, 1/sqrt2) is wave-uniform: it rides in an SGPR pair (one scalar source per VOP3P instruction is allowed)
+__device__ __forceinline__ f2 fma_mi_s(f2 a, f2 S, f2 c) { f2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "s"(S), "v"(c)); return d; }
+__device__ __forceinline__ f2 fms_mi_s(f2 a, f2 S, f2 c) { f2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(a), "s"(S), "v"(c)); return d; }
+
+// Eight 8-byte LDS reads at base + STEP * r bytes, as eight ds_read_b64.  Written in asm because hipcc fuses neighbouring
+// reads into ds_read2_b64 / ds_read2st64_b64, which move 16 bytes per lane in 8 LDS cycles where two ds_read_b64 take 2 + 2
+// (MI355X_MICROARCH.md, LDS table) -- and the LDS pipe is this kernel's most loaded unit.  The wait is inside the
+// statement: hipcc does not count an asm load.
+template <int STEP>
+__device__ __forceinline__ void lds_read8_b64(f2 v[8], const float *base) {
+    const unsigned addr = (unsigned)(size_t)base;     // LDS pointers are 32-bit offsets in the low half
+    asm volatile("ds_read_b64 %0, %8\n\t"
+                 "ds_read_b64 %1, %8 offset:%c9\n\t"
+                 "ds_read_b64 %2, %8 offset:%c10\n\t"
+                 "ds_read_b64 %3, %8 offset:%c11\n\t"
+                 "ds_read_b64 %4, %8 offset:%c12\n\t"
+                 "ds_read_b64 %5, %8 offset:%c13\n\t"
+                 "ds_read_b64 %6, %8 offset:%c14\n\t"
+                 "ds_read_b64 %7, %8 offset:%c15\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                 : "v"(addr), "i"(STEP), "i"(2 * STEP), "i"(3 * STEP), "i"(4 * STEP), "i"(5 * STEP), "i"(6 * STEP), "i"(7 * STEP)
+                 : "memory");
+}
+
+// forward 8-point DFT in registers, natural-order output: 26 packed instructions (24 when v[7] is known to be zero).
+// S = (1/sqrt2, 1/sqrt2).  Even outputs: 4-point DFT of the sums; odd outputs: 4-point DFT of (a4, w1 a5, -i a6, w3 a7)
+// with the two 1/sqrt2 factors riding in the last butterflies' FMAs.
+template <bool V7ZERO>
+__device__ __forceinline__ void fft8(f2 v[8], const f2 S) {
+    const f2 a0 = v[0] + v[4], a4 = v[0] - v[4];
+    const f2 a1 = v[1] + v[5], a5 = v[1] - v[5];
+    const f2 a2 = v[2] + v[6], a6 = v[2] - v[6];
+    f2 a3, a7;
+    if (V7ZERO) { a3 = v[3]; a7 = v[3]; } else { a3 = v[3] + v[7]; a7 = v[3] - v[7]; }
+    const f2 b0 = a0 + a2, b2 = a0 - a2, b1 = a1 + a3, b3 = a1 - a3;
+    v[0] = b0 + b1;
+    v[4] = b0 - b1;
+    v[2] = add_mi(b2, b3);
+    v[6] = sub_mi(b2, b3);
+    const f2 c4 = add_mi(a4, a6), c6 = sub_mi(a4, a6);
+    const f2 t5 = rot_w1(a5), t7 = rot_w3(a7);
+    const f2 u = t5 + t7, w = t5 - t7;
+    v[1] = __builtin_elementwise_fma(u, S, c4);
+    v[5] = __builtin_elementwise_fma(u, -S, c4);
+    v[3] = fma_mi_s(w, S, c6);
+    v[7] = fms_mi_s(w, S, c6);
 }
 
 // Every wavefront owns its private LDS image and a wave's DS instructions execute in
@@ -58,8 +130,7 @@ __device__ __forceinline__ void fft8(f2 v[8]) {
 #define WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
                              __builtin_amdgcn_wave_barrier();                        \
                              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-#define SPEC_LDS_PER_WAVE 592      // 512 + 8 * 8 padding, rounded to a multiple of 16
-__device__ __forceinline__ int pidx(int i) { return i + ((i >> 6) << 3); }
+#define SPEC_LDS_FLOATS 1184      // per wave: exchange 1 uses 1024 floats, exchange 2 uses 8 * 144 = 1152; multiple of 16 B
 
 __device__ __forceinline__ float finish_bin(const SpecParams &p, float re, float im, int k) {
     if (p.fft_norm != 1.0f) { re *= p.fft_norm; im *= p.fft_norm; }
@@ -71,32 +142,60 @@ __device__ __forceinline__ float finish_bin(const SpecParams &p, float re, float
     return m * (2.0f * p.inv_scale);
 }
 
-// The kernel was VALU-bound in its first form (~900 vector instructions per frame pair,
-// a third of them 64-bit address arithmetic, range guards and an integer division), so:
-// grid.y walks utterances (no division), each utterance gets its own buffer descriptor
-// (32-bit offsets, hardware range check instead of per-load guards), complex math is
-// written on 2-vectors so it issues as packed f32, and everything that depends only on
-// the lane (window taps, both twiddle sets) is hoisted out of the frame loop.
-template <int MODE, bool NORM>
+// One 64-lane wavefront transforms TWO consecutive frames as one 512-point complex FFT (frame A real, frame B
+// imaginary), 8 points per lane, three radix-8 Stockham passes, everything through a wave-private LDS image
+// (no s_barrier anywhere: a wave's DS instructions execute in order).
+//
+// Memory side.  Measured with the transform removed, the round-1 access pattern (28 four-byte sample loads and 10
+// four-byte stores per pair, every one fully coalesced) ALONE took as long as the whole kernel: a vector-memory
+// instruction occupies the CU's address path for ~15 (load) / ~25 (store) cycles whatever its width, so 4-byte
+// accesses cap a CU at ~17 B/clk.  Now a pair's step + window contiguous samples come in as 3 (at most 4) 16-byte
+// loads per lane, are laid down in LDS, and pass 1 picks its samples (lane + 64 r for frame A, step + lane + 64 r for
+// frame B) from there -- which also serves the 2.5x overlap between neighbouring frames from LDS instead of L1.  The
+// two finished rows (2 x 257 floats, contiguous in the output) are assembled in LDS and leave as two 16-byte stores
+// per lane plus an 8-byte tail.  38 -> 6..7 vector-memory instructions per pair.
+//
+// LDS images (all in the same 4.7 KB region, separated by wave-level fences):
+//   samples:    word n = sample n of the pair.
+//   exchange 1 (after pass 1): lane j writes its 8 outputs as one 64-byte row; pass 2 reads element j + 64 r, i.e.
+//     row (j >> 3) + 8 r, column j & 7.  Rows are 16 words apart, so plain rows would put the 8 lanes of a
+//     ds_write_b128 group on two 4-bank columns (4-way conflict: 32 LDS cycles instead of 8 per instruction, the
+//     6 % SQ_LDS_BANK_CONFLICT of the round-1 profile; now 0).  The 16-byte pairs of row j are therefore rotated by
+//     (j >> 1) & 3 slots: a group's 8 rows land on 8 different 4-bank columns, and the reads (4 rows x 8 columns per
+//     32-lane group) still cover 64 different banks.  The rotation of row (j >> 3) + 8 r does not depend on r, so the
+//     8 reads are ONE per-lane address plus immediates.
+//   exchange 2 (after pass 2): element 64 a + 8 b + c at word 144 a + 16 b + 2 c (writes: a, c from the lane, b =
+//     register; reads: a = register, 8 b + c = lane): conflict-free both ways.
+//   output:     word k = bin k of frame A, word 257 + k = bin k of frame B.
+// NZ7 = the window is 385..448 samples (the BASELINE 400 is): register row 7 of pass 1 is zero padding for every lane
+// (not read, its butterfly disappears) and only row 6 straddles the window's end.  Otherwise all 8 rows are masked.
+// Zero padding is exact even next to inf / nan samples: out-of-window samples are ANDed away, not multiplied by 0.
+// NLD = 16-byte loads per lane that cover step + window samples (3 for 160 + 400).
+template <int MODE, bool NORM, bool NZ7, int NLD>
 __global__ __launch_bounds__(256) void spectrogram512_kernel(SpecParams p) {
-    __shared__ __attribute__((aligned(16))) f2 lds_z[4][SPEC_LDS_PER_WAVE];      // interleaved (re, im)
+    __shared__ __attribute__((aligned(16))) float lds_z[4][SPEC_LDS_FLOATS];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // scalar: frame offsets stay in SGPRs
-    f2 *z = lds_z[wave];
+    float *z = lds_z[wave];
     const int ppu = (p.nts + 1) >> 1;                 // frame pairs per utterance
+    constexpr int NR = NZ7 ? 7 : 8;                   // register rows of pass 1 that can hold samples
 
     // lane-only constants
-    // window taps, and the per-lane sample offset: taps beyond the window get an out-of-range offset,
-    // so the load itself returns the exact zero padding (no select, even next to inf/nan samples)
-    float wtap[8];
-    int loff[8];
+    // window taps, and the AND mask that clears samples beyond the window (rows that lie fully inside the window need
+    // none: NZ7 knows rows 0..5 do).  The window multiply is two plain v_mul_f32 per row: frame A's and frame B's samples
+    // arrive in unrelated registers, and a packed multiply would first need them moved into a register pair.
+    float wtap[NR];
+    unsigned wmask[NZ7 ? 1 : 8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < NR; ++r) {
         const int n = lane + 64 * r;
         const bool inwin = n < p.window_size;
         wtap[r] = inwin ? p.window[n] : 0.0f;
-        loff[r] = inwin ? n * 4 : 0x7ffffff0;
+        if (!NZ7) wmask[r] = inwin ? 0xffffffffu : 0u;
+        else if (r == 6) wmask[0] = inwin ? 0xffffffffu : 0u;
     }
+#pragma unroll
+    for (int r = 0; r < (NZ7 ? 1 : 8); ++r) asm volatile("" : "+v"(wmask[r]));     // keep them masks: hipcc turned x & mask back into a v_cndmask
     f2 tw2[8], tw3[8];
     {
         const f2 *tw = reinterpret_cast<const f2 *>(p.tw);
@@ -106,118 +205,185 @@ __global__ __launch_bounds__(256) void spectrogram512_kernel(SpecParams p) {
             tw3[r] = tw[lane * r];                    // exp(-2 pi i j r / 512)
         }
     }
-    // output scale per bin (magnitude: 1/sum(w); PSD: 2/(fs sum w^2), edges 1/(..): spectrogram.c:41-47),
-    // with fft_normalization_factor folded in AFTER the reference's own rounding points would not be
-    // exact, so the factor still multiplies re/im first (NORM) exactly like spectrogram.c:130-131
-    float osc[5];
+    // The two real spectra come out of the split below as 2 X_a, 2 X_b, so the factor 1/2 (1/4 for the PSD's squares)
+    // rides in the output scale -- exact, a power of two.  Output scale per bin (magnitude: 1/sum(w); PSD:
+    // 2/(fs sum w^2), edges 1/(..): spectrogram.c:41-47): wave-uniform except the PSD's two edge bins, which lane 0
+    // owns in rows 0 and 4.  fft_normalization_factor still multiplies re/im first (NORM), like spectrogram.c:130-131.
+    const float o_in = 0.5f * p.inv_scale;            // interior bins (PSD: 2 / 4)
+    const float o_edge = MODE == 0 ? 0.5f * p.inv_scale : 0.25f * p.inv_scale;
+    const f2 osc_in = (f2){o_in, o_in};
+    const float o0 = lane == 0 ? o_edge : o_in;
+    const f2 osc_r0 = (f2){o0, o0}, osc_r4 = (f2){o_edge, o_edge};
+    const f2 S = (f2){0.70710678118654752440f, 0.70710678118654752440f};
+    const f2 norm2 = (f2){p.fft_norm, p.fft_norm};
+    // lane 0 pairs bin 64 r with bin 64 (8 - r) of ITSELF, every other lane with a register of lane 64 - j: the
+    // partner is blended as own * m.x + shuffled * m.y with m = (1, 0) on lane 0 and (0, 1) elsewhere -- exact, and
+    // two packed instructions instead of two v_cndmask (measured 4.4x the issue time of a v_pk_* each)
+    const f2 msel = lane == 0 ? (f2){1.0f, 0.0f} : (f2){0.0f, 1.0f};
+    // sample image: 16-byte pieces in, 4-byte picks out
+    const int need_bytes = (p.step + p.window_size) * 4;
+    int ld_off[NLD];                                         // lanes past the pair's last sample load nothing
 #pragma unroll
-    for (int r = 0; r < 5; ++r) {
-        const int k = lane + 64 * r;
-        osc[r] = (MODE == 0 || k == 0 || k == p.nfreq - 1) ? p.inv_scale : 2.0f * p.inv_scale;
-    }
-    const int i1 = pidx(lane * 8);                    // pass-1 write base (8 contiguous floats)
-    // pass-2 write base, already padded: pidx(i2w + 8 r) = i2w + 8 r + 8 (lane >> 3) for r < 8
-    const int i2w = (lane >> 3) * 64 + (lane & 7) + 8 * (lane >> 3);
-    const int src = (64 - lane) & 63;
+    for (int i = 0; i < NLD; ++i) ld_off[i] = (lane * 16 + 1024 * i < need_bytes) ? lane * 16 + 1024 * i : 0x7ffffff0;
+    const int sA = lane, sB = p.step + lane;                 // + 64 r (floats)
+    // exchange 1: write address of 16-byte pair q of this lane's row; read address (floats) of element lane + 64 r
+    int w1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w1[q] = 16 * lane + 4 * ((q + (lane >> 1)) & 3);
+    const int r1 = 16 * (lane >> 3) + 4 * ((((lane & 7) >> 1) + (lane >> 4)) & 3) + 2 * (lane & 1);      // + 128 r
+    // exchange 2
+    const int w2 = 144 * (lane >> 3) + 2 * (lane & 7);      // + 16 k
+    const int r2 = 2 * lane;                                 // + 144 r
+    const int src = ((64 - lane) & 63) * 4;                  // ds_bpermute address of the conjugate-partner lane
+    const int stride = gridDim.x * 4;                        // pairs between two pairs of one wave
+    const int st_tail = lane == 0 ? 2048 : 0x7ffffff0;       // the 8-byte tail of a pair's two rows (bins 255, 256 of B)
+    const int vo = lane * 4, vo4 = lane == 0 ? 0 : 0x7ffffff0;     // odd last frame: only lane 0 owns bin 256
 
     for (int b = blockIdx.y; b < p.B; b += gridDim.y) {
+        // descriptors of this utterance: every offset that must be clipped at its end rides in the (range-checked)
+        // vector offset -- a pair at the very end reads zeros past the signal, never the next utterance
         const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(p.in + (size_t)b * p.input_size), 0, p.input_size * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(p.out + (size_t)b * p.nts * p.nfreq), 0, p.nts * p.nfreq * 4, 0x00020000);
-        // software prefetch: the 16 sample loads of this wave's NEXT frame pair are issued
-        // before the current pair is transformed, so HBM latency overlaps the FFT math
+        // Software prefetch, TWO pairs deep: the sample loads of pair n + 2 are issued while pair n is transformed
+        // (two register sets, loop unrolled by two).
         int pr = blockIdx.x * 4 + wave;
-        unsigned nxa[8], nxb[8];
-        bool nhas_b = false;
-        // the frame's start is wave-uniform: it rides in the scalar offset, the vector offset is the
-        // lane-only loff[] (a missing frame B re-reads frame A; its outputs are never stored)
-        if (pr < ppu) {
+        if (pr >= ppu) continue;
+        v4u32x ld0[NLD], ld1[NLD];
+
+        // a pair beyond the wave's last one re-reads the last valid one (cache hit, result unused): no branches around loads
+#define SPEC_ISSUE(ld, pair) do {                                                                       \
+            const int soa_ = 2 * ((pair) < ppu ? (pair) : pr) * p.step * 4;                              \
+            _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                            \
+                if (SPEC_DBG(2)) { ld[i] = (v4u32x){0x3f000000u + lane, 0x3e000000u + i, 0x3d800000u, 0x3e800000u}; continue; } \
+                ld[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, ld_off[i] + soa_, 0, 0);              \
+            } } while (0)
+
+        auto transform = [&](v4u32x (&ld)[NLD]) __attribute__((always_inline)) {
             const int fa = 2 * pr;
-            nhas_b = fa + 1 < p.nts;
-            const int soa = fa * p.step * 4;
-            const int sob = nhas_b ? soa + p.step * 4 : soa;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                nxa[r] = __builtin_amdgcn_raw_buffer_load_b32(rin, loff[r], soa, 0);
-                nxb[r] = __builtin_amdgcn_raw_buffer_load_b32(rin, loff[r], sob, 0);
-            }
-        }
-        for (; pr < ppu; pr += gridDim.x * 4) {
-            const int fa = 2 * pr;
-            const bool has_b = nhas_b;                // wave-uniform
+            const bool has_b = fa + 1 < p.nts;        // wave-uniform
             f2 v[8];
+            // ---- samples: registers -> LDS image -> the 2 x NR picks of pass 1 ----
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) *reinterpret_cast<v4u32x *>(z + lane * 4 + 256 * i) = ld[i];
+            SPEC_ISSUE(ld, pr + 2 * stride);          // this register set is free again: fetch the pair after next
+            WAVE_LDS_SYNC();
+            unsigned xa[NR], xb[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                xa[r] = __float_as_uint(z[sA + 64 * r]);
+                xb[r] = __float_as_uint(z[sB + 64 * r]);
+            }
+            WAVE_LDS_SYNC();
             // ---- pass 1 (Ns = 1): windowed samples, no twiddles ----
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const f2 x = (f2){__uint_as_float(nxa[r]), __uint_as_float(nxb[r])};
-                v[r] = x * wtap[r];                                   // taps beyond the window were loaded as 0
+            for (int r = 0; r < NR; ++r) {
+                if (!NZ7) { xa[r] &= wmask[r]; xb[r] &= wmask[r]; }
+                else if (r == 6) { xa[r] &= wmask[0]; xb[r] &= wmask[0]; }
+                float va, vb;
+                asm("v_mul_f32 %0, %1, %2" : "=v"(va) : "v"(__uint_as_float(xa[r])), "v"(wtap[r]));
+                asm("v_mul_f32 %0, %1, %2" : "=v"(vb) : "v"(__uint_as_float(xb[r])), "v"(wtap[r]));
+                v[r] = (f2){va, vb};
             }
-            {
-                const int npr = pr + gridDim.x * 4;
-                if (npr < ppu) {
-                    const int nfa = 2 * npr;
-                    nhas_b = nfa + 1 < p.nts;
-                    const int soa = nfa * p.step * 4;
-                    const int sob = nhas_b ? soa + p.step * 4 : soa;
+            if (NZ7) v[7] = (f2){0.f, 0.f};
+            if (SPEC_DBG(16)) {      // memory pattern only: no transform at all
+                const int soa = fa * p.nfreq * 4;
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        nxa[r] = __builtin_amdgcn_raw_buffer_load_b32(rin, loff[r], soa, 0);
-                        nxb[r] = __builtin_amdgcn_raw_buffer_load_b32(rin, loff[r], sob, 0);
-                    }
-                }
+                for (int i = 0; i < 2; ++i)
+                    __builtin_amdgcn_raw_buffer_store_b128((v4u32x){__float_as_uint(v[2 * i].x), __float_as_uint(v[2 * i].y),
+                                                            __float_as_uint(v[2 * i + 1].x), __float_as_uint(v[2 * i + 1].y)},
+                                                           rout, lane * 16 + 1024 * i, soa, 0);
+                return;
             }
-            fft8(v);
+            fft8<NZ7>(v, S);
+            if (!SPEC_DBG(4)) {
 #pragma unroll
-            for (int r = 0; r < 8; r += 2)               // 8 contiguous complex per lane: 4 x ds_write_b128
-                *reinterpret_cast<float4 *>(z + i1 + r) = make_float4(v[r].x, v[r].y, v[r + 1].x, v[r + 1].y);
+            for (int q = 0; q < 4; ++q) {                // the lane's row, 16-byte pairs rotated (see above)
+                *reinterpret_cast<f2 *>(z + w1[q]) = v[2 * q];
+                *reinterpret_cast<f2 *>(z + w1[q] + 2) = v[2 * q + 1];
+            }
             WAVE_LDS_SYNC();
             // ---- pass 2 (Ns = 8) ----
-#pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = z[pidx(lane + 64 * r)];
+            lds_read8_b64<512>(v, z + r1);
+            }
 #pragma unroll
             for (int r = 1; r < 8; ++r) v[r] = cmul2(v[r], tw2[r]);
-            fft8(v);
+            fft8<false>(v, S);
+            if (!SPEC_DBG(4)) {
             WAVE_LDS_SYNC();
 #pragma unroll
-            for (int r = 0; r < 8; ++r) z[i2w + 8 * r] = v[r];
+            for (int k = 0; k < 8; ++k) *reinterpret_cast<f2 *>(z + w2 + 16 * k) = v[k];
             WAVE_LDS_SYNC();
             // ---- pass 3 (Ns = 64) ----
-#pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = z[pidx(lane + 64 * r)];
+            lds_read8_b64<576>(v, z + r2);
+            }
 #pragma unroll
             for (int r = 1; r < 8; ++r) v[r] = cmul2(v[r], tw3[r]);
-            fft8(v);
-            WAVE_LDS_SYNC();   // LDS image is free for the next pair
+            fft8<false>(v, S);
+            WAVE_LDS_SYNC();   // the exchange image is dead: the output rows are assembled in its place
             // lane j now holds Z[j + 64 r], r = 0..7.
             // ---- split the two real spectra; bins k = j + 64 r for r = 0..3 (+ k = 256 on lane 0) ----
-            // output rows: frame offset in the scalar offset, lane offset in the vector offset; a missing
-            // frame B (wave-uniform) is simply not stored
-            const int soa = fa * p.nfreq * 4, sob = soa + p.nfreq * 4;
-            const int vo = lane * 4, vo4 = lane == 0 ? 0 : 0x7ffffff0;     // only lane 0 owns bin 256
+            //   2 X_a[k] = Z[k] + conj Z[512 - k],  2i X_b[k] = Z[k] - conj Z[512 - k]; with c = Z[512 - k]:
+            //   P = (z.x + c.x, z.x - c.x), Q = (z.y - c.y, z.y + c.y)  ->  (|2 X_a|^2, |2 X_b|^2) = P P + Q Q
+            f2 m[5];
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
                 f2 c;
                 if (r < 4) {
-                    // lane != 0: partner register 7 - r on lane 64 - j; lane 0: register (8 - r) & 7 of itself
-                    const f2 pz = (f2){__shfl(v[7 - r].x, src), __shfl(v[7 - r].y, src)};
-                    c = lane == 0 ? v[(8 - r) & 7] : pz;
+                    f2 pz = v[7 - r];
+                    if (!SPEC_DBG(8))
+                        pz = (f2){__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(pz.x))),
+                                  __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(pz.y)))};
+                    c = fma_bhi(pz, msel, mul_blo(v[(8 - r) & 7], msel));
                 } else {
                     c = v[4];                        // k = 256 pairs with itself (lane 0 only)
                 }
-                const f2 z = v[r];
-                // X_a = (Z + conj(Zc)) / 2 ; X_b = (Z - conj(Zc)) / (2i)
-                f2 xa = (f2){0.5f * (z.x + c.x), 0.5f * (z.y - c.y)};
-                f2 xb = (f2){0.5f * (z.y + c.y), -0.5f * (z.x - c.x)};
-                if (NORM) { xa = xa * p.fft_norm; xb = xb * p.fft_norm; }
-                float ma = xa.x * xa.x + xa.y * xa.y, mb = xb.x * xb.x + xb.y * xb.y;
+                f2 P = split_p(v[r], c), Q = split_q(v[r], c);
+                if (NORM) { P = P * norm2; Q = Q * norm2; }
+                f2 mm = __builtin_elementwise_fma(Q, Q, P * P);
                 // hardware square root (<= 1 ulp; libm's correctly rounded sqrtf costs 12 instructions a bin)
-                if (MODE == 0) { ma = __builtin_amdgcn_sqrtf(ma); mb = __builtin_amdgcn_sqrtf(mb); }
-                const int vor = r == 4 ? vo4 : vo;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ma * osc[r]), rout, vor, soa + 256 * r, 0);
-                if (has_b) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mb * osc[r]), rout, vor, sob + 256 * r, 0);
+                if (MODE == 0) mm = (f2){__builtin_amdgcn_sqrtf(mm.x), __builtin_amdgcn_sqrtf(mm.y)};
+                m[r] = mm * (r == 0 ? osc_r0 : r == 4 ? osc_r4 : osc_in);
             }
+            const int soa = fa * p.nfreq * 4;         // the pair's first output row (bytes): wave-uniform scalar offset
+            if (has_b) {
+                // ---- both rows are contiguous in the output (2 x 257 floats from row fa): LDS, then 16-byte stores ----
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    z[lane + 64 * r] = m[r].x;
+                    z[257 + lane + 64 * r] = m[r].y;
+                }
+                if (lane == 0) { z[256] = m[4].x; z[513] = m[4].y; }
+                WAVE_LDS_SYNC();
+                const v4u32x q0 = *reinterpret_cast<const v4u32x *>(z + lane * 4);
+                const v4u32x q1 = *reinterpret_cast<const v4u32x *>(z + 256 + lane * 4);
+                const v2u32x qt = *reinterpret_cast<const v2u32x *>(z + 512);
+                if (!SPEC_DBG(1)) {
+                    __builtin_amdgcn_raw_buffer_store_b128(q0, rout, lane * 16, soa, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(q1, rout, lane * 16 + 1024, soa, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(qt, rout, st_tail, soa, 0);
+                }
+                WAVE_LDS_SYNC();   // the image is free for the next pair's samples
+            } else {
+                // odd frame count: the utterance's last pair has only frame A (once per utterance at most)
+#pragma unroll
+                for (int r = 0; r < 5; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m[r].x), rout, r == 4 ? vo4 : vo, soa + 256 * r, 0);
+            }
+        };
+
+        SPEC_ISSUE(ld0, pr);
+        SPEC_ISSUE(ld1, pr + stride);
+        for (;;) {
+            transform(ld0);
+            pr += stride;
+            if (pr >= ppu) break;
+            transform(ld1);
+            pr += stride;
+            if (pr >= ppu) break;
         }
+#undef SPEC_ISSUE
     }
 }
 
@@ -255,6 +421,9 @@ extern "C" int nntk_shim_spectrogram(const float *d_in, const float *d_window, c
     p.B = B;
     p.input_size = input_size; p.nfft = nfft; p.window_size = window_size; p.step = step;
     p.nfreq = nfreq; p.nts = nts; p.fft_norm = fft_norm; p.scale = scale; p.inv_scale = (float)(1.0 / (double)scale); p.mode = mode;
+#ifdef NNTK_SPEC_DBG
+    p.dbg = nntk_options().conv_dbg;
+#endif
     if (nfft == 512) {
         if ((long)input_size * 4 >= 0x7ffffff0L || (long)nts * nfreq * 4 >= 0x7ffffff0L)
             return nntk_fail_msg("spectrogram: one utterance must stay below 2 GiB");
@@ -264,14 +433,19 @@ extern "C" int nntk_shim_spectrogram(const float *d_in, const float *d_window, c
         // 1 / 2 / 4 / 8 / 16 pairs = 0.245 / 0.225 / 0.220 / 0.207 / 0.199 ms; config 2 (12.5 k pairs): 4 is best.
         long ppw_l = (long)B * ppu / 4096;
         int ppw = ppw_l < 4 ? 4 : ppw_l > 16 ? 16 : (int)ppw_l;
-        { const char *e = getenv("NNTK_SPEC_PPW"); if (e && atoi(e) > 0) ppw = atoi(e); }
+        if (nntk_options().spec_ppw > 0) ppw = nntk_options().spec_ppw;
         unsigned gx = (unsigned)((ppu + 4 * ppw - 1) / (4 * ppw));
         unsigned gy = (unsigned)(B < 65535 ? B : 65535);
         // keep the grid near 8 workgroups per CU; the kernel strides over the rest
         while ((long)gx * gy > 256L * 8 * 8 && gy > 1) gy = (gy + 1) / 2;
         const bool norm = fft_norm != 1.0f;
-        auto kern = mode == 0 ? (norm ? spectrogram512_kernel<0, true> : spectrogram512_kernel<0, false>)
-                              : (norm ? spectrogram512_kernel<1, true> : spectrogram512_kernel<1, false>);
+        const bool nz7 = window_size > 384 && window_size <= 448;
+        const bool ld3 = (step + window_size) * 4 <= 3072;          // 16-byte loads per lane for one pair's samples: 3 or 4
+#define SPEC_KERN2(M, N, Z) (ld3 ? spectrogram512_kernel<M, N, Z, 3> : spectrogram512_kernel<M, N, Z, 4>)
+#define SPEC_KERN(M, N) (nz7 ? SPEC_KERN2(M, N, true) : SPEC_KERN2(M, N, false))
+        auto kern = mode == 0 ? (norm ? SPEC_KERN(0, true) : SPEC_KERN(0, false))
+                              : (norm ? SPEC_KERN(1, true) : SPEC_KERN(1, false));
+        p.ppw = ppw;
         hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), 0, nntk_stream(), p);
         NNTK_LAUNCH_CHECK("spectrogram512_kernel");
     } else {

@@ -35,7 +35,11 @@ typedef struct {
     RecurrentWeights *weights;
     nntk_wblock wb;
     float *d_wp, *d_bi, *d_ut, *d_bh;
-    float *d_h, *d_c;           /* persistent single-sequence state [H] */
+    /* persistent single-sequence state [H], double-buffered: a stateful call reads state[cur] and writes
+     * state[cur ^ 1]; cur flips only once the call is known to be good, so a call that has to be repeated
+     * (persistent-kernel fault, see core_apply_host) still finds its initial state intact */
+    float *d_h[2], *d_c[2];
+    int cur;
     nntk_devbuf d_in, d_out, d_xw, d_work;
 } rec_core;
 
@@ -53,18 +57,20 @@ static int core_init(rec_core *c, int G, RecurrentConfig base) {
     c->weights->U = c->weights->W + w;
     c->weights->b_i = c->weights->U + u;
     c->weights->b_h = c->weights->b_i + b;
-    c->d_h = (float *)nntk_shim_malloc((size_t)c->H * sizeof(float));
-    c->d_c = (float *)nntk_shim_malloc((size_t)c->H * sizeof(float));
-    if (!c->d_h || !c->d_c) return -1;
-    if (nntk_shim_memset(c->d_h, 0, (size_t)c->H * sizeof(float))) return -1;
-    if (nntk_shim_memset(c->d_c, 0, (size_t)c->H * sizeof(float))) return -1;
+    /* one allocation: h[0] | h[1] | c[0] | c[1], each padded to 64 floats */
+    size_t hs = ((size_t)c->H + 63) & ~(size_t)63;
+    float *st = (float *)nntk_shim_malloc(4 * hs * sizeof(float));
+    if (!st) return -1;
+    c->d_h[0] = st; c->d_h[1] = st + hs; c->d_c[0] = st + 2 * hs; c->d_c[1] = st + 3 * hs;
+    c->cur = 0;
+    if (nntk_shim_memset(st, 0, 4 * hs * sizeof(float))) return -1;
     return 0;
 }
 
 static void core_free(rec_core *c) {
     nntk_shim_synchronize();
     nntk_shim_free(c->d_wp); nntk_shim_free(c->d_bi); nntk_shim_free(c->d_ut); nntk_shim_free(c->d_bh);
-    nntk_shim_free(c->d_h); nntk_shim_free(c->d_c);
+    nntk_shim_free(c->d_h[0]);
     nntk_devbuf_free(&c->d_in); nntk_devbuf_free(&c->d_out); nntk_devbuf_free(&c->d_xw); nntk_devbuf_free(&c->d_work);
     nntk_wblock_free(&c->wb);
     free(c->weights);
@@ -98,8 +104,14 @@ static int core_ensure(rec_core *c, int check_edits) {
     return 0;
 }
 
+static int core_reset_state(rec_core *c) {
+    size_t hs = ((size_t)c->H + 63) & ~(size_t)63;
+    c->cur = 0;
+    return nntk_shim_memset(c->d_h[0], 0, 4 * hs * sizeof(float));
+}
+
 /* stateful != 0: continue from / store into the handle's state (B must be 1) */
-static int core_apply_device(rec_core *c, int is_lstm, int use_bh, const int *acts,
+static int core_apply_device(rec_core *c, int is_lstm, int use_bh, const int *acts, const float *scales,
                              const float *d_in, float *d_out, int B, int stateful) {
     int G = c->G, H = c->H, T = c->T;
     if (B <= 0 || T <= 0) return 0;
@@ -111,18 +123,16 @@ static int core_apply_device(rec_core *c, int is_lstm, int use_bh, const int *ac
                          B, T, c->in, G * H, 1, 1, T, 1))
         return -1;
     const float *bh = use_bh ? c->d_bh : NULL;
+    const float *h0 = stateful ? c->d_h[c->cur] : NULL, *c0 = stateful ? c->d_c[c->cur] : NULL;
+    float *hT = stateful ? c->d_h[c->cur ^ 1] : NULL, *cT = stateful ? c->d_c[c->cur ^ 1] : NULL;
     if (G == 1)
-        return nntk_shim_rnn(d_xw, c->d_ut, bh, stateful ? c->d_h : NULL, d_out, stateful ? c->d_h : NULL, d_work,
-                             B, T, H, c->return_sequences, acts[0]);
+        return nntk_shim_rnn(d_xw, c->d_ut, bh, h0, d_out, hT, d_work, B, T, H, c->return_sequences, acts[0], scales[0]);
     if (is_lstm)
-        return nntk_shim_lstm(d_xw, c->d_ut, bh, stateful ? c->d_h : NULL, stateful ? c->d_c : NULL, d_out,
-                              stateful ? c->d_h : NULL, stateful ? c->d_c : NULL, d_work, B, T, H,
-                              c->return_sequences, acts);
-    return nntk_shim_gru(d_xw, c->d_ut, bh, stateful ? c->d_h : NULL, d_out, stateful ? c->d_h : NULL, d_work,
-                         B, T, H, c->return_sequences, acts);
+        return nntk_shim_lstm(d_xw, c->d_ut, bh, h0, c0, d_out, hT, cT, d_work, B, T, H, c->return_sequences, acts, scales);
+    return nntk_shim_gru(d_xw, c->d_ut, bh, h0, d_out, hT, d_work, B, T, H, c->return_sequences, acts, scales);
 }
 
-static int core_apply_host(rec_core *c, int is_lstm, int use_bh, const int *acts,
+static int core_apply_host(rec_core *c, int is_lstm, int use_bh, const int *acts, const float *scales,
                            const float *input, float *output, int B, int stateful) {
     if (B <= 0) return 0;
     if (core_ensure(c, 1)) return -1;
@@ -132,16 +142,27 @@ static int core_apply_host(rec_core *c, int is_lstm, int use_bh, const int *acts
     float *d_out = nntk_devbuf_reserve(&c->d_out, n_out);
     if (!d_in || !d_out) return -1;
     if (nntk_shim_upload(d_in, input, n_in * sizeof(float))) return -1;
-    if (core_apply_device(c, is_lstm, use_bh, acts, d_in, d_out, B, stateful)) return -1;
-    return nntk_shim_download(output, d_out, n_out * sizeof(float));
+    if (core_apply_device(c, is_lstm, use_bh, acts, scales, d_in, d_out, B, stateful)) return -1;
+    if (nntk_shim_download_nocheck(output, d_out, n_out * sizeof(float))) return -1;
+    if (nntk_shim_take_fault()) {
+        /* the persistent kernel's workgroups were not all resident (another kernel held the CUs) and it gave up:
+         * the library has switched to the per-timestep kernels, which need no co-residency and produce the same
+         * bits; repeat this call on them.  The initial state is intact (double-buffered above). */
+        if (core_apply_device(c, is_lstm, use_bh, acts, scales, d_in, d_out, B, stateful)) return -1;
+        if (nntk_shim_download(output, d_out, n_out * sizeof(float))) return -1;
+    }
+    if (stateful) c->cur ^= 1;
+    return 0;
 }
 
-static int gate_kind(ActivationFunction a, int *out) {
+/* kind + ReLU's output scale (activation_default.c:123-129) of one gate activation */
+static int gate_kind(ActivationFunction a, int *kind, float *scale) {
     if (!a) NNTK_FAIL("recurrent layer: NULL gate activation");
     if (!nntk_act_fusable(a))
         NNTK_FAIL("recurrent layer: gate activations must be built-in identity/sigmoid/tanh/relu "
                   "(custom host callbacks and softmax cannot run inside the device step kernel)");
-    *out = a->kind;
+    *kind = a->kind;
+    *scale = a->kind == NNTK_ACT_RELU ? a->relu_a : 1.0f;
     return 0;
 }
 
@@ -200,10 +221,10 @@ void GRUDestroy(GRU filter) {
     free(filter);
 }
 
-static int gru_acts(GRU f, int acts[3]) {
-    if (gate_kind(f->config.activations.z_gate_activation, &acts[0])) return -1;
-    if (gate_kind(f->config.activations.h_gate_activation, &acts[1])) return -1;
-    if (gate_kind(f->config.activations.r_gate_activation, &acts[2])) return -1;
+static int gru_acts(GRU f, int acts[3], float scales[3]) {
+    if (gate_kind(f->config.activations.z_gate_activation, &acts[0], &scales[0])) return -1;
+    if (gate_kind(f->config.activations.h_gate_activation, &acts[1], &scales[1])) return -1;
+    if (gate_kind(f->config.activations.r_gate_activation, &acts[2], &scales[2])) return -1;
     return 0;
 }
 
@@ -218,35 +239,38 @@ int GRUSyncWeights(GRU filter) {
 int GRUApplyInference(GRU filter, const float *input, float *output) {
     nntk_shim_clear_error();
     int acts[3];
+    float sc[3];
     if (!filter) NNTK_FAIL("GRUApplyInference: NULL handle");
-    if (gru_acts(filter, acts)) return -1;
-    return core_apply_host(&filter->core, 0, 1, acts, input, output, 1, 1);
+    if (gru_acts(filter, acts, sc)) return -1;
+    return core_apply_host(&filter->core, 0, 1, acts, sc, input, output, 1, 1);
 }
 /* gru.c:246-293 forward semantics */
 int GRUApplyInferenceBatch(GRU filter, const float *input, float *output, int batch) {
     nntk_shim_clear_error();
     int acts[3];
+    float sc[3];
     if (!filter) NNTK_FAIL("GRUApplyInferenceBatch: NULL handle");
-    if (gru_acts(filter, acts)) return -1;
-    return core_apply_host(&filter->core, 0, 1, acts, input, output, batch, 0);
+    if (gru_acts(filter, acts, sc)) return -1;
+    return core_apply_host(&filter->core, 0, 1, acts, sc, input, output, batch, 0);
 }
 int GRUApplyDevice(GRU filter, const float *d_input, float *d_output, int batch) {
     nntk_shim_clear_error();
     int acts[3];
+    float sc[3];
     if (!filter) NNTK_FAIL("GRUApplyDevice: NULL handle");
-    if (gru_acts(filter, acts)) return -1;
+    if (gru_acts(filter, acts, sc)) return -1;
     if (core_ensure(&filter->core, 0)) return -1;
-    return core_apply_device(&filter->core, 0, 1, acts, d_input, d_output, batch, 0);
+    return core_apply_device(&filter->core, 0, 1, acts, sc, d_input, d_output, batch, 0);
 }
 int GRUResetState(GRU filter) {
     nntk_shim_clear_error();
     if (!filter) NNTK_FAIL("GRUResetState: NULL handle");
-    return nntk_shim_memset(filter->core.d_h, 0, (size_t)filter->core.H * sizeof(float));
+    return core_reset_state(&filter->core);
 }
 int GRUGetState(GRU filter, float *h_host) {
     nntk_shim_clear_error();
     if (!filter) NNTK_FAIL("GRUGetState: NULL handle");
-    return nntk_shim_download(h_host, filter->core.d_h, (size_t)filter->core.H * sizeof(float));
+    return nntk_shim_download(h_host, filter->core.d_h[filter->core.cur], (size_t)filter->core.H * sizeof(float));
 }
 
 /* ================================= LSTM =================================== */
@@ -309,13 +333,13 @@ void LSTMDestroy(LSTM filter) {
     free(filter);
 }
 
-static int lstm_acts(LSTM f, int acts[5]) {
+static int lstm_acts(LSTM f, int acts[5], float scales[5]) {
     const LSTMActivations *a = &f->config.activations;
-    if (gate_kind(a->input_gate_activation, &acts[0])) return -1;
-    if (gate_kind(a->forget_gate_activation, &acts[1])) return -1;
-    if (gate_kind(a->candidate_gate_activation, &acts[2])) return -1;
-    if (gate_kind(a->output_gate_activation, &acts[3])) return -1;
-    if (gate_kind(a->output_activation, &acts[4])) return -1;
+    if (gate_kind(a->input_gate_activation, &acts[0], &scales[0])) return -1;
+    if (gate_kind(a->forget_gate_activation, &acts[1], &scales[1])) return -1;
+    if (gate_kind(a->candidate_gate_activation, &acts[2], &scales[2])) return -1;
+    if (gate_kind(a->output_gate_activation, &acts[3], &scales[3])) return -1;
+    if (gate_kind(a->output_activation, &acts[4], &scales[4])) return -1;
     return 0;
 }
 
@@ -330,38 +354,41 @@ int LSTMSyncWeights(LSTM filter) {
 int LSTMApplyInference(LSTM filter, const float *input, float *output) {
     nntk_shim_clear_error();
     int acts[5];
+    float sc[5];
     if (!filter) NNTK_FAIL("LSTMApplyInference: NULL handle");
-    if (lstm_acts(filter, acts)) return -1;
-    return core_apply_host(&filter->core, 1, filter->config.v2, acts, input, output, 1, 1);
+    if (lstm_acts(filter, acts, sc)) return -1;
+    return core_apply_host(&filter->core, 1, filter->config.v2, acts, sc, input, output, 1, 1);
 }
 /* lstm.c:426-475 forward semantics */
 int LSTMApplyInferenceBatch(LSTM filter, const float *input, float *output, int batch) {
     nntk_shim_clear_error();
     int acts[5];
+    float sc[5];
     if (!filter) NNTK_FAIL("LSTMApplyInferenceBatch: NULL handle");
-    if (lstm_acts(filter, acts)) return -1;
-    return core_apply_host(&filter->core, 1, filter->config.v2, acts, input, output, batch, 0);
+    if (lstm_acts(filter, acts, sc)) return -1;
+    return core_apply_host(&filter->core, 1, filter->config.v2, acts, sc, input, output, batch, 0);
 }
 int LSTMApplyDevice(LSTM filter, const float *d_input, float *d_output, int batch) {
     nntk_shim_clear_error();
     int acts[5];
+    float sc[5];
     if (!filter) NNTK_FAIL("LSTMApplyDevice: NULL handle");
-    if (lstm_acts(filter, acts)) return -1;
+    if (lstm_acts(filter, acts, sc)) return -1;
     if (core_ensure(&filter->core, 0)) return -1;
-    return core_apply_device(&filter->core, 1, filter->config.v2, acts, d_input, d_output, batch, 0);
+    return core_apply_device(&filter->core, 1, filter->config.v2, acts, sc, d_input, d_output, batch, 0);
 }
 /* lstm.c:270-274 (lstm_zero_state) */
 int LSTMResetState(LSTM filter) {
     nntk_shim_clear_error();
     if (!filter) NNTK_FAIL("LSTMResetState: NULL handle");
-    if (nntk_shim_memset(filter->core.d_h, 0, (size_t)filter->core.H * sizeof(float))) return -1;
-    return nntk_shim_memset(filter->core.d_c, 0, (size_t)filter->core.H * sizeof(float));
+    return core_reset_state(&filter->core);
 }
 int LSTMGetState(LSTM filter, float *h_host, float *c_host) {
     nntk_shim_clear_error();
     if (!filter) NNTK_FAIL("LSTMGetState: NULL handle");
-    if (h_host && nntk_shim_download(h_host, filter->core.d_h, (size_t)filter->core.H * sizeof(float))) return -1;
-    if (c_host && nntk_shim_download(c_host, filter->core.d_c, (size_t)filter->core.H * sizeof(float))) return -1;
+    const rec_core *c = &filter->core;
+    if (h_host && nntk_shim_download(h_host, c->d_h[c->cur], (size_t)c->H * sizeof(float))) return -1;
+    if (c_host && nntk_shim_download(c_host, c->d_c[c->cur], (size_t)c->H * sizeof(float))) return -1;
     return 0;
 }
 
@@ -411,42 +438,46 @@ int RNNSyncWeights(RNN filter) {
 int RNNApplyInference(RNN filter, const float *input, float *output) {
     nntk_shim_clear_error();
     int act;
+    float sc;
     if (!filter) NNTK_FAIL("RNNApplyInference: NULL handle");
-    if (gate_kind(filter->config.activation, &act)) return -1;
-    return core_apply_host(&filter->core, 0, filter->config.v2, &act, input, output, 1, 1);
+    if (gate_kind(filter->config.activation, &act, &sc)) return -1;
+    return core_apply_host(&filter->core, 0, filter->config.v2, &act, &sc, input, output, 1, 1);
 }
 /* rnn.c:249-291 forward semantics */
 int RNNApplyInferenceBatch(RNN filter, const float *input, float *output, int batch) {
     nntk_shim_clear_error();
     int act;
+    float sc;
     if (!filter) NNTK_FAIL("RNNApplyInferenceBatch: NULL handle");
-    if (gate_kind(filter->config.activation, &act)) return -1;
-    return core_apply_host(&filter->core, 0, filter->config.v2, &act, input, output, batch, 0);
+    if (gate_kind(filter->config.activation, &act, &sc)) return -1;
+    return core_apply_host(&filter->core, 0, filter->config.v2, &act, &sc, input, output, batch, 0);
 }
 int RNNApplyDevice(RNN filter, const float *d_input, float *d_output, int batch) {
     nntk_shim_clear_error();
     int act;
+    float sc;
     if (!filter) NNTK_FAIL("RNNApplyDevice: NULL handle");
-    if (gate_kind(filter->config.activation, &act)) return -1;
+    if (gate_kind(filter->config.activation, &act, &sc)) return -1;
     if (core_ensure(&filter->core, 0)) return -1;
-    return core_apply_device(&filter->core, 0, filter->config.v2, &act, d_input, d_output, batch, 0);
+    return core_apply_device(&filter->core, 0, filter->config.v2, &act, &sc, d_input, d_output, batch, 0);
 }
 int RNNResetState(RNN filter) {
     nntk_shim_clear_error();
     if (!filter) NNTK_FAIL("RNNResetState: NULL handle");
-    return nntk_shim_memset(filter->core.d_h, 0, (size_t)filter->core.H * sizeof(float));
+    return core_reset_state(&filter->core);
 }
 int RNNGetState(RNN filter, float *h_host) {
     nntk_shim_clear_error();
     if (!filter) NNTK_FAIL("RNNGetState: NULL handle");
-    return nntk_shim_download(h_host, filter->core.d_h, (size_t)filter->core.H * sizeof(float));
+    return nntk_shim_download(h_host, filter->core.d_h[filter->core.cur], (size_t)filter->core.H * sizeof(float));
 }
 
 /* ============================ bidirectional helpers ======================== */
 /* layers/bidirectional.c forward helpers.  The device forms are the product; the host-pointer forms keep the
  * reference's signatures (void, caller-owned host buffers) and stage through device scratch. */
 
-static nntk_devbuf g_bd_a, g_bd_b, g_bd_out;
+/* scratch of the host-pointer helpers: per calling thread (they have no handle to own it) */
+static _Thread_local nntk_devbuf g_bd_a, g_bd_b, g_bd_out;
 
 int bd_reverse_input_batch_device(const float *d_input, float *d_output, RecurrentConfig config, int batch) {
     nntk_shim_clear_error();

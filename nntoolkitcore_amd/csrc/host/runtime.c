@@ -19,7 +19,10 @@ void nntk_hip_profile_enable(int on) { nntk_shim_profile_enable(on); }
 int nntk_hip_profile_get(const char *name, double *total_ms, long *launches, long *timesteps) {
     return nntk_shim_profile_get(name, total_ms, launches, timesteps);
 }
-const char *nntk_version(void) { return "nntoolkitcore_hip 0.1 (gfx950)"; }
+const char *nntk_version(void) { return "nntoolkitcore_hip 0.2 (gfx950)"; }
+int nntk_hip_set_option(const char *name, const char *value) { nntk_shim_clear_error(); return nntk_shim_set_option(name, value); }
+int nntk_hip_get_option(const char *name, int *value) { nntk_shim_clear_error(); return nntk_shim_get_option(name, value); }
+int nntk_hip_device_status(void) { return nntk_shim_device_status(); }
 
 float *nntk_device_alloc(size_t n_floats) { return (float *)nntk_shim_malloc(n_floats * sizeof(float)); }
 void nntk_device_free(float *ptr) { nntk_shim_free(ptr); }
@@ -43,9 +46,29 @@ void nntk_wblock_free(nntk_wblock *wb) {
     free(wb->shadow);
     wb->host = wb->shadow = NULL;
 }
+/* The reference reads the caller's weight block on every Apply (no upload step), so a caller may edit it in
+ * place without telling anyone.  The host-pointer Apply calls therefore look for edits before they launch:
+ *   weights_check = 2  compare the whole block with its shadow (exact; 5 MB for LSTM-512 = ~0.2 ms per call)
+ *   weights_check = 1  (default) compare 256 evenly spaced 64-byte probes plus the block's head and tail: a
+ *                      replaced weight set (the realistic edit: memcpy of another model) always shows, a change
+ *                      of a few floats may not -- call <Layer>SyncWeights after such an edit
+ *   weights_check = 0  never look; <Layer>SyncWeights is the only way to re-upload
+ * (the single-sequence streaming calls are latency-bound: the full compare was most of a T = 1 call) */
+#define NNTK_PROBE 16            /* floats per probe */
 int nntk_wblock_dirty(const nntk_wblock *wb, int check_edits) {
     if (!wb->uploaded) return 1;
-    if (check_edits && memcmp(wb->host, wb->shadow, wb->n * sizeof(float)) != 0) return 1;
+    if (!check_edits) return 0;
+    int mode = 1;
+    (void)nntk_shim_get_option("weights_check", &mode);
+    if (mode < 0) mode = 1;
+    if (mode == 0) return 0;
+    if (mode >= 2 || wb->n <= 258 * NNTK_PROBE)
+        return memcmp(wb->host, wb->shadow, wb->n * sizeof(float)) != 0;
+    const size_t last = wb->n - NNTK_PROBE;
+    for (int i = 0; i <= 256; ++i) {
+        size_t off = (size_t)((double)last * i / 256.0);
+        if (memcmp(wb->host + off, wb->shadow + off, NNTK_PROBE * sizeof(float)) != 0) return 1;
+    }
     return 0;
 }
 void nntk_wblock_mark_uploaded(nntk_wblock *wb) {

@@ -103,6 +103,8 @@ void ref_gru_sequence(const float *x, const float *W, const float *U,
                       const float *b_i, const float *b_h, float *h_state, float *out,
                       int T, int in, int H, int return_sequences,
                       int act_z, int act_h, int act_r);
+/* ReLU output scale per gate activation (index = position in the act_* lists; default 1) for the next calls of this thread */
+void ref_set_gate_relu_scales(const float *a, int n);
 void ref_gru_batch(const float *x, const float *W, const float *U,
                    const float *b_i, const float *b_h, float *out,
                    int B, int T, int in, int H, int return_sequences,

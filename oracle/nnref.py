@@ -164,9 +164,26 @@ def activation(kind, x, relu_a=1.0, softmax_vector_size=0):
     return out
 
 
-def gru(x, W, U, b_i, b_h, h0=None, return_sequences=True, acts=(ACT_SIGMOID, ACT_TANH, ACT_SIGMOID)):
+def _gate_scales(relu_a):
+    """ReLU output scales of the gate activations for the NEXT oracle call (None = all 1)."""
+    if relu_a is None:
+        lib().ref_set_gate_relu_scales(None, 0)
+    else:
+        a = _f32(list(relu_a))
+        lib().ref_set_gate_relu_scales(_p(a), int(a.size))
+
+
+def gru(x, W, U, b_i, b_h, h0=None, return_sequences=True, acts=(ACT_SIGMOID, ACT_TANH, ACT_SIGMOID), relu_a=None):
     """x: [T,in] (stateful single sequence; returns (out, h_final)) or [B,T,in]
-    (zero state per sequence; returns out).  acts = (z, h, r)."""
+    (zero state per sequence; returns out).  acts = (z, h, r); relu_a = their ReLU output scales."""
+    _gate_scales(relu_a)
+    try:
+        return _gru(x, W, U, b_i, b_h, h0, return_sequences, acts)
+    finally:
+        _gate_scales(None)
+
+
+def _gru(x, W, U, b_i, b_h, h0, return_sequences, acts):
     x, W, U, b_i, b_h = _f32(x), _f32(W), _f32(U), _f32(b_i), _f32(b_h)
     H = U.shape[0]
     if x.ndim == 2:
@@ -183,8 +200,16 @@ def gru(x, W, U, b_i, b_h, h0=None, return_sequences=True, acts=(ACT_SIGMOID, AC
     return out
 
 
-def rnn(x, W, U, b_i, b_h, h0=None, return_sequences=True, v2=True, act=ACT_TANH):
+def rnn(x, W, U, b_i, b_h, h0=None, return_sequences=True, v2=True, act=ACT_TANH, relu_a=None):
     """One-gate RNN.  x: [T,in] (stateful single sequence; returns (out, h_final)) or [B,T,in] (zero state)."""
+    _gate_scales(None if relu_a is None else [relu_a])
+    try:
+        return _rnn(x, W, U, b_i, b_h, h0, return_sequences, v2, act)
+    finally:
+        _gate_scales(None)
+
+
+def _rnn(x, W, U, b_i, b_h, h0, return_sequences, v2, act):
     x, W, U, b_i, b_h = _f32(x), _f32(W), _f32(U), _f32(b_i), _f32(b_h)
     H = U.shape[0]
     if x.ndim == 2:
@@ -224,8 +249,16 @@ def bd_merge(fwd, bwd, mode="concat"):
 
 
 def lstm(x, W, U, b_i, b_h, h0=None, c0=None, return_sequences=True, v2=True,
-         acts=(ACT_SIGMOID, ACT_SIGMOID, ACT_TANH, ACT_SIGMOID, ACT_TANH)):
-    """acts = (input, forget, candidate, output_gate, output)."""
+         acts=(ACT_SIGMOID, ACT_SIGMOID, ACT_TANH, ACT_SIGMOID, ACT_TANH), relu_a=None):
+    """acts = (input, forget, candidate, output_gate, output); relu_a = their ReLU output scales."""
+    _gate_scales(relu_a)
+    try:
+        return _lstm(x, W, U, b_i, b_h, h0, c0, return_sequences, v2, acts)
+    finally:
+        _gate_scales(None)
+
+
+def _lstm(x, W, U, b_i, b_h, h0, c0, return_sequences, v2, acts):
     x, W, U, b_i, b_h = _f32(x), _f32(W), _f32(U), _f32(b_i), _f32(b_h)
     H = U.shape[0]
     if x.ndim == 2:

@@ -109,6 +109,15 @@ void ref_batch_norm(const float *in, const float *gamma, const float *beta,
 
 /* ------------------------------------------------------------------- GRU --- */
 
+/* ReLU output scale `a` of each gate's ActivationFunction handle (activation_default.c:123-129: the cell calls
+ * ActivationFunctionApply on the gate's own handle, gru.c:157-173 / lstm.c:213-237 / rnn.c:163, so a ReLU gate
+ * carries its a).  Index = position in the act_* argument lists below (GRU: z, h, r; LSTM: i, f, g, o, out; RNN: 0).
+ * Default 1; set with ref_set_gate_relu_scales before a call. */
+static _Thread_local float g_gate_a[5] = {1.f, 1.f, 1.f, 1.f, 1.f};
+void ref_set_gate_relu_scales(const float *a, int n) {
+    for (int i = 0; i < 5; ++i) g_gate_a[i] = (a && i < n) ? a[i] : 1.0f;
+}
+
 static void vec_add(const float *a, const float *b, float *c, int n) {
     for (int i = 0; i < n; ++i) c[i] = a[i] + b[i];
 }
@@ -130,13 +139,13 @@ static void gru_cell(const float *x, const float *W, const float *U, const float
     vec_add(x_W, h_pr_U, Z_zr, 2 * H);
     float *z = Z_zr + 3 * H;
     float *r = z + H;
-    ref_activation(act_z, 1.0f, 0, Z_zr, z, H);
-    ref_activation(act_r, 1.0f, 0, Z_zr + H, r, H);
+    ref_activation(act_z, g_gate_a[0], 0, Z_zr, z, H);
+    ref_activation(act_r, g_gate_a[2], 0, Z_zr + H, r, H);
     float *Z_h = Z_zr + 2 * H;
     float *h_tilda = r + H;
     vec_mul(r, h_pr_U + 2 * H, Z_h, H);
     vec_add(Z_h, x_W + 2 * H, Z_h, H);
-    ref_activation(act_h, 1.0f, 0, Z_h, h_tilda, H);
+    ref_activation(act_h, g_gate_a[1], 0, Z_h, h_tilda, H);
     float *minus_z = h_pr_U + 3 * H; /* H */
     for (int i = 0; i < H; ++i) minus_z[i] = -z[i];
     for (int i = 0; i < H; ++i) minus_z[i] = minus_z[i] + 1;
@@ -189,20 +198,20 @@ static void lstm_cell(const float *x, const float *W, const float *U, const floa
     if (v2) vec_add(u_H, b_h, u_H, 4 * H);
     vec_add(Z, u_H, Z, 4 * H);
     float *ig = Z + 4 * H;
-    ref_activation(act_i, 1.0f, 0, Z, ig, H);
+    ref_activation(act_i, g_gate_a[0], 0, Z, ig, H);
     float *fg = ig + H;
-    ref_activation(act_f, 1.0f, 0, Z + H, fg, H);
+    ref_activation(act_f, g_gate_a[1], 0, Z + H, fg, H);
     float *gg = fg + H;
-    ref_activation(act_g, 1.0f, 0, Z + 2 * H, gg, H);
+    ref_activation(act_g, g_gate_a[2], 0, Z + 2 * H, gg, H);
     float *og = gg + H;
-    ref_activation(act_o, 1.0f, 0, Z + 3 * H, og, H);
+    ref_activation(act_o, g_gate_a[3], 0, Z + 3 * H, og, H);
     float *i_g = u_H + 4 * H;
     vec_mul(ig, gg, i_g, H);
     float *f_c = i_g + H;
     vec_mul(fg, c_prev, f_c, H);
     vec_add(f_c, i_g, c, H);
     float *c_t = f_c + H;
-    ref_activation(act_out, 1.0f, 0, c, c_t, H);
+    ref_activation(act_out, g_gate_a[4], 0, c, c_t, H);
     vec_mul(og, c_t, h, H);
 }
 
@@ -252,7 +261,7 @@ static void rnn_cell(const float *x, const float *W, const float *U, const float
     ref_op_mat_mul(h_prev, U, h_U, 1, H, H);
     if (v2) vec_add(h_U, b_h, h_U, H);
     vec_add(h_U, x_W, gate, H);
-    ref_activation(act, 1.0f, 0, gate, h, H);
+    ref_activation(act, g_gate_a[0], 0, gate, h, H);
 }
 
 /* The layer that layers/rnn.c:249-291 (the batch forward pass) computes, one sequence, state carried in

@@ -30,3 +30,17 @@ def gpu(built_lib):
     from nntoolkitcore_amd import layers
     layers.use_torch_stream()
     return torch.device("cuda:0")
+
+
+OPTION_NAMES = ("rec_persistent", "rec_xw", "rec_pingpong", "rec_groups", "rec_spin_us", "rec_stream", "rec_fused2",
+                "spec_ppw", "spec_variant", "bn_fast", "gemm_tm_batch", "gemm_split_bf16", "weights_check")
+
+
+@pytest.fixture(autouse=True)
+def _restore_library_options():
+    """Tests flip tuning knobs with capi.set_option(); every test starts from the defaults again."""
+    yield
+    from nntoolkitcore_amd import capi
+    if capi._lib is not None:
+        for name in OPTION_NAMES:
+            capi._lib.nntk_hip_set_option(name.encode(), b"auto")

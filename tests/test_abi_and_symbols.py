@@ -135,3 +135,40 @@ def test_mel_filterbank_weights_match_oracle_restatement(built_lib):
         assert np.array_equal(w, O.mel_filterbank_weights(n_mels, n_fft, sr, lo, hi))
         assert (w[0] == 0).all() and (w >= 0).all()
         built_lib.MelFilterBankDestroy(bank)
+
+
+def test_current_stream_and_error_string_are_per_host_thread(built_lib):
+    """SURVEY 8(b) Threading: no process-global mutable state a second thread could trip over.  Needs no GPU: the
+    stream pointer is only stored."""
+    import ctypes as C
+    import threading
+    L = built_lib
+    L.nntk_hip_set_stream(C.c_void_p(0x1000))
+    seen = {}
+
+    def other():
+        seen["initial"] = L.nntk_hip_get_stream()          # a fresh thread starts on the default stream
+        L.nntk_hip_set_stream(C.c_void_p(0x2000))
+        seen["own"] = L.nntk_hip_get_stream()
+        L.nntk_hip_set_option(b"no_such_option", b"1")      # leaves an error string in THIS thread only
+        seen["err"] = L.nntk_last_error().decode()
+
+    t = threading.Thread(target=other)
+    t.start(); t.join()
+    assert seen["initial"] in (None, 0) and seen["own"] == 0x2000 and "unknown option" in seen["err"]
+    assert L.nntk_hip_get_stream() == 0x1000                # untouched by the other thread
+    assert L.nntk_last_error().decode() == ""
+    L.nntk_hip_set_stream(None)
+
+
+def test_options_by_name(built_lib):
+    from nntoolkitcore_amd import capi
+    assert capi.get_option("rec_persistent") == -1 and capi.get_option("weights_check") == -1
+    capi.set_option("rec_persistent", 0)
+    assert capi.get_option("rec_persistent") == 0
+    capi.set_option("rec_persistent", "auto")
+    assert capi.get_option("rec_persistent") == -1
+    assert capi.get_option("rec_spin_us") == 1000000
+    import pytest
+    with pytest.raises(capi.NNTKError):
+        capi.set_option("nope", 1)

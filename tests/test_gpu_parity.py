@@ -332,6 +332,30 @@ def test_spectrogram_batch_geometries(gpu, nfft, win, nov, N, B):
     sp.destroy()
 
 
+def test_spectrogram_zero_padding_is_exact_next_to_inf_and_nan(gpu):
+    """The reference zero-pads each frame to nfft (spectrogram.c:120-121): a non-finite sample just outside a frame's
+    window must not leak into that frame (the kernel clears out-of-window samples with an AND, it does not multiply
+    them by a zero tap)."""
+    N = 4000
+    x = (0.1 * rng(3).standard_normal(N)).astype(np.float32)
+    x[1000] = np.inf
+    x[2500] = np.nan
+    sp = NL.Spectrogram(512, 400, 240, N)
+    got = sp.apply(x)
+    ref = O.spectrogram(x, O.window("hann", 400), 512, 240)
+    bad = ~np.isfinite(ref).all(axis=1)
+    assert bad.sum() in (5, 6)                       # exactly the frames whose window holds sample 1000 or 2500
+    # the kernel transforms frames 2p, 2p+1 as ONE complex FFT, so a non-finite frame takes its pair partner with it --
+    # but nothing else: every other frame is finite and equal to the reference
+    pair_bad = bad.copy()
+    pair_bad[0::2] |= bad[1::2] if len(bad) % 2 == 0 else np.append(bad[1::2], False)
+    pair_bad[1::2] |= bad[0::2][:len(bad[1::2])]
+    got_bad = ~np.isfinite(got).all(axis=1)
+    assert not (got_bad & ~pair_bad).any() and (got_bad | ~bad).all()
+    close(got[~pair_bad], ref[~pair_bad], atol=1e-6 * float(np.abs(ref[~pair_bad]).max()), rtol=2e-5)
+    sp.destroy()
+
+
 def test_spectrogram_default_window_is_ones_and_scale_override(gpu):
     L = capi.load()
     x = (0.1 * rng(2).standard_normal(4000)).astype(np.float32)
@@ -488,7 +512,7 @@ def test_persistent_and_per_step_recurrent_paths_agree_bitwise_in_sharding(gpu, 
     W, U, bi, bh = lstm_weights(r, I, H)
     ref = O.lstm(xs, W, U, bi, bh, v2=True)
     for mode in ("1", "0"):
-        monkeypatch.setenv("NNTK_REC_PERSISTENT", mode)
+        capi.set_option("rec_persistent", mode)
         lstm = NL.LSTM(I, H, True, T, v2=True)
         lstm.set_weights(W, U, bi, bh)
         whole = lstm.apply_device(x).clone()
@@ -513,7 +537,7 @@ def test_lstm512_pingpong_and_classic_kernels_agree_bitwise(gpu, monkeypatch):
         ref = O.lstm(xs, W, U, bi, bh, return_sequences=seq, v2=True)
         outs = []
         for mode in ("1", "0"):
-            monkeypatch.setenv("NNTK_REC_PINGPONG", mode)
+            capi.set_option("rec_pingpong", mode)
             lstm = NL.LSTM(I, H, seq, T, v2=True)
             lstm.set_weights(W, U, bi, bh)
             o = lstm.apply_device(x).clone()
@@ -526,7 +550,7 @@ def test_lstm512_pingpong_and_classic_kernels_agree_bitwise(gpu, monkeypatch):
     o1, h1, c1 = O.lstm(x1, W, U, bi, bh, v2=True)
     o2, h2, c2 = O.lstm(x2, W, U, bi, bh, h0=h1, c0=c1, v2=True)
     for mode in ("1", "0"):
-        monkeypatch.setenv("NNTK_REC_PINGPONG", mode)
+        capi.set_option("rec_pingpong", mode)
         lstm = NL.LSTM(I, H, True, T, v2=True)
         lstm.set_weights(W, U, bi, bh)
         close(lstm.apply(x1), o1)
@@ -554,7 +578,7 @@ def test_pingpong_default_shapes_match_classic_bitwise(gpu, monkeypatch, cell, H
         ref = O.lstm(xs, W, U, bi, bh, v2=True)
     outs = []
     for mode in ("1", "0"):
-        monkeypatch.setenv("NNTK_REC_PINGPONG", mode)
+        capi.set_option("rec_pingpong", mode)
         l = NL.GRU(I, H, True, T) if cell == "gru" else NL.LSTM(I, H, True, T, v2=True)
         l.set_weights(W, U, bi, bh)
         outs.append(l.apply_device(x).clone())
@@ -609,7 +633,7 @@ def test_time_major_projection_tiled_over_batch_is_bit_identical(gpu, monkeypatc
         W, U, bi, bh = gru_weights(r, I, H)
         outs = []
         for mode in ("1", "0"):
-            monkeypatch.setenv("NNTK_GEMM_TM_BATCH", mode)
+            capi.set_option("gemm_tm_batch", mode)
             g = NL.GRU(I, H, True, T)
             g.set_weights(W, U, bi, bh)
             outs.append(g.apply_device(x).clone())
@@ -653,7 +677,7 @@ def test_rnn_relu_and_both_recurrent_paths(gpu, monkeypatch):
     x = u(r, B, T, I)
     ref = O.rnn(x, W, U, bi, bh, act=O.ACT_RELU)
     for mode in ("1", "0"):
-        monkeypatch.setenv("NNTK_REC_PERSISTENT", mode)
+        capi.set_option("rec_persistent", mode)
         rnn = NL.RNN(I, H, True, T, act=L.ActivationFunctionCreateReLU(H, 1.0))
         rnn.set_weights(W, U, bi, bh)
         close(rnn.apply(x), ref)
@@ -757,7 +781,7 @@ def test_random_recurrent_shapes(gpu, monkeypatch):
         I, H = int(r.integers(1, 40)), int(r.integers(1, 90))
         T, B = int(r.integers(1, 12)), int(r.integers(1, 80))
         seq, v2 = bool(r.integers(0, 2)), bool(r.integers(0, 2))
-        monkeypatch.setenv("NNTK_REC_PERSISTENT", "1" if i % 2 else "0")
+        capi.set_option("rec_persistent", "1" if i % 2 else "0")
         x = u(r, B, T, I)
         W, U, bi, bh = gru_weights(r, I, H)
         g = NL.GRU(I, H, seq, T)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B kernel variants in ONE process, interleaved rounds (guide rule 24).
-usage: python tools/ab.py <workload> ENVVAR=v1,v2,... [--rounds N] [--batch B] [--frames F]
+usage: python tools/ab.py <workload> OPTION=v1,v2,... [--rounds N] [--batch B] [--frames F]
 Prints the median / min per-phase milliseconds for each variant."""
 import os
 import sys
@@ -18,6 +18,7 @@ def main():
     wl_name = sys.argv[1]
     var, vals = sys.argv[2].split("=")
     vals = vals.split(",")
+    opt = var[5:].lower() if var.startswith("NNTK_") else var      # option name of nntk_hip_set_option
     rounds, batch, frames = 7, 0, 1000
     for i, a in enumerate(sys.argv):
         if a == "--rounds": rounds = int(sys.argv[i + 1])
@@ -32,12 +33,12 @@ def main():
     wl = bench.Workload(wl_name, B, frames, weights, torch, NL)
     res = {v: {} for v in vals}
     for v in vals:                      # warm-up each variant
-        os.environ[var] = v
+        capi.set_option(opt, v)
         wl.step()
     torch.cuda.synchronize()
     for r in range(rounds):
         for v in vals:
-            os.environ[var] = v
+            capi.set_option(opt, v)
             ev = wl.step(timed=True)
             torch.cuda.synchronize()
             for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):

@@ -19,7 +19,7 @@ def main():
         x = torch.randn(B, T, K, device="cuda"); y = torch.empty(B, T, N, device="cuda")
         res = []
         for dbg in ("0", "1", "8", "2", "4", "7"):
-            os.environ["NNTK_CONV_DBG"] = dbg
+            capi.set_option("conv_dbg", dbg)
             tdd.apply_device(x, out=y); torch.cuda.synchronize()
             ts = []
             for _ in range(5):
@@ -30,7 +30,7 @@ def main():
         flops = 2.0 * B * T * K * N
         print(name, " ".join(res), " ms | MFMA floor %.3f ms" % (flops / 157.3e12 * 1e3))
         tdd.destroy()
-    os.environ["NNTK_CONV_DBG"] = "0"
+    capi.set_option("conv_dbg", "0")
 
 if __name__ == "__main__":
     main()

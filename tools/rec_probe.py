@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time one recurrent layer at a given shape for each value of an env knob: rec_probe.py lstm|gru|rnn H B T VAR=v1,v2"""
+"""Time one recurrent layer at a given shape for each value of a library option (nntk_hip_set_option): rec_probe.py lstm|gru|rnn H B T VAR=v1,v2"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,6 +10,7 @@ def main():
     from nntoolkitcore_amd import capi, layers as NL
     kind, H, B, T = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     var, vals = sys.argv[5].split("="); vals = vals.split(",")
+    opt = var[5:].lower() if var.startswith("NNTK_") else var      # option name of nntk_hip_set_option
     torch.cuda.set_device(0); capi.load(); NL.use_torch_stream()
     G = {"lstm": 4, "gru": 3, "rnn": 1}[kind]
     r = np.random.default_rng(0)
@@ -21,11 +22,11 @@ def main():
     x = torch.randn(B, T, 128, device="cuda"); out = torch.empty((B, T, H) if seq else (B, H), device="cuda")
     res = {v: [] for v in vals}
     for v in vals:
-        os.environ[var] = v; l.apply_device(x, out=out)
+        capi.set_option(opt, v); l.apply_device(x, out=out)
     torch.cuda.synchronize()
     for _ in range(5):
         for v in vals:
-            os.environ[var] = v
+            capi.set_option(opt, v)
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record(); l.apply_device(x, out=out); e1.record(); torch.cuda.synchronize()
             res[v].append(e0.elapsed_time(e1))

@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 def main():
     import torch, bench
     from nntoolkitcore_amd import capi, layers as NL
-    os.environ["NNTK_REC_PINGPONG"] = sys.argv[1]
+    capi.set_option("rec_pingpong", sys.argv[1])
     if len(sys.argv) > 2: os.environ["NNTK_REC_WAVEMAP"] = sys.argv[2]
     torch.cuda.set_device(0); capi.load(); NL.use_torch_stream()
     B, T = 512, 996
