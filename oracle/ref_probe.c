@@ -209,6 +209,69 @@ int main(int argc, char **argv) {
                bd_merge_concat_buffer_size_p(rc), bd_merge_concat_buffer_size_p(last));
     }
 
+    /* ---- round 2: the remaining op-free behaviour of the hot path's boundary ---- */
+    {
+        /* (1) wrong-mode handles: *ApplyInference on a handle made by *CreateForTraining returns -1 before any
+         *     arithmetic (conv_1d.c:150-152, gru.c:190-192, lstm.c:242-244, dense.c:136-138, batch_norm.c:167-169) */
+        typedef Conv1d (*conv_train_fn)(Conv1dConfig, ConvTrainingConfig);
+        typedef int (*conv_apply_fn)(Conv1d, const float *, float *);
+        typedef GRU (*gru_train_fn)(GRUConfig, GRUTrainingConfig);
+        typedef int (*gru_apply_fn)(GRU, const float *, float *);
+        typedef LSTM (*lstm_train_fn)(LSTMConfig, LSTMTrainingConfig);
+        typedef int (*lstm_apply_fn)(LSTM, const float *, float *);
+        typedef Dense (*dense_train_fn)(DenseConfig, DenseTrainingConfig);
+        typedef int (*dense_apply_fn)(Dense, const float *, float *);
+        typedef BatchNorm (*bn_train_fn)(BatchNormConfig, BatchNormTrainingConfig);
+        typedef int (*bn_apply_fn)(BatchNorm, const float *, float *);
+        SYM(conv_train_fn, Conv1dCreateForTraining) SYM(conv_apply_fn, Conv1dApplyInference)
+        SYM(gru_train_fn, GRUCreateForTraining) SYM(gru_apply_fn, GRUApplyInference)
+        SYM(lstm_train_fn, LSTMCreateForTraining) SYM(lstm_apply_fn, LSTMApplyInference)
+        SYM(dense_train_fn, DenseCreateForTraining) SYM(dense_apply_fn, DenseApplyInference)
+        SYM(bn_train_fn, BatchNormCreateForTraining) SYM(bn_apply_fn, BatchNormApplyInference)
+        float in[64] = {0}, out[64] = {0};
+        Conv1d c = Conv1dCreateForTraining_p(Conv1dConfigCreate_p(2, 3, 2, 1, 8), (ConvTrainingConfig){2});
+        GRU g = GRUCreateForTraining_p(GRUConfigCreate_p(2, 3, true, 2, GRUActivationsCreateDefault_p(3)), (GRUTrainingConfig){2});
+        LSTM l = LSTMCreateForTraining_p(LSTMConfigCreate_p(2, 3, true, 2, true, LSTMActivationsCreateDefault_p(3)), (LSTMTrainingConfig){2});
+        Dense d = DenseCreateForTraining_p(DenseConfigCreate_p(2, 3, NULL), (DenseTrainingConfig){2});
+        BatchNormTrainingConfig btc; btc.momentum = 0.9f; btc.mini_batch_size = 2;
+        BatchNorm bnh = BatchNormCreateForTraining_p(BatchNormConfigCreate_p(3, 1e-3f, 2), btc);
+        printf("  \"wrong_mode_apply_inference\": {\"conv1d\": %d, \"gru\": %d, \"lstm\": %d, \"dense\": %d, \"batch_norm\": %d},\n",
+               Conv1dApplyInference_p(c, in, out), GRUApplyInference_p(g, in, out), LSTMApplyInference_p(l, in, out),
+               DenseApplyInference_p(d, in, out), BatchNormApplyInference_p(bnh, in, out));
+    }
+    {
+        /* (2) activation handles: identity copies exactly the size given at create (activation.c:23-25,
+         *     activation_default.c:98-103); a custom handle's callback receives (implementer, input, output, size) */
+        typedef ActivationFunction (*act_id_fn)(int);
+        typedef ActivationFunction (*act_create_fn)(int, ActivationImplementerDestroy, void *, ActivationFunctionImpl,
+                                                    ActivationFunctionDerivative, ActivationFunctionDerivative);
+        typedef void (*act_apply_fn)(ActivationFunction, const float *, float *);
+        typedef void (*act_destroy_fn)(ActivationFunction);
+        SYM(act_id_fn, ActivationFunctionCreateIdentity) SYM(act_create_fn, ActivationFunctionCreate)
+        SYM(act_apply_fn, ActivationFunctionApply) SYM(act_destroy_fn, ActivationFunctionDestroy)
+        float in[8] = {1, 2, 3, 4, 5, 6, 7, 8}, out[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+        ActivationFunction id = ActivationFunctionCreateIdentity_p(5);
+        ActivationFunctionApply_p(id, in, out);
+        printf("  \"identity_size5_on_8\": [%g, %g, %g, %g, %g, %g, %g, %g],\n", out[0], out[1], out[2], out[3], out[4], out[5], out[6], out[7]);
+        static struct { void *impl; const float *in; float *out; int size; int destroyed; } seen;
+        int token = 42;
+        void cb(void *impl, const float *i, float *o, int n) { seen.impl = impl; seen.in = i; seen.out = o; seen.size = n; }
+        void dtor(void *p) { seen.destroyed = (p == seen.impl); }
+        ActivationFunction cu = ActivationFunctionCreate_p(7, dtor, &token, cb, NULL, NULL);
+        ActivationFunctionApply_p(cu, in, out);
+        ActivationFunctionDestroy_p(cu);
+        printf("  \"custom_activation_callback\": {\"implementer_passed\": %d, \"input_passed\": %d, \"output_passed\": %d, \"size\": %d, \"destroy_called_with_implementer\": %d},\n",
+               seen.impl == (void *)&token, seen.in == in, seen.out == out, seen.size, seen.destroyed);
+    }
+    {
+        /* (3) mel filter bank config (mel_filterbank.c:32-41): by-value struct, field order is ABI */
+        typedef MelFilterBankConfig (*mel_cfg_fn)(int, int, int, float, float);
+        SYM(mel_cfg_fn, MelFilterBankConfigCreate)
+        MelFilterBankConfig m = MelFilterBankConfigCreate_p(40, 512, 16000, 20.0f, 8000.0f);
+        printf("  \"mel_config\": {\"n_mels\": %d, \"n_fft\": %d, \"sample_rate\": %d, \"lower_hz\": %g, \"upper_hz\": %g, \"sizeof\": %zu},\n",
+               m.n_mels, m.n_fft, m.sample_rate, m.lower_hz, m.upper_hz, sizeof(MelFilterBankConfig));
+    }
+
     /* ---- windows (size 16 and the first/last 8 taps of size 400) ---- */
     float w16[16], w400[400];
     struct { const char *name; win_fn fn; } wins[] = {

@@ -172,3 +172,46 @@ def test_options_by_name(built_lib):
     import pytest
     with pytest.raises(capi.NNTKError):
         capi.set_option("nope", 1)
+
+
+def test_boundary_behaviour_pinned_by_the_real_reference_round2(built_lib):
+    """tests/golden/ref_probe.json, round-2 additions: results of the REAL reference's op-free functions
+    (oracle/ref_probe.c).  The product must behave the same at the C boundary."""
+    import ctypes as C
+    import json
+    import os
+    from nntoolkitcore_amd import capi
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_probe.json")))
+    L = built_lib
+    # a custom ActivationFunction is the caller's host function: called with (implementer, input, output, size-at-create);
+    # Destroy hands the implementer to the caller's destroy function (activation.c:23-45)
+    assert gold["custom_activation_callback"] == {"implementer_passed": 1, "input_passed": 1, "output_passed": 1, "size": 7,
+                                                   "destroy_called_with_implementer": 1}
+    seen = {}
+    token = C.c_int(42)
+
+    @capi.ACT_IMPL_FN
+    def cb(impl, i, o, n):
+        seen.update(impl=impl, inp=C.addressof(i.contents), out=C.addressof(o.contents), size=n)
+
+    DTOR = C.CFUNCTYPE(None, C.c_void_p)
+
+    @DTOR
+    def dtor(p):
+        seen["destroyed_with"] = p
+
+    x = np.arange(8, dtype=np.float32)
+    y = np.full(8, -1, np.float32)
+    h = L.ActivationFunctionCreate(7, C.cast(dtor, C.c_void_p), C.cast(C.pointer(token), C.c_void_p), C.cast(cb, C.c_void_p), None, None)
+    L.ActivationFunctionApply(h, x.ctypes.data_as(capi.fp), y.ctypes.data_as(capi.fp))
+    L.ActivationFunctionDestroy(h)
+    assert seen["impl"] == C.addressof(token) and seen["inp"] == x.ctypes.data and seen["out"] == y.ctypes.data
+    assert seen["size"] == gold["custom_activation_callback"]["size"] and seen["destroyed_with"] == C.addressof(token)
+    # MelFilterBankConfig: by-value struct, field order and size are ABI (mel_filterbank.h:14-20)
+    m = L.MelFilterBankConfigCreate(40, 512, 16000, C.c_float(20.0), C.c_float(8000.0))
+    g = gold["mel_config"]
+    assert (m.n_mels, m.n_fft, m.sample_rate, m.lower_hz, m.upper_hz, C.sizeof(capi.MelFilterBankConfig)) == \
+        (g["n_mels"], g["n_fft"], g["sample_rate"], g["lower_hz"], g["upper_hz"], g["sizeof"])
+    # recorded for INTEGRATION.md: the reference returns -1 from *ApplyInference on a training-mode handle; the
+    # product has no training-mode handles (out of scope), its -1 cases are NULL handles and device errors
+    assert set(gold["wrong_mode_apply_inference"].values()) == {-1}

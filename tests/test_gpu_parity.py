@@ -125,6 +125,20 @@ def test_elementwise_activations(gpu, kind, okind, n):
     act.destroy()
 
 
+def test_identity_activation_copies_exactly_its_created_size(gpu):
+    """Pinned by the REAL reference (tests/golden/ref_probe.json "identity_size5_on_8"): ActivationFunctionApply on an
+    identity handle created with size 5 copies 5 floats and leaves the rest of the output alone."""
+    import json, os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_probe.json")))
+    L = capi.load()
+    x = np.arange(1, 9, dtype=np.float32)
+    y = np.full(8, -1, np.float32)
+    h = L.ActivationFunctionCreateIdentity(5)
+    L.ActivationFunctionApply(h, x.ctypes.data_as(capi.fp), y.ctypes.data_as(capi.fp))
+    L.ActivationFunctionDestroy(h)
+    assert y.tolist() == gold["identity_size5_on_8"]
+
+
 def test_softmax_no_max_subtraction(gpu):
     x = u(rng(3), 6, 1000, sc=4)
     act = NL.Activation("softmax", 6, vector_size=1000)

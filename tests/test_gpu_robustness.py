@@ -194,3 +194,59 @@ def test_persistent_fault_is_reported_and_heals(gpu):
     g1.destroy(); gru.destroy()
     capi.set_option("rec_spin_us", "auto"); capi.set_option("rec_persistent", "auto")
     assert L.nntk_hip_synchronize() == 0
+
+
+# ---- achieved error of the T ~ 1000 recurrences at the BASELINE shapes (VERDICT r01 "What's weak" #2) ----
+# The gate activations are hardware exp2 / rcp forms (nntk_common.hpp), not libm expf / tanhf with a true divide
+# (SURVEY a22): the deviation is a NUMBER here, against the oracle and against torch in float64, and the bound is
+# what was measured x 3 (the fp32 noise floor of the reference itself at T = 1000 is ~6e-7).
+
+def _torch64(kind, x, W, U, bi, bh):
+    import torch
+    H = U.shape[0]
+    if kind == "lstm":
+        m = torch.nn.LSTM(W.shape[0], H, batch_first=True).double()
+        p = lambda a: torch.tensor(a).double()
+    else:
+        m = torch.nn.GRU(W.shape[0], H, batch_first=True).double()
+        perm = lambda a: np.concatenate([a[..., H:2 * H], a[..., :H], a[..., 2 * H:]], axis=-1)     # [z|r|h] -> torch's [r|z|n]
+        p = lambda a: torch.tensor(perm(a)).double()
+    with torch.no_grad():
+        m.weight_ih_l0.copy_(p(W).T); m.weight_hh_l0.copy_(p(U).T); m.bias_ih_l0.copy_(p(bi)); m.bias_hh_l0.copy_(p(bh))
+        return m(torch.tensor(x).double())[0].numpy()
+
+
+def _uw(r, fan, *shape):
+    return r.uniform(-fan ** -0.5, fan ** -0.5, shape).astype(np.float32)
+
+
+def test_achieved_error_lstm512_T996(gpu):
+    r = rng(501)
+    B, I, H, T = 3, 128, 512, 996
+    x = r.standard_normal((B, T, I)).astype(np.float32)
+    W, U, bi, bh = _uw(r, I, I, 4 * H), _uw(r, H, H, 4 * H), _uw(r, H, 4 * H), _uw(r, H, 4 * H)
+    lstm = NL.LSTM(I, H, True, T, v2=True)
+    lstm.set_weights(W, U, bi, bh)
+    got = lstm.apply(x)
+    e_or = float(np.abs(got - O.lstm(x, W, U, bi, bh, v2=True)).max())
+    e_64 = float(np.abs(got - _torch64("lstm", x, W, U, bi, bh)).max())
+    print("HIP LSTM(128->512, v2) T=996: max abs err vs oracle %.2e, vs torch float64 %.2e" % (e_or, e_64))
+    assert e_or < 3e-6 and e_64 < 3e-6
+    lstm.destroy()
+
+
+def test_achieved_error_two_layer_gru256_T1000(gpu):
+    r = rng(502)
+    B, T = 3, 1000
+    x = r.standard_normal((B, T, 128)).astype(np.float32)
+    W1, U1, bi1, bh1 = _uw(r, 128, 128, 768), _uw(r, 256, 256, 768), _uw(r, 256, 768), _uw(r, 256, 768)
+    W2, U2, bi2, bh2 = _uw(r, 256, 256, 768), _uw(r, 256, 256, 768), _uw(r, 256, 768), _uw(r, 256, 768)
+    g1, g2 = NL.GRU(128, 256, True, T), NL.GRU(256, 256, True, T)
+    g1.set_weights(W1, U1, bi1, bh1); g2.set_weights(W2, U2, bi2, bh2)
+    got = g2.apply(g1.apply(x))
+    ref = O.gru(O.gru(x, W1, U1, bi1, bh1), W2, U2, bi2, bh2)
+    r64 = _torch64("gru", _torch64("gru", x, W1, U1, bi1, bh1).astype(np.float32), W2, U2, bi2, bh2)
+    e_or, e_64 = float(np.abs(got - ref).max()), float(np.abs(got - r64).max())
+    print("HIP GRU 128->256->256 T=1000: max abs err vs oracle %.2e, vs torch float64 %.2e" % (e_or, e_64))
+    assert e_or < 3e-6 and e_64 < 3e-6
+    g1.destroy(); g2.destroy()
