@@ -109,6 +109,14 @@ int nntk_shim_lstm(const float *d_xw, const float *d_ut, const float *d_bh,
                    const float *d_h0, const float *d_c0, float *d_out, float *d_hT, float *d_cT,
                    float *d_work, int B, int T, int H, int return_sequences, const int acts[5], const float act_scales[5]);
 
+/* streaming form: ONE sequence, T small; x [T, in] and out ([T, H] or [H]) may be pinned host memory (read / written by
+ * the kernel directly, no copies); state h[cur] (c[cur]) -> h[(cur + T) & 1]; the last launch stores `seq` to *flag (a
+ * pinned host word) once all outputs are visible to the host.  Bit-compatible with nntk_shim_gru / _lstm / _rnn. */
+int nntk_shim_rec_stream(int G, int is_lstm, const float *x, const float *d_wp, const float *d_bi,
+                         const float *d_ut, const float *d_bh, float *d_h0, float *d_h1, float *d_c0, float *d_c1,
+                         int cur, float *out, int T, int in, int H, int return_sequences,
+                         const int *acts, const float *scales, unsigned *d_done, unsigned *flag, unsigned seq);
+
 /* ---- K1: framed STFT magnitude / PSD ---------------------------------------
  * d_in [B, input_size], d_window [window_size], d_out [B, nts, nfreq]
  * d_twiddle [nfft] complex interleaved: exp(-2*pi*i*m/nfft), evaluated in double on the host

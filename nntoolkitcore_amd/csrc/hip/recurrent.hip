@@ -225,8 +225,8 @@ __global__ __launch_bounds__(256 * NG) void rec_step_kernel(RecParams p) {
             const float hz = fin[rr][0] + bh[0], hr = fin[rr][1] + bh[1], hh = fin[rr][2] + bh[2];
             const float z = nntk_gate_act(p.a0, xwv[rr][0] + hz, p.s0);
             const float rg = nntk_gate_act(p.a2, xwv[rr][1] + hr, p.s2);
-            const float ht = nntk_gate_act(p.a1, rg * hh + xwv[rr][2], p.s1);
-            hn = (-z + 1.0f) * ht + z * prev[rr];
+            const float ht = nntk_gate_act(p.a1, fmaf(rg, hh, xwv[rr][2]), p.s1);
+            hn = fmaf(-z + 1.0f, ht, z * prev[rr]);
         } else {
             // lstm.c:201-238
             const float zi = xwv[rr][0] + (fin[rr][0] + bh[0]);
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256 * NG) void rec_step_kernel(RecParams p) {
             const float fg = nntk_gate_act(p.a1, zf, p.s1);
             const float gg = nntk_gate_act(p.a2, zg, p.s2);
             const float og = nntk_gate_act(p.a3, zo, p.s3);
-            const float cn = fg * prev[rr] + ig * gg;
+            const float cn = fmaf(fg, prev[rr], ig * gg);
             p.c[(size_t)b * p.H + j] = cn;
             hn = og * nntk_gate_act(p.a4, cn, p.s4);
         }
@@ -597,8 +597,8 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
                 const float hz = fin[e][0] + bh[e][0], hr = fin[e][1] + bh[e][1], hh = fin[e][2] + bh[e][2];
                 const float z = nntk_gate_act(A0, xwv[e][0] + hz, S0);
                 const float rg = nntk_gate_act(A2, xwv[e][1] + hr, S2);
-                const float ht = nntk_gate_act(A1, rg * hh + xwv[e][2], S1);
-                hn[e] = (-z + 1.0f) * ht + z * prev[e];
+                const float ht = nntk_gate_act(A1, fmaf(rg, hh, xwv[e][2]), S1);
+                hn[e] = fmaf(-z + 1.0f, ht, z * prev[e]);
                 prev[e] = hn[e];
             } else {
                 const float zi = xwv[e][0] + (fin[e][0] + bh[e][0]);
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
                 const float fg = nntk_gate_act(A1, zf, S1);
                 const float gg = nntk_gate_act(A2, zg, S2);
                 const float og = nntk_gate_act(A3, zo, S3);
-                const float cn = fg * prev[e] + ig * gg;
+                const float cn = fmaf(fg, prev[e], ig * gg);
                 prev[e] = cn;
                 hn[e] = og * nntk_gate_act(A4, cn, S4);
             }
@@ -677,6 +677,202 @@ __global__ __launch_bounds__(256) void rec_tile_h0_kernel(const float *src, floa
     }
 }
 
+static int act_ok(int a) {
+    return a == NNTK_ACT_IDENTITY || a == NNTK_ACT_SIGMOID || a == NNTK_ACT_TANH || a == NNTK_ACT_RELU;
+}
+
+// ============================================================================
+// Streaming variant: ONE sequence (the reference's own call shape: GRUApplyInference / LSTMApplyInference with carried
+// state, gru.c:189-204, lstm.c:241-268), a few timesteps per call.  At batch 1 the step is a pair of GEMVs over 1..5 MB
+// of weights -- nothing for an MFMA tile to do, and every fixed cost of the batch path (projection GEMM launch, two
+// memsets, the 128 KB U^T -> LDS reload of 32 co-resident workgroups, counters, the blocking upload and download)
+// is pure latency.  Here a call is T launches of ONE small kernel and no copies: x_t is read from, and h_t written
+// to, pinned host memory directly; state ping-pongs in device memory.
+//
+// Bit-compatible with the batch path by construction: each (hidden unit j, gate g) is three sequential fmaf chains
+// that visit k in exactly the order the MFMA kernels do --
+//   xW  : the projection GEMM's order (conv1d.hip): 8-deep blocks, inside a block k = 0,4,1,5,2,6,3,7, then + b_i
+//   hU  : the persistent kernel's two split-K halves: for chunk, for s, for q: k = 32 chunk + 16 half + 4 q + s;
+//         then (half 0) + (half 1), then xW + (hU + b_h)
+// (an f32 MFMA is bit for bit a k-ordered fmaf chain), followed by the same gate code.  One lane per chain, 16 lanes
+// per hidden unit (4 gates x {xW, hU half 0, hU half 1, idle}), 16 hidden units per 256-thread workgroup.
+// ============================================================================
+struct RecStreamParams {
+    const float *x;       // [in] this step's input row (pinned host or device memory)
+    const float *wp;      // [G*H (padded)][Kin_p] packed input weights, K-contiguous (nntk_upload_gemm_weights)
+    const float *bi;      // [G*H]
+    const float *ut;      // [G][Hj_p][Hk_p] U^T
+    const float *bh;      // [G*H] or NULL
+    const float *h_prev;  // [H]
+    const float *c_prev;  // [H] (LSTM)
+    float *h_next, *c_next;
+    float *out;           // [H] this step's output row or NULL
+    int in, Kin_p, H, Hj_p, Hk_p, nch_p;
+    int a0, a1, a2, a3, a4;
+    float s0, s1, s2, s3, s4;
+    unsigned *done_cnt;   // device counter of finished workgroups (last launch of a call only, else NULL)
+    unsigned *flag;       // pinned host word: the last workgroup to finish writes `seq` into it
+    unsigned seq;
+};
+
+template <int G, bool IS_LSTM>
+__global__ __launch_bounds__(256) void rec_stream_step_kernel(RecStreamParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp16 = lane >> 4, l = lane & 15;
+    const int g = l >> 2, role = l & 3;
+    const int j = blockIdx.x * 16 + wave * 4 + grp16;
+    const bool live = j < p.H && g < G && role < 3;
+    // x_t (possibly in pinned host memory: one coalesced read over PCIe instead of one per chain element) and h_{t-1}
+    // are staged once in LDS; every chain then reads them as LDS broadcasts
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *xs = sm, *hs = sm + p.Kin_p;
+    for (int k = threadIdx.x; k < p.Kin_p; k += 256) xs[k] = k < p.in ? p.x[k] : 0.0f;
+    for (int k = threadIdx.x; k < p.Hk_p; k += 256) hs[k] = k < p.H ? p.h_prev[k] : 0.0f;
+    __syncthreads();
+    float acc = 0.0f;
+    if (live && role == 0) {
+        const float4 *w = reinterpret_cast<const float4 *>(p.wp + (size_t)(g * p.H + j) * p.Kin_p);
+        for (int kb = 0; kb < p.Kin_p; kb += 8) {
+            const float4 w0 = w[kb >> 2], w1 = w[(kb >> 2) + 1];
+            const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+            const float4 x0 = *reinterpret_cast<const float4 *>(xs + kb), x1 = *reinterpret_cast<const float4 *>(xs + kb + 4);
+            const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {                   // the GEMM's MFMA u multiplies k = u (lane half 0), then k = 4 + u
+                acc = fmaf(xv[u], wv[u], acc);
+                acc = fmaf(xv[4 + u], wv[4 + u], acc);
+            }
+        }
+        acc += p.bi[g * p.H + j];
+    } else if (live) {
+        const int half = role - 1;
+        const float4 *u4 = reinterpret_cast<const float4 *>(p.ut + ((size_t)g * p.Hj_p + j) * p.Hk_p);
+        const int nch = p.Hk_p / REC_KC;                    // chunks that exist in memory; the kernel's padding chunks add + 0
+        for (int ch = 0; ch < nch; ++ch) {
+            const int k0 = ch * REC_KC + half * 16;
+            float4 uq[4];
+            float hq[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uq[q] = u4[(k0 >> 2) + q];
+                const float4 h4 = *reinterpret_cast<const float4 *>(hs + k0 + 4 * q);
+                hq[q][0] = h4.x; hq[q][1] = h4.y; hq[q][2] = h4.z; hq[q][3] = h4.w;
+            }
+#pragma unroll
+            for (int sI = 0; sI < 4; ++sI)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float uv = sI == 0 ? uq[q].x : sI == 1 ? uq[q].y : sI == 2 ? uq[q].z : uq[q].w;
+                    acc = fmaf(uv, hq[q][sI], acc);
+                }
+        }
+    }
+    // gather the three chains of every gate on the hidden unit's first lane
+    const int base = lane & ~15;
+    float xw[G], fin[G];
+#pragma unroll
+    for (int gg = 0; gg < G; ++gg) {
+        xw[gg] = __shfl(acc, base + 4 * gg);
+        const float h0 = __shfl(acc, base + 4 * gg + 1), h1 = __shfl(acc, base + 4 * gg + 2);
+        fin[gg] = h0 + h1;                                   // always (half 0) + (half 1)
+    }
+    if (l == 0 && j < p.H) {
+        float bh[G];
+#pragma unroll
+        for (int gg = 0; gg < G; ++gg) bh[gg] = p.bh ? p.bh[gg * p.H + j] : 0.0f;
+        float hn;
+        if constexpr (G == 1) {
+            hn = nntk_gate_act(p.a0, xw[0] + (fin[0] + bh[0]), p.s0);
+        } else if constexpr (!IS_LSTM) {
+            const float prev = hs[j];
+            const float hz = fin[0] + bh[0], hr = fin[1] + bh[1], hh = fin[2] + bh[2];
+            const float z = nntk_gate_act(p.a0, xw[0] + hz, p.s0);
+            const float rg = nntk_gate_act(p.a2, xw[1] + hr, p.s2);
+            const float ht = nntk_gate_act(p.a1, fmaf(rg, hh, xw[2]), p.s1);
+            hn = fmaf(-z + 1.0f, ht, z * prev);
+        } else {
+            const float prev = p.c_prev[j];
+            const float zi = xw[0] + (fin[0] + bh[0]);
+            const float zf = xw[1] + (fin[1] + bh[1]);
+            const float zg = xw[2] + (fin[2] + bh[2]);
+            const float zo = xw[G - 1] + (fin[G - 1] + bh[G - 1]);
+            const float ig = nntk_gate_act(p.a0, zi, p.s0);
+            const float fg = nntk_gate_act(p.a1, zf, p.s1);
+            const float gg_ = nntk_gate_act(p.a2, zg, p.s2);
+            const float og = nntk_gate_act(p.a3, zo, p.s3);
+            const float cn = fmaf(fg, prev, ig * gg_);
+            p.c_next[j] = cn;
+            hn = og * nntk_gate_act(p.a4, cn, p.s4);
+        }
+        p.h_next[j] = hn;
+        if (p.out) p.out[j] = hn;
+    }
+    // completion signal for the host (last launch of a call): outputs first, system-wide, then count in; the
+    // workgroup that counts in last raises the flag the host is spinning on
+    if (p.done_cnt) {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned n = __hip_atomic_fetch_add(p.done_cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (n == gridDim.x - 1) {
+                __hip_atomic_store(p.done_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __threadfence_system();
+                __hip_atomic_store(p.flag, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+}
+
+template <int G, bool IS_LSTM>
+static int run_stream(const float *x, const float *d_wp, const float *d_bi, const float *d_ut, const float *d_bh,
+                      float *const h[2], float *const c[2], int cur, float *out, int T, int in, int H,
+                      int return_sequences, const int *acts, const float *scales, int nacts,
+                      unsigned *d_done, unsigned *flag, unsigned seq) {
+    for (int i = 0; i < nacts; ++i)
+        if (!act_ok(acts[i]))
+            return nntk_fail_msg("recurrent: gate activation must be one of the built-in identity/sigmoid/tanh/relu");
+    RecStreamParams p;
+    p.wp = d_wp; p.bi = d_bi; p.ut = d_ut; p.bh = d_bh;
+    p.in = in; p.H = H;
+    int cin_p, cout_p;
+    nntk_shim_conv_pack_sizes(in, G * H, 1, &cin_p, &cout_p);
+    p.Kin_p = cin_p;
+    p.Hj_p = (H + 15) & ~15;
+    p.Hk_p = (H + 31) & ~31;
+    p.nch_p = p.Hk_p / REC_KC;
+    p.a0 = acts[0]; p.a1 = nacts > 1 ? acts[1] : 0; p.a2 = nacts > 2 ? acts[2] : 0;
+    p.a3 = nacts > 3 ? acts[3] : 0; p.a4 = nacts > 4 ? acts[4] : 0;
+    auto sc = [&](int i) { return (scales && i < nacts && acts[i] == NNTK_ACT_RELU) ? scales[i] : 1.0f; };
+    p.s0 = sc(0); p.s1 = sc(1); p.s2 = sc(2); p.s3 = sc(3); p.s4 = sc(4);
+    p.flag = flag; p.seq = seq;
+    const unsigned grid = (unsigned)((H + 15) / 16);
+    for (int t = 0; t < T; ++t) {
+        p.x = x + (size_t)t * in;
+        p.h_prev = h[(cur + t) & 1]; p.h_next = h[(cur + t + 1) & 1];
+        p.c_prev = c[(cur + t) & 1]; p.c_next = c[(cur + t + 1) & 1];
+        p.out = return_sequences ? out + (size_t)t * H : (t == T - 1 ? out : nullptr);
+        p.done_cnt = t == T - 1 ? d_done : nullptr;
+        hipLaunchKernelGGL((rec_stream_step_kernel<G, IS_LSTM>), dim3(grid), dim3(256), (size_t)(p.Kin_p + p.Hk_p) * sizeof(float), nntk_stream(), p);
+    }
+    NNTK_LAUNCH_CHECK("rec_stream_step_kernel");
+    return 0;
+}
+
+// One sequence, T steps, state h[cur] (c[cur]) -> h[(cur + T) & 1]; x and out may be pinned host memory.  The last
+// launch stores `seq` to *flag (pinned host word) once every output byte is visible system-wide.
+extern "C" int nntk_shim_rec_stream(int G, int is_lstm, const float *x, const float *d_wp, const float *d_bi,
+                                    const float *d_ut, const float *d_bh, float *d_h0, float *d_h1, float *d_c0, float *d_c1,
+                                    int cur, float *out, int T, int in, int H, int return_sequences,
+                                    const int *acts, const float *scales, unsigned *d_done, unsigned *flag, unsigned seq) {
+    if (T <= 0) return 0;
+    float *const h[2] = {d_h0, d_h1};
+    float *const c[2] = {d_c0, d_c1};
+    if (G == 1) return run_stream<1, false>(x, d_wp, d_bi, d_ut, d_bh, h, c, cur, out, T, in, H, return_sequences, acts, scales, 1, d_done, flag, seq);
+    if (G == 3) return run_stream<3, false>(x, d_wp, d_bi, d_ut, d_bh, h, c, cur, out, T, in, H, return_sequences, acts, scales, 3, d_done, flag, seq);
+    if (G == 4 && is_lstm) return run_stream<4, true>(x, d_wp, d_bi, d_ut, d_bh, h, c, cur, out, T, in, H, return_sequences, acts, scales, 5, d_done, flag, seq);
+    return nntk_fail_msg("rec_stream: unsupported cell");
+}
+
 // floats per parity of the h ping-pong area: the persistent kernel's tiled layout pads rows to 64
 // and k to a multiple of 128 (4 chunks); the per-step kernels use the first B*H floats of each half
 static size_t rec_hb_floats(int B, int H) {
@@ -692,10 +888,6 @@ static size_t rec_cnt_words(int B) {
 extern "C" size_t nntk_shim_recurrent_work_floats(int B, int H) {
     // h ping | h pong | c | arrival counters of the persistent kernel
     return 2 * rec_hb_floats(B, H) + (size_t)B * H + rec_cnt_words(B);
-}
-
-static int act_ok(int a) {
-    return a == NNTK_ACT_IDENTITY || a == NNTK_ACT_SIGMOID || a == NNTK_ACT_TANH || a == NNTK_ACT_RELU;
 }
 
 template <int G, bool IS_LSTM>

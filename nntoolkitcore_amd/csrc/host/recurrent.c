@@ -13,7 +13,12 @@
  */
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include "nntk_internal.h"
+
+/* single-sequence calls of at most this many timesteps take the streaming kernels (one small launch per step, no
+ * projection GEMM, no copies); longer ones amortise the batch path's fixed costs */
+#define NNTK_STREAM_MAX_T 32
 
 /* recurrent.c:7-19 */
 RecurrentConfig RecurrentConfigCreate(int input_feature_channels, int output_feature_channels,
@@ -40,6 +45,13 @@ typedef struct {
      * (persistent-kernel fault, see core_apply_host) still finds its initial state intact */
     float *d_h[2], *d_c[2];
     int cur;
+    /* streaming path: pinned host staging the kernels read / write directly, a device counter of finished workgroups
+     * and the pinned word the last one raises */
+    float *pin_in, *pin_out;
+    size_t pin_in_n, pin_out_n;
+    unsigned *d_done;
+    volatile unsigned *flag;
+    unsigned seq;
     nntk_devbuf d_in, d_out, d_xw, d_work;
 } rec_core;
 
@@ -71,6 +83,8 @@ static void core_free(rec_core *c) {
     nntk_shim_synchronize();
     nntk_shim_free(c->d_wp); nntk_shim_free(c->d_bi); nntk_shim_free(c->d_ut); nntk_shim_free(c->d_bh);
     nntk_shim_free(c->d_h[0]);
+    nntk_shim_host_free(c->pin_in); nntk_shim_host_free(c->pin_out); nntk_shim_host_free((void *)c->flag);
+    nntk_shim_free(c->d_done);
     nntk_devbuf_free(&c->d_in); nntk_devbuf_free(&c->d_out); nntk_devbuf_free(&c->d_xw); nntk_devbuf_free(&c->d_work);
     nntk_wblock_free(&c->wb);
     free(c->weights);
@@ -132,10 +146,65 @@ static int core_apply_device(rec_core *c, int is_lstm, int use_bh, const int *ac
     return nntk_shim_gru(d_xw, c->d_ut, bh, h0, d_out, hT, d_work, B, T, H, c->return_sequences, acts, scales);
 }
 
+/* The reference's own call shape -- one sequence, carried state, a handful of timesteps (gru.c:189-204,
+ * lstm.c:241-268) -- is latency, not throughput: T launches of the streaming step kernel, x_t read from and h_t written
+ * to pinned host memory by the kernels themselves, and the host waits on a pinned word the last workgroup raises
+ * (a stream synchronisation alone costs more than the kernels).  Same bits as the batch path (recurrent.hip). */
+static int core_apply_stream(rec_core *c, int is_lstm, int use_bh, const int *acts, const float *scales,
+                             const float *input, float *output) {
+    const size_t n_in = (size_t)c->T * c->in, n_out = c->return_sequences ? (size_t)c->T * c->H : (size_t)c->H;
+    if (c->pin_in_n < n_in) {
+        nntk_shim_synchronize();
+        nntk_shim_host_free(c->pin_in);
+        c->pin_in = (float *)nntk_shim_host_alloc(n_in * sizeof(float));
+        c->pin_in_n = c->pin_in ? n_in : 0;
+    }
+    if (c->pin_out_n < n_out) {
+        nntk_shim_synchronize();
+        nntk_shim_host_free(c->pin_out);
+        c->pin_out = (float *)nntk_shim_host_alloc(n_out * sizeof(float));
+        c->pin_out_n = c->pin_out ? n_out : 0;
+    }
+    if (!c->flag) {
+        c->flag = (volatile unsigned *)nntk_shim_host_alloc(64);
+        c->d_done = (unsigned *)nntk_shim_malloc(64);
+        if (c->d_done && nntk_shim_memset(c->d_done, 0, 64)) return -1;
+    }
+    if (!c->pin_in || !c->pin_out || !c->flag || !c->d_done) return -1;
+    memcpy(c->pin_in, input, n_in * sizeof(float));
+    const unsigned seq = ++c->seq ? c->seq : ++c->seq;         /* never 0: the word's initial value */
+    if (nntk_shim_rec_stream(c->G, is_lstm, c->pin_in, c->d_wp, c->d_bi, c->d_ut, use_bh ? c->d_bh : NULL,
+                             c->d_h[0], c->d_h[1], c->d_c[0], c->d_c[1], c->cur, c->pin_out, c->T, c->in, c->H,
+                             c->return_sequences, acts, scales, c->d_done, (unsigned *)c->flag, seq))
+        return -1;
+    /* spin on the pinned word; after 5 ms fall back to a stream synchronisation (which also surfaces launch errors) */
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (unsigned spins = 0; *c->flag != seq; ++spins) {
+        if ((spins & 1023) == 1023) {
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 5000000L) {
+                if (nntk_shim_synchronize()) return -1;
+                if (*c->flag != seq) NNTK_FAIL("streaming recurrent kernel did not complete");
+                break;
+            }
+        }
+        __builtin_ia32_pause();
+    }
+    memcpy(output, c->pin_out, n_out * sizeof(float));
+    c->cur = (c->cur + c->T) & 1;
+    return 0;
+}
+
 static int core_apply_host(rec_core *c, int is_lstm, int use_bh, const int *acts, const float *scales,
                            const float *input, float *output, int B, int stateful) {
     if (B <= 0) return 0;
     if (core_ensure(c, 1)) return -1;
+    if (stateful && B == 1 && c->T >= 1 && c->T <= NNTK_STREAM_MAX_T) {
+        int on = -1;
+        (void)nntk_shim_get_option("rec_stream", &on);
+        if (on != 0) return core_apply_stream(c, is_lstm, use_bh, acts, scales, input, output);
+    }
     size_t n_in = (size_t)B * c->T * c->in;
     size_t n_out = c->return_sequences ? (size_t)B * c->T * c->H : (size_t)B * c->H;
     float *d_in = nntk_devbuf_reserve(&c->d_in, n_in);

@@ -250,3 +250,52 @@ def test_achieved_error_two_layer_gru256_T1000(gpu):
     print("HIP GRU 128->256->256 T=1000: max abs err vs oracle %.2e, vs torch float64 %.2e" % (e_or, e_64))
     assert e_or < 3e-6 and e_64 < 3e-6
     g1.destroy(); g2.destroy()
+
+
+# ---- streaming path: the reference's own call shape, one sequence with carried state ----
+
+@pytest.mark.parametrize("cell,I,H", [("gru", 128, 256), ("lstm", 128, 512), ("rnn", 40, 64), ("gru", 5, 7), ("lstm", 33, 40)])
+def test_streaming_calls_are_bit_identical_to_the_batch_kernels(gpu, cell, I, H):
+    """GRU/LSTM/RNNApplyInference with T <= 32 take the streaming step kernel (no projection GEMM, no persistent
+    launch); each output element is the same k-ordered fmaf chain the MFMA kernels compute, so the results equal the
+    batch path's bit for bit -- checked against (a) the same calls with rec_stream = 0 and (b) the oracle.  (Shapes the
+    MFMA / persistent kernels do not take -- H % 4 != 0, fewer than 16 inputs -- run other batch kernels with other
+    summation orders; there the comparison is the oracle's tolerance.)"""
+    r = rng(len(cell) * 1000 + H)
+    G = {"gru": 3, "lstm": 4, "rnn": 1}[cell]
+    T = 8
+    x = u(r, 3 * T, I)
+    W, U, bi, bh = u(r, I, G * H, sc=I ** -0.5), u(r, H, G * H, sc=H ** -0.5), u(r, G * H, sc=0.1), u(r, G * H, sc=0.1)
+    mk = {"gru": lambda: NL.GRU(I, H, True, T), "lstm": lambda: NL.LSTM(I, H, True, T, v2=True), "rnn": lambda: NL.RNN(I, H, True, T)}[cell]
+    outs = {}
+    for mode in ("auto", "0"):
+        capi.set_option("rec_stream", mode)
+        l = mk()
+        l.set_weights(W, U, bi, bh)
+        outs[mode] = np.concatenate([l.apply(x[i * T:(i + 1) * T]) for i in range(3)])      # three calls, carried state
+        st = l.state()
+        outs[mode + "_state"] = st if cell != "lstm" else np.concatenate(st)
+        l.destroy()
+    if H % 4 == 0 and I >= 16 and G * H >= 32:
+        assert np.array_equal(outs["auto"], outs["0"]) and np.array_equal(outs["auto_state"], outs["0_state"])
+    else:
+        np.testing.assert_allclose(outs["auto"], outs["0"], rtol=1e-5, atol=1e-5)
+    ofn = {"gru": O.gru, "lstm": O.lstm, "rnn": O.rnn}[cell]
+    ref = ofn(x, W, U, bi, bh)[0]
+    np.testing.assert_allclose(outs["auto"], ref, rtol=1e-5, atol=1e-5)
+
+
+def test_streaming_last_state_only_and_reset(gpu):
+    r = rng(71)
+    I, H, T = 24, 48, 5
+    W, U, bi, bh = u(r, I, 4 * H, sc=0.2), u(r, H, 4 * H, sc=0.15), u(r, 4 * H, sc=0.1), u(r, 4 * H, sc=0.1)
+    x = u(r, 2 * T, I)
+    l = NL.LSTM(I, H, False, T, v2=False)           # return_sequences = false, Keras one-bias form
+    l.set_weights(W, U, bi, bh)
+    a = l.apply(x[:T]); b = l.apply(x[T:])
+    full, _, _ = O.lstm(x, W, U, bi, bh, v2=False)
+    np.testing.assert_allclose(a, full[T - 1], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(b, full[2 * T - 1], rtol=1e-5, atol=1e-5)
+    l.reset_state()
+    np.testing.assert_allclose(l.apply(x[:T]), full[T - 1], rtol=1e-5, atol=1e-5)
+    l.destroy()
