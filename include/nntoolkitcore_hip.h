@@ -307,6 +307,32 @@ int RNNSyncWeights(RNN filter);
 int DenseSyncWeights(Dense filter);
 int TimeDistributedDenseSyncWeights(TimeDistributedDense filter);
 
+/* ---- multi-GPU: one process per GPU, utterances sharded, NO collective on the data path --------------------
+ * (every utterance is independent: BatchNorm uses stored statistics, batch_norm.c:178-181; every sequence owns
+ * its recurrent state).  The only communication is one RCCL broadcast of each layer's weight block from the root
+ * at start-up, over xGMI.  RCCL is dlopen()ed at the first nntk_dist_* call; a single-GPU caller never loads it.
+ *   rank 0:      nntk_dist_get_unique_id(id)  -> carry the 128 bytes to the other ranks (file, env, socket ...)
+ *   every rank:  nntk_hip_set_device(local); nntk_dist_init(id, rank, world);
+ *                <Layer>BroadcastWeights(handle, 0) for each layer;  nntk_dist_shard_range(B, world, rank, &lo, &hi);
+ *                run utterances [lo, hi) with the *ApplyDevice / *ApplyInferenceBatch calls;  nntk_dist_finalize().
+ * All return 0 / -1 (nntk_last_error()).  Without a communicator the broadcasts are no-ops. */
+#define NNTK_DIST_ID_BYTES 128
+int  nntk_dist_get_unique_id(unsigned char id[NNTK_DIST_ID_BYTES]);
+int  nntk_dist_init(const unsigned char id[NNTK_DIST_ID_BYTES], int rank, int world_size);   /* collective */
+int  nntk_dist_rank(void);
+int  nntk_dist_world_size(void);
+int  nntk_dist_broadcast(float *host_block, size_t n_floats, int root);      /* any host block, in place, blocking */
+int  nntk_dist_barrier(void);
+int  nntk_dist_finalize(void);
+void nntk_dist_shard_range(int n_utterances, int world_size, int rank, int *lo, int *hi);
+int Conv1dBroadcastWeights(Conv1d filter, int root);
+int BatchNormBroadcastWeights(BatchNorm filter, int root);
+int GRUBroadcastWeights(GRU filter, int root);
+int LSTMBroadcastWeights(LSTM filter, int root);
+int RNNBroadcastWeights(RNN filter, int root);
+int DenseBroadcastWeights(Dense filter, int root);
+int TimeDistributedDenseBroadcastWeights(TimeDistributedDense filter, int root);
+
 /* ---- batched host-pointer forms: semantics of the reference's
  *      *ApplyTrainingBatch forward pass (conv_1d.c:167, gru.c:246, lstm.c:426,
  *      dense.c:144) without the training caches: input [batch, T, in],

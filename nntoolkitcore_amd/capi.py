@@ -192,6 +192,21 @@ SIGNATURES = {
     "nntk_device_free": (None, [vp]),
     "nntk_device_upload": (C.c_int, [vp, fp, C.c_size_t]),
     "nntk_device_download": (C.c_int, [fp, vp, C.c_size_t]),
+    "nntk_dist_get_unique_id": (C.c_int, [C.c_char_p]),
+    "nntk_dist_init": (C.c_int, [C.c_char_p, C.c_int, C.c_int]),
+    "nntk_dist_rank": (C.c_int, []),
+    "nntk_dist_world_size": (C.c_int, []),
+    "nntk_dist_broadcast": (C.c_int, [fp, C.c_size_t, C.c_int]),
+    "nntk_dist_barrier": (C.c_int, []),
+    "nntk_dist_finalize": (C.c_int, []),
+    "nntk_dist_shard_range": (None, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "Conv1dBroadcastWeights": (C.c_int, [vp, C.c_int]),
+    "BatchNormBroadcastWeights": (C.c_int, [vp, C.c_int]),
+    "GRUBroadcastWeights": (C.c_int, [vp, C.c_int]),
+    "LSTMBroadcastWeights": (C.c_int, [vp, C.c_int]),
+    "RNNBroadcastWeights": (C.c_int, [vp, C.c_int]),
+    "DenseBroadcastWeights": (C.c_int, [vp, C.c_int]),
+    "TimeDistributedDenseBroadcastWeights": (C.c_int, [vp, C.c_int]),
     "Conv1dSyncWeights": (C.c_int, [vp]),
     "BatchNormSyncWeights": (C.c_int, [vp]),
     "GRUSyncWeights": (C.c_int, [vp]),

@@ -117,6 +117,15 @@ int nntk_shim_rec_stream(int G, int is_lstm, const float *x, const float *d_wp, 
                          int cur, float *out, int T, int in, int H, int return_sequences,
                          const int *acts, const float *scales, unsigned *d_done, unsigned *flag, unsigned seq);
 
+/* ---- multi-GPU: one RCCL communicator per process, weight-block broadcast at start-up (dist.hip) ---- */
+int nntk_shim_dist_unique_id(unsigned char *id128);
+int nntk_shim_dist_init(const unsigned char *id128, int rank, int world);
+int nntk_shim_dist_rank(void);
+int nntk_shim_dist_world(void);
+int nntk_shim_dist_broadcast_host(float *block, size_t n, int root);
+int nntk_shim_dist_barrier(void);
+int nntk_shim_dist_finalize(void);
+
 /* ---- K1: framed STFT magnitude / PSD ---------------------------------------
  * d_in [B, input_size], d_window [window_size], d_out [B, nts, nfreq]
  * d_twiddle [nfft] complex interleaved: exp(-2*pi*i*m/nfft), evaluated in double on the host

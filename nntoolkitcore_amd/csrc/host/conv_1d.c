@@ -93,6 +93,14 @@ int Conv1dSyncWeights(Conv1d filter) {
     return conv_upload(filter);
 }
 
+/* multi-GPU: the root's weight block replaces every rank's (one RCCL broadcast over xGMI), then re-upload */
+int Conv1dBroadcastWeights(Conv1d filter, int root) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("Conv1dBroadcastWeights: NULL handle");
+    if (nntk_shim_dist_broadcast_host(filter->wb.host, filter->wb.n, root)) return -1;
+    return conv_upload(filter);
+}
+
 static int conv_launch(Conv1d f, const float *d_bn, float eps, int act_kind, float relu_a,
                        const float *d_in, float *d_out, int batch) {
     const Conv1dConfig *c = &f->config;
@@ -213,6 +221,13 @@ int BatchNormSyncWeights(BatchNorm filter) {
     nntk_shim_clear_error();
     if (!filter) NNTK_FAIL("BatchNormSyncWeights: NULL handle");
     nntk_shim_synchronize();
+    return bn_upload(filter);
+}
+
+int BatchNormBroadcastWeights(BatchNorm filter, int root) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("BatchNormBroadcastWeights: NULL handle");
+    if (nntk_shim_dist_broadcast_host(filter->wb.host, filter->wb.n, root)) return -1;
     return bn_upload(filter);
 }
 

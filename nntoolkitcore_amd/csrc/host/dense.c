@@ -73,6 +73,13 @@ int DenseSyncWeights(Dense filter) {
     return dense_upload(filter);
 }
 
+int DenseBroadcastWeights(Dense filter, int root) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("DenseBroadcastWeights: NULL handle");
+    if (nntk_shim_dist_broadcast_host(filter->wb.host, filter->wb.n, root)) return -1;
+    return dense_upload(filter);
+}
+
 static int dense_rows_device(Dense f, const float *d_in, float *d_out, long rows) {
     if (rows <= 0) return 0;
     if (rows > 0x7fffffffL) NNTK_FAIL("dense: too many rows");
@@ -155,6 +162,12 @@ int TimeDistributedDenseSyncWeights(TimeDistributedDense filter) {
     nntk_shim_clear_error();
     if (!filter) NNTK_FAIL("TimeDistributedDenseSyncWeights: NULL handle");
     return DenseSyncWeights(filter->dense);
+}
+
+int TimeDistributedDenseBroadcastWeights(TimeDistributedDense filter, int root) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("TimeDistributedDenseBroadcastWeights: NULL handle");
+    return DenseBroadcastWeights(filter->dense, root);
 }
 
 /* time_distributed_dense.c:52-58 (always returns 0 there; here -1 on device errors) */

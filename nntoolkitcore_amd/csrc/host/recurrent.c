@@ -124,6 +124,11 @@ static int core_reset_state(rec_core *c) {
     return nntk_shim_memset(c->d_h[0], 0, 4 * hs * sizeof(float));
 }
 
+static int core_broadcast(rec_core *c, int root) {
+    if (nntk_shim_dist_broadcast_host(c->wb.host, c->wb.n, root)) return -1;
+    return core_upload(c);
+}
+
 /* stateful != 0: continue from / store into the handle's state (B must be 1) */
 static int core_apply_device(rec_core *c, int is_lstm, int use_bh, const int *acts, const float *scales,
                              const float *d_in, float *d_out, int B, int stateful) {
@@ -297,6 +302,11 @@ static int gru_acts(GRU f, int acts[3], float scales[3]) {
     return 0;
 }
 
+int GRUBroadcastWeights(GRU filter, int root) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("GRUBroadcastWeights: NULL handle");
+    return core_broadcast(&filter->core, root);
+}
 int GRUSyncWeights(GRU filter) {
     nntk_shim_clear_error();
     if (!filter) NNTK_FAIL("GRUSyncWeights: NULL handle");
@@ -412,6 +422,11 @@ static int lstm_acts(LSTM f, int acts[5], float scales[5]) {
     return 0;
 }
 
+int LSTMBroadcastWeights(LSTM filter, int root) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("LSTMBroadcastWeights: NULL handle");
+    return core_broadcast(&filter->core, root);
+}
 int LSTMSyncWeights(LSTM filter) {
     nntk_shim_clear_error();
     if (!filter) NNTK_FAIL("LSTMSyncWeights: NULL handle");
@@ -496,6 +511,11 @@ void RNNDestroy(RNN filter) {
     free(filter);
 }
 
+int RNNBroadcastWeights(RNN filter, int root) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("RNNBroadcastWeights: NULL handle");
+    return core_broadcast(&filter->core, root);
+}
 int RNNSyncWeights(RNN filter) {
     nntk_shim_clear_error();
     if (!filter) NNTK_FAIL("RNNSyncWeights: NULL handle");

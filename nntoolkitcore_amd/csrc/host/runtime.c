@@ -24,6 +24,21 @@ int nntk_hip_set_option(const char *name, const char *value) { nntk_shim_clear_e
 int nntk_hip_get_option(const char *name, int *value) { nntk_shim_clear_error(); return nntk_shim_get_option(name, value); }
 int nntk_hip_device_status(void) { return nntk_shim_device_status(); }
 
+/* ---- multi-GPU (dist.hip) ---- */
+int nntk_dist_get_unique_id(unsigned char id[NNTK_DIST_ID_BYTES]) { nntk_shim_clear_error(); return nntk_shim_dist_unique_id(id); }
+int nntk_dist_init(const unsigned char id[NNTK_DIST_ID_BYTES], int rank, int world_size) { nntk_shim_clear_error(); return nntk_shim_dist_init(id, rank, world_size); }
+int nntk_dist_rank(void) { return nntk_shim_dist_rank(); }
+int nntk_dist_world_size(void) { return nntk_shim_dist_world(); }
+int nntk_dist_broadcast(float *host_block, size_t n_floats, int root) { nntk_shim_clear_error(); return nntk_shim_dist_broadcast_host(host_block, n_floats, root); }
+int nntk_dist_barrier(void) { nntk_shim_clear_error(); return nntk_shim_dist_barrier(); }
+int nntk_dist_finalize(void) { nntk_shim_clear_error(); return nntk_shim_dist_finalize(); }
+/* contiguous, balanced utterance shard of `rank` (the first ranks take the remainder) */
+void nntk_dist_shard_range(int n_utterances, int world_size, int rank, int *lo, int *hi) {
+    int base = n_utterances / world_size, rem = n_utterances % world_size;
+    *lo = rank * base + (rank < rem ? rank : rem);
+    *hi = *lo + base + (rank < rem ? 1 : 0);
+}
+
 float *nntk_device_alloc(size_t n_floats) { return (float *)nntk_shim_malloc(n_floats * sizeof(float)); }
 void nntk_device_free(float *ptr) { nntk_shim_free(ptr); }
 int nntk_device_upload(float *dst_device, const float *src_host, size_t n_floats) {
