@@ -387,7 +387,113 @@ __global__ __launch_bounds__(256) void spectrogram512_kernel(SpecParams p) {
     }
 }
 
-// Generic path: one workgroup per frame, direct DFT over the window support.
+// ---------------------------------------------------------------------------------------------------------------
+// Mixed-radix path: any nfft = 2^a 3^b 5^c up to 4096 that is not 512 (256 / 1024 / 2048 are ordinary speech settings;
+// the reference takes every size through kissfft's mixed-radix plan, signal/dft.c:23-47).  One workgroup transforms
+// two consecutive frames as ONE complex FFT of nfft points (frame A real, frame B imaginary), Stockham autosort
+// passes of radix 4 / 2 / 3 / 5 ping-ponging between two LDS images, twiddles from the host's table
+// exp(-2 pi i m / nfft) (evaluated in double).  O(N log N) instead of the direct kernel's O(window x nfreq).
+// ---------------------------------------------------------------------------------------------------------------
+struct MixedPlan { int nfac; int fac[12]; };
+
+__device__ __forceinline__ f2 cmulf(f2 a, f2 b) { return (f2){a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+
+template <int R>
+__device__ __forceinline__ void dft_small(f2 (&v)[5]) {
+    if (R == 2) {
+        const f2 a = v[0], b = v[1];
+        v[0] = a + b; v[1] = a - b;
+    } else if (R == 4) {
+        const f2 a = v[0] + v[2], b = v[0] - v[2], c = v[1] + v[3], d = v[1] - v[3];
+        const f2 dmi = (f2){d.y, -d.x};                      // -i d
+        v[0] = a + c; v[1] = b + dmi; v[2] = a - c; v[3] = b - dmi;
+    } else if (R == 3) {
+        const float s3 = 0.86602540378443864676f;            // sin(2 pi / 3)
+        const f2 t = v[1] + v[2], d = v[1] - v[2];
+        const f2 m = v[0] - 0.5f * t;
+        const f2 e = (f2){s3 * d.y, -s3 * d.x};              // -i sin * d
+        v[0] = v[0] + t; v[1] = m + e; v[2] = m - e;
+    } else {                                                 // 5
+        const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;      // cos(2 pi / 5), cos(4 pi / 5)
+        const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;       // sin(2 pi / 5), sin(4 pi / 5)
+        const f2 t1 = v[1] + v[4], t2 = v[2] + v[3], d1 = v[1] - v[4], d2 = v[2] - v[3];
+        const f2 m1 = v[0] + c1 * t1 + c2 * t2, m2 = v[0] + c2 * t1 + c1 * t2;
+        const f2 u1 = s1 * d1 + s2 * d2, u2 = s2 * d1 - s1 * d2;
+        const f2 e1 = (f2){u1.y, -u1.x}, e2 = (f2){u2.y, -u2.x};                        // -i u
+        v[0] = v[0] + t1 + t2; v[1] = m1 + e1; v[4] = m1 - e1; v[2] = m2 + e2; v[3] = m2 - e2;
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void stockham_pass(const f2 *in, f2 *out, const f2 *tw, int N, int Ns) {
+    const int nb = N / R;                                    // butterflies of this pass
+    const int tstep = N / (Ns * R);                          // table stride of exp(-2 pi i / (Ns R))
+    for (int j = threadIdx.x; j < nb; j += blockDim.x) {
+        const int k = j % Ns;
+        f2 v[5];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            v[r] = in[j + r * nb];
+            if (r > 0) v[r] = cmulf(v[r], tw[(r * k * tstep) % N]);
+        }
+        dft_small<R>(v);
+        const int j0 = (j / Ns) * Ns * R + k;
+#pragma unroll
+        for (int r = 0; r < R; ++r) out[j0 + r * Ns] = v[r];
+    }
+}
+
+__global__ __launch_bounds__(256) void spectrogram_mixed_kernel(SpecParams p, MixedPlan plan) {
+    extern __shared__ __attribute__((aligned(16))) float smem_mixed[];
+    const int N = p.nfft;
+    f2 *za = reinterpret_cast<f2 *>(smem_mixed), *zb = za + N;
+    const f2 *tw = reinterpret_cast<const f2 *>(p.tw);
+    const int ppu = (p.nts + 1) >> 1;
+    const long total_pairs = (long)p.B * ppu;
+    for (long pair = blockIdx.x; pair < total_pairs; pair += gridDim.x) {
+        const int b = (int)(pair / ppu), fa = 2 * (int)(pair % ppu);
+        const bool has_b = fa + 1 < p.nts;
+        const float *xa = p.in + (size_t)b * p.input_size + (size_t)fa * p.step;
+        const float *xb = has_b ? xa + p.step : xa;
+        for (int n = threadIdx.x; n < N; n += blockDim.x) {
+            f2 v = (f2){0.f, 0.f};
+            if (n < p.window_size) { const float w = p.window[n]; v = (f2){w * xa[n], w * xb[n]}; }     // zero-padded to nfft (spectrogram.c:120-124)
+            za[n] = v;
+        }
+        __syncthreads();
+        f2 *src = za, *dst = zb;
+        int Ns = 1;
+        for (int i = 0; i < plan.nfac; ++i) {
+            const int R = plan.fac[i];
+            if (R == 4) stockham_pass<4>(src, dst, tw, N, Ns);
+            else if (R == 2) stockham_pass<2>(src, dst, tw, N, Ns);
+            else if (R == 3) stockham_pass<3>(src, dst, tw, N, Ns);
+            else stockham_pass<5>(src, dst, tw, N, Ns);
+            Ns *= R;
+            __syncthreads();
+            f2 *t = src; src = dst; dst = t;
+        }
+        // split the two real spectra: X_a[k] = (Z[k] + conj Z[N-k]) / 2, X_b[k] = (Z[k] - conj Z[N-k]) / (2i)
+        float *oa = p.out + ((size_t)b * p.nts + fa) * p.nfreq;
+        for (int k = threadIdx.x; k < p.nfreq; k += blockDim.x) {
+            const f2 z = src[k], c = src[k == 0 ? 0 : N - k];
+            oa[k] = finish_bin(p, 0.5f * (z.x + c.x), 0.5f * (z.y - c.y), k);
+            if (has_b) oa[p.nfreq + k] = finish_bin(p, 0.5f * (z.y + c.y), -0.5f * (z.x - c.x), k);
+        }
+        __syncthreads();
+    }
+}
+
+// nfft -> radix list (4s first, then 2, 3, 5); false if another prime divides it
+static bool mixed_plan(int n, MixedPlan *plan) {
+    plan->nfac = 0;
+    if (n < 2) return false;
+    for (int r : {4, 2, 3, 5})
+        while (n % r == 0 && plan->nfac < 12) { plan->fac[plan->nfac++] = r; n /= r; }
+    return n == 1;
+}
+
+// Last resort (nfft with a prime factor above 5, or above 4096): one workgroup per frame, direct DFT over the window support.
 __global__ __launch_bounds__(256) void spectrogram_dft_kernel(SpecParams p) {
     extern __shared__ __attribute__((aligned(16))) float frame[];   // [window_size]
     for (long f = blockIdx.x; f < p.total_frames; f += gridDim.x) {
@@ -448,6 +554,13 @@ extern "C" int nntk_shim_spectrogram(const float *d_in, const float *d_window, c
         p.ppw = ppw;
         hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), 0, nntk_stream(), p);
         NNTK_LAUNCH_CHECK("spectrogram512_kernel");
+    } else if (MixedPlan plan; nfft <= 4096 && mixed_plan(nfft, &plan)) {
+        const long pairs = (long)B * ((nts + 1) / 2);
+        const long g = pairs < 8192 ? pairs : 8192;
+        int bs = (nfft / 4 + 63) & ~63;                     // one radix-4 butterfly per thread where the frame is long enough
+        bs = bs < 64 ? 64 : bs > 256 ? 256 : bs;
+        hipLaunchKernelGGL(spectrogram_mixed_kernel, dim3((unsigned)g), dim3(bs), (size_t)nfft * 2 * sizeof(f2), nntk_stream(), p, plan);
+        NNTK_LAUNCH_CHECK("spectrogram_mixed_kernel");
     } else {
         long g = p.total_frames < 4096 ? p.total_frames : 4096;
         size_t lds = (size_t)window_size * sizeof(float);

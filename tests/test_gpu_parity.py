@@ -336,7 +336,13 @@ def test_spectrogram_512_all_windows(gpu, wname, mode):
                                               (512, 40, 8, 2000, 2), (512, 64, 0, 1300, 1), (512, 100, 20, 3000, 3),
                                               (512, 192, 64, 2500, 2), (512, 256, 128, 3000, 2), (512, 300, 37, 4000, 2),
                                               (512, 384, 100, 5000, 2), (512, 385, 0, 5000, 3), (512, 448, 200, 6000, 2),
-                                              (512, 449, 10, 6000, 2)])
+                                              (512, 449, 10, 6000, 2),
+                                              # the mixed-radix path: 2^a 3^b 5^c (256 / 1024 / 2048 are ordinary speech settings)
+                                              (1024, 800, 480, 16000, 3), (2048, 2048, 1024, 20000, 2), (4096, 3000, 0, 12288, 1),
+                                              (480, 400, 240, 8000, 2), (100, 100, 50, 2000, 2), (250, 160, 80, 3000, 3),
+                                              (4, 4, 0, 64, 1), (3, 3, 1, 50, 2), (1000, 999, 998, 1100, 1),
+                                              # a prime factor above 5: the direct-DFT kernel
+                                              (77, 70, 7, 1000, 2), (1022, 600, 100, 5000, 1)])
 def test_spectrogram_batch_geometries(gpu, nfft, win, nov, N, B):
     r = rng(nfft + N)
     x = (0.1 * r.standard_normal((B, N))).astype(np.float32)
