@@ -135,6 +135,13 @@ int nntk_shim_spectrogram(const float *d_in, const float *d_window, const float 
                           int B, int input_size, int nfft, int window_size, int step,
                           int nfreq, int nts, float fft_norm, int mode, float scale);
 
+/* K1 with the mel projection (+ optional log(x + eps)) fused into its output stage; returns 1 when the configuration
+ * is not taken by the fused kernel (nothing launched) */
+int nntk_shim_spectrogram_mel(const float *d_in, const float *d_window, const float *d_twiddle, float *d_out,
+                              int B, int input_size, int nfft, int window_size, int step,
+                              int nfreq, int nts, float fft_norm, int mode, float scale,
+                              const int *d_mel_tab, const float *d_mel_w, int n_mels, float eps, int do_log);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,7 +30,12 @@ struct SpecParams {
     int input_size, nfft, window_size, step, nfreq, nts;
     float fft_norm, scale, inv_scale;
     int mode;
-    int ppw;              // frame pairs per wavefront (consecutive-run variant)
+    int ppw;              // frame pairs per wavefront
+    // fused mel projection: out becomes [B, nts, n_mels] = (log of) spec x W, W's nonzero run per filter
+    const int *mel_tab;   // [3][n_mels]: first bin, run length, offset into mel_w
+    const float *mel_w;   // the runs, packed
+    int n_mels, mel_log;
+    float mel_eps;
 #ifdef NNTK_SPEC_DBG
     int dbg;              // timing experiments only: 1 no stores, 2 no sample loads, 4 no LDS passes (wrong results), 8 no split / shuffles
 #endif
@@ -171,14 +176,27 @@ __device__ __forceinline__ float finish_bin(const SpecParams &p, float re, float
 // (not read, its butterfly disappears) and only row 6 straddles the window's end.  Otherwise all 8 rows are masked.
 // Zero padding is exact even next to inf / nan samples: out-of-window samples are ANDed away, not multiplied by 0.
 // NLD = 16-byte loads per lane that cover step + window samples (3 for 160 + 400).
-template <int MODE, bool NORM, bool NZ7, int NLD>
+// MEL = the mel projection (signal/mel_filterbank.c:116-118) and log(x + 1.5849e-13) (log_mel_spectrogram.c:31-36)
+// are applied to the two finished rows while they are still in LDS: each filter is a triangle, i.e. ONE contiguous run
+// of nonzero weights (2 .. ~40 bins), so a lane takes one (frame, filter) pair and sums its run in ascending bin order
+// -- the order of the reference's dense product with the exact zeros left out.  The kernel then writes n_mels values
+// per frame instead of 257 (6.4x less write traffic for n_mels = 40) and the [B, nts, 257] tensor never exists.
+template <int MODE, bool NORM, bool NZ7, int NLD, bool MEL = false>
 __global__ __launch_bounds__(256) void spectrogram512_kernel(SpecParams p) {
     __shared__ __attribute__((aligned(16))) float lds_z[4][SPEC_LDS_FLOATS];
+    __shared__ int mel_tab_s[MEL ? 3 * 257 : 1];      // MEL: the run table and the runs, shared by the workgroup
+    __shared__ float mel_w_s[MEL ? 2 * 257 + 8 : 1];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // scalar: frame offsets stay in SGPRs
     float *z = lds_z[wave];
     const int ppu = (p.nts + 1) >> 1;                 // frame pairs per utterance
     constexpr int NR = NZ7 ? 7 : 8;                   // register rows of pass 1 that can hold samples
+    if (MEL) {
+        for (int i = threadIdx.x; i < 3 * p.n_mels; i += 256) mel_tab_s[i] = p.mel_tab[i];
+        const int nw = p.mel_tab[3 * p.n_mels - 1] + p.mel_tab[2 * p.n_mels - 1];      // offset + length of the last run
+        for (int i = threadIdx.x; i < nw; i += 256) mel_w_s[i] = p.mel_w[i];
+        __syncthreads();
+    }
 
     // lane-only constants
     // window taps, and the AND mask that clears samples beyond the window (rows that lie fully inside the window need
@@ -244,8 +262,9 @@ __global__ __launch_bounds__(256) void spectrogram512_kernel(SpecParams p) {
         // vector offset -- a pair at the very end reads zeros past the signal, never the next utterance
         const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(p.in + (size_t)b * p.input_size), 0, p.input_size * 4, 0x00020000);
+        const int orow = MEL ? p.n_mels : p.nfreq;       // floats per output row
         const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(p.out + (size_t)b * p.nts * p.nfreq), 0, p.nts * p.nfreq * 4, 0x00020000);
+            (void *)(p.out + (size_t)b * p.nts * orow), 0, p.nts * orow * 4, 0x00020000);
         // Software prefetch, TWO pairs deep: the sample loads of pair n + 2 are issued while pair n is transformed
         // (two register sets, loop unrolled by two).
         int pr = blockIdx.x * 4 + wave;
@@ -347,7 +366,31 @@ __global__ __launch_bounds__(256) void spectrogram512_kernel(SpecParams p) {
                 m[r] = mm * (r == 0 ? osc_r0 : r == 4 ? osc_r4 : osc_in);
             }
             const int soa = fa * p.nfreq * 4;         // the pair's first output row (bytes): wave-uniform scalar offset
-            if (has_b) {
+            if (MEL) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    z[lane + 64 * r] = m[r].x;
+                    z[257 + lane + 64 * r] = m[r].y;
+                }
+                if (lane == 0) { z[256] = m[4].x; z[513] = m[4].y; }
+                WAVE_LDS_SYNC();
+                // one lane per filter, both frames in the same pass over the filter's run (table and runs are in LDS)
+                for (int mm = lane; mm < p.n_mels; mm += 64) {
+                    const int k0 = mel_tab_s[mm], len = mel_tab_s[p.n_mels + mm];
+                    const float *w = mel_w_s + mel_tab_s[2 * p.n_mels + mm];
+                    const float *row = z + k0;
+                    float acc_a = 0.0f, acc_b = 0.0f;
+                    for (int i = 0; i < len; ++i) {
+                        const float wi = w[i];
+                        acc_a = fmaf(row[i], wi, acc_a);
+                        acc_b = fmaf(row[257 + i], wi, acc_b);
+                    }
+                    if (p.mel_log) { acc_a = logf(acc_a + p.mel_eps); acc_b = logf(acc_b + p.mel_eps); }
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc_a), rout, mm * 4, fa * p.n_mels * 4, 0);
+                    if (has_b) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc_b), rout, (p.n_mels + mm) * 4, fa * p.n_mels * 4, 0);
+                }
+                WAVE_LDS_SYNC();
+            } else if (has_b) {
                 // ---- both rows are contiguous in the output (2 x 257 floats from row fa): LDS, then 16-byte stores ----
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -516,9 +559,10 @@ __global__ __launch_bounds__(256) void spectrogram_dft_kernel(SpecParams p) {
     }
 }
 
-extern "C" int nntk_shim_spectrogram(const float *d_in, const float *d_window, const float *d_twiddle, float *d_out,
-                                     int B, int input_size, int nfft, int window_size, int step,
-                                     int nfreq, int nts, float fft_norm, int mode, float scale) {
+static int spectrogram_launch(const float *d_in, const float *d_window, const float *d_twiddle, float *d_out,
+                              int B, int input_size, int nfft, int window_size, int step,
+                              int nfreq, int nts, float fft_norm, int mode, float scale,
+                              const int *d_mel_tab, const float *d_mel_w, int n_mels, float mel_eps, int mel_log) {
     if (B <= 0 || nts <= 0) return 0;
     if (window_size > nfft) return nntk_fail_msg("spectrogram: window_size must be <= nfft");
     SpecParams p;
@@ -527,12 +571,16 @@ extern "C" int nntk_shim_spectrogram(const float *d_in, const float *d_window, c
     p.B = B;
     p.input_size = input_size; p.nfft = nfft; p.window_size = window_size; p.step = step;
     p.nfreq = nfreq; p.nts = nts; p.fft_norm = fft_norm; p.scale = scale; p.inv_scale = (float)(1.0 / (double)scale); p.mode = mode;
+    p.mel_tab = d_mel_tab; p.mel_w = d_mel_w; p.n_mels = n_mels; p.mel_eps = mel_eps; p.mel_log = mel_log;
+    const bool mel = d_mel_tab != nullptr;
+    if (mel && nfft != 512) return 1;       // the caller runs the two-kernel form (K1, then the k = 1 GEMM)
 #ifdef NNTK_SPEC_DBG
     p.dbg = nntk_options().conv_dbg;
 #endif
     if (nfft == 512) {
         if ((long)input_size * 4 >= 0x7ffffff0L || (long)nts * nfreq * 4 >= 0x7ffffff0L)
             return nntk_fail_msg("spectrogram: one utterance must stay below 2 GiB");
+        if (mel && n_mels > 257) return 1;
         const int ppu = (nts + 1) / 2;
         // frame pairs per wavefront per utterance: long runs amortise the per-utterance prologue (descriptor +
         // un-overlapped first prefetch) as long as the chip stays full.  Measured at the stack's size (256 k pairs):
@@ -547,7 +595,8 @@ extern "C" int nntk_shim_spectrogram(const float *d_in, const float *d_window, c
         const bool norm = fft_norm != 1.0f;
         const bool nz7 = window_size > 384 && window_size <= 448;
         const bool ld3 = (step + window_size) * 4 <= 3072;          // 16-byte loads per lane for one pair's samples: 3 or 4
-#define SPEC_KERN2(M, N, Z) (ld3 ? spectrogram512_kernel<M, N, Z, 3> : spectrogram512_kernel<M, N, Z, 4>)
+#define SPEC_KERN2(M, N, Z) (mel ? (ld3 ? spectrogram512_kernel<M, N, Z, 3, true> : spectrogram512_kernel<M, N, Z, 4, true>) \
+                                 : (ld3 ? spectrogram512_kernel<M, N, Z, 3> : spectrogram512_kernel<M, N, Z, 4>))
 #define SPEC_KERN(M, N) (nz7 ? SPEC_KERN2(M, N, true) : SPEC_KERN2(M, N, false))
         auto kern = mode == 0 ? (norm ? SPEC_KERN(0, true) : SPEC_KERN(0, false))
                               : (norm ? SPEC_KERN(1, true) : SPEC_KERN(1, false));
@@ -569,4 +618,23 @@ extern "C" int nntk_shim_spectrogram(const float *d_in, const float *d_window, c
         NNTK_LAUNCH_CHECK("spectrogram_dft_kernel");
     }
     return 0;
+}
+
+extern "C" int nntk_shim_spectrogram(const float *d_in, const float *d_window, const float *d_twiddle, float *d_out,
+                                     int B, int input_size, int nfft, int window_size, int step,
+                                     int nfreq, int nts, float fft_norm, int mode, float scale) {
+    return spectrogram_launch(d_in, d_window, d_twiddle, d_out, B, input_size, nfft, window_size, step, nfreq, nts, fft_norm,
+                              mode, scale, nullptr, nullptr, 0, 0.f, 0);
+}
+
+// K1 with the mel projection (and optionally log(x + eps)) fused into its output stage: d_out is [B, nts, n_mels].
+// d_mel_tab = [3][n_mels] ints (first bin, run length, offset of the run in d_mel_w).  Returns 1 (nothing launched) for
+// configurations the fused kernel does not take (nfft != 512): the caller then runs K1 and the k = 1 GEMM.
+extern "C" int nntk_shim_spectrogram_mel(const float *d_in, const float *d_window, const float *d_twiddle, float *d_out,
+                                         int B, int input_size, int nfft, int window_size, int step,
+                                         int nfreq, int nts, float fft_norm, int mode, float scale,
+                                         const int *d_mel_tab, const float *d_mel_w, int n_mels, float eps, int do_log) {
+    if (!d_mel_tab || !d_mel_w || n_mels <= 0) return nntk_fail_msg("spectrogram_mel: missing filter table");
+    return spectrogram_launch(d_in, d_window, d_twiddle, d_out, B, input_size, nfft, window_size, step, nfreq, nts, fft_norm,
+                              mode, scale, d_mel_tab, d_mel_w, n_mels, eps, do_log);
 }

@@ -17,6 +17,10 @@ struct MelFilterBankStruct {
     float *weights;          /* host [nbins, n_mels] */
     float *d_wp;             /* packed for the GEMM kernel */
     int uploaded;
+    /* sparse form for the fused K1 epilogue: every filter is one run of nonzero weights */
+    int *d_tab;              /* [3][n_mels]: first bin, run length, offset into d_runs */
+    float *d_runs;
+    int sparse_state;        /* 0 not built, 1 ready, -1 not representable (a filter with a gap) */
     nntk_devbuf d_in, d_out;
 };
 
@@ -76,6 +80,8 @@ void MelFilterBankDestroy(MelFilterBank bank) {
     if (!bank) return;
     nntk_shim_synchronize();
     nntk_shim_free(bank->d_wp);
+    nntk_shim_free(bank->d_tab);
+    nntk_shim_free(bank->d_runs);
     nntk_devbuf_free(&bank->d_in);
     nntk_devbuf_free(&bank->d_out);
     free(bank->weights);
@@ -89,6 +95,36 @@ static int mel_ensure(MelFilterBank b) {
     if (nntk_upload_gemm_weights(&b->d_wp, b->weights, b->config.n_fft / 2 + 1, b->config.n_mels)) return -1;
     b->uploaded = 1;
     return 0;
+}
+
+/* run-length form of the filter matrix: filter m's nonzero weights are bins [k0, k0 + len) */
+static int mel_ensure_sparse(MelFilterBank b) {
+    if (b->sparse_state) return b->sparse_state > 0 ? 0 : 1;
+    const int nb = b->config.n_fft / 2 + 1, nm = b->config.n_mels;
+    int *tab = (int *)calloc((size_t)3 * nm, sizeof(int));
+    float *runs = (float *)calloc((size_t)nb * 2 + 8, sizeof(float));
+    if (!tab || !runs) { free(tab); free(runs); NNTK_FAIL("out of host memory for the mel run table"); }
+    int total = 0, ok = 1;
+    for (int m = 0; m < nm && ok; ++m) {
+        int k0 = -1, k1 = -1;
+        for (int k = 0; k < nb; ++k)
+            if (b->weights[(size_t)k * nm + m] != 0.0f) { if (k0 < 0) k0 = k; k1 = k; }
+        const int len = k0 < 0 ? 0 : k1 - k0 + 1;
+        if (total + len > nb * 2) { ok = 0; break; }          /* triangles overlap two-fold at most */
+        tab[m] = k0 < 0 ? 0 : k0; tab[nm + m] = len; tab[2 * nm + m] = total;
+        for (int i = 0; i < len; ++i) runs[total + i] = b->weights[(size_t)(k0 + i) * nm + m];     /* zeros inside a run stay */
+        total += len;
+    }
+    int rc = 1;
+    if (ok) {
+        b->d_tab = (int *)nntk_shim_malloc((size_t)3 * nm * sizeof(int));
+        rc = b->d_tab ? nntk_shim_upload(b->d_tab, tab, (size_t)3 * nm * sizeof(int)) : -1;
+        if (!rc) rc = nntk_upload_floats(&b->d_runs, runs, (size_t)(total > 0 ? total : 1));
+    }
+    free(tab); free(runs);
+    if (rc < 0) return -1;
+    b->sparse_state = ok ? 1 : -1;
+    return ok ? 0 : 1;
 }
 
 static int mel_rows_device(MelFilterBank b, const float *d_spec, float *d_out, long rows, int log_eps) {
@@ -158,6 +194,18 @@ int LogMelSpectrogramApplyDevice(LogMelSpectrogram filter, const float *d_input,
     if (batch <= 0) return 0;
     const SpectrogramConfig c = SpectrogramGetConfig(filter->spectrogram);
     const long rows = (long)batch * c.ntime_series;
+    /* fused form (nfft = 512): mel + log inside K1's output stage, the [rows, 257] tensor never exists */
+    int fused_off = 0;
+    (void)nntk_shim_get_option("spec_variant", &fused_off);          /* spec_variant = 1: force the two-kernel form (A/B, tests) */
+    if (fused_off != 1) {
+        int rs = mel_ensure_sparse(filter->bank);
+        if (rs < 0) return -1;
+        if (rs == 0) {
+            int rc = nntk_spectrogram_apply_mel_device(filter->spectrogram, d_input, d_output, batch, filter->bank->d_tab,
+                                                       filter->bank->d_runs, filter->bank->config.n_mels, 1.5849e-13f, 1);
+            if (rc <= 0) return rc;
+        }
+    }
     float *d_spec = nntk_devbuf_reserve(&filter->d_spec, (size_t)rows * c.nfreq);
     if (!d_spec) return -1;
     if (SpectrogramApplyDevice(filter->spectrogram, d_input, d_spec, batch)) return -1;

@@ -61,6 +61,8 @@ int   nntk_batch_norm_channels(BatchNorm bn);
 float nntk_batch_norm_epsilon(BatchNorm bn);
 
 const float *nntk_mel_weights(MelFilterBank bank);   /* host [nbins, n_mels] */
+int nntk_spectrogram_apply_mel_device(Spectrogram filter, const float *d_input, float *d_output, int batch,
+                                      const int *d_mel_tab, const float *d_mel_w, int n_mels, float eps, int do_log);
 
 void nntk_set_error(const char *msg);
 #define NNTK_FAIL(msg) do { nntk_set_error(msg); return -1; } while (0)

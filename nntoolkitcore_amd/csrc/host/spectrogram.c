@@ -144,6 +144,16 @@ int SpectrogramApplyDevice(Spectrogram filter, const float *d_input, float *d_ou
                                  filter->mode, filter->scale_factor);
 }
 
+/* K1 with the mel projection fused (mel.c); 1 = not taken for this configuration */
+int nntk_spectrogram_apply_mel_device(Spectrogram filter, const float *d_input, float *d_output, int batch,
+                                      const int *d_mel_tab, const float *d_mel_w, int n_mels, float eps, int do_log) {
+    if (spectrogram_ensure(filter)) return -1;
+    const SpectrogramConfig *c = &filter->config;
+    return nntk_shim_spectrogram_mel(d_input, filter->d_window, filter->d_twiddle, d_output, batch, c->input_size, c->nfft,
+                                     c->window_size, c->step, c->nfreq, c->ntime_series, c->fft_normalization_factor,
+                                     filter->mode, filter->scale_factor, d_mel_tab, d_mel_w, n_mels, eps, do_log);
+}
+
 int SpectrogramApplyBatch(Spectrogram filter, const float *input, float *output, int batch) {
     nntk_shim_clear_error();
     if (!filter) NNTK_FAIL("SpectrogramApplyBatch: NULL handle");

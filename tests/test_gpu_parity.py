@@ -773,6 +773,38 @@ def test_mel_filterbank_and_log_mel_spectrogram(gpu):
     check = L.LogMelSpectrogramApplyBatch(lm, x.ctypes.data_as(capi.fp), outb.ctypes.data_as(capi.fp), B)
     assert check == 0, capi.last_error()
     close(outb, ref, atol=2e-5, rtol=1e-5)
+    # the calls above ran the FUSED kernel (mel + log inside the STFT kernel's output stage, nfft = 512); the two-kernel
+    # form (STFT, then the k = 1 GEMM with the log epilogue) must agree with it and with the oracle
+    capi.set_option("spec_variant", 1)
+    out2 = np.empty((B, T, 40), np.float32)
+    assert L.LogMelSpectrogramApplyBatch(lm, x.ctypes.data_as(capi.fp), out2.ctypes.data_as(capi.fp), B) == 0
+    capi.set_option("spec_variant", "auto")
+    close(out2, ref, atol=2e-5, rtol=1e-5)
+    close(out2, outb, atol=2e-5, rtol=1e-5)
+    print("log-mel fused vs two-kernel: max abs diff %.2e; fused vs oracle %.2e" % (np.abs(out2 - outb).max(), np.abs(outb - ref).max()))
+    L.LogMelSpectrogramDestroy(lm)
+    sp.destroy()
+
+
+@pytest.mark.parametrize("n_mels,nts_odd,mode", [(80, True, "magnitude"), (13, False, "psd"), (128, True, "magnitude")])
+def test_fused_log_mel_other_banks(gpu, n_mels, nts_odd, mode):
+    """Fused path with more filters than lanes per frame pair (2 x 80, 2 x 128 > 64), an odd frame count (the last pair has
+    one frame), and PSD input."""
+    L = capi.load()
+    r = rng(n_mels)
+    N = 240 + 160 * (21 if nts_odd else 20)
+    x = (0.1 * r.standard_normal((2, N))).astype(np.float32)
+    sp = NL.Spectrogram(512, 400, 240, N, mode=mode, fs=16000)
+    T = sp.out_shape[0]
+    assert T % 2 == (1 if nts_odd else 0)
+    cfg = L.MelFilterBankConfigCreate(n_mels, 512, 16000, 0.0, 8000.0)
+    w = O.mel_filterbank_weights(n_mels, 512, 16000, 0.0, 8000.0)
+    spec = O.spectrogram(x, O.window("hann", 400), 512, 240, mode=mode, fs=16000)
+    ref = np.stack([O.log_mel(spec[i], w) for i in range(2)])
+    lm = L.LogMelSpectrogramCreate(sp.h, cfg)
+    out = np.full((2, T, n_mels), np.nan, np.float32)
+    assert L.LogMelSpectrogramApplyBatch(lm, x.ctypes.data_as(capi.fp), out.ctypes.data_as(capi.fp), 2) == 0, capi.last_error()
+    close(out, ref, atol=3e-5, rtol=2e-5)
     L.LogMelSpectrogramDestroy(lm)
     sp.destroy()
 
