@@ -226,10 +226,14 @@ class Workload:
             self.conv.apply_device(self.x, out=self.conv_out, bn=self.bn, act=self.relu)
             mark("conv_bn_relu")
         if self.name == "gru":
-            self.g1.apply_device(self.x, out=self.h1)
-            mark("gru1")
-            self.g2.apply_device(self.h1, out=self.h2)
-            mark("gru2")
+            if os.environ.get("NNTK_BENCH_GRU_UNFUSED"):          # A/B: the two layers as two calls
+                self.g1.apply_device(self.x, out=self.h1)
+                mark("gru1")
+                self.g2.apply_device(self.h1, out=self.h2)
+                mark("gru2")
+            else:                                                  # one call: both layers in one persistent launch
+                self.NL.gru_stack2_apply_device(self.g1, self.g2, self.x, out=self.h2)
+                mark("gru_stack2")
         return ev
 
     def destroy(self):
@@ -289,6 +293,11 @@ def roofline_for(wl, phase_ms, prof):
     persistent = tpl > 1
     kern = ("rec_persistent_kernel" if persistent else "rec_step_kernel") + ("<4,LSTM>" if G == 4 else "<3,GRU>")
     flops = 2.0 * B * H * G * H * tpl          # algorithmic flops of ONE launch (tpl timesteps of h[B,H] x U[H,G*H])
+    if wl.name == "gru" and persistent and abs(prof.get("rec_launches_per_step", 2.0) - 1.0) < 0.01:
+        # fused two-layer launch: T + 1 iterations, three [B,H] x [H,3H] products per timestep (U1, W2, U2)
+        kern = "gru2_persistent_kernel<8>"
+        tpl = tpl - 1
+        flops = 3.0 * 2.0 * B * H * G * H * tpl
     ach = flops / (ms * 1e-3) / 1e12
     traffic, traffic_source = (pmc_traffic("rec_persistent_kernel<4" if G == 4 else "rec_persistent_kernel<3", B)
                                if (persistent and wl.name == "stack") else (None, "not profiled for this workload"))

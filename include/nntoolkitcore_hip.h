@@ -362,6 +362,12 @@ int BatchNormApplyDevice(BatchNorm filter, const float *d_input, float *d_output
 int ActivationFunctionApplyDevice(ActivationFunction filter, const float *d_input, float *d_output, int size);
 int GRUApplyDevice(GRU filter, const float *d_input /*[batch,T,in]*/, float *d_output, int batch);
 int LSTMApplyDevice(LSTM filter, const float *d_input /*[batch,T,in]*/, float *d_output, int batch);
+/* Two stacked GRU layers (layer 1 returns sequences and feeds layer 2) in ONE persistent launch: layer 2 runs one step
+ * behind layer 1 inside the same kernel, so its input projection and the inter-layer [batch,T,H] tensor never reach HBM.
+ * Results = GRUApplyDevice(l1) then GRUApplyDevice(l2) from zero state (gru.c:246-293 forward semantics), within the
+ * layer tolerance; shapes or activations the fused kernel does not take run exactly those two calls. */
+int GRUStack2ApplyDevice(GRU layer1, GRU layer2, const float *d_input /*[batch,T,in]*/, float *d_output, int batch);
+int GRUStack2ApplyInferenceBatch(GRU layer1, GRU layer2, const float *input, float *output, int batch);
 int RNNApplyDevice(RNN filter, const float *d_input /*[batch,T,in]*/, float *d_output, int batch);
 int bd_reverse_input_batch_device(const float *d_input, float *d_output, RecurrentConfig config, int batch);
 int bd_reverse_backward_batch_device(const float *d_input, float *d_output, RecurrentConfig config, int batch);

@@ -229,6 +229,8 @@ SIGNATURES = {
     "BatchNormApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
     "ActivationFunctionApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
     "GRUApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
+    "GRUStack2ApplyDevice": (C.c_int, [vp, vp, vp, vp, C.c_int]),
+    "GRUStack2ApplyInferenceBatch": (C.c_int, [vp, vp, fp, fp, C.c_int]),
     "LSTMApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
     "RNNApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
     "bd_reverse_input_batch_device": (C.c_int, [vp, vp, RecurrentConfig, C.c_int]),

@@ -109,6 +109,14 @@ int nntk_shim_lstm(const float *d_xw, const float *d_ut, const float *d_bh,
                    const float *d_h0, const float *d_c0, float *d_out, float *d_hT, float *d_cT,
                    float *d_work, int B, int T, int H, int return_sequences, const int acts[5], const float act_scales[5]);
 
+/* fused two-layer GRU (standard activations, zero initial state, both layers H units): layer 2's input projection and
+ * recurrence run inside layer 1's persistent launch, one step behind.  d_wt2 = W2^T packed like U^T.  Returns 1 when
+ * the shape is not taken (nothing launched). */
+size_t nntk_shim_gru2_work_floats(int B, int H);
+int nntk_shim_gru2(const float *d_xw1, const float *d_ut1, const float *d_bh1, const float *d_wt2,
+                   const float *d_bi2, const float *d_ut2, const float *d_bh2, float *d_out, float *d_out1,
+                   float *d_work, int B, int T, int H, int return_sequences);
+
 /* streaming form: ONE sequence, T small; x [T, in] and out ([T, H] or [H]) may be pinned host memory (read / written by
  * the kernel directly, no copies); state h[cur] (c[cur]) -> h[(cur + T) & 1]; the last launch stores `seq` to *flag (a
  * pinned host word) once all outputs are visible to the host.  Bit-compatible with nntk_shim_gru / _lstm / _rnn. */

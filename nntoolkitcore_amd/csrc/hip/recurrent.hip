@@ -668,6 +668,350 @@ __global__ __launch_bounds__(512, 2) void rec_persistent_kernel(RecPParams p) {
     }
 }
 
+static size_t rec_hb_floats_fwd(int B, int H);
+static size_t rec_cnt_words_fwd(int B);
+
+// ============================================================================
+// Fused two-layer GRU (BASELINE configs[3]: GRU 128 -> 256 -> 256): ONE persistent launch runs both layers, layer 2
+// one step behind layer 1.  In iteration i a workgroup computes, for its 64 batch rows x 16 hidden units,
+//     layer 1, step i     :  U1^T . h1_{i-1}                       (split-K over the two waves of a slab, as above)
+//     layer 2, step i - 1 :  W2^T . h1_{i-1}   and   U2^T . h2_{i-2}   (one full-K product per wave of the slab)
+// -- everything it needs was published in iteration i-1, so there is ONE hand-off (one arrival counter, one poll)
+// per iteration for both layers instead of two, layer 2's input projection (a 403 GFLOP GEMM launch and its
+// [T, B, 3H] tensor) disappears into the resident W2^T tile, and the inter-layer [B, T, H] tensor never reaches HBM.
+// Three 48 x K tiles stay in LDS (H = 256: 2 x 50.7 KB + 49.9 KB + the 12 KB exchange = 163.6 of 160 KiB = 163.8 KB;
+// W2^T takes the 260-float row stride -- one 2-way bank conflict per b128 group -- because three 264-float tiles do
+// not fit).  Layer 1's numbers are bit-identical to the single-layer kernel; layer 2's input projection is summed in
+// the MFMA's k order here instead of the GEMM kernel's (same tolerance, not the same bits).
+// Standard GRU activations, zero initial state, both layers H hidden units (H % 16 == 0, H <= 256).
+// ============================================================================
+struct Gru2Params {
+    const float *xw1;     // [T, B, 3H] layer-1 input projections incl. b_i1 (projection GEMM)
+    const float *ut1, *bh1;          // layer 1: U1^T [3][Hj_p][Hk_p], b_h1 [3H]
+    const float *wt2, *bi2;          // layer 2: W2^T in the same layout, b_i2 [3H]
+    const float *ut2, *bh2;          // layer 2: U2^T, b_h2
+    float *hbuf1, *hbuf2;            // [2][hb_floats] tiled hand-off buffers of the two layers (zeroed before the launch)
+    size_t hb_floats;
+    float *out;                      // [B, T, H] layer-2 outputs (or [B, H] when !return_sequences)
+    float *out1;                     // [B, T, H] layer-1 outputs, or NULL (not needed by the stack itself)
+    unsigned *cnt;                   // [NBT] arrival counters
+    unsigned *fault;
+    unsigned long long spin_ticks;
+    int B, T, H, Hj_p, Hk_p, NBT, NCT, b_base, return_sequences;
+};
+
+template <int NCH>
+__global__ __launch_bounds__(512, 2) void gru2_persistent_kernel(Gru2Params p) {
+    constexpr int G = 3;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KP = NCH * REC_KC;
+    constexpr int US = KP + 8, WS = KP + 4;       // row strides: U1^T / U2^T conflict-free, W2^T one 2-way conflict (LDS budget)
+    float *U1s = smem;                            // [48][US]
+    float *U2s = U1s + G * 16 * US;               // [48][US]
+    float *W2s = U2s + G * 16 * US;               // [48][WS]
+    float *red = W2s + G * 16 * WS;               // [4 slabs][2 waves][G][2][64] exchange
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = w8 >> 2, slab = w8 & 3;       // grp: split-K half for layer 1; layer 2: 0 = the W2 product, 1 = the U2 product
+    const int l15 = lane & 15, q = lane >> 4;
+    const int bt = blockIdx.x % p.NBT, ct = blockIdx.x / p.NBT;
+    const int b0 = p.b_base + bt * REC_BM, j0 = ct * REC_HN;
+    const int GH = G * p.H;
+    unsigned *cnt = p.cnt + (size_t)bt * RECP_CNT_STRIDE;
+    const int b = b0 + slab * 16 + l15;
+    const int j = j0 + q * 4 + grp * 2;           // this lane finishes hidden units j, j + 1 of row b, in both layers
+    const bool row_ok = b < p.B;
+    const bool ok0 = row_ok && j < p.H, ok1 = row_ok && j + 1 < p.H;
+
+    {   // resident tiles
+        constexpr int f4_per_row = KP / 4;
+        constexpr int total = G * 16 * f4_per_row;
+        for (int e = tid; e < total; e += 512) {
+            const int r = e / f4_per_row, c4 = e % f4_per_row;
+            const int g = r >> 4, jj = r & 15;
+            float4 u1 = make_float4(0.f, 0.f, 0.f, 0.f), u2 = u1, w2 = u1;
+            if (c4 * 4 < p.Hk_p) {
+                const size_t off = ((size_t)g * p.Hj_p + j0 + jj) * p.Hk_p + c4 * 4;
+                u1 = *reinterpret_cast<const float4 *>(p.ut1 + off);
+                u2 = *reinterpret_cast<const float4 *>(p.ut2 + off);
+                w2 = *reinterpret_cast<const float4 *>(p.wt2 + off);
+            }
+            *reinterpret_cast<float4 *>(&U1s[r * US + c4 * 4]) = u1;
+            *reinterpret_cast<float4 *>(&U2s[r * US + c4 * 4]) = u2;
+            *reinterpret_cast<float4 *>(&W2s[r * WS + c4 * 4]) = w2;
+        }
+    }
+    float bh1[2][G], bh2[2][G], bi2[2][G];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const bool in = j + e < p.H;
+            bh1[e][g] = in ? p.bh1[g * p.H + j + e] : 0.0f;
+            bh2[e][g] = in ? p.bh2[g * p.H + j + e] : 0.0f;
+            bi2[e][g] = in ? p.bi2[g * p.H + j + e] : 0.0f;
+        }
+    float prev1[2] = {0.f, 0.f}, prev2[2] = {0.f, 0.f};      // own h of each layer (zero initial state)
+
+    constexpr int KB = KP / 16;
+    const int slab_abs = (b0 >> 4) + slab;
+    const int hb_bytes = (int)(p.hb_floats * 4);
+    const __amdgpu_buffer_rsrc_t r1a = __builtin_amdgcn_make_buffer_rsrc((void *)p.hbuf1, 0, hb_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1b = __builtin_amdgcn_make_buffer_rsrc((void *)(p.hbuf1 + p.hb_floats), 0, hb_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2a = __builtin_amdgcn_make_buffer_rsrc((void *)p.hbuf2, 0, hb_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2b = __builtin_amdgcn_make_buffer_rsrc((void *)(p.hbuf2 + p.hb_floats), 0, hb_bytes, 0x00020000);
+    const int h_lane_off = lane * 16;
+    const int h_slab_off = slab_abs * KB * 1024;              // + (2 ch + half) * 1024
+    const size_t h_pub_off = ((((size_t)slab_abs * KB + ct) * 4 + q) * 16 + l15) * 4 + grp * 2;
+    float *my_red = red + ((slab * 2 + grp) * G * 2) * 64;
+    const float *peer_red = red + ((slab * 2 + (1 - grp)) * G * 2) * 64;
+    const int uoff = l15 * US + q * 4, woff = l15 * WS + q * 4;
+    __syncthreads();
+
+    for (int i = 0; i <= p.T; ++i) {
+        const bool do1 = i < p.T, do2 = i > 0;                // layer 1 runs step i, layer 2 step i - 1
+        // ---- wait for iteration i - 1's publication (both layers' h ride on the same counter) ----
+        if (i > 0) {
+            if (w8 == 0 && lane == 0) {
+                const unsigned target = (unsigned)p.NCT * (unsigned)i;
+                const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+                bool expired = p.spin_ticks == 0;
+                while (!expired && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    expired = __builtin_amdgcn_s_memrealtime() - t_start > p.spin_ticks;
+                }
+                if (expired) {
+                    __hip_atomic_fetch_or(p.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_or(cnt, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            __syncthreads();
+        }
+        // ---- operands: h1_{i-1} (parity i & 1 of layer 1's buffers), h2_{i-2} (parity (i - 1) & 1 of layer 2's) ----
+        // wave grp 0: all of h1 (its layer-1 half is pieces (ch, 0)); wave grp 1: h1 pieces (ch, 1) and all of h2
+        v4u32 h1own[NCH], hfull[2 * NCH];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int so = h_slab_off + (2 * ch + grp) * 1024;
+            h1own[ch] = (i & 1) ? __builtin_amdgcn_raw_buffer_load_b128(r1b, h_lane_off, so, 16)
+                                : __builtin_amdgcn_raw_buffer_load_b128(r1a, h_lane_off, so, 16);
+        }
+        if (do2) {
+#pragma unroll
+            for (int pc = 0; pc < 2 * NCH; ++pc) {
+                const int so = h_slab_off + pc * 1024;
+                if (grp == 0) hfull[pc] = (i & 1) ? __builtin_amdgcn_raw_buffer_load_b128(r1b, h_lane_off, so, 16)
+                                                  : __builtin_amdgcn_raw_buffer_load_b128(r1a, h_lane_off, so, 16);
+                else          hfull[pc] = ((i - 1) & 1) ? __builtin_amdgcn_raw_buffer_load_b128(r2b, h_lane_off, so, 16)
+                                                        : __builtin_amdgcn_raw_buffer_load_b128(r2a, h_lane_off, so, 16);
+            }
+        }
+        // layer 1's xW for step i: one 16-byte load per gate (the quad of hidden units this lane and its partner share)
+        float xw1[2][G];
+        if (do1) {
+            const float *xw = p.xw1 + ((size_t)i * p.B + b) * GH + (j & ~3);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok0) x4 = *reinterpret_cast<const float4 *>(xw + g * p.H);
+                xw1[0][g] = grp ? x4.z : x4.x;
+                xw1[1][g] = grp ? x4.w : x4.y;
+            }
+        }
+        // ---- layer 1: U1^T . h1_{i-1}, this wave's K half ----
+        f32x4 acc1[G], acc2[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) { acc1[g] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[g] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        if (do1) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const float hv[4] = {__uint_as_float(h1own[ch].x), __uint_as_float(h1own[ch].y),
+                                     __uint_as_float(h1own[ch].z), __uint_as_float(h1own[ch].w)};
+                float4 uf[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) uf[g] = *reinterpret_cast<const float4 *>(&U1s[uoff + g * 16 * US + ch * REC_KC + grp * 16]);
+#pragma unroll
+                for (int sI = 0; sI < 4; ++sI)
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const float u = sI == 0 ? uf[g].x : sI == 1 ? uf[g].y : sI == 2 ? uf[g].z : uf[g].w;
+                        acc1[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(u, hv[sI], acc1[g], 0, 0, 0);
+                    }
+            }
+        }
+        // ---- layer 2, full K in one wave: grp 0 multiplies W2^T . h1_{i-1}, grp 1 multiplies U2^T . h2_{i-2} ----
+        if (do2) {
+#pragma unroll
+            for (int pc = 0; pc < 2 * NCH; ++pc) {
+                const float hv[4] = {__uint_as_float(hfull[pc].x), __uint_as_float(hfull[pc].y),
+                                     __uint_as_float(hfull[pc].z), __uint_as_float(hfull[pc].w)};
+                float4 wf[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    wf[g] = grp == 0 ? *reinterpret_cast<const float4 *>(&W2s[woff + g * 16 * WS + pc * 16])
+                                     : *reinterpret_cast<const float4 *>(&U2s[uoff + g * 16 * US + pc * 16]);
+#pragma unroll
+                for (int sI = 0; sI < 4; ++sI)
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const float u = sI == 0 ? wf[g].x : sI == 1 ? wf[g].y : sI == 2 ? wf[g].z : wf[g].w;
+                        acc2[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(u, hv[sI], acc2[g], 0, 0, 0);
+                    }
+            }
+        }
+        // ---- exchange 1 (layer 1 split-K): send the half the partner wave finishes ----
+        float fin1[2][G];
+        if (do1) {
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) my_red[(g * 2 + e) * 64 + lane] = grp ? acc1[g][e] : acc1[g][2 + e];
+        }
+        __syncthreads();
+        if (do1) {
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float other = peer_red[(g * 2 + e) * 64 + lane];
+                    const float mine = grp ? acc1[g][2 + e] : acc1[g][e];
+                    fin1[e][g] = grp == 0 ? mine + other : other + mine;      // always (half 0) + (half 1)
+                }
+        }
+        __syncthreads();                                          // red is read: free for exchange 2
+        // ---- exchange 2 (layer 2): the W2 wave and the U2 wave swap the halves the other one finishes ----
+        float xw2[2][G], hu2[2][G];
+        if (do2) {
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) my_red[(g * 2 + e) * 64 + lane] = grp ? acc2[g][e] : acc2[g][2 + e];
+        }
+        __syncthreads();
+        if (do2) {
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float other = peer_red[(g * 2 + e) * 64 + lane];
+                    const float mine = grp ? acc2[g][2 + e] : acc2[g][e];
+                    xw2[e][g] = (grp == 0 ? mine : other) + bi2[e][g];       // x W2 + b_i2, as the projection GEMM's epilogue
+                    hu2[e][g] = grp == 0 ? other : mine;
+                }
+        }
+        // ---- gates (gru.c:144-186, same code as the single-layer kernel) and publication ----
+        float h1n[2] = {0.f, 0.f}, h2n[2] = {0.f, 0.f};
+        if (do1) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float hz = fin1[e][0] + bh1[e][0], hr = fin1[e][1] + bh1[e][1], hh = fin1[e][2] + bh1[e][2];
+                const float z = nntk_fast_sigmoid(xw1[e][0] + hz);
+                const float rg = nntk_fast_sigmoid(xw1[e][1] + hr);
+                const float ht = nntk_fast_tanh(fmaf(rg, hh, xw1[e][2]));
+                h1n[e] = fmaf(-z + 1.0f, ht, z * prev1[e]);
+                prev1[e] = h1n[e];
+            }
+            float *hdst = p.hbuf1 + (size_t)((i + 1) & 1) * p.hb_floats + h_pub_off;
+            if (ok1) {
+                const unsigned long long pk = ((unsigned long long)__float_as_uint(h1n[1]) << 32) | __float_as_uint(h1n[0]);
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(hdst), pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (ok0) {
+                __hip_atomic_store(reinterpret_cast<unsigned *>(hdst), __float_as_uint(h1n[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (do2) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float hz = hu2[e][0] + bh2[e][0], hr = hu2[e][1] + bh2[e][1], hh = hu2[e][2] + bh2[e][2];
+                const float z = nntk_fast_sigmoid(xw2[e][0] + hz);
+                const float rg = nntk_fast_sigmoid(xw2[e][1] + hr);
+                const float ht = nntk_fast_tanh(fmaf(rg, hh, xw2[e][2]));
+                h2n[e] = fmaf(-z + 1.0f, ht, z * prev2[e]);
+                prev2[e] = h2n[e];
+            }
+            float *hdst = p.hbuf2 + (size_t)(i & 1) * p.hb_floats + h_pub_off;      // h2_{i-1}: read next iteration as parity ((i + 1) - 1) & 1
+            if (ok1) {
+                const unsigned long long pk = ((unsigned long long)__float_as_uint(h2n[1]) << 32) | __float_as_uint(h2n[0]);
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(hdst), pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (ok0) {
+                __hip_atomic_store(reinterpret_cast<unsigned *>(hdst), __float_as_uint(h2n[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // R1: every storing wave drains ...
+        __syncthreads();                                          // ... the workgroup meets (this also frees `red`) ...
+        if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... ONE lane arrives
+        // layer outputs (never read inside this launch) go out after the arrival
+        if (do2 && (p.return_sequences || i == p.T)) {
+            float *o = p.return_sequences ? p.out + ((size_t)b * p.T + (i - 1)) * p.H + j : p.out + (size_t)b * p.H + j;
+            if (ok1) *reinterpret_cast<float2 *>(o) = make_float2(h2n[0], h2n[1]);
+            else if (ok0) o[0] = h2n[0];
+        }
+        if (do1 && p.out1) {
+            float *o = p.out1 + ((size_t)b * p.T + i) * p.H + j;
+            if (ok1) *reinterpret_cast<float2 *>(o) = make_float2(h1n[0], h1n[1]);
+            else if (ok0) o[0] = h1n[0];
+        }
+    }
+}
+
+// Both layers' work areas: [hbuf1 ping | pong][hbuf2 ping | pong][counters]
+extern "C" size_t nntk_shim_gru2_work_floats(int B, int H) {
+    return 4 * rec_hb_floats_fwd(B, H) + rec_cnt_words_fwd(B);
+}
+
+// 0 = launched; 1 = this shape / configuration is not taken by the fused kernel (caller runs the two layers one after
+// the other); -1 = error.  d_xw1 [T, B, 3H] from the projection GEMM; d_wt2 = W2^T packed like U^T.
+extern "C" int nntk_shim_gru2(const float *d_xw1, const float *d_ut1, const float *d_bh1, const float *d_wt2,
+                              const float *d_bi2, const float *d_ut2, const float *d_bh2, float *d_out, float *d_out1,
+                              float *d_work, int B, int T, int H, int return_sequences) {
+    if (B <= 0 || T <= 0) return 0;
+    const NntkOptions &opt = nntk_options();
+    if (opt.rec_fused2 == 0 || opt.rec_persistent == 0 || nntk_persistent_disabled()) return 1;
+    const int Hj_p = (H + 15) & ~15, Hk_p = (H + 31) & ~31;
+    const int nch = Hk_p / REC_KC;
+    if ((H % 4) != 0 || nch > 8) return 1;
+    const int nch_p = nch <= 4 ? 4 : 8;
+    const int KP = nch_p * REC_KC;
+    const size_t lds = ((size_t)3 * 16 * (2 * (KP + 8) + (KP + 4)) + (size_t)4 * 2 * 3 * 2 * 64) * sizeof(float);
+    if (lds > 160 * 1024) return 1;
+    const int NCT = Hj_p / REC_HN;
+    const int cus = nntk_cu_count();
+    const int tiles_per_launch = NCT > 0 ? cus / NCT : 0;
+    if (tiles_per_launch < 1) return 1;
+    unsigned *fault = nntk_fault_word();
+    if (!fault) return 1;
+    const size_t hbmax = rec_hb_floats_fwd(B, H);
+    const size_t hb_floats = (size_t)((B + 63) & ~63) * (size_t)KP;
+    if (hb_floats * 4 >= 0x3ffffff0ULL) return 1;
+    auto kern = nch_p == 4 ? gru2_persistent_kernel<4> : gru2_persistent_kernel<8>;
+    if (nntk_set_max_dynamic_lds((const void *)kern, lds)) return -1;
+    unsigned *cnt = reinterpret_cast<unsigned *>(d_work + 4 * hbmax);
+    const int nbt_total = (B + REC_BM - 1) / REC_BM;
+    if (nntk_shim_memset(d_work, 0, 4 * hbmax * 4 + (size_t)nbt_total * RECP_CNT_STRIDE * sizeof(unsigned))) return -1;
+    Gru2Params q;
+    q.xw1 = d_xw1; q.ut1 = d_ut1; q.bh1 = d_bh1; q.wt2 = d_wt2; q.bi2 = d_bi2; q.ut2 = d_ut2; q.bh2 = d_bh2;
+    q.hbuf1 = d_work; q.hbuf2 = d_work + 2 * hbmax; q.hb_floats = hb_floats;
+    q.out = d_out; q.out1 = d_out1; q.fault = fault;
+    q.spin_ticks = (unsigned long long)(opt.rec_spin_us > 0 ? opt.rec_spin_us : 0) * 100ull;
+    q.B = B; q.T = T; q.H = H; q.Hj_p = Hj_p; q.Hk_p = Hk_p; q.NCT = NCT; q.return_sequences = return_sequences;
+    const int span = nntk_prof_span_begin(NNTK_SPAN_REC);
+    nntk_persistent_launch_begin();
+    for (int bt0 = 0; bt0 < nbt_total; bt0 += tiles_per_launch) {
+        const int nbt = nbt_total - bt0 < tiles_per_launch ? nbt_total - bt0 : tiles_per_launch;
+        q.NBT = nbt; q.b_base = bt0 * REC_BM;
+        q.cnt = cnt + (size_t)bt0 * RECP_CNT_STRIDE;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(nbt * NCT)), dim3(512), lds, nntk_stream(), q);
+    }
+    const int copy_rc = nntk_fault_enqueue_copy();
+    nntk_persistent_launch_end();
+    if (copy_rc) return -1;
+    nntk_prof_span_end(span, (nbt_total + tiles_per_launch - 1) / tiles_per_launch, T + 1);
+    NNTK_LAUNCH_CHECK("gru2_persistent_kernel");
+    return 0;
+}
+
 // h_0 from the caller's [B][H] layout into the tiled hand-off layout (parity 0)
 __global__ __launch_bounds__(256) void rec_tile_h0_kernel(const float *src, float *dst, int B, int H, int KB) {
     const long total = (long)B * H;
@@ -884,6 +1228,9 @@ static size_t rec_cnt_words(int B) {
     const size_t nbt = (size_t)(B + REC_BM - 1) / REC_BM;
     return (2 * nbt < 256 ? 256 : 2 * nbt) * RECP_CNT_STRIDE;
 }
+
+static size_t rec_hb_floats_fwd(int B, int H) { return rec_hb_floats(B, H); }
+static size_t rec_cnt_words_fwd(int B) { return rec_cnt_words(B); }
 
 extern "C" size_t nntk_shim_recurrent_work_floats(int B, int H) {
     // h ping | h pong | c | arrival counters of the persistent kernel

@@ -40,6 +40,8 @@ typedef struct {
     RecurrentWeights *weights;
     nntk_wblock wb;
     float *d_wp, *d_bi, *d_ut, *d_bh;
+    float *d_wt;                /* W^T packed like U^T (only when in == H): layer-2 operand of the fused two-layer GRU */
+    int wt_valid;
     /* persistent single-sequence state [H], double-buffered: a stateful call reads state[cur] and writes
      * state[cur ^ 1]; cur flips only once the call is known to be good, so a call that has to be repeated
      * (persistent-kernel fault, see core_apply_host) still finds its initial state intact */
@@ -81,7 +83,7 @@ static int core_init(rec_core *c, int G, RecurrentConfig base) {
 
 static void core_free(rec_core *c) {
     nntk_shim_synchronize();
-    nntk_shim_free(c->d_wp); nntk_shim_free(c->d_bi); nntk_shim_free(c->d_ut); nntk_shim_free(c->d_bh);
+    nntk_shim_free(c->d_wp); nntk_shim_free(c->d_bi); nntk_shim_free(c->d_ut); nntk_shim_free(c->d_bh); nntk_shim_free(c->d_wt);
     nntk_shim_free(c->d_h[0]);
     nntk_shim_host_free(c->pin_in); nntk_shim_host_free(c->pin_out); nntk_shim_host_free((void *)c->flag);
     nntk_shim_free(c->d_done);
@@ -109,7 +111,29 @@ static int core_upload(rec_core *c) {
     int rc = nntk_upload_floats(&c->d_ut, tmp, n);
     free(tmp);
     if (rc) return rc;
+    c->wt_valid = 0;
     nntk_wblock_mark_uploaded(&c->wb);
+    return 0;
+}
+
+/* W [in = H, G*H] transposed per gate into the U^T layout [G][Hj_p][Hk_p] */
+static int core_ensure_wt(rec_core *c) {
+    if (c->wt_valid) return 0;
+    if (c->in != c->H) NNTK_FAIL("fused GRU stack: layer 2's input size must equal its hidden size");
+    int G = c->G, H = c->H;
+    int Hj_p = (H + 15) & ~15, Hk_p = (H + 31) & ~31;
+    size_t n = (size_t)G * Hj_p * Hk_p;
+    float *tmp = (float *)calloc(n, sizeof(float));
+    if (!tmp) NNTK_FAIL("out of host memory while packing recurrent weights");
+    const float *W = c->weights->W;
+    for (int k = 0; k < H; ++k)
+        for (int g = 0; g < G; ++g)
+            for (int j = 0; j < H; ++j)
+                tmp[((size_t)g * Hj_p + j) * Hk_p + k] = W[(size_t)k * G * H + (size_t)g * H + j];
+    int rc = nntk_upload_floats(&c->d_wt, tmp, n);
+    free(tmp);
+    if (rc) return rc;
+    c->wt_valid = 1;
     return 0;
 }
 
@@ -350,6 +374,65 @@ int GRUGetState(GRU filter, float *h_host) {
     nntk_shim_clear_error();
     if (!filter) NNTK_FAIL("GRUGetState: NULL handle");
     return nntk_shim_download(h_host, filter->core.d_h[filter->core.cur], (size_t)filter->core.H * sizeof(float));
+}
+
+/* ---- two stacked GRU layers in one persistent launch (BASELINE configs[3]; recurrent.hip gru2_persistent_kernel) ----
+ * Same results as GRUApplyDevice(l1) followed by GRUApplyDevice(l2) on zero initial state (layer 1 bit for bit, layer 2
+ * within the layer tolerance: its input projection is summed in another order); falls back to exactly those two calls
+ * for shapes / activations the fused kernel does not take. */
+static int gru_default_acts(GRU f) {
+    int a[3]; float sc[3];
+    if (gru_acts(f, a, sc)) return -1;
+    return (a[0] == NNTK_ACT_SIGMOID && a[1] == NNTK_ACT_TANH && a[2] == NNTK_ACT_SIGMOID) ? 1 : 0;
+}
+int GRUStack2ApplyDevice(GRU l1, GRU l2, const float *d_input, float *d_output, int batch) {
+    nntk_shim_clear_error();
+    if (!l1 || !l2) NNTK_FAIL("GRUStack2ApplyDevice: NULL handle");
+    rec_core *c1 = &l1->core, *c2 = &l2->core;
+    if (!c1->return_sequences || c2->in != c1->H || c2->T != c1->T)
+        NNTK_FAIL("GRUStack2ApplyDevice: layer 1 must return sequences and feed layer 2 (in2 = H1, same timesteps)");
+    if (batch <= 0) return 0;
+    if (core_ensure(c1, 0) || core_ensure(c2, 0)) return -1;
+    const int H = c1->H, T = c1->T, B = batch;
+    int d1 = gru_default_acts(l1), d2 = gru_default_acts(l2);
+    if (d1 < 0 || d2 < 0) return -1;
+    if (d1 && d2 && c2->H == H) {
+        if (core_ensure_wt(c2)) return -1;
+        float *d_xw = nntk_devbuf_reserve(&c1->d_xw, (size_t)T * B * 3 * H);
+        float *d_work = nntk_devbuf_reserve(&c1->d_work, nntk_shim_gru2_work_floats(B, H) > nntk_shim_recurrent_work_floats(B, H)
+                                                           ? nntk_shim_gru2_work_floats(B, H) : nntk_shim_recurrent_work_floats(B, H));
+        if (!d_xw || !d_work) return -1;
+        if (nntk_shim_conv1d(d_input, c1->d_wp, c1->d_bi, NULL, 0.f, NNTK_ACT_IDENTITY, 1.f, d_xw, B, T, c1->in, 3 * H, 1, 1, T, 1))
+            return -1;
+        int rc = nntk_shim_gru2(d_xw, c1->d_ut, c1->d_bh, c2->d_wt, c2->d_bi, c2->d_ut, c2->d_bh, d_output, NULL, d_work,
+                                B, T, H, c2->return_sequences);
+        if (rc <= 0) return rc;
+    }
+    /* not taken by the fused kernel: the two layers one after the other, through a scratch inter-layer tensor */
+    float *d_mid = nntk_devbuf_reserve(&c1->d_out, (size_t)B * T * H);
+    if (!d_mid) return -1;
+    if (GRUApplyDevice(l1, d_input, d_mid, batch)) return -1;
+    return GRUApplyDevice(l2, d_mid, d_output, batch);
+}
+int GRUStack2ApplyInferenceBatch(GRU l1, GRU l2, const float *input, float *output, int batch) {
+    nntk_shim_clear_error();
+    if (!l1 || !l2) NNTK_FAIL("GRUStack2ApplyInferenceBatch: NULL handle");
+    if (batch <= 0) return 0;
+    rec_core *c1 = &l1->core, *c2 = &l2->core;
+    if (core_ensure(c1, 1) || core_ensure(c2, 1)) return -1;
+    size_t n_in = (size_t)batch * c1->T * c1->in;
+    size_t n_out = c2->return_sequences ? (size_t)batch * c2->T * c2->H : (size_t)batch * c2->H;
+    float *d_in = nntk_devbuf_reserve(&c1->d_in, n_in);
+    float *d_out = nntk_devbuf_reserve(&c2->d_out, n_out);
+    if (!d_in || !d_out) return -1;
+    if (nntk_shim_upload(d_in, input, n_in * sizeof(float))) return -1;
+    if (GRUStack2ApplyDevice(l1, l2, d_in, d_out, batch)) return -1;
+    if (nntk_shim_download_nocheck(output, d_out, n_out * sizeof(float))) return -1;
+    if (nntk_shim_take_fault()) {      /* persistent launch faulted: repeat on the per-timestep kernels (see core_apply_host) */
+        if (GRUStack2ApplyDevice(l1, l2, d_in, d_out, batch)) return -1;
+        if (nntk_shim_download(output, d_out, n_out * sizeof(float))) return -1;
+    }
+    return 0;
 }
 
 /* ================================= LSTM =================================== */

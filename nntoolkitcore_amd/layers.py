@@ -218,6 +218,24 @@ class GRU(_Recurrent):
         return h
 
 
+def gru_stack2_apply_device(g1, g2, x, out=None):
+    """GRUStack2ApplyDevice: two stacked GRU layers in one persistent launch (zero initial state)."""
+    H, T = g2.cfg.base.output_feature_channels, g2.cfg.base.timesteps
+    if out is None:
+        out = x.new_empty((x.shape[0], T, H) if g2.cfg.base.return_sequences else (x.shape[0], H))
+    check(capi.load().GRUStack2ApplyDevice(g1.h, g2.h, _dp(x), _dp(out), x.shape[0]), "GRUStack2ApplyDevice")
+    return out
+
+
+def gru_stack2_apply(g1, g2, x):
+    """GRUStack2ApplyInferenceBatch on host arrays [B, T, in]."""
+    x = _f32(x)
+    H, T = g2.cfg.base.output_feature_channels, g2.cfg.base.timesteps
+    out = np.empty((x.shape[0], T, H) if g2.cfg.base.return_sequences else (x.shape[0], H), np.float32)
+    check(capi.load().GRUStack2ApplyInferenceBatch(g1.h, g2.h, _p(x), _p(out), x.shape[0]), "GRUStack2ApplyInferenceBatch")
+    return out
+
+
 class RNN(_Recurrent):
     """One-gate recurrent layer (rnn.h); `act` is an ActivationFunction handle (default tanh over H)."""
 

@@ -299,3 +299,48 @@ def test_streaming_last_state_only_and_reset(gpu):
     l.reset_state()
     np.testing.assert_allclose(l.apply(x[:T]), full[T - 1], rtol=1e-5, atol=1e-5)
     l.destroy()
+
+
+# ---- fused two-layer GRU (BASELINE configs[3]) ----
+
+@pytest.mark.parametrize("B,I,H,T,seq", [(70, 128, 256, 40, True), (3, 24, 64, 17, True), (130, 16, 128, 9, False), (65, 40, 256, 5, True)])
+def test_fused_two_layer_gru_matches_two_calls_and_oracle(gpu, B, I, H, T, seq):
+    """GRUStack2ApplyDevice: both layers in ONE persistent launch, layer 2 one step behind.  Against the oracle, and
+    against the two single-layer calls: equal within the layer tolerance (layer 2's input projection is summed in the
+    MFMA's k order instead of the GEMM kernel's), and the fused form itself is reproducible and shard-independent."""
+    import torch
+    r = rng(B * 7 + H)
+    x = u(r, B, T, I)
+    W1, U1, bi1, bh1 = u(r, I, 3 * H, sc=I ** -0.5), u(r, H, 3 * H, sc=H ** -0.5), u(r, 3 * H, sc=0.1), u(r, 3 * H, sc=0.1)
+    W2, U2, bi2, bh2 = u(r, H, 3 * H, sc=H ** -0.5), u(r, H, 3 * H, sc=H ** -0.5), u(r, 3 * H, sc=0.1), u(r, 3 * H, sc=0.1)
+    g1, g2 = NL.GRU(I, H, True, T), NL.GRU(H, H, seq, T)
+    g1.set_weights(W1, U1, bi1, bh1); g2.set_weights(W2, U2, bi2, bh2)
+    ref = O.gru(O.gru(x, W1, U1, bi1, bh1), W2, U2, bi2, bh2, return_sequences=seq)
+    fused = NL.gru_stack2_apply(g1, g2, x)
+    capi.set_option("rec_fused2", 0)
+    two = NL.gru_stack2_apply(g1, g2, x)                       # falls back to the two calls
+    capi.set_option("rec_fused2", "auto")
+    e_f, e_t, e_ft = float(np.abs(fused - ref).max()), float(np.abs(two - ref).max()), float(np.abs(fused - two).max())
+    print("fused GRU stack B=%d H=%d T=%d: vs oracle %.2e (two calls %.2e), fused vs two calls %.2e" % (B, H, T, e_f, e_t, e_ft))
+    assert e_f < 1e-5 and e_t < 1e-5 and e_ft < 5e-6
+    xd = torch.from_numpy(x).cuda()
+    a = NL.gru_stack2_apply_device(g1, g2, xd).cpu().numpy()
+    assert np.array_equal(a, fused)                            # reproducible
+    lo = NL.gru_stack2_apply_device(g1, g2, xd[: B // 2 + 1].contiguous()).cpu().numpy()
+    assert np.array_equal(lo, fused[: B // 2 + 1])             # a shard gives the same bits as the whole batch
+    g1.destroy(); g2.destroy()
+
+
+def test_fused_gru_stack_falls_back_for_other_activations(gpu):
+    L = capi.load()
+    r = rng(9)
+    B, I, H, T = 4, 8, 16, 6
+    x = u(r, B, T, I)
+    W1, U1, bi1, bh1 = u(r, I, 3 * H, sc=0.3), u(r, H, 3 * H, sc=0.2), u(r, 3 * H, sc=0.1), u(r, 3 * H, sc=0.1)
+    W2, U2, bi2, bh2 = u(r, H, 3 * H, sc=0.3), u(r, H, 3 * H, sc=0.2), u(r, 3 * H, sc=0.1), u(r, 3 * H, sc=0.1)
+    acts = L.GRUActivationsCreate(L.ActivationFunctionCreateSigmoid(H), L.ActivationFunctionCreateReLU(H, C.c_float(0.5)), L.ActivationFunctionCreateSigmoid(H))
+    g1, g2 = NL.GRU(I, H, True, T), NL.GRU(H, H, True, T, acts=acts)
+    g1.set_weights(W1, U1, bi1, bh1); g2.set_weights(W2, U2, bi2, bh2)
+    ref = O.gru(O.gru(x, W1, U1, bi1, bh1), W2, U2, bi2, bh2, acts=(O.ACT_SIGMOID, O.ACT_RELU, O.ACT_SIGMOID), relu_a=(1, 0.5, 1))
+    np.testing.assert_allclose(NL.gru_stack2_apply(g1, g2, x), ref, rtol=1e-5, atol=1e-5)
+    g1.destroy(); g2.destroy()
