@@ -676,8 +676,9 @@ static size_t rec_cnt_words_fwd(int B);
 // one step behind layer 1.  In iteration i a workgroup computes, for its 64 batch rows x 16 hidden units,
 //     layer 1, step i     :  U1^T . h1_{i-1}                       (split-K over the two waves of a slab, as above)
 //     layer 2, step i - 1 :  W2^T . h1_{i-1}   and   U2^T . h2_{i-2}   (one full-K product per wave of the slab)
-// -- everything it needs was published in iteration i-1, so there is ONE hand-off (one arrival counter, one poll)
-// per iteration for both layers instead of two, layer 2's input projection (a 403 GFLOP GEMM launch and its
+// -- everything it needs was published in iteration i-1.  Each layer keeps its own hand-off chain (own arrival counter):
+// while the workgroup multiplies for one layer, the other layer's publication -> arrival -> poll latency elapses, which
+// is what bounds the single-layer GRU-256 kernel.  Layer 2's input projection (a 403 GFLOP GEMM launch and its
 // [T, B, 3H] tensor) disappears into the resident W2^T tile, and the inter-layer [B, T, H] tensor never reaches HBM.
 // Three 48 x K tiles stay in LDS (H = 256: 2 x 50.7 KB + 49.9 KB + the 12 KB exchange = 163.6 of 160 KiB = 163.8 KB;
 // W2^T takes the 260-float row stride -- one 2-way bank conflict per b128 group -- because three 264-float tiles do
@@ -719,7 +720,7 @@ __global__ __launch_bounds__(512, 2) void gru2_persistent_kernel(Gru2Params p) {
     const int bt = blockIdx.x % p.NBT, ct = blockIdx.x / p.NBT;
     const int b0 = p.b_base + bt * REC_BM, j0 = ct * REC_HN;
     const int GH = G * p.H;
-    unsigned *cnt = p.cnt + (size_t)bt * RECP_CNT_STRIDE;
+    unsigned *cnt = p.cnt + (size_t)bt * 2 * RECP_CNT_STRIDE;       // two counters per batch tile: layer 1, layer 2
     const int b = b0 + slab * 16 + l15;
     const int j = j0 + q * 4 + grp * 2;           // this lane finishes hidden units j, j + 1 of row b, in both layers
     const bool row_ok = b < p.B;
@@ -770,61 +771,53 @@ __global__ __launch_bounds__(512, 2) void gru2_persistent_kernel(Gru2Params p) {
     const int uoff = l15 * US + q * 4, woff = l15 * WS + q * 4;
     __syncthreads();
 
+    // Two hand-off chains, one per layer, each with its own arrival counter: while the workgroup multiplies for one
+    // layer, the other layer's publication -> arrival -> poll latency elapses (the two layers play the roles of the
+    // ping-pong halves of the LSTM kernel, in one instruction stream).
+    auto wait_for = [&](unsigned *c, unsigned target) {
+        if (w8 == 0 && lane == 0) {
+            const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+            bool expired = p.spin_ticks == 0;
+            while (!expired && __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                expired = __builtin_amdgcn_s_memrealtime() - t_start > p.spin_ticks;
+            }
+            if (expired) {
+                __hip_atomic_fetch_or(p.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_or(c, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+    };
+    unsigned *cnt1 = cnt, *cnt2 = cnt + RECP_CNT_STRIDE;
+
     for (int i = 0; i <= p.T; ++i) {
         const bool do1 = i < p.T, do2 = i > 0;                // layer 1 runs step i, layer 2 step i - 1
-        // ---- wait for iteration i - 1's publication (both layers' h ride on the same counter) ----
-        if (i > 0) {
-            if (w8 == 0 && lane == 0) {
-                const unsigned target = (unsigned)p.NCT * (unsigned)i;
-                const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-                bool expired = p.spin_ticks == 0;
-                while (!expired && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                    __builtin_amdgcn_s_sleep(1);
-                    expired = __builtin_amdgcn_s_memrealtime() - t_start > p.spin_ticks;
-                }
-                if (expired) {
-                    __hip_atomic_fetch_or(p.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_fetch_or(cnt, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            __syncthreads();
-        }
-        // ---- operands: h1_{i-1} (parity i & 1 of layer 1's buffers), h2_{i-2} (parity (i - 1) & 1 of layer 2's) ----
-        // wave grp 0: all of h1 (its layer-1 half is pieces (ch, 0)); wave grp 1: h1 pieces (ch, 1) and all of h2
-        v4u32 h1own[NCH], hfull[2 * NCH];
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-            const int so = h_slab_off + (2 * ch + grp) * 1024;
-            h1own[ch] = (i & 1) ? __builtin_amdgcn_raw_buffer_load_b128(r1b, h_lane_off, so, 16)
-                                : __builtin_amdgcn_raw_buffer_load_b128(r1a, h_lane_off, so, 16);
-        }
-        if (do2) {
-#pragma unroll
-            for (int pc = 0; pc < 2 * NCH; ++pc) {
-                const int so = h_slab_off + pc * 1024;
-                if (grp == 0) hfull[pc] = (i & 1) ? __builtin_amdgcn_raw_buffer_load_b128(r1b, h_lane_off, so, 16)
-                                                  : __builtin_amdgcn_raw_buffer_load_b128(r1a, h_lane_off, so, 16);
-                else          hfull[pc] = ((i - 1) & 1) ? __builtin_amdgcn_raw_buffer_load_b128(r2b, h_lane_off, so, 16)
-                                                        : __builtin_amdgcn_raw_buffer_load_b128(r2a, h_lane_off, so, 16);
-            }
-        }
-        // layer 1's xW for step i: one 16-byte load per gate (the quad of hidden units this lane and its partner share)
-        float xw1[2][G];
+        // =============================== layer 1, step i ===============================
         if (do1) {
-            const float *xw = p.xw1 + ((size_t)i * p.B + b) * GH + (j & ~3);
+            if (i > 0) wait_for(cnt1, (unsigned)p.NCT * (unsigned)i);      // h1_{i-1} is published
+            v4u32 h1own[NCH];
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok0) x4 = *reinterpret_cast<const float4 *>(xw + g * p.H);
-                xw1[0][g] = grp ? x4.z : x4.x;
-                xw1[1][g] = grp ? x4.w : x4.y;
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int so = h_slab_off + (2 * ch + grp) * 1024;
+                h1own[ch] = (i & 1) ? __builtin_amdgcn_raw_buffer_load_b128(r1b, h_lane_off, so, 16)
+                                    : __builtin_amdgcn_raw_buffer_load_b128(r1a, h_lane_off, so, 16);
             }
-        }
-        // ---- layer 1: U1^T . h1_{i-1}, this wave's K half ----
-        f32x4 acc1[G], acc2[G];
+            // xW for this step: one 16-byte load per gate (the quad of hidden units this lane and its partner share)
+            float xw1[2][G];
+            {
+                const float *xw = p.xw1 + ((size_t)i * p.B + b) * GH + (j & ~3);
 #pragma unroll
-        for (int g = 0; g < G; ++g) { acc1[g] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[g] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-        if (do1) {
+                for (int g = 0; g < G; ++g) {
+                    float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ok0) x4 = *reinterpret_cast<const float4 *>(xw + g * p.H);
+                    xw1[0][g] = grp ? x4.z : x4.x;
+                    xw1[1][g] = grp ? x4.w : x4.y;
+                }
+            }
+            f32x4 acc1[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc1[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 const float hv[4] = {__uint_as_float(h1own[ch].x), __uint_as_float(h1own[ch].y),
@@ -840,9 +833,65 @@ __global__ __launch_bounds__(512, 2) void gru2_persistent_kernel(Gru2Params p) {
                         acc1[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(u, hv[sI], acc1[g], 0, 0, 0);
                     }
             }
+            // split-K exchange: send the half the partner wave finishes
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) my_red[(g * 2 + e) * 64 + lane] = grp ? acc1[g][e] : acc1[g][2 + e];
+            __syncthreads();
+            float h1n[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float fin[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const float other = peer_red[(g * 2 + e) * 64 + lane];
+                    const float mine = grp ? acc1[g][2 + e] : acc1[g][e];
+                    fin[g] = grp == 0 ? mine + other : other + mine;          // always (half 0) + (half 1)
+                }
+                // gru.c:144-186, same code as the single-layer kernel
+                const float hz = fin[0] + bh1[e][0], hr = fin[1] + bh1[e][1], hh = fin[2] + bh1[e][2];
+                const float z = nntk_fast_sigmoid(xw1[e][0] + hz);
+                const float rg = nntk_fast_sigmoid(xw1[e][1] + hr);
+                const float ht = nntk_fast_tanh(fmaf(rg, hh, xw1[e][2]));
+                h1n[e] = fmaf(-z + 1.0f, ht, z * prev1[e]);
+                prev1[e] = h1n[e];
+            }
+            float *hdst = p.hbuf1 + (size_t)((i + 1) & 1) * p.hb_floats + h_pub_off;
+            if (ok1) {
+                const unsigned long long pk = ((unsigned long long)__float_as_uint(h1n[1]) << 32) | __float_as_uint(h1n[0]);
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(hdst), pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (ok0) {
+                __hip_atomic_store(reinterpret_cast<unsigned *>(hdst), __float_as_uint(h1n[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // R1: every storing wave drains ...
+            __syncthreads();                                      // ... the workgroup meets (this also frees `red`) ...
+            if (tid == 0) __hip_atomic_fetch_add(cnt1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... ONE lane arrives
+            if (p.out1) {
+                float *o = p.out1 + ((size_t)b * p.T + i) * p.H + j;
+                if (ok1) *reinterpret_cast<float2 *>(o) = make_float2(h1n[0], h1n[1]);
+                else if (ok0) o[0] = h1n[0];
+            }
         }
-        // ---- layer 2, full K in one wave: grp 0 multiplies W2^T . h1_{i-1}, grp 1 multiplies U2^T . h2_{i-2} ----
+        // =============================== layer 2, step i - 1 ===============================
         if (do2) {
+            // its inputs: h1_{i-1} (arrival i on layer 1's counter: seen by this workgroup's own poll above, or, in the
+            // last iteration, polled here) and h2_{i-2} (arrival i - 1 on layer 2's counter)
+            if (!do1) wait_for(cnt1, (unsigned)p.NCT * (unsigned)i);
+            if (i > 1) wait_for(cnt2, (unsigned)p.NCT * (unsigned)(i - 1));
+            // one full-K product per wave of the slab: grp 0 multiplies W2^T . h1_{i-1}, grp 1 multiplies U2^T . h2_{i-2}
+            v4u32 hfull[2 * NCH];
+#pragma unroll
+            for (int pc = 0; pc < 2 * NCH; ++pc) {
+                const int so = h_slab_off + pc * 1024;
+                if (grp == 0) hfull[pc] = (i & 1) ? __builtin_amdgcn_raw_buffer_load_b128(r1b, h_lane_off, so, 16)
+                                                  : __builtin_amdgcn_raw_buffer_load_b128(r1a, h_lane_off, so, 16);
+                else          hfull[pc] = ((i - 1) & 1) ? __builtin_amdgcn_raw_buffer_load_b128(r2b, h_lane_off, so, 16)
+                                                        : __builtin_amdgcn_raw_buffer_load_b128(r2a, h_lane_off, so, 16);
+            }
+            f32x4 acc2[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc2[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int pc = 0; pc < 2 * NCH; ++pc) {
                 const float hv[4] = {__uint_as_float(hfull[pc].x), __uint_as_float(hfull[pc].y),
@@ -860,98 +909,46 @@ __global__ __launch_bounds__(512, 2) void gru2_persistent_kernel(Gru2Params p) {
                         acc2[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(u, hv[sI], acc2[g], 0, 0, 0);
                     }
             }
-        }
-        // ---- exchange 1 (layer 1 split-K): send the half the partner wave finishes ----
-        float fin1[2][G];
-        if (do1) {
-#pragma unroll
-            for (int g = 0; g < G; ++g)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) my_red[(g * 2 + e) * 64 + lane] = grp ? acc1[g][e] : acc1[g][2 + e];
-        }
-        __syncthreads();
-        if (do1) {
-#pragma unroll
-            for (int g = 0; g < G; ++g)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const float other = peer_red[(g * 2 + e) * 64 + lane];
-                    const float mine = grp ? acc1[g][2 + e] : acc1[g][e];
-                    fin1[e][g] = grp == 0 ? mine + other : other + mine;      // always (half 0) + (half 1)
-                }
-        }
-        __syncthreads();                                          // red is read: free for exchange 2
-        // ---- exchange 2 (layer 2): the W2 wave and the U2 wave swap the halves the other one finishes ----
-        float xw2[2][G], hu2[2][G];
-        if (do2) {
+            // the W2 wave and the U2 wave swap the halves the other one finishes
 #pragma unroll
             for (int g = 0; g < G; ++g)
 #pragma unroll
                 for (int e = 0; e < 2; ++e) my_red[(g * 2 + e) * 64 + lane] = grp ? acc2[g][e] : acc2[g][2 + e];
-        }
-        __syncthreads();
-        if (do2) {
+            __syncthreads();
+            float h2n[2];
 #pragma unroll
-            for (int g = 0; g < G; ++g)
+            for (int e = 0; e < 2; ++e) {
+                float xw2[G], hu2[G];
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
+                for (int g = 0; g < G; ++g) {
                     const float other = peer_red[(g * 2 + e) * 64 + lane];
                     const float mine = grp ? acc2[g][2 + e] : acc2[g][e];
-                    xw2[e][g] = (grp == 0 ? mine : other) + bi2[e][g];       // x W2 + b_i2, as the projection GEMM's epilogue
-                    hu2[e][g] = grp == 0 ? other : mine;
+                    xw2[g] = (grp == 0 ? mine : other) + bi2[e][g];          // x W2 + b_i2, as the projection GEMM's epilogue
+                    hu2[g] = grp == 0 ? other : mine;
                 }
-        }
-        // ---- gates (gru.c:144-186, same code as the single-layer kernel) and publication ----
-        float h1n[2] = {0.f, 0.f}, h2n[2] = {0.f, 0.f};
-        if (do1) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const float hz = fin1[e][0] + bh1[e][0], hr = fin1[e][1] + bh1[e][1], hh = fin1[e][2] + bh1[e][2];
-                const float z = nntk_fast_sigmoid(xw1[e][0] + hz);
-                const float rg = nntk_fast_sigmoid(xw1[e][1] + hr);
-                const float ht = nntk_fast_tanh(fmaf(rg, hh, xw1[e][2]));
-                h1n[e] = fmaf(-z + 1.0f, ht, z * prev1[e]);
-                prev1[e] = h1n[e];
-            }
-            float *hdst = p.hbuf1 + (size_t)((i + 1) & 1) * p.hb_floats + h_pub_off;
-            if (ok1) {
-                const unsigned long long pk = ((unsigned long long)__float_as_uint(h1n[1]) << 32) | __float_as_uint(h1n[0]);
-                __hip_atomic_store(reinterpret_cast<unsigned long long *>(hdst), pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else if (ok0) {
-                __hip_atomic_store(reinterpret_cast<unsigned *>(hdst), __float_as_uint(h1n[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        if (do2) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const float hz = hu2[e][0] + bh2[e][0], hr = hu2[e][1] + bh2[e][1], hh = hu2[e][2] + bh2[e][2];
-                const float z = nntk_fast_sigmoid(xw2[e][0] + hz);
-                const float rg = nntk_fast_sigmoid(xw2[e][1] + hr);
-                const float ht = nntk_fast_tanh(fmaf(rg, hh, xw2[e][2]));
+                const float hz = hu2[0] + bh2[e][0], hr = hu2[1] + bh2[e][1], hh = hu2[2] + bh2[e][2];
+                const float z = nntk_fast_sigmoid(xw2[0] + hz);
+                const float rg = nntk_fast_sigmoid(xw2[1] + hr);
+                const float ht = nntk_fast_tanh(fmaf(rg, hh, xw2[2]));
                 h2n[e] = fmaf(-z + 1.0f, ht, z * prev2[e]);
                 prev2[e] = h2n[e];
             }
-            float *hdst = p.hbuf2 + (size_t)(i & 1) * p.hb_floats + h_pub_off;      // h2_{i-1}: read next iteration as parity ((i + 1) - 1) & 1
+            float *hdst = p.hbuf2 + (size_t)(i & 1) * p.hb_floats + h_pub_off;      // h2_{i-1}: read next iteration at parity ((i + 1) - 1) & 1
             if (ok1) {
                 const unsigned long long pk = ((unsigned long long)__float_as_uint(h2n[1]) << 32) | __float_as_uint(h2n[0]);
                 __hip_atomic_store(reinterpret_cast<unsigned long long *>(hdst), pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else if (ok0) {
                 __hip_atomic_store(reinterpret_cast<unsigned *>(hdst), __float_as_uint(h2n[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // R1: every storing wave drains ...
-        __syncthreads();                                          // ... the workgroup meets (this also frees `red`) ...
-        if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... ONE lane arrives
-        // layer outputs (never read inside this launch) go out after the arrival
-        if (do2 && (p.return_sequences || i == p.T)) {
-            float *o = p.return_sequences ? p.out + ((size_t)b * p.T + (i - 1)) * p.H + j : p.out + (size_t)b * p.H + j;
-            if (ok1) *reinterpret_cast<float2 *>(o) = make_float2(h2n[0], h2n[1]);
-            else if (ok0) o[0] = h2n[0];
-        }
-        if (do1 && p.out1) {
-            float *o = p.out1 + ((size_t)b * p.T + i) * p.H + j;
-            if (ok1) *reinterpret_cast<float2 *>(o) = make_float2(h1n[0], h1n[1]);
-            else if (ok0) o[0] = h1n[0];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(cnt2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // layer-2 output (never read inside this launch) goes out after the arrival
+            if (p.return_sequences || i == p.T) {
+                float *o = p.return_sequences ? p.out + ((size_t)b * p.T + (i - 1)) * p.H + j : p.out + (size_t)b * p.H + j;
+                if (ok1) *reinterpret_cast<float2 *>(o) = make_float2(h2n[0], h2n[1]);
+                else if (ok0) o[0] = h2n[0];
+            }
         }
     }
 }
@@ -989,7 +986,7 @@ extern "C" int nntk_shim_gru2(const float *d_xw1, const float *d_ut1, const floa
     if (nntk_set_max_dynamic_lds((const void *)kern, lds)) return -1;
     unsigned *cnt = reinterpret_cast<unsigned *>(d_work + 4 * hbmax);
     const int nbt_total = (B + REC_BM - 1) / REC_BM;
-    if (nntk_shim_memset(d_work, 0, 4 * hbmax * 4 + (size_t)nbt_total * RECP_CNT_STRIDE * sizeof(unsigned))) return -1;
+    if (nntk_shim_memset(d_work, 0, 4 * hbmax * 4 + (size_t)nbt_total * 2 * RECP_CNT_STRIDE * sizeof(unsigned))) return -1;
     Gru2Params q;
     q.xw1 = d_xw1; q.ut1 = d_ut1; q.bh1 = d_bh1; q.wt2 = d_wt2; q.bi2 = d_bi2; q.ut2 = d_ut2; q.bh2 = d_bh2;
     q.hbuf1 = d_work; q.hbuf2 = d_work + 2 * hbmax; q.hb_floats = hb_floats;
@@ -1001,7 +998,7 @@ extern "C" int nntk_shim_gru2(const float *d_xw1, const float *d_ut1, const floa
     for (int bt0 = 0; bt0 < nbt_total; bt0 += tiles_per_launch) {
         const int nbt = nbt_total - bt0 < tiles_per_launch ? nbt_total - bt0 : tiles_per_launch;
         q.NBT = nbt; q.b_base = bt0 * REC_BM;
-        q.cnt = cnt + (size_t)bt0 * RECP_CNT_STRIDE;
+        q.cnt = cnt + (size_t)bt0 * 2 * RECP_CNT_STRIDE;
         hipLaunchKernelGGL(kern, dim3((unsigned)(nbt * NCT)), dim3(512), lds, nntk_stream(), q);
     }
     const int copy_rc = nntk_fault_enqueue_copy();
