@@ -78,8 +78,18 @@ Conv1dConfig Conv1dConfigCreate(int input_feature_channels, int output_feature_c
                                 int stride, int inputSize);
 Conv1d Conv1dCreateForInference(Conv1dConfig config);
 ConvWeights *Conv1dGetWeights(Conv1d filter);            /* W [Cout][Cin][k] then b [Cout], one block */
-int  Conv1dApplyInference(Conv1d filter, const float *input, float *output);   /* host, one sequence */
+int  Conv1dApplyInference(Conv1d filter, const float *input, float *output);   /* host, one sequence; -1 on a training handle */
 void Conv1dDestroy(Conv1d filter);
+/* training, first slice (layers/conv_1d.h:20, :43-51, shared.h:12-36): mini-batch forward that keeps its
+ * input, and the gradient d_W / d_b (added to the block) / d_X (overwritten).  Deterministic, untuned. */
+typedef DefaultTrainingConfig ConvTrainingConfig;
+typedef struct { float *d_W; float *d_b; float *d_X; } DefaultGradient;      /* one zeroed block d_W | d_b | d_X */
+typedef DefaultGradient ConvGradient;
+Conv1d Conv1dCreateForTraining(Conv1dConfig config, ConvTrainingConfig training_config);
+ConvGradient *Conv1dCreateGradient(Conv1dConfig config, ConvTrainingConfig training_config);
+void ConvGradientDestroy(ConvGradient *gradient);
+int  Conv1dApplyTrainingBatch(Conv1d filter, const float *input /*[mini_batch,T,Cin]*/, float *output);   /* -1 on an inference handle */
+void Conv1dCalculateGradient(Conv1d filter, ConvGradient *gradient, const float *d_out /*[mini_batch,Tout,Cout]*/);
 
 /* ---- nntoolkitcore/layers/batch_norm.h:19-66 --------------------------- */
 typedef struct { float *gamma; float *beta; float *moving_mean; float *moving_variance; } BatchNormWeights;

@@ -23,6 +23,14 @@ class Conv1dConfig(C.Structure):
                 ("kernel_size", C.c_int), ("stride", C.c_int), ("input_size", C.c_int), ("output_size", C.c_int)]
 
 
+class ConvTrainingConfig(C.Structure):
+    _fields_ = [("mini_batch_size", C.c_int)]
+
+
+class DefaultGradient(C.Structure):
+    _fields_ = [("d_W", fp), ("d_b", fp), ("d_X", fp)]
+
+
 class DefaultWeights(C.Structure):
     _fields_ = [("W", fp), ("b", fp)]
 
@@ -104,6 +112,11 @@ SIGNATURES = {
     "Conv1dGetWeights": (C.POINTER(DefaultWeights), [vp]),
     "Conv1dApplyInference": (C.c_int, [vp, fp, fp]),
     "Conv1dDestroy": (None, [vp]),
+    "Conv1dCreateForTraining": (vp, [Conv1dConfig, ConvTrainingConfig]),
+    "Conv1dCreateGradient": (C.POINTER(DefaultGradient), [Conv1dConfig, ConvTrainingConfig]),
+    "ConvGradientDestroy": (None, [C.POINTER(DefaultGradient)]),
+    "Conv1dApplyTrainingBatch": (C.c_int, [vp, fp, fp]),
+    "Conv1dCalculateGradient": (None, [vp, C.POINTER(DefaultGradient), fp]),
     # batch_norm.h
     "BatchNormConfigCreate": (BatchNormConfig, [C.c_int, C.c_float, C.c_int]),
     "BatchNormCreateForInference": (vp, [BatchNormConfig]),

@@ -74,6 +74,11 @@ int  nntk_shim_conv1d(const float *d_in, const float *d_wp, const float *d_bias,
                       float bn_eps, int act_kind, float relu_a, float *d_out,
                       int B, int T, int Cin, int Cout, int k, int stride, int Tout, int out_mode);
 
+/* ---- training, first slice: Conv1dCalculateGradient (conv_1d.c:185-245); untuned VALU kernels, deterministic ---- */
+size_t nntk_shim_conv1d_grad_scratch_floats(int Cin, int Cout, int k);
+int nntk_shim_conv1d_grad(const float *d_in, const float *d_W, const float *d_dout, float *d_dW, float *d_db,
+                          float *d_dX, float *d_scratch, int B, int T, int Cin, int Cout, int k, int stride, int Tout);
+
 /* ---- standalone BatchNorm (batch_norm.c:140-163 op order) and activations -- */
 int nntk_shim_batch_norm(const float *d_in, const float *d_bn /*gamma|beta|mean|var*/, float eps,
                          float *d_out, long rows, int C);

@@ -16,6 +16,10 @@ struct Conv1dStruct {
     nntk_wblock wb;
     float *d_wp, *d_bias;
     nntk_devbuf d_in, d_out;
+    /* training mode (conv_1d.c:104-108): mini-batch size, the last forward pass's input kept on the device for the
+     * gradient, and the gradient scratch */
+    int training, mini_batch;
+    nntk_devbuf d_cache, d_dout, d_grad, d_wraw, d_scratch;
 };
 
 /* conv_1d.c:77-87 */
@@ -45,6 +49,15 @@ Conv1d Conv1dCreateForInference(Conv1dConfig config) {
     return f;
 }
 
+/* conv_1d.c:104-108 */
+Conv1d Conv1dCreateForTraining(Conv1dConfig config, ConvTrainingConfig training_config) {
+    Conv1d f = Conv1dCreateForInference(config);
+    if (!f) return NULL;
+    f->training = 1;
+    f->mini_batch = training_config.mini_batch_size;
+    return f;
+}
+
 ConvWeights *Conv1dGetWeights(Conv1d filter) { return filter->weights; }
 
 void Conv1dDestroy(Conv1d filter) {
@@ -54,6 +67,8 @@ void Conv1dDestroy(Conv1d filter) {
     nntk_shim_free(filter->d_bias);
     nntk_devbuf_free(&filter->d_in);
     nntk_devbuf_free(&filter->d_out);
+    nntk_devbuf_free(&filter->d_cache); nntk_devbuf_free(&filter->d_dout); nntk_devbuf_free(&filter->d_grad);
+    nntk_devbuf_free(&filter->d_wraw); nntk_devbuf_free(&filter->d_scratch);
     nntk_wblock_free(&filter->wb);
     free(filter->weights);
     free(filter);
@@ -152,9 +167,78 @@ int Conv1dApplyInferenceBatch(Conv1d filter, const float *input, float *output, 
     return nntk_shim_download(output, d_out, n_out * sizeof(float));
 }
 
-/* conv_1d.c:149-155: one [T, Cin] sequence -> [Tout, Cout] */
+/* conv_1d.c:149-155: one [T, Cin] sequence -> [Tout, Cout]; -1 for a training-mode handle (:150-152, pinned by the real
+ * reference: tests/golden/ref_probe.json "wrong_mode_apply_inference") */
 int Conv1dApplyInference(Conv1d filter, const float *input, float *output) {
+    nntk_shim_clear_error();
+    if (filter && filter->training) NNTK_FAIL("Conv1dApplyInference: the handle was created for training");
     return Conv1dApplyInferenceBatch(filter, input, output, 1);
+}
+
+/* ---- training, first slice: forward over the mini-batch with the input kept for the gradient
+ *      (conv_1d.c:167-183) and Conv1dCalculateGradient (conv_1d.c:185-245) ---- */
+int Conv1dApplyTrainingBatch(Conv1d filter, const float *input, float *output) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("Conv1dApplyTrainingBatch: NULL handle");
+    if (!filter->training) NNTK_FAIL("Conv1dApplyTrainingBatch: the handle was created for inference");     /* conv_1d.c:168-170 */
+    const Conv1dConfig *c = &filter->config;
+    const int B = filter->mini_batch;
+    if (B <= 0) return 0;
+    if (conv_ensure(filter, 1)) return -1;
+    size_t n_in = (size_t)B * c->input_size * c->input_feature_channels;
+    size_t n_out = (size_t)B * c->output_size * c->output_feature_channels;
+    float *d_in = nntk_devbuf_reserve(&filter->d_cache, n_in);
+    float *d_out = nntk_devbuf_reserve(&filter->d_out, n_out);
+    if (!d_in || !d_out) return -1;
+    if (nntk_shim_upload(d_in, input, n_in * sizeof(float))) return -1;
+    if (conv_launch(filter, NULL, 0.f, NNTK_ACT_IDENTITY, 1.f, d_in, d_out, B)) return -1;
+    return nntk_shim_download(output, d_out, n_out * sizeof(float));
+}
+
+/* conv_1d.c:157-161 with weights_private.c:29-36: ONE zeroed block d_W | d_b | d_X */
+ConvGradient *Conv1dCreateGradient(Conv1dConfig config, ConvTrainingConfig training_config) {
+    ConvGradient *g = (ConvGradient *)malloc(sizeof(ConvGradient));
+    if (!g) return NULL;
+    size_t w = (size_t)config.kernel_size * config.input_feature_channels * config.output_feature_channels;
+    size_t x = (size_t)training_config.mini_batch_size * config.input_size * config.input_feature_channels;
+    g->d_W = (float *)calloc(w + config.output_feature_channels + x + 1, sizeof(float));
+    if (!g->d_W) { free(g); return NULL; }
+    g->d_b = g->d_W + w;
+    g->d_X = g->d_b + config.output_feature_channels;
+    return g;
+}
+void ConvGradientDestroy(ConvGradient *gradient) {
+    if (!gradient) return;
+    free(gradient->d_W);
+    free(gradient);
+}
+
+/* d_W and d_b are ADDED to the gradient block (as default_gradient_sum does, weights_private.c:50-55), d_X is overwritten
+ * (conv_1d.c:242).  void in the reference; errors through nntk_last_error(). */
+void Conv1dCalculateGradient(Conv1d filter, ConvGradient *gradient, const float *d_out) {
+    nntk_shim_clear_error();
+    if (!filter || !gradient) { nntk_set_error("Conv1dCalculateGradient: NULL argument"); return; }
+    if (!filter->training || !filter->d_cache.p) { nntk_set_error("Conv1dCalculateGradient: run Conv1dApplyTrainingBatch on a training handle first"); return; }
+    const Conv1dConfig *c = &filter->config;
+    const int B = filter->mini_batch, Cin = c->input_feature_channels, Cout = c->output_feature_channels, k = c->kernel_size;
+    const size_t w = (size_t)k * Cin * Cout, n_x = (size_t)B * c->input_size * Cin, n_do = (size_t)B * c->output_size * Cout;
+    float *d_dout = nntk_devbuf_reserve(&filter->d_dout, n_do);
+    float *d_grad = nntk_devbuf_reserve(&filter->d_grad, w + Cout + n_x);
+    float *d_wraw = nntk_devbuf_reserve(&filter->d_wraw, w);
+    float *d_scr = nntk_devbuf_reserve(&filter->d_scratch, nntk_shim_conv1d_grad_scratch_floats(Cin, Cout, k));
+    if (!d_dout || !d_grad || !d_wraw || !d_scr) return;
+    if (nntk_shim_upload(d_dout, d_out, n_do * sizeof(float))) return;
+    if (nntk_shim_upload(d_wraw, filter->weights->W, w * sizeof(float))) return;         /* caller layout [Cout][Cin][k] */
+    if (nntk_shim_conv1d_grad(filter->d_cache.p, d_wraw, d_dout, d_grad, d_grad + w, d_grad + w + Cout, d_scr,
+                              B, c->input_size, Cin, Cout, k, c->stride, c->output_size)) return;
+    float *tmp = (float *)malloc((w + Cout) * sizeof(float));
+    if (!tmp) { nntk_set_error("out of host memory"); return; }
+    if (nntk_shim_download(tmp, d_grad, (w + Cout) * sizeof(float)) == 0 &&
+        nntk_shim_download(gradient->d_X, d_grad + w + Cout, n_x * sizeof(float)) == 0) {
+        for (size_t i = 0; i < w; ++i) gradient->d_W[i] += tmp[i];
+        for (int i = 0; i < Cout; ++i) gradient->d_b[i] += tmp[w + i];
+    }
+    free(tmp);
 }
 
 /* ============================== BatchNorm ================================= */

@@ -88,6 +88,10 @@ void ref_conv1d(const float *in, const float *W, const float *b, float *out,
 void ref_conv1d_batch(const float *in, const float *W, const float *b, float *out,
                       int B, int T, int Cin, int Cout, int k, int stride);
 
+/* training, first slice: Conv1dCalculateGradient (conv_1d.c:185-245): dW, db are added to, dX overwritten */
+void ref_conv1d_gradient(const float *in, const float *W, const float *dout, float *dW, float *db, float *dX,
+                         int B, int T, int Cin, int Cout, int k, int stride);
+
 void ref_batch_norm(const float *in, const float *gamma, const float *beta,
                     const float *mean, const float *variance, float *out,
                     float epsilon, int count, int C);

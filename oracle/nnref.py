@@ -147,6 +147,16 @@ def conv1d(x, W, b, stride=1):
     return out[0] if squeeze else out
 
 
+def conv1d_gradient(x, W, dout, stride=1):
+    """Conv1dCalculateGradient on a fresh (zeroed) gradient block: returns (dW [Cout,Cin,k], db [Cout], dX [B,T,Cin])."""
+    x, W, dout = _f32(x), _f32(W), _f32(dout)
+    B, T, Cin = x.shape
+    Cout, _, k = W.shape
+    dW, db, dX = np.zeros_like(W), np.zeros(Cout, np.float32), np.empty_like(x)
+    lib().ref_conv1d_gradient(_p(x), _p(W), _p(dout), _p(dW), _p(db), _p(dX), B, T, Cin, Cout, k, stride)
+    return dW, db, dX
+
+
 def batch_norm(x, gamma, beta, mean, var, eps):
     x = _f32(x)
     C_ = x.shape[-1]

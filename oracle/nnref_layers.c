@@ -88,6 +88,42 @@ void ref_conv1d_batch(const float *in, const float *W, const float *b, float *ou
 
 /* ------------------------------------------------------------ batch norm --- */
 
+/* layers/conv_1d.c:185-245 (Conv1dCalculateGradient) + weights_private.c:50-55 (default_gradient_sum), in the
+ * reference's loop order: per batch entry b: d_b += rows of d_out; for out_f, out_n, in_f: d_W[out_f][in_f][:] +=
+ * x_row[:] * d_o, d_X_transposed[in_f][out_n*stride + :] += W[out_f][in_f][:] * d_o; then per-batch d_W, d_b summed over b.
+ * dW [Cout][Cin][k] and db [Cout] are ADDED to (the caller's zeroed gradient block), dX [B][T][Cin] is overwritten. */
+void ref_conv1d_gradient(const float *in, const float *W, const float *dout, float *dW, float *db, float *dX,
+                         int B, int T, int Cin, int Cout, int k, int stride) {
+    int Tout = ref_conv1d_output_size(T, k, stride);
+    if (Tout < 0) Tout = 0;
+    size_t w = (size_t)Cout * Cin * k;
+    float *bw = (float *)calloc(w ? w : 1, sizeof(float)), *bb = (float *)calloc((size_t)Cout, sizeof(float));
+    float *xt = (float *)calloc((size_t)Cin * T + 1, sizeof(float)), *dxt = (float *)calloc((size_t)Cin * T + 1, sizeof(float));
+    for (int b = 0; b < B; ++b) {
+        memset(bw, 0, w * sizeof(float)); memset(bb, 0, (size_t)Cout * sizeof(float));
+        memset(dxt, 0, (size_t)Cin * T * sizeof(float));
+        for (int t = 0; t < T; ++t) for (int i = 0; i < Cin; ++i) xt[(size_t)i * T + t] = in[((size_t)b * T + t) * Cin + i];
+        const float *d = dout + (size_t)b * Tout * Cout;
+        for (int o = 0; o < Tout; ++o) for (int f = 0; f < Cout; ++f) bb[f] = bb[f] + d[(size_t)o * Cout + f];
+        for (int of = 0; of < Cout; ++of)
+            for (int on = 0; on < Tout; ++on) {
+                const float d_o = d[(size_t)on * Cout + of];
+                for (int f = 0; f < Cin; ++f) {
+                    const float *row = xt + (size_t)f * T + (size_t)on * stride;
+                    const float *wp = W + ((size_t)of * Cin + f) * k;
+                    float *dw = bw + ((size_t)of * Cin + f) * k;
+                    float *dx = dxt + (size_t)f * T + (size_t)on * stride;
+                    for (int kk = 0; kk < k; ++kk) { float p = row[kk] * d_o; dw[kk] = dw[kk] + p; }
+                    for (int kk = 0; kk < k; ++kk) { float p = wp[kk] * d_o; dx[kk] = dx[kk] + p; }
+                }
+            }
+        for (int t = 0; t < T; ++t) for (int i = 0; i < Cin; ++i) dX[((size_t)b * T + t) * Cin + i] = dxt[(size_t)i * T + t];
+        for (size_t e = 0; e < w; ++e) dW[e] = bw[e] + dW[e];
+        for (int f = 0; f < Cout; ++f) db[f] = bb[f] + db[f];
+    }
+    free(bw); free(bb); free(xt); free(dxt);
+}
+
 /* layers/batch_norm.c:140-163, :166-189:
  * ((x - mean) / sqrt(var + eps)) * gamma + beta, each op a separate rounding */
 void ref_batch_norm(const float *in, const float *gamma, const float *beta,

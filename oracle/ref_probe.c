@@ -240,6 +240,16 @@ int main(int argc, char **argv) {
                DenseApplyInference_p(d, in, out), BatchNormApplyInference_p(bnh, in, out));
     }
     {
+        /* (1b) gradient block of the training path's first slice (conv_1d.c:157-161, weights_private.c:29-36) */
+        typedef ConvGradient *(*conv_grad_fn)(Conv1dConfig, ConvTrainingConfig);
+        SYM(conv_grad_fn, Conv1dCreateGradient)
+        Conv1dConfig cc = Conv1dConfigCreate_p(3, 4, 5, 2, 23);
+        ConvGradient *g = Conv1dCreateGradient_p(cc, (ConvTrainingConfig){2});
+        int zero = 1;
+        for (int i = 0; i < 4 * 3 * 5 + 4 + 2 * 23 * 3; ++i) zero &= g->d_W[i] == 0.0f;
+        printf("  \"conv1d_gradient_block\": {\"d_b_offset\": %td, \"d_X_offset\": %td, \"all_zero\": %d},\n", g->d_b - g->d_W, g->d_X - g->d_W, zero);
+    }
+    {
         /* (2) activation handles: identity copies exactly the size given at create (activation.c:23-25,
          *     activation_default.c:98-103); a custom handle's callback receives (implementer, input, output, size) */
         typedef ActivationFunction (*act_id_fn)(int);

@@ -344,3 +344,53 @@ def test_fused_gru_stack_falls_back_for_other_activations(gpu):
     ref = O.gru(O.gru(x, W1, U1, bi1, bh1), W2, U2, bi2, bh2, acts=(O.ACT_SIGMOID, O.ACT_RELU, O.ACT_SIGMOID), relu_a=(1, 0.5, 1))
     np.testing.assert_allclose(NL.gru_stack2_apply(g1, g2, x), ref, rtol=1e-5, atol=1e-5)
     g1.destroy(); g2.destroy()
+
+
+# ---- training, first slice: Conv1dCalculateGradient ----
+
+@pytest.mark.parametrize("B,T,Cin,Cout,k,s", [(2, 23, 3, 4, 5, 2), (3, 40, 8, 16, 5, 1), (2, 17, 5, 3, 3, 3), (4, 300, 40, 128, 5, 1)])
+def test_conv1d_training_forward_and_gradient(gpu, B, T, Cin, Cout, k, s):
+    """Conv1dCreateForTraining / ApplyTrainingBatch / CreateGradient / CalculateGradient through the C boundary against
+    the oracle (reference loop order) and torch autograd (float64).  d_W, d_b accumulate into the block, d_X is overwritten."""
+    import torch
+    import torch.nn.functional as F
+    L = capi.load()
+    r = rng(B * 31 + T)
+    x = u(r, B, T, Cin)
+    W, b = u(r, Cout, Cin, k, sc=(Cin * k) ** -0.5), u(r, Cout, sc=0.1)
+    cfg = L.Conv1dConfigCreate(Cin, Cout, k, s, T)
+    tc = capi.ConvTrainingConfig(B)
+    h = L.Conv1dCreateForTraining(cfg, tc)
+    w = L.Conv1dGetWeights(h).contents
+    C.memmove(w.W, W.ctypes.data, W.nbytes); C.memmove(w.b, b.ctypes.data, b.nbytes)
+    Tout = cfg.output_size
+    y = np.empty((B, Tout, Cout), np.float32)
+    # wrong-mode calls behave like the reference (golden "wrong_mode_apply_inference": -1)
+    assert L.Conv1dApplyInference(h, x.ctypes.data_as(capi.fp), y.ctypes.data_as(capi.fp)) == -1
+    assert L.Conv1dApplyTrainingBatch(h, x.ctypes.data_as(capi.fp), y.ctypes.data_as(capi.fp)) == 0, capi.last_error()
+    np.testing.assert_allclose(y, O.conv1d(x, W, b, s), rtol=1e-5, atol=1e-5)
+    dout = u(r, B, Tout, Cout)
+    g = L.Conv1dCreateGradient(cfg, tc)
+    L.Conv1dCalculateGradient(h, g, dout.ctypes.data_as(capi.fp))
+    assert capi.last_error() == ""
+    gw = np.ctypeslib.as_array(g.contents.d_W, shape=(Cout, Cin, k)).copy()
+    gb = np.ctypeslib.as_array(g.contents.d_b, shape=(Cout,)).copy()
+    gx = np.ctypeslib.as_array(g.contents.d_X, shape=(B, T, Cin)).copy()
+    dW, db, dX = O.conv1d_gradient(x, W, dout, s)
+    xt, Wt = torch.tensor(x).double().requires_grad_(True), torch.tensor(W).double().requires_grad_(True)
+    bt = torch.zeros(Cout).double().requires_grad_(True)
+    F.conv1d(xt.transpose(1, 2), Wt, bt, stride=s).transpose(1, 2)[:, :Tout].backward(torch.tensor(dout).double())
+    tol = 3e-6 * np.sqrt(B * Tout)
+    for name, got, ora, t64 in (("dW", gw, dW, Wt.grad.numpy()), ("db", gb, db, bt.grad.numpy()), ("dX", gx, dX, xt.grad.numpy())):
+        sc = max(1.0, float(np.abs(t64).max()))
+        e_o, e_t = float(np.abs(got - ora).max()), float(np.abs(got - t64).max())
+        print("conv grad %s (%d,%d,%d,%d,%d,%d): vs oracle %.2e, vs torch float64 %.2e" % (name, B, T, Cin, Cout, k, s, e_o, e_t))
+        assert e_o <= tol * sc and e_t <= tol * sc
+    # a second call accumulates d_W / d_b and rewrites d_X
+    L.Conv1dCalculateGradient(h, g, dout.ctypes.data_as(capi.fp))
+    np.testing.assert_allclose(np.ctypeslib.as_array(g.contents.d_W, shape=(Cout, Cin, k)), 2 * gw, rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(np.ctypeslib.as_array(g.contents.d_X, shape=(B, T, Cin)), gx)
+    # an inference handle refuses the training call
+    hi = L.Conv1dCreateForInference(cfg)
+    assert L.Conv1dApplyTrainingBatch(hi, x.ctypes.data_as(capi.fp), y.ctypes.data_as(capi.fp)) == -1
+    L.Conv1dDestroy(hi); L.ConvGradientDestroy(g); L.Conv1dDestroy(h)

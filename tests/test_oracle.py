@@ -345,3 +345,24 @@ def test_tdd_baseline_shape_vs_float64():
     err = float(np.abs(O.time_distributed_dense(x, W, b) - (x.astype(np.float64) @ W.astype(np.float64) + b)).max())
     print("oracle TDD 512->1000 vs float64: max abs %.2e" % err)
     assert err < 4e-6        # K = 512 left-to-right fp32 sums of terms up to 0.04: ~ sqrt(K) ulp
+
+
+@pytest.mark.parametrize("B,T,Cin,Cout,k,s", [(2, 23, 3, 4, 5, 2), (3, 40, 8, 16, 5, 1), (1, 9, 1, 2, 9, 1), (2, 17, 5, 3, 3, 3), (2, 120, 40, 32, 5, 1)])
+def test_conv1d_gradient_oracle_vs_torch_autograd(B, T, Cin, Cout, k, s):
+    """Training, first slice: the oracle's restatement of Conv1dCalculateGradient (conv_1d.c:185-245)
+    against torch autograd in float64."""
+    import torch
+    import torch.nn.functional as F
+    r = rng(B * 100 + T)
+    x, W = r.standard_normal((B, T, Cin)).astype(np.float32), (r.standard_normal((Cout, Cin, k)) * (Cin * k) ** -0.5).astype(np.float32)
+    Tout = O.conv1d_output_size(T, k, s)
+    dout = r.standard_normal((B, Tout, Cout)).astype(np.float32)
+    dW, db, dX = O.conv1d_gradient(x, W, dout, s)
+    xt, Wt = torch.tensor(x).double().requires_grad_(True), torch.tensor(W).double().requires_grad_(True)
+    bt = torch.zeros(Cout).double().requires_grad_(True)
+    F.conv1d(xt.transpose(1, 2), Wt, bt, stride=s).transpose(1, 2)[:, :Tout].backward(torch.tensor(dout).double())
+    for got, want in ((dW, Wt.grad), (db, bt.grad), (dX, xt.grad)):
+        want = want.numpy()
+        assert np.abs(got - want).max() <= 2e-6 * max(1.0, np.abs(want).max()) * np.sqrt(B * Tout)
+    g = GOLD["conv1d_gradient_block"]          # the real reference's block layout: d_W | d_b | d_X, zeroed
+    assert g == {"d_b_offset": 4 * 3 * 5, "d_X_offset": 4 * 3 * 5 + 4, "all_zero": 1}
