@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Random-shape soak of the conv / dense / recurrent kernels against the oracle (440 cases incl. spectrogram geometries and the RNN, ~30 s on the GPU):
+"""Random-shape soak of the conv / dense / recurrent kernels against the oracle (~580 cases incl. spectrogram geometries, the RNN, and round 2's streaming / fused-GRU / mixed-radix / log-mel paths, ~1 min on the GPU):
 python tools/soak.py [seed]"""
 import os, sys
 import numpy as np
@@ -55,4 +55,62 @@ for _ in range(30):
     v2 = bool(r.integers(0, 2))
     m = NL.RNN(I, H, True, T, v2=v2); m.set_weights(W, U, bi, bh)
     close(m.apply(x), O.rnn(x, W, U, bi, bh, v2=v2), 1e-4); m.destroy(); n += 1
+# ---- round 2 paths: streaming single-sequence calls, fused GRU stack, mixed-radix FFT, fused log-mel ----
+for _ in range(60):
+    I, H = int(r.integers(1, 150)), int(r.integers(1, 130)) * 4
+    T = int(r.integers(1, 33))
+    kind = ("gru", "lstm", "rnn")[int(r.integers(0, 3))]
+    G = {"gru": 3, "lstm": 4, "rnn": 1}[kind]
+    W, U, bi, bh = u(I, G * H, sc=I ** -0.5), u(H, G * H, sc=H ** -0.5), u(G * H, sc=0.1), u(G * H, sc=0.1)
+    x = u(2 * T, I)
+    seq = bool(r.integers(0, 2))
+    l = {"gru": lambda: NL.GRU(I, H, seq, T), "lstm": lambda: NL.LSTM(I, H, seq, T, v2=bool(r.integers(0, 2))), "rnn": lambda: NL.RNN(I, H, seq, T)}[kind]()
+    l.set_weights(W, U, bi, bh)
+    a, b2 = l.apply(x[:T]), l.apply(x[T:])                      # two streaming calls, carried state
+    if kind == "lstm":
+        full = O.lstm(x, W, U, bi, bh, v2=bool(l.cfg.v2))[0]
+    elif kind == "gru":
+        full = O.gru(x, W, U, bi, bh)[0]
+    else:
+        full = O.rnn(x, W, U, bi, bh)[0]
+    ra, rb = (full[:T], full[T:]) if seq else (full[T - 1], full[2 * T - 1])
+    close(a, ra, 1e-4); close(b2, rb, 1e-4); l.destroy(); n += 1
+for _ in range(30):
+    I, H = int(r.integers(1, 150)), int(r.integers(1, 65)) * 4
+    T, B = int(r.integers(1, 12)), int(r.integers(1, 200))
+    x = u(B, T, I)
+    W1, U1, bi1, bh1 = u(I, 3 * H, sc=I ** -0.5), u(H, 3 * H, sc=H ** -0.5), u(3 * H, sc=0.1), u(3 * H, sc=0.1)
+    W2, U2, bi2, bh2 = u(H, 3 * H, sc=H ** -0.5), u(H, 3 * H, sc=H ** -0.5), u(3 * H, sc=0.1), u(3 * H, sc=0.1)
+    seq = bool(r.integers(0, 2))
+    g1, g2 = NL.GRU(I, H, True, T), NL.GRU(H, H, seq, T)
+    g1.set_weights(W1, U1, bi1, bh1); g2.set_weights(W2, U2, bi2, bh2)
+    close(NL.gru_stack2_apply(g1, g2, x), O.gru(O.gru(x, W1, U1, bi1, bh1), W2, U2, bi2, bh2, return_sequences=seq), 1e-4)
+    g1.destroy(); g2.destroy(); n += 1
+for _ in range(40):
+    nfft = int((2 ** r.integers(1, 9)) * (3 ** r.integers(0, 3)) * (5 ** r.integers(0, 2)))
+    if nfft > 4096 or nfft < 4: continue
+    win = int(r.integers(max(2, nfft // 4), nfft + 1)); nov = int(r.integers(0, win))
+    N = int(r.integers(win, win + 40 * (win - nov) + 1)); B = int(r.integers(1, 4))
+    x = u(B, N, sc=0.1)
+    sp = NL.Spectrogram(nfft, win, nov, N, window_name="hamming_window")
+    ref = O.spectrogram(x, O.window("hamming", win), nfft, nov)
+    got = sp.apply(x)
+    assert got.shape == ref.shape and np.abs(got - ref).max() <= 3e-5 * (1e-6 + np.abs(ref).max()), (nfft, win, nov, N)
+    sp.destroy(); n += 1
+import ctypes as C
+L = capi.load()
+for _ in range(15):
+    n_mels = int(r.integers(8, 129)); N = 240 + 160 * int(r.integers(1, 40)); B = int(r.integers(1, 4))
+    x = u(B, N, sc=0.1)
+    sp = NL.Spectrogram(512, 400, 240, N)
+    T = sp.out_shape[0]
+    cfg = L.MelFilterBankConfigCreate(n_mels, 512, 16000, C.c_float(20.0), C.c_float(7600.0))
+    w = O.mel_filterbank_weights(n_mels, 512, 16000, 20.0, 7600.0)
+    spec = O.spectrogram(x, O.window("hann", 400), 512, 240)
+    ref = np.stack([O.log_mel(spec[i], w) for i in range(B)])
+    lm = L.LogMelSpectrogramCreate(sp.h, cfg)
+    out = np.empty((B, T, n_mels), np.float32)
+    assert L.LogMelSpectrogramApplyBatch(lm, x.ctypes.data_as(capi.fp), out.ctypes.data_as(capi.fp), B) == 0
+    assert np.abs(out - ref).max() < 5e-5, (n_mels, N)
+    L.LogMelSpectrogramDestroy(lm); sp.destroy(); n += 1
 print("soak ok:", n, "cases")
