@@ -53,7 +53,7 @@ struct ConvParams {
     long in_seq, in_row; // element strides (T * Cin, Cin for the plain layout)
     const float *wp;     // [Cout_p][k * Cin_p]   (K-contiguous)
     const float *bias;   // [Cout]
-    const float *bn;     // NULL or gamma|beta|mean|var, each [Cout]
+    const float *bn;     // NULL or gamma|beta|mean|var|sd|1/sd, each [Cout] (sd = sqrtf(var + eps), nntk_shim_bn_derive)
     float *out;
     float bn_eps;
     float relu_a;
@@ -64,6 +64,7 @@ struct ConvParams {
     int out_mode;        // 0: row b*Tout+x ; 1: row x*B+b
     int rows_a;          // (BM-1)*stride + k window rows per tile
     int bn_fast;         // A/B: multiply by 1/sd instead of the reference's divide
+    int store16;         // Cout % 4 == 0 and out / bias / bn 16-byte aligned: 16-byte stores of channel quads
 #ifdef NNTK_CONV_DBG
     int dbg;             // timing experiments only: 1 no stores, 2 no MFMAs, 4 no global loads in the loop
 #endif
@@ -84,6 +85,128 @@ typedef unsigned v4u32_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t conv_rsrc(const void *base, size_t bytes) {
     const unsigned n = bytes > (size_t)CONV_OOB ? (unsigned)CONV_OOB : (unsigned)bytes;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)n, 0x00020000);
+}
+
+// ---- epilogue shared by the exact-f32 and the split-bf16 kernels (the C/D layout of a 32x32 MFMA is dtype-independent) ----
+// Both kernels feed the WEIGHTS as the MFMA's A operand and the window as B, so the accumulator tile is TRANSPOSED:
+// a lane owns ONE output position (tile row l31) and register r holds channel 8 (r >> 2) + 4 kh + (r & 3) of the
+// 32-channel tile -- four consecutive channels per register quad, i.e. 16 contiguous bytes of the channels-last output
+// row.  The tile leaves with 16 buffer_store_b128 per wavefront instead of 64 buffer_store_b32 (a vector-memory
+// instruction costs the same ~25 address-unit cycles whatever its width: the 4-byte stores were 150 us of config 3's
+// 490 us on the split path).  Swapping the operands does not change a single product or the order they are summed in.
+//
+// bias, BatchNorm (batch_norm.c:140-163 op order; sd and 1/sd come precomputed behind the four BatchNorm vectors,
+// nntk_shim_bn_derive) and the activation are applied per register quad; the uniform choices (BatchNorm or not, which
+// activation, which store path) are taken ONCE outside the loops.  The descriptor is THIS TILE's output rows (based at
+// the tile's first row, never longer than CONV_OOB bytes): positions past the sequence's end and padded channels get
+// the out-of-range sentinel as their vector offset, so the last row tile needs no separate path.
+template <int TM, int TN, int WN>
+__device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)[TM][TN], int b, int x0, int n0,
+                                              int wm, int wn, int l31, int kh) {
+    const size_t row_elems = (size_t)(p.out_mode ? p.B : 1) * p.Cout;           // distance between output rows x, x+1
+    const size_t row_bytes = row_elems * 4;
+    const size_t obase = (p.out_mode ? (size_t)b * p.Cout : (size_t)b * p.Tout * p.Cout) + (size_t)x0 * row_elems;
+    const size_t oend = p.out_mode ? (size_t)p.Tout * p.B * p.Cout : ((size_t)b + 1) * p.Tout * p.Cout;
+    const __amdgpu_buffer_rsrc_t rs_out = conv_rsrc(p.out + obase, (oend - obase) * 4);
+    const bool vec_store = p.store16 && row_bytes * (size_t)(CONV_BM + 4) < (size_t)CONV_OOB;   // 32-bit offsets reach the tile
+    const int rb = (int)row_bytes;
+
+    auto epilogue = [&](auto bn_tag, auto act_tag, auto vec_tag) {
+        constexpr bool HAS_BN = decltype(bn_tag)::value;
+        constexpr int ACT = decltype(act_tag)::value;            // -1: run-time kind
+        constexpr bool VEC = decltype(vec_tag)::value;
+        int row_voff[TM];                                        // per-lane: this lane's position inside the tile
+        bool row_ok[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int xr = wm * TM * 32 + i * 32 + l31;
+            row_ok[i] = x0 + xr < p.Tout;
+            row_voff[i] = row_ok[i] ? xr * rb + 16 * kh : CONV_OOB;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cu = n0 + wn * TN * 32 + j * 32 + 8 * g;           // wave-uniform first channel of the quad pair
+                const int cb = cu + 4 * kh;                                  // this lane's four channels cb .. cb + 3
+                float bias[4] = {0.f, 0.f, 0.f, 0.f}, ga[4] = {1.f, 1.f, 1.f, 1.f}, be[4] = {0.f, 0.f, 0.f, 0.f},
+                      mu[4] = {0.f, 0.f, 0.f, 0.f}, sd[4] = {1.f, 1.f, 1.f, 1.f}, rsd[4] = {1.f, 1.f, 1.f, 1.f};
+                if (VEC) {                                                   // Cout % 4 == 0: a quad is all in or all out
+                    if (cb < p.Cout) {
+                        if (p.bias) { const float4 t = *reinterpret_cast<const float4 *>(p.bias + cb); bias[0] = t.x; bias[1] = t.y; bias[2] = t.z; bias[3] = t.w; }
+                        if (HAS_BN) {
+                            const float4 t0 = *reinterpret_cast<const float4 *>(p.bn + cb);
+                            const float4 t1 = *reinterpret_cast<const float4 *>(p.bn + p.Cout + cb);
+                            const float4 t2 = *reinterpret_cast<const float4 *>(p.bn + 2 * p.Cout + cb);
+                            const float4 t4 = *reinterpret_cast<const float4 *>(p.bn + 4 * p.Cout + cb);
+                            const float4 t5 = *reinterpret_cast<const float4 *>(p.bn + 5 * p.Cout + cb);
+                            ga[0] = t0.x; ga[1] = t0.y; ga[2] = t0.z; ga[3] = t0.w;
+                            be[0] = t1.x; be[1] = t1.y; be[2] = t1.z; be[3] = t1.w;
+                            mu[0] = t2.x; mu[1] = t2.y; mu[2] = t2.z; mu[3] = t2.w;
+                            sd[0] = t4.x; sd[1] = t4.y; sd[2] = t4.z; sd[3] = t4.w;
+                            rsd[0] = t5.x; rsd[1] = t5.y; rsd[2] = t5.z; rsd[3] = t5.w;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (cb + e < p.Cout) {
+                            if (p.bias) bias[e] = p.bias[cb + e];
+                            if (HAS_BN) {
+                                ga[e] = p.bn[cb + e]; be[e] = p.bn[p.Cout + cb + e]; mu[e] = p.bn[2 * p.Cout + cb + e];
+                                sd[e] = p.bn[4 * p.Cout + cb + e]; rsd[e] = p.bn[5 * p.Cout + cb + e];
+                            }
+                        }
+                }
+                const bool col_ok = cb < p.Cout;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[i][j][4 * g + e] + bias[e];
+                        if (HAS_BN) {
+                            // (v - mu) / sd with the quotient refined by one FMA step: the correctly rounded
+                            // quotient without the 11-instruction IEEE division sequence
+                            const float d = v[e] - mu[e];
+                            float qn = d * rsd[e];
+                            qn = fmaf(fmaf(-qn, sd[e], d), rsd[e], qn);
+                            v[e] = p.bn_fast ? (d * rsd[e]) * ga[e] + be[e] : qn * ga[e] + be[e];
+                        }
+                        v[e] = ACT == -1 ? nntk_act(p.act_kind, v[e], p.relu_a)
+                             : ACT == NNTK_ACT_RELU ? nntk_act(NNTK_ACT_RELU, v[e], p.relu_a)
+                             : v[e];
+                    }
+                    if (VEC) {
+                        const v4u32_t pk = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                        // soffset stays IMMEDIATE on purpose: with an SGPR soffset the compiler inserts no wait state
+                        // before the next VALU write of these data registers (it believes that form has no hazard) and
+                        // MI355X then stores the overwritten value in some lanes (tools/check_store_hazard.py)
+                        __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, col_ok ? row_voff[i] + cu * 4 : CONV_OOB, 0, 0);
+                    } else if (row_ok[i]) {
+                        const int x = x0 + wm * TM * 32 + i * 32 + l31;
+                        const size_t orow = p.out_mode ? ((size_t)x * p.B + b) : ((size_t)b * p.Tout + x);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (cb + e < p.Cout) p.out[orow * p.Cout + cb + e] = v[e];
+                    }
+                }
+            }
+        }
+    };
+    using T_ = std::true_type; using F_ = std::false_type;
+    using AId = std::integral_constant<int, NNTK_ACT_IDENTITY>;
+    using ARelu = std::integral_constant<int, NNTK_ACT_RELU>;
+    using AAny = std::integral_constant<int, -1>;
+    if (vec_store) {
+        if (!p.bn && p.act_kind == NNTK_ACT_IDENTITY) epilogue(F_{}, AId{}, T_{});
+        else if (p.bn && p.act_kind == NNTK_ACT_RELU) epilogue(T_{}, ARelu{}, T_{});
+        else if (p.bn)                                epilogue(T_{}, AAny{}, T_{});
+        else                                          epilogue(F_{}, AAny{}, T_{});
+    } else {
+        if (p.bn) epilogue(T_{}, AAny{}, F_{});
+        else      epilogue(F_{}, AAny{}, F_{});
+    }
 }
 
 // WM x WN wavefronts, each computing TM x TN MFMA tiles of 32x32.
@@ -244,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
                     for (int j = 0; j < TN; ++j) {
                         const float av = u == 0 ? a[i].x : u == 1 ? a[i].y : u == 2 ? a[i].z : a[i].w;
                         const float wv = u == 0 ? w[j].x : u == 1 ? w[j].y : u == 2 ? w[j].z : w[j].w;
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wv, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, av, acc[i][j], 0, 0, 0);   // D = W x window^T
                     }
         };
         if (!CONV_DBG(2)) {
@@ -255,85 +378,241 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
         cc = ncc; kk = nkk;
     }
 
-    // ---- epilogue: bias, BatchNorm (batch_norm.c:140-163 op order), activation, buffer stores ----
-    // descriptor = THIS TILE's output rows: based at the tile's first row (so offsets inside it stay small however
-    // large the tensor is -- a TimeDistributedDense output passes 2 GiB at ~540 k rows of 1000) and never longer than
-    // CONV_OOB bytes (so the padded columns' sentinel offset is out of range by construction).  Interior row tiles
-    // store with the row advance in the (unchecked) scalar offset and the padded columns on the out-of-range vector
-    // offset; the last row tile of a sequence compares every element's row instead.  The uniform choices (BatchNorm
-    // or not, which activation, which store path) are taken ONCE, outside the 64-element loops: inside them every
-    // instruction is VALU time taken from the MFMAs.
-    const size_t row_elems = (size_t)(p.out_mode ? p.B : 1) * p.Cout;           // distance between output rows x, x+1
-    const size_t row_bytes = row_elems * 4;
-    const size_t obase = (p.out_mode ? (size_t)b * p.Cout : (size_t)b * p.Tout * p.Cout) + (size_t)x0 * row_elems;
-    const size_t oend = p.out_mode ? (size_t)p.Tout * p.B * p.Cout : ((size_t)b + 1) * p.Tout * p.Cout;
-    const __amdgpu_buffer_rsrc_t rs_out = conv_rsrc(p.out + obase, (oend - obase) * 4);
-    const bool fast_store = x0 + CONV_BM <= p.Tout &&                              // every row of the tile exists
-                            row_bytes * (size_t)(CONV_BM + 4) < (size_t)CONV_OOB;  // and is reachable by 32-bit offsets
-    const int rb = (int)row_bytes;
+    if (CONV_DBG(1) && acc[0][0][0] != 12345.678f) return;
+    conv_epilogue<TM, TN, WN>(p, acc, b, x0, n0, wm, wn, l31, kh);
+}
 
-    auto epilogue = [&](auto bn_tag, auto act_tag, auto fast_tag) {
-        constexpr bool HAS_BN = decltype(bn_tag)::value;
-        constexpr int ACT = decltype(act_tag)::value;            // -1: run-time kind
-        constexpr bool FAST = decltype(fast_tag)::value;
+// ---------------------------------------------------------------------------------------------------------------
+// Option gemm_split_bf16: the same implicit GEMM on the bf16 MFMA with every f32 operand split into three bf16
+// terms, x = hi + mid + lo EXACTLY (8 + 8 + 8 significand bits; each remainder is exact in f32), and the six
+// products of weight <= 2 accumulated in f32:  x*y ~ hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi.  The dropped
+// terms (mid*lo, lo*mid, lo*lo) are <= 2^-23 |x*y|, the size of ONE f32 rounding, and bf16 x bf16 products are exact in
+// the f32 accumulator -- so this is an f32-accuracy contraction, but NOT the k-ordered fmaf chain of the exact path
+// (results differ in the last bits; against a float64 contraction it measures slightly CLOSER than the exact chain,
+// tools/split_error.py).  6 x v_mfma_f32_32x32x16_bf16 (32 cycles each) replace 8 x v_mfma_f32_32x32x2_f32
+// (64 cycles each) per 16-deep block: 2.67x less MFMA time.
+//
+// Weights are split ONCE at upload (nntk_shim_split_bf16x3 writes the three images behind the packed f32 matrix) and
+// stored in MFMA FRAGMENT ORDER: one 1 KB block per (32-column tile, 16-deep k step) holding [k half][column][8 bf16],
+// so a wave fetches its B operand with one fully coalesced 16-byte load per lane straight from L2 into registers --
+// no LDS round trip, and no barrier per tap: only the window goes through LDS (it has to be split, and all k taps
+// and all column tiles reuse it), so there is ONE barrier per staged window chunk instead of one per (chunk, tap).
+// The window is split while it is staged (11 VALU per two elements).  LDS rows are [row][image 0..2][16 bf16] = 96
+// bytes with the two 16-byte halves of an image swapped on rows with bit 3 set: row stride 6 slots (of 16 B) + that
+// swap makes the 16 lanes of a ds_read_b128 group hit 16 distinct slots (rows {0-3, 12-15, 20-27} -> slots
+// {0,6,12,2, 9,15,5,11, 8,14,4,10, 1,7,13,3}).
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {     // RNE, a in the low half
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));
+}
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo) {
+    hi = cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+    mid = cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(mid << 16), s1 = r1 - __uint_as_float(mid & 0xffff0000u);
+    lo = cvt_pk_bf16(s0, s1);
+}
+
+// src [rows][ktot] f32 (rows % 32 == 0, ktot % 16 == 0) -> dst [3 images][rows / 32][ktot / 16][2][32][8] bf16
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float *__restrict__ src, unsigned *__restrict__ dst,
+                                                           int rows, int ktot) {
+    const size_t n_pairs = (size_t)rows * ktot / 2;
+    const int ksteps = ktot >> 4;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n_pairs; e += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(e / (ktot / 2)), kt = (int)(e % (ktot / 2)) * 2;
+        unsigned h, m, l;
+        split3_pair(src[2 * e], src[2 * e + 1], h, m, l);
+        const size_t d = ((((size_t)(row >> 5) * ksteps + (kt >> 4)) * 2 + ((kt >> 3) & 1)) * 32 + (row & 31)) * 4 + ((kt & 7) >> 1);
+        dst[d] = h; dst[n_pairs + d] = m; dst[2 * n_pairs + d] = l;
+    }
+}
+extern "C" int nntk_shim_split_bf16x3(const float *d_src, void *d_dst, int rows, int ktot) {
+    if (rows <= 0 || ktot <= 0) return 0;
+    if ((rows & 31) || (ktot & 15)) return nntk_fail_msg("split_bf16x3: rows must be a multiple of 32 and ktot of 16");
+    size_t g = ((size_t)rows * ktot / 2 + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)g), dim3(256), 0, nntk_stream(), d_src, (unsigned *)d_dst, rows, ktot);
+    NNTK_LAUNCH_CHECK("split_bf16x3_kernel");
+    return 0;
+}
+
+#define SPLIT_ROW 96              // LDS bytes per window row: 3 images x 16 bf16
+
+// CS = channel chunks staged per barrier (2 for the k = 1 GEMMs, where a chunk is only one MFMA step)
+template <int WM, int WN, int TM, int TN, bool A4, int CS>
+__global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16x3_kernel(ConvParams p) {
+    constexpr int BN = WN * TN * 32;
+    constexpr int KC = CONV_KC;
+    static_assert(WM * WN == 4 && WM * TM * 32 == CONV_BM, "4 wavefronts, BM = 128");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char *lds = reinterpret_cast<char *>(smem);
+    const int a_bytes = p.rows_a * SPLIT_ROW;         // one staged chunk; LDS = [2 buffers][CS chunks][rows_a][96]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, kh = lane >> 5;
+
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;          // same XCD-aware tile order as the f32 kernel
+    const int tile = (local / p.n_tiles) * 8 + xcd;
+    if (tile >= p.m_tiles) return;
+    const int b = tile / p.tiles_per_seq;
+    const int x0 = (tile % p.tiles_per_seq) * CONV_BM;
+    const int n0 = (local % p.n_tiles) * BN;
+    const int Ktot = p.k * p.Cin_p;
+    const int ksteps = Ktot >> 4, cin_steps = p.Cin_p >> 4;
+
+    f32x16 acc[TM][TN];
+
+    constexpr int A_TPR = A4 ? KC / 4 : KC;
+    constexpr int AR_STEP = 256 / A_TPR;
+    constexpr int A_PT = (192 + AR_STEP - 1) / AR_STEP;
+    const int ac = A4 ? (tid % A_TPR) * 4 : (tid % A_TPR);
+    const int ar = tid / A_TPR;
+    v4u32_t areg4[A4 ? CS * A_PT : 1];
+    unsigned areg[A4 ? 1 : CS * A_PT];
+    int a_voff[A_PT];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int o = n0 + wn * TN * 32 + j * 32 + l31;
-            const bool col_ok = o < p.Cout;
-            const float bias = (p.bias && col_ok) ? p.bias[o] : 0.0f;
-            float g = 1.f, be = 0.f, mu = 0.f, sd = 1.f;
-            if (HAS_BN && col_ok) {
-                g = p.bn[o]; be = p.bn[p.Cout + o]; mu = p.bn[2 * p.Cout + o];
-                sd = sqrtf(p.bn[3 * p.Cout + o] + p.bn_eps);
+    for (int q = 0; q < A_PT; ++q) a_voff[q] = (int)(((long)(ar + q * AR_STEP) * p.in_row + ac) * 4);
+    const bool cin_ragged = (p.Cin % KC) != 0;
+    const int n_cchunks = p.Cin_p / KC;
+    const int n_chunks = n_cchunks * p.k;
+
+    // B operand: fragment blocks behind the packed f32 matrix, one coalesced 16-byte load per lane
+    const size_t w_elems_total = (size_t)p.Cout_p * Ktot;
+    const int img_bytes = (int)(w_elems_total * 2);
+    const __amdgpu_buffer_rsrc_t rs_w = conv_rsrc(p.wp + w_elems_total, (size_t)3 * img_bytes);
+    const int w_tile0 = (n0 >> 5) + wn * TN;          // this wave's first 32-column tile
+    auto load_w = [&](bf16x8_t (&w)[3][TN], int cc, int kk) {
+        const int ks = kk * cin_steps + cc;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+                w[m][j] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(
+                              rs_w, lane * 16, m * img_bytes + ((w_tile0 + j) * ksteps + ks) * 1024, 0));
+    };
+    const size_t in_total = (size_t)p.B * p.T * p.Cin;
+    auto load_a = [&](int cc0) {                      // chunks cc0 .. cc0 + CS - 1 (missing ones read as zero)
+        const size_t in_off = (size_t)b * p.in_seq + (size_t)x0 * p.stride * p.in_row;
+        const __amdgpu_buffer_rsrc_t rs_in = conv_rsrc(p.in + in_off, (in_total - in_off) * 4);
+#pragma unroll
+        for (int c = 0; c < CS; ++c) {
+            const int cc = cc0 + c;
+            const bool ch_ok = cc < n_cchunks && (!(cin_ragged && cc == n_cchunks - 1) || cc * KC + ac < p.Cin);
+#pragma unroll
+            for (int q = 0; q < A_PT; ++q) {
+                const int vo = ch_ok ? a_voff[q] : CONV_OOB;
+                if (A4) areg4[c * A_PT + q] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, cc * KC * 4, 0);
+                else    areg[c * A_PT + q] = __builtin_amdgcn_raw_buffer_load_b32(rs_in, vo, cc * KC * 4, 0);
             }
-            const float rsd = 1.0f / sd;
-            // per-lane part of the address: column, and the +4 rows of the upper lane half
-            const int voff = col_ok ? o * 4 + kh * 4 * rb : CONV_OOB;
+        }
+    };
+    auto stage_a = [&](int buf) {                     // registers -> three bf16 images in LDS
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
+        for (int c = 0; c < CS; ++c) {
+            char *As = lds + (buf * CS + c) * a_bytes;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int xr = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2);          // row inside the tile, wave-uniform
-                    const int xs = x0 + xr;
-                    float v = acc[i][j][r] + bias;
-                    if (HAS_BN) {
-                        // (v - mu) / sd with the quotient refined by one FMA step: the correctly rounded
-                        // quotient without the 11-instruction IEEE division sequence
-                        const float d = v - mu;
-                        float qn = d * rsd;
-                        qn = fmaf(fmaf(-qn, sd, d), rsd, qn);
-                        v = p.bn_fast ? (d * rsd) * g + be : qn * g + be;
+            for (int q = 0; q < A_PT; q += (A4 ? 1 : 2)) {
+                const int r = ar + q * AR_STEP;
+                if (A4) {
+                    if (r < p.rows_a) {
+                        const v4u32_t v = areg4[c * A_PT + q];
+                        unsigned h0, m0, l0, h1, m1, l1;
+                        split3_pair(__uint_as_float(v.x), __uint_as_float(v.y), h0, m0, l0);
+                        split3_pair(__uint_as_float(v.z), __uint_as_float(v.w), h1, m1, l1);
+                        char *dst = As + r * SPLIT_ROW + 16 * ((ac >> 3) ^ ((r >> 3) & 1)) + (ac & 7) * 2;
+                        *reinterpret_cast<uint2 *>(dst) = make_uint2(h0, h1);
+                        *reinterpret_cast<uint2 *>(dst + 32) = make_uint2(m0, m1);
+                        *reinterpret_cast<uint2 *>(dst + 64) = make_uint2(l0, l1);
                     }
-                    v = ACT == -1 ? nntk_act(p.act_kind, v, p.relu_a)
-                      : ACT == NNTK_ACT_RELU ? nntk_act(NNTK_ACT_RELU, v, p.relu_a)
-                      : v;
-                    if (FAST) {
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, voff, xr * rb, 0);
-                    } else {
-                        const int x = xs + 4 * kh;
-                        if (x < p.Tout && col_ok) {
-                            const size_t orow = p.out_mode ? ((size_t)x * p.B + b) : ((size_t)b * p.Tout + x);
-                            p.out[orow * p.Cout + o] = v;
+                } else {
+                    // one element per thread and pass: split two passes' elements together (rows r and r + AR_STEP)
+                    unsigned h, m, l;
+                    split3_pair(__uint_as_float(areg[c * A_PT + q]), __uint_as_float(areg[c * A_PT + (q + 1 < A_PT ? q + 1 : q)]), h, m, l);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int re = r + e * AR_STEP;
+                        if (q + e < A_PT && re < p.rows_a) {
+                            char *dst = As + re * SPLIT_ROW + 16 * ((ac >> 3) ^ ((re >> 3) & 1)) + (ac & 7) * 2;
+                            *reinterpret_cast<unsigned short *>(dst) = (unsigned short)(e ? h >> 16 : h);
+                            *reinterpret_cast<unsigned short *>(dst + 32) = (unsigned short)(e ? m >> 16 : m);
+                            *reinterpret_cast<unsigned short *>(dst + 64) = (unsigned short)(e ? l >> 16 : l);
                         }
                     }
                 }
             }
         }
     };
-    using T_ = std::true_type; using F_ = std::false_type;
-    using AId = std::integral_constant<int, NNTK_ACT_IDENTITY>;
-    using ARelu = std::integral_constant<int, NNTK_ACT_RELU>;
-    using AAny = std::integral_constant<int, -1>;
-    if (CONV_DBG(1) && acc[0][0][0] != 12345.678f) {
-    } else if (fast_store) {
-        if (!p.bn && p.act_kind == NNTK_ACT_IDENTITY) epilogue(F_{}, AId{}, T_{});
-        else if (p.bn && p.act_kind == NNTK_ACT_RELU) epilogue(T_{}, ARelu{}, T_{});
-        else if (p.bn)                                epilogue(T_{}, AAny{}, T_{});
-        else                                          epilogue(F_{}, AAny{}, T_{});
-    } else {
-        if (p.bn) epilogue(T_{}, AAny{}, F_{});
-        else      epilogue(F_{}, AAny{}, F_{});
+
+    const int a_row0 = (wm * TM * 32 + l31) * p.stride;       // window row of tile i at tap kk: a_row0 + i * 32 * stride + kk
+
+    bf16x8_t wA[3][TN], wB[3][TN];
+    load_a(0);
+    load_w(wA, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    int cc = 0, kk = 0;
+    // one (chunk, tap) step: stage the window if a new group of chunks starts, prefetch the next step's weights,
+    // multiply.  Steps alternate between the two weight register sets.
+    auto step = [&](bf16x8_t (&wc)[3][TN], bf16x8_t (&wn_)[3][TN], bool has_next) {
+        if (kk == 0 && cc % CS == 0) {
+            // buffer (cc / CS) & 1 was last read two groups ago: every wave has passed the previous barrier since
+            if (!CONV_DBG(16)) stage_a((cc / CS) & 1);
+            __syncthreads();
+            if (cc + CS < n_cchunks && !CONV_DBG(32)) load_a(cc + CS);
+        }
+        int ncc = cc, nkk = kk + 1;
+        if (nkk == p.k) { nkk = 0; ncc = cc + 1; }
+        if (has_next && !CONV_DBG(4)) load_w(wn_, ncc, nkk);
+        const char *Ab = lds + (((cc / CS) & 1) * CS + cc % CS) * a_bytes;
+        bf16x8_t a[3][TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = a_row0 + i * 32 * p.stride + kk;
+            const char *src = Ab + row * SPLIT_ROW + 16 * (kh ^ ((row >> 3) & 1));
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+                if (!CONV_DBG(8)) a[m][i] = *reinterpret_cast<const bf16x8_t *>(src + 32 * m);
+                else a[m][i] = wc[m][0];
+        }
+        // smallest terms first; the TM x TN accumulators interleave so dependent MFMAs are TM * TN apart
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0};      // window image (0 hi, 1 mid, 2 lo)
+        constexpr int PW[6] = {0, 2, 1, 0, 1, 0};      // weight image
+        if (!CONV_DBG(2)) {
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[PW[t]][j], a[PA[t]][i], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int m = 0; m < 3; ++m)
+                        acc[i][j][m] += __builtin_bit_cast(v4u32_t, a[m][i]).x + __builtin_bit_cast(v4u32_t, wc[m][j]).x;
+        }
+        cc = ncc; kk = nkk;
+    };
+    for (int chunk = 0; chunk < n_chunks; chunk += 2) {
+        step(wA, wB, chunk + 1 < n_chunks);
+        if (chunk + 1 < n_chunks) step(wB, wA, chunk + 2 < n_chunks);
     }
+    if (CONV_DBG(1) && acc[0][0][0] != 12345.678f) return;
+    conv_epilogue<TM, TN, WN>(p, acc, b, x0, n0, wm, wn, l31, kh);
 }
 
 // Generic VALU kernel for shapes the MFMA tile does not cover (tiny K such as
@@ -366,18 +645,36 @@ __global__ __launch_bounds__(256) void conv1d_valu_kernel(ConvParams p) {
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool A4>
+// sd = sqrtf(var + eps) and 1/sd behind the four BatchNorm vectors: block = gamma|beta|mean|var|sd|rsd (6 * C floats)
+__global__ void bn_derive_kernel(float *blk, float eps, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float sd = sqrtf(blk[3 * C + c] + eps);
+        blk[4 * C + c] = sd;
+        blk[5 * C + c] = 1.0f / sd;
+    }
+}
+extern "C" int nntk_shim_bn_derive(float *d_block, float eps, int C) {
+    if (C <= 0) return 0;
+    hipLaunchKernelGGL(bn_derive_kernel, dim3((C + 255) / 256), dim3(256), 0, nntk_stream(), d_block, eps, C);
+    NNTK_LAUNCH_CHECK("bn_derive_kernel");
+    return 0;
+}
+
+template <int WM, int WN, int TM, int TN, bool A4, int SPLIT_CS = 0>
 static int launch_mfma(const ConvParams &p) {
     constexpr int BN = WN * TN * 32;
+    constexpr bool SPLIT = SPLIT_CS > 0;
     // 41 KB at BN = 128: three workgroups per CU, which is what hides the barrier / staging latency
-    size_t lds = (size_t)(2 * p.rows_a * CONV_LS + 2 * BN * CONV_LS) * sizeof(float);
+    size_t lds = SPLIT ? (size_t)2 * SPLIT_CS * p.rows_a * SPLIT_ROW
+                       : (size_t)(2 * p.rows_a * CONV_LS + 2 * BN * CONV_LS) * sizeof(float);
     ConvParams q = p;
     q.m_tiles = p.B * p.tiles_per_seq;
     q.n_tiles = p.Cout_p / BN;
     const long blocks = (long)((q.m_tiles + 7) / 8) * 8 * q.n_tiles;
     if ((long)p.B * p.tiles_per_seq > 0x7fffffffL / 8 || blocks > 0x7fffffffL)
         return nntk_fail_msg("conv1d: too many tiles for one launch");
-    auto kern = conv1d_mfma_kernel<WM, WN, TM, TN, A4>;
+    auto kern = SPLIT ? conv1d_mfma_bf16x3_kernel<WM, WN, TM, TN, A4, SPLIT ? SPLIT_CS : 1> : conv1d_mfma_kernel<WM, WN, TM, TN, A4>;
     if (lds > 64 * 1024) {
         if (nntk_set_max_dynamic_lds((const void *)kern, lds)) return -1;
     }
@@ -405,6 +702,7 @@ extern "C" int nntk_shim_conv1d(const float *d_in, const float *d_wp, const floa
     p.rows_a = (CONV_BM - 1) * stride + k;
     const NntkOptions &opt = nntk_options();
     p.bn_fast = opt.bn_fast == 1 ? 1 : 0;
+    p.store16 = Cout % 4 == 0 && (((size_t)d_out | (size_t)d_bias | (size_t)d_bn) & 15) == 0;
 #ifdef NNTK_CONV_DBG
     p.dbg = opt.conv_dbg;
 #endif
@@ -438,6 +736,16 @@ extern "C" int nntk_shim_conv1d(const float *d_in, const float *d_wp, const floa
         p.in_seq = Cin; p.in_row = (long)T * Cin;
         p.out_mode = 0;                               // row (t, b) -> t * B + b: exactly the time-major layout
         p.tiles_per_seq = (p.Tout + CONV_BM - 1) / CONV_BM;
+    }
+    if (opt.gemm_split_bf16 == 1 && (long)p.Cout_p * k * p.Cin_p * 6 < (long)CONV_OOB) {
+        if (k == 1 && a4) {        // dense GEMMs: two channel chunks per barrier
+            if (p.Cout_p % 128 == 0) return launch_mfma<2, 2, 2, 2, true, 2>(p);
+            if (p.Cout_p % 64 == 0)  return launch_mfma<4, 1, 1, 2, true, 2>(p);
+            return launch_mfma<4, 1, 1, 1, true, 2>(p);
+        }
+        if (p.Cout_p % 128 == 0) return a4 ? launch_mfma<2, 2, 2, 2, true, 1>(p) : launch_mfma<2, 2, 2, 2, false, 1>(p);
+        if (p.Cout_p % 64 == 0)  return a4 ? launch_mfma<4, 1, 1, 2, true, 1>(p) : launch_mfma<4, 1, 1, 2, false, 1>(p);
+        return a4 ? launch_mfma<4, 1, 1, 1, true, 1>(p) : launch_mfma<4, 1, 1, 1, false, 1>(p);
     }
     if (p.Cout_p % 128 == 0) return a4 ? launch_mfma<2, 2, 2, 2, true>(p) : launch_mfma<2, 2, 2, 2, false>(p);
     if (p.Cout_p % 64 == 0)  return a4 ? launch_mfma<4, 1, 1, 2, true>(p) : launch_mfma<4, 1, 1, 2, false>(p);

@@ -65,11 +65,17 @@ int   nntk_shim_memset(void *d_ptr, int value, size_t bytes);             /* asy
  *   d_in   [B, T, Cin]           channels-last
  *   d_wp   packed weights [Cout_p][k*Cin_p], K-contiguous, zero padded (see nntk_shim_conv_pack_sizes)
  *   d_bias [Cout]
- *   d_bn   NULL or 4*Cout floats: gamma | beta | mean | variance (batch_norm.c:79-84 order)
+ *   d_bn   NULL or 6*Cout floats: gamma | beta | mean | variance (batch_norm.c:79-84 order) | sd | 1/sd, the last
+ *          two written by nntk_shim_bn_derive(d_bn, eps, Cout) after an upload of the first four
  *   out_mode 0: out[b, x, :] at row b*Tout + x;  1: time-major row x*B + b (for recurrent input projections)
  * Dense / TimeDistributedDense / input projection = the k=1, stride=1 case with T = rows.
  */
 void nntk_shim_conv_pack_sizes(int Cin, int Cout, int k, int *Cin_p, int *Cout_p);
+/* d_wp of nntk_shim_conv1d is the packed f32 matrix [Cout_p][k * Cin_p] FOLLOWED BY its three bf16 split images
+ * (hi | mid | lo, each Cout_p * k * Cin_p bf16 in MFMA fragment order) written by
+ * nntk_shim_split_bf16x3(d_wp, d_wp + n, Cout_p, k * Cin_p); the images are read only by the split-bf16 kernel */
+int  nntk_shim_bn_derive(float *d_block, float eps, int C);
+int  nntk_shim_split_bf16x3(const float *d_src, void *d_dst, int rows, int ktot);
 int  nntk_shim_conv1d(const float *d_in, const float *d_wp, const float *d_bias, const float *d_bn,
                       float bn_eps, int act_kind, float relu_a, float *d_out,
                       int B, int T, int Cin, int Cout, int k, int stride, int Tout, int out_mode);

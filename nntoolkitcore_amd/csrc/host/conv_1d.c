@@ -88,7 +88,7 @@ static int conv_upload(Conv1d f) {
         for (int i = 0; i < Cin; ++i)
             for (int kk = 0; kk < k; ++kk)
                 tmp[((size_t)o * k + kk) * Cin_p + i] = W[((size_t)o * Cin + i) * k + kk];
-    int rc = nntk_upload_floats(&f->d_wp, tmp, n);
+    int rc = nntk_upload_packed_weights(&f->d_wp, tmp, Cout_p, k * Cin_p);
     free(tmp);
     if (rc) return rc;
     if (nntk_upload_floats(&f->d_bias, f->weights->b, (size_t)Cout)) return -1;
@@ -289,7 +289,14 @@ void BatchNormDestroy(BatchNorm filter) {
 }
 
 static int bn_upload(BatchNorm f) {
-    if (nntk_upload_floats(&f->d_block, f->wb.host, f->wb.n)) return -1;
+    /* device block = the four vectors + sd | 1/sd derived on the device (the fused conv epilogue reads those) */
+    int C = f->config.feature_channels;
+    if (!f->d_block) {
+        f->d_block = (float *)nntk_shim_malloc((size_t)6 * C * sizeof(float));
+        if (!f->d_block) return -1;
+    }
+    if (nntk_shim_upload(f->d_block, f->wb.host, f->wb.n * sizeof(float))) return -1;
+    if (nntk_shim_bn_derive(f->d_block, f->config.epsilon, C)) return -1;
     nntk_wblock_mark_uploaded(&f->wb);
     return 0;
 }

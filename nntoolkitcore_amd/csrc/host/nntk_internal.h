@@ -37,6 +37,7 @@ int nntk_upload_floats(float **d_dst, const float *h_src, size_t n);
 
 /* pack a row-major [K, N] matrix into the conv/GEMM kernel's [N_p][K_p] (K-contiguous) layout and upload */
 int nntk_upload_gemm_weights(float **d_wp, const float *W, int K, int N);
+int nntk_upload_packed_weights(float **d_wp, const float *h_packed, int rows, int ktot);
 
 struct ActivationFunctionStruct {
     int kind;                 /* NNTK_ACT_* */

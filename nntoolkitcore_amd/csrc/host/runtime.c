@@ -118,6 +118,18 @@ int nntk_upload_floats(float **d_dst, const float *h_src, size_t n) {
     return nntk_shim_upload(*d_dst, h_src, n * sizeof(float));
 }
 
+/* packed GEMM / conv weights: [n f32] followed by their three bf16 split images [3][n] (conv1d.hip's opt-in
+ * split-bf16 kernel reads those; they are always produced so the option can be flipped at run time) */
+int nntk_upload_packed_weights(float **d_wp, const float *h_packed, int rows, int ktot) {
+    size_t n = (size_t)rows * ktot;
+    if (!*d_wp) {
+        *d_wp = (float *)nntk_shim_malloc(n * sizeof(float) + 3 * n * sizeof(unsigned short));
+        if (!*d_wp) return -1;
+    }
+    if (nntk_shim_upload(*d_wp, h_packed, n * sizeof(float))) return -1;
+    return nntk_shim_split_bf16x3(*d_wp, *d_wp + n, rows, ktot);
+}
+
 int nntk_upload_gemm_weights(float **d_wp, const float *W, int K, int N) {
     int K_p, N_p;
     nntk_shim_conv_pack_sizes(K, N, 1, &K_p, &N_p);
@@ -126,7 +138,7 @@ int nntk_upload_gemm_weights(float **d_wp, const float *W, int K, int N) {
     if (!tmp) NNTK_FAIL("out of host memory while packing weights");
     for (int k = 0; k < K; ++k)                 /* [K, N] row-major -> [N_p][K_p], K-contiguous */
         for (int j = 0; j < N; ++j) tmp[(size_t)j * K_p + k] = W[(size_t)k * N + j];
-    int rc = nntk_upload_floats(d_wp, tmp, n);
+    int rc = nntk_upload_packed_weights(d_wp, tmp, N_p, K_p);
     free(tmp);
     return rc;
 }

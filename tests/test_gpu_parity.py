@@ -57,6 +57,36 @@ def test_conv1d_single_sequence(gpu, cin, cout, k, stride, T):
     conv.destroy()
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,T", [
+    (40, 128, 5, 1, 300),      # config 3 shape, 16-byte window loads
+    (33, 32, 3, 1, 130),       # odd Cin: 4-byte window loads, ragged last chunk, BN = 32
+    (257, 128, 5, 1, 200),     # stack conv: 17 channel chunks, 4-byte loads
+    (64, 192, 1, 1, 257),      # dense GEMM, BN = 64 tile, partial row tile, two chunks per barrier
+    (48, 96, 1, 1, 200),       # dense GEMM with an odd number of channel chunks, BN = 32
+    (128, 1000, 1, 1, 140),    # TimeDistributedDense-like: Cout padded to 1024
+])
+def test_split_bf16_contraction_matches_oracle(gpu, cin, cout, k, stride, T):
+    """Option gemm_split_bf16 = 1: the 3-way split-bf16 MFMA contraction (conv1d.hip).  It is an f32-accuracy
+    contraction but not the exact k-ordered chain, so the check is the oracle tolerance, plus: it must differ from the
+    exact path by no more than a few f32 roundings of the row's magnitude."""
+    r = rng(cin * 7 + cout)
+    B = 3
+    x, W, b = u(r, B, T, cin), u(r, cout, cin, k, sc=(cin * k) ** -0.5), u(r, cout, sc=0.2)
+    conv = NL.Conv1d(cin, cout, k, stride, T)
+    conv.set_weights(W, b)
+    exact = conv.apply(x)
+    capi.set_option("gemm_split_bf16", "1")
+    try:
+        split = conv.apply(x)
+    finally:
+        capi.set_option("gemm_split_bf16", "0")
+    ref = O.conv1d(x, W, b, stride)
+    close(split, ref)
+    assert not np.array_equal(split, exact)                     # the option really selected the other kernel
+    assert np.abs(split - exact).max() < 4e-6
+    conv.destroy()
+
+
 def test_conv1d_output_shorter_than_kernel_is_empty(gpu):
     conv = NL.Conv1d(2, 3, 5, 1, 4)        # output_size = 0 (conv_1d.c:84)
     assert conv.cfg.output_size == 0
