@@ -41,6 +41,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: exact-f32 MFMA = f32 vector peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA
+SPLIT_PRODUCTS = 6               # bf16 MFMA products per f32 product in the split-bf16x3 contraction (conv1d.hip)
 HBM_PEAK_GBS = 8000.0            # HBM3E spec (6290 GB/s measured copy)
 
 
@@ -263,6 +265,12 @@ def pmc_traffic(kernel_prefix, B):
     return None, "no profiles/*_pmc_traffic.json stamped with this library's source_hash %s at %d utterances/GPU" % (want, B)
 
 
+def gemm_mode():
+    """Which contraction the conv / dense / TDD kernels run (library option gemm_split_bf16; auto = split)."""
+    from nntoolkitcore_amd import capi
+    return "exact-f32" if capi.get_option("gemm_split_bf16") == 0 else "split-bf16x3 (f32 operands as 3 bf16 terms, f32 accumulate)"
+
+
 def roofline_for(wl, phase_ms, prof):
     """Dominant-kernel roofline from live HIP-event timings (ms per launch)."""
     B = wl.B
@@ -280,10 +288,18 @@ def roofline_for(wl, phase_ms, prof):
         bytes_ = B * (wl.conv.cfg.input_size * cin + Tc * 128) * 4
         ms = phase_ms["conv_bn_relu"]
         ach = flops / (ms * 1e-3) / 1e12
-        return {"kernel": "conv1d_mfma_kernel<2,2,2,2>", "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None, "ms_per_launch": ms,
-                "algorithmic_flops": flops, "algorithmic_bytes": bytes_,
-                "hbm_frac": bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        hbm_frac = bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if gemm_mode() == "exact-f32":
+            return {"kernel": "conv1d_mfma_kernel<2,2,2,2>", "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None, "ms_per_launch": ms,
+                    "algorithmic_flops": flops, "algorithmic_bytes": bytes_, "hbm_frac": hbm_frac}
+        # split-bf16x3: six bf16 MFMA products per f32 product, so the MFMA ceiling in ALGORITHMIC flops is the dense
+        # bf16 peak / 6 (still above the HBM ceiling's time here: 125 us vs 86 us at config 3)
+        peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
+        return {"kernel": "conv1d_mfma_bf16x3_kernel<2,2,2,2>", "bound": "mfma", "achieved": ach, "peak": peak,
+                "peak_note": "dense bf16 MFMA peak / 6 products per f32 product", "unit": "TFLOP/s", "frac": ach / peak,
+                "traffic": None, "ms_per_launch": ms, "algorithmic_flops": flops, "algorithmic_bytes": bytes_,
+                "hbm_frac": hbm_frac, "frac_of_exact_f32_mfma_peak": ach / F32_MFMA_PEAK_TFLOPS}
     # recurrent step kernel: one launch = one timestep of hU = h[B,H] x U[H,G*H] + fused gates
     H, G = (512, 4) if wl.name == "stack" else (256, 3)
     ms = prof.get("rec_launch_ms", None)
@@ -532,7 +548,8 @@ def main():
             "utterances_per_gpu": B, "frames_per_utterance": wl.frames_per_utt, "global_batch": B * world,
             "parallelism": "utterance shards, dp%d, no data-path collective" % world,
             "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
-            "ranks_seen": ranks_seen},
+            "ranks_seen": ranks_seen,
+            "gemm": gemm_mode() + " for conv / TDD" + ("; exact-f32 for the recurrent input projection and recurrences" if a.workload in ("stack", "gru") else "")},
         "phase_ms": {k: round(v, 4) for k, v in phase_ms.items()},
     }
     if rank == 0:

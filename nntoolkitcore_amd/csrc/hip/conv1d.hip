@@ -64,7 +64,7 @@ struct ConvParams {
     int out_mode;        // 0: row b*Tout+x ; 1: row x*B+b
     int rows_a;          // (BM-1)*stride + k window rows per tile
     int bn_fast;         // A/B: multiply by 1/sd instead of the reference's divide
-    int store16;         // Cout % 4 == 0 and out / bias / bn 16-byte aligned: 16-byte stores of channel quads
+    int store16;         // Cout % 4 == 0 and out 16-byte aligned: 16-byte stores of channel quads
 #ifdef NNTK_CONV_DBG
     int dbg;             // timing experiments only: 1 no stores, 2 no MFMAs, 4 no global loads in the loop
 #endif
@@ -100,9 +100,34 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t conv_rsrc(const void *base, si
 // activation, which store path) are taken ONCE outside the loops.  The descriptor is THIS TILE's output rows (based at
 // the tile's first row, never longer than CONV_OOB bytes): positions past the sequence's end and padded channels get
 // the out-of-range sentinel as their vector offset, so the last row tile needs no separate path.
+//
+// The per-channel constants come from LDS (conv_stage_constants, written before the K loop's first barrier): fetched
+// from global memory inside the epilogue they were eight serial load -> use round trips per tile, a quarter of the
+// fused Conv+BN+ReLU time.
+template <int BN>
+__device__ __forceinline__ void conv_load_constants(const ConvParams &p, int n0, int tid, float (&c)[6]) {
+    c[0] = 0.f; c[1] = 1.f; c[2] = 0.f; c[3] = 0.f; c[4] = 1.f; c[5] = 1.f;      // bias | gamma | beta | mean | sd | 1/sd
+    const int col = n0 + tid;
+    if (tid < BN && col < p.Cout) {
+        if (p.bias) c[0] = p.bias[col];
+        if (p.bn) {
+            c[1] = p.bn[col]; c[2] = p.bn[p.Cout + col]; c[3] = p.bn[2 * p.Cout + col];
+            c[4] = p.bn[4 * p.Cout + col]; c[5] = p.bn[5 * p.Cout + col];
+        }
+    }
+}
+template <int BN>
+__device__ __forceinline__ void conv_stage_constants(float *cst, int tid, const float (&c)[6]) {
+    if (tid < BN) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) cst[a * BN + tid] = c[a];
+    }
+}
+
 template <int TM, int TN, int WN>
 __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)[TM][TN], int b, int x0, int n0,
-                                              int wm, int wn, int l31, int kh) {
+                                              int wm, int wn, int l31, int kh, const float *cst) {
+    constexpr int BN = WN * TN * 32;
     const size_t row_elems = (size_t)(p.out_mode ? p.B : 1) * p.Cout;           // distance between output rows x, x+1
     const size_t row_bytes = row_elems * 4;
     const size_t obase = (p.out_mode ? (size_t)b * p.Cout : (size_t)b * p.Tout * p.Cout) + (size_t)x0 * row_elems;
@@ -129,34 +154,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
             for (int g = 0; g < 4; ++g) {
                 const int cu = n0 + wn * TN * 32 + j * 32 + 8 * g;           // wave-uniform first channel of the quad pair
                 const int cb = cu + 4 * kh;                                  // this lane's four channels cb .. cb + 3
-                float bias[4] = {0.f, 0.f, 0.f, 0.f}, ga[4] = {1.f, 1.f, 1.f, 1.f}, be[4] = {0.f, 0.f, 0.f, 0.f},
-                      mu[4] = {0.f, 0.f, 0.f, 0.f}, sd[4] = {1.f, 1.f, 1.f, 1.f}, rsd[4] = {1.f, 1.f, 1.f, 1.f};
-                if (VEC) {                                                   // Cout % 4 == 0: a quad is all in or all out
-                    if (cb < p.Cout) {
-                        if (p.bias) { const float4 t = *reinterpret_cast<const float4 *>(p.bias + cb); bias[0] = t.x; bias[1] = t.y; bias[2] = t.z; bias[3] = t.w; }
-                        if (HAS_BN) {
-                            const float4 t0 = *reinterpret_cast<const float4 *>(p.bn + cb);
-                            const float4 t1 = *reinterpret_cast<const float4 *>(p.bn + p.Cout + cb);
-                            const float4 t2 = *reinterpret_cast<const float4 *>(p.bn + 2 * p.Cout + cb);
-                            const float4 t4 = *reinterpret_cast<const float4 *>(p.bn + 4 * p.Cout + cb);
-                            const float4 t5 = *reinterpret_cast<const float4 *>(p.bn + 5 * p.Cout + cb);
-                            ga[0] = t0.x; ga[1] = t0.y; ga[2] = t0.z; ga[3] = t0.w;
-                            be[0] = t1.x; be[1] = t1.y; be[2] = t1.z; be[3] = t1.w;
-                            mu[0] = t2.x; mu[1] = t2.y; mu[2] = t2.z; mu[3] = t2.w;
-                            sd[0] = t4.x; sd[1] = t4.y; sd[2] = t4.z; sd[3] = t4.w;
-                            rsd[0] = t5.x; rsd[1] = t5.y; rsd[2] = t5.z; rsd[3] = t5.w;
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (cb + e < p.Cout) {
-                            if (p.bias) bias[e] = p.bias[cb + e];
-                            if (HAS_BN) {
-                                ga[e] = p.bn[cb + e]; be[e] = p.bn[p.Cout + cb + e]; mu[e] = p.bn[2 * p.Cout + cb + e];
-                                sd[e] = p.bn[4 * p.Cout + cb + e]; rsd[e] = p.bn[5 * p.Cout + cb + e];
-                            }
-                        }
+                const int cl = (wn * TN + j) * 32 + 8 * g + 4 * kh;           // column inside the workgroup's BN
+                const float4 bias4 = *reinterpret_cast<const float4 *>(cst + cl);
+                const float bias[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
+                float ga[4] = {1.f, 1.f, 1.f, 1.f}, be[4] = {0.f, 0.f, 0.f, 0.f}, mu[4] = {0.f, 0.f, 0.f, 0.f},
+                      sd[4] = {1.f, 1.f, 1.f, 1.f}, rsd[4] = {1.f, 1.f, 1.f, 1.f};
+                if (HAS_BN) {
+                    const float4 t1 = *reinterpret_cast<const float4 *>(cst + BN + cl);
+                    const float4 t2 = *reinterpret_cast<const float4 *>(cst + 2 * BN + cl);
+                    const float4 t3 = *reinterpret_cast<const float4 *>(cst + 3 * BN + cl);
+                    const float4 t4 = *reinterpret_cast<const float4 *>(cst + 4 * BN + cl);
+                    const float4 t5 = *reinterpret_cast<const float4 *>(cst + 5 * BN + cl);
+                    ga[0] = t1.x; ga[1] = t1.y; ga[2] = t1.z; ga[3] = t1.w;
+                    be[0] = t2.x; be[1] = t2.y; be[2] = t2.z; be[3] = t2.w;
+                    mu[0] = t3.x; mu[1] = t3.y; mu[2] = t3.z; mu[3] = t3.w;
+                    sd[0] = t4.x; sd[1] = t4.y; sd[2] = t4.z; sd[3] = t4.w;
+                    rsd[0] = t5.x; rsd[1] = t5.y; rsd[2] = t5.z; rsd[3] = t5.w;
                 }
                 const bool col_ok = cb < p.Cout;
 #pragma unroll
@@ -315,6 +328,12 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
 
     load_a(b, x0, 0);
     load_w(n0, 0, 0);
+    float *cst = smem + 2 * a_elems + 2 * w_elems;     // [6][BN] epilogue constants
+    {
+        float c[6];
+        conv_load_constants<BN>(p, n0, tid, c);
+        conv_stage_constants<BN>(cst, tid, c);           // visible to the epilogue: at least one barrier follows
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -379,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
     }
 
     if (CONV_DBG(1) && acc[0][0][0] != 12345.678f) return;
-    conv_epilogue<TM, TN, WN>(p, acc, b, x0, n0, wm, wn, l31, kh);
+    conv_epilogue<TM, TN, WN>(p, acc, b, x0, n0, wm, wn, l31, kh, cst);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -394,13 +413,19 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
 //
 // Weights are split ONCE at upload (nntk_shim_split_bf16x3 writes the three images behind the packed f32 matrix) and
 // stored in MFMA FRAGMENT ORDER: one 1 KB block per (32-column tile, 16-deep k step) holding [k half][column][8 bf16],
-// so a wave fetches its B operand with one fully coalesced 16-byte load per lane straight from L2 into registers --
-// no LDS round trip, and no barrier per tap: only the window goes through LDS (it has to be split, and all k taps
-// and all column tiles reuse it), so there is ONE barrier per staged window chunk instead of one per (chunk, tap).
-// The window is split while it is staged (11 VALU per two elements).  LDS rows are [row][image 0..2][16 bf16] = 96
-// bytes with the two 16-byte halves of an image swapped on rows with bit 3 set: row stride 6 slots (of 16 B) + that
-// swap makes the 16 lanes of a ds_read_b128 group hit 16 distinct slots (rows {0-3, 12-15, 20-27} -> slots
-// {0,6,12,2, 9,15,5,11, 8,14,4,10, 1,7,13,3}).
+// so a block moves HBM/L2 -> LDS -> registers as 64 lanes x 16 bytes in lane order: coalesced, conflict-free, no
+// address arithmetic.  The window is split while it is staged (11 VALU per two elements, once per channel chunk and
+// reused by all k taps).  Window LDS rows are [row][image 0..2][16 bf16] = 96 bytes with the two 16-byte halves of an
+// image swapped on rows with bit 3 set: row stride 6 slots (of 16 B) + that swap makes the 16 lanes of a ds_read_b128
+// group hit 16 distinct slots (rows {0-3, 12-15, 20-27} -> slots {0,6,12,2, 9,15,5,11, 8,14,4,10, 1,7,13,3}).
+//
+// What bounds it (tools/conv_probe.py on the -DNNTK_CONV_DBG build): with the MFMA time cut to a third the
+// kernel is bound by the weight re-reads out of L2 -- every 128-row tile streams its whole [BN x K] weight slab again
+// (config 3: 7,969 tiles x 184 KB = 1.5 GB against 0.69 GB of HBM traffic), and L2 serves shared data at ~30 B/clk/CU
+// (MI355X_MICROARCH.md "Indexed rows").  Measured and NOT kept: weight fragments loaded straight from L2 into
+// registers by every wave (no LDS round trip, one barrier per window chunk instead of one per tap: twice the L2
+// traffic, 3-25 % slower on the dense GEMMs) and persistent workgroups with the next tile's first loads under the
+// epilogue (+7 %: launch latency was not the limit).
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -441,15 +466,17 @@ extern "C" int nntk_shim_split_bf16x3(const float *d_src, void *d_dst, int rows,
 
 #define SPLIT_ROW 96              // LDS bytes per window row: 3 images x 16 bf16
 
-// CS = channel chunks staged per barrier (2 for the k = 1 GEMMs, where a chunk is only one MFMA step)
-template <int WM, int WN, int TM, int TN, bool A4, int CS>
+template <int WM, int WN, int TM, int TN, bool A4>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16x3_kernel(ConvParams p) {
     constexpr int BN = WN * TN * 32;
     constexpr int KC = CONV_KC;
     static_assert(WM * WN == 4 && WM * TM * 32 == CONV_BM, "4 wavefronts, BM = 128");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char *lds = reinterpret_cast<char *>(smem);
-    const int a_bytes = p.rows_a * SPLIT_ROW;         // one staged chunk; LDS = [2 buffers][CS chunks][rows_a][96]
+    // LDS carve (bytes): window [2][rows_a][96] | weights [2][BN / 32 column tiles][3 images][1 KB fragment block]
+    const int a_bytes = p.rows_a * SPLIT_ROW;
+    constexpr int w_bytes = (BN / 32) * 3 * 1024;
+    const int w_base = 2 * a_bytes;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -473,8 +500,9 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16x3_kernel(ConvParams p
     constexpr int A_PT = (192 + AR_STEP - 1) / AR_STEP;
     const int ac = A4 ? (tid % A_TPR) * 4 : (tid % A_TPR);
     const int ar = tid / A_TPR;
-    v4u32_t areg4[A4 ? CS * A_PT : 1];
-    unsigned areg[A4 ? 1 : CS * A_PT];
+    v4u32_t areg4[A4 ? A_PT : 1];
+    unsigned areg[A4 ? 1 : A_PT];
+    v4u32_t wreg[3];
     int a_voff[A_PT];
 #pragma unroll
     for (int q = 0; q < A_PT; ++q) a_voff[q] = (int)(((long)(ar + q * AR_STEP) * p.in_row + ac) * 4);
@@ -482,67 +510,56 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16x3_kernel(ConvParams p
     const int n_cchunks = p.Cin_p / KC;
     const int n_chunks = n_cchunks * p.k;
 
-    // B operand: fragment blocks behind the packed f32 matrix, one coalesced 16-byte load per lane
+    // weights: wavefront w stages column tile w of the workgroup's BN / 32 (one 1 KB block per image and step)
     const size_t w_elems_total = (size_t)p.Cout_p * Ktot;
     const int img_bytes = (int)(w_elems_total * 2);
     const __amdgpu_buffer_rsrc_t rs_w = conv_rsrc(p.wp + w_elems_total, (size_t)3 * img_bytes);
-    const int w_tile0 = (n0 >> 5) + wn * TN;          // this wave's first 32-column tile
-    auto load_w = [&](bf16x8_t (&w)[3][TN], int cc, int kk) {
-        const int ks = kk * cin_steps + cc;
+    const bool w_thread = wave < BN / 32;
+    const int w_voff = w_thread ? (((n0 >> 5) + wave) * ksteps) * 1024 + lane * 16 : CONV_OOB;
+    auto load_w = [&](int cc, int kk) {
+        const int soff = (kk * cin_steps + cc) * 1024;
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int m = 0; m < 3; ++m)
-                w[m][j] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(
-                              rs_w, lane * 16, m * img_bytes + ((w_tile0 + j) * ksteps + ks) * 1024, 0));
+        for (int m = 0; m < 3; ++m) wreg[m] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_voff, soff + m * img_bytes, 0);
     };
     const size_t in_total = (size_t)p.B * p.T * p.Cin;
-    auto load_a = [&](int cc0) {                      // chunks cc0 .. cc0 + CS - 1 (missing ones read as zero)
-        const size_t in_off = (size_t)b * p.in_seq + (size_t)x0 * p.stride * p.in_row;
-        const __amdgpu_buffer_rsrc_t rs_in = conv_rsrc(p.in + in_off, (in_total - in_off) * 4);
+    const size_t in_off = (size_t)b * p.in_seq + (size_t)x0 * p.stride * p.in_row;
+    const __amdgpu_buffer_rsrc_t rs_in = conv_rsrc(p.in + in_off, (in_total - in_off) * 4);
+    auto load_a = [&](int cc) {
+        const bool ch_ok = !(cin_ragged && cc == n_cchunks - 1) || cc * KC + ac < p.Cin;
 #pragma unroll
-        for (int c = 0; c < CS; ++c) {
-            const int cc = cc0 + c;
-            const bool ch_ok = cc < n_cchunks && (!(cin_ragged && cc == n_cchunks - 1) || cc * KC + ac < p.Cin);
-#pragma unroll
-            for (int q = 0; q < A_PT; ++q) {
-                const int vo = ch_ok ? a_voff[q] : CONV_OOB;
-                if (A4) areg4[c * A_PT + q] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, cc * KC * 4, 0);
-                else    areg[c * A_PT + q] = __builtin_amdgcn_raw_buffer_load_b32(rs_in, vo, cc * KC * 4, 0);
-            }
+        for (int q = 0; q < A_PT; ++q) {
+            const int vo = ch_ok ? a_voff[q] : CONV_OOB;
+            if (A4) areg4[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, cc * KC * 4, 0);
+            else    areg[q] = __builtin_amdgcn_raw_buffer_load_b32(rs_in, vo, cc * KC * 4, 0);
         }
     };
-    auto stage_a = [&](int buf) {                     // registers -> three bf16 images in LDS
+    auto stage_a = [&](char *As) {                    // registers -> three bf16 images in LDS
 #pragma unroll
-        for (int c = 0; c < CS; ++c) {
-            char *As = lds + (buf * CS + c) * a_bytes;
+        for (int q = 0; q < A_PT; q += (A4 ? 1 : 2)) {
+            const int r = ar + q * AR_STEP;
+            if (A4) {
+                if (r < p.rows_a) {
+                    const v4u32_t x = areg4[q];
+                    unsigned h0, m0, l0, h1, m1, l1;
+                    split3_pair(__uint_as_float(x.x), __uint_as_float(x.y), h0, m0, l0);
+                    split3_pair(__uint_as_float(x.z), __uint_as_float(x.w), h1, m1, l1);
+                    char *dst = As + r * SPLIT_ROW + 16 * ((ac >> 3) ^ ((r >> 3) & 1)) + (ac & 7) * 2;
+                    *reinterpret_cast<uint2 *>(dst) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2 *>(dst + 32) = make_uint2(m0, m1);
+                    *reinterpret_cast<uint2 *>(dst + 64) = make_uint2(l0, l1);
+                }
+            } else {
+                // one element per thread and pass: split two passes' elements together (rows r and r + AR_STEP)
+                unsigned h, m, l;
+                split3_pair(__uint_as_float(areg[q]), __uint_as_float(areg[q + 1 < A_PT ? q + 1 : q]), h, m, l);
 #pragma unroll
-            for (int q = 0; q < A_PT; q += (A4 ? 1 : 2)) {
-                const int r = ar + q * AR_STEP;
-                if (A4) {
-                    if (r < p.rows_a) {
-                        const v4u32_t v = areg4[c * A_PT + q];
-                        unsigned h0, m0, l0, h1, m1, l1;
-                        split3_pair(__uint_as_float(v.x), __uint_as_float(v.y), h0, m0, l0);
-                        split3_pair(__uint_as_float(v.z), __uint_as_float(v.w), h1, m1, l1);
-                        char *dst = As + r * SPLIT_ROW + 16 * ((ac >> 3) ^ ((r >> 3) & 1)) + (ac & 7) * 2;
-                        *reinterpret_cast<uint2 *>(dst) = make_uint2(h0, h1);
-                        *reinterpret_cast<uint2 *>(dst + 32) = make_uint2(m0, m1);
-                        *reinterpret_cast<uint2 *>(dst + 64) = make_uint2(l0, l1);
-                    }
-                } else {
-                    // one element per thread and pass: split two passes' elements together (rows r and r + AR_STEP)
-                    unsigned h, m, l;
-                    split3_pair(__uint_as_float(areg[c * A_PT + q]), __uint_as_float(areg[c * A_PT + (q + 1 < A_PT ? q + 1 : q)]), h, m, l);
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int re = r + e * AR_STEP;
-                        if (q + e < A_PT && re < p.rows_a) {
-                            char *dst = As + re * SPLIT_ROW + 16 * ((ac >> 3) ^ ((re >> 3) & 1)) + (ac & 7) * 2;
-                            *reinterpret_cast<unsigned short *>(dst) = (unsigned short)(e ? h >> 16 : h);
-                            *reinterpret_cast<unsigned short *>(dst + 32) = (unsigned short)(e ? m >> 16 : m);
-                            *reinterpret_cast<unsigned short *>(dst + 64) = (unsigned short)(e ? l >> 16 : l);
-                        }
+                for (int e = 0; e < 2; ++e) {
+                    const int re = r + e * AR_STEP;
+                    if (q + e < A_PT && re < p.rows_a) {
+                        char *dst = As + re * SPLIT_ROW + 16 * ((ac >> 3) ^ ((re >> 3) & 1)) + (ac & 7) * 2;
+                        *reinterpret_cast<unsigned short *>(dst) = (unsigned short)(e ? h >> 16 : h);
+                        *reinterpret_cast<unsigned short *>(dst + 32) = (unsigned short)(e ? m >> 16 : m);
+                        *reinterpret_cast<unsigned short *>(dst + 64) = (unsigned short)(e ? l >> 16 : l);
                     }
                 }
             }
@@ -550,32 +567,43 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16x3_kernel(ConvParams p
     };
 
     const int a_row0 = (wm * TM * 32 + l31) * p.stride;       // window row of tile i at tap kk: a_row0 + i * 32 * stride + kk
+    const int w_rd = w_base + (wn * TN * 3) * 1024 + lane * 16;     // this wave's first column tile, image 0
+    const int w_wr = w_base + (wave * 3) * 1024 + lane * 16;
 
-    bf16x8_t wA[3][TN], wB[3][TN];
     load_a(0);
-    load_w(wA, 0, 0);
+    load_w(0, 0);
+    float *cst = reinterpret_cast<float *>(lds + 2 * a_bytes + 2 * w_bytes);     // [6][BN] epilogue constants
+    {
+        float c[6];
+        conv_load_constants<BN>(p, n0, tid, c);
+        conv_stage_constants<BN>(cst, tid, c);           // visible to the epilogue: at least one barrier follows
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
     int cc = 0, kk = 0;
-    // one (chunk, tap) step: stage the window if a new group of chunks starts, prefetch the next step's weights,
-    // multiply.  Steps alternate between the two weight register sets.
-    auto step = [&](bf16x8_t (&wc)[3][TN], bf16x8_t (&wn_)[3][TN], bool has_next) {
-        if (kk == 0 && cc % CS == 0) {
-            // buffer (cc / CS) & 1 was last read two groups ago: every wave has passed the previous barrier since
-            if (!CONV_DBG(16)) stage_a((cc / CS) & 1);
-            __syncthreads();
-            if (cc + CS < n_cchunks && !CONV_DBG(32)) load_a(cc + CS);
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        const int wbuf = chunk & 1;
+        const int abuf = cc & 1;
+        if (kk == 0 && !CONV_DBG(16)) stage_a(lds + abuf * a_bytes);
+        if (w_thread) {
+            char *dst = lds + wbuf * w_bytes + w_wr;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) *reinterpret_cast<v4u32_t *>(dst + 1024 * m) = wreg[m];
         }
+        __syncthreads();
         int ncc = cc, nkk = kk + 1;
         if (nkk == p.k) { nkk = 0; ncc = cc + 1; }
-        if (has_next && !CONV_DBG(4)) load_w(wn_, ncc, nkk);
-        const char *Ab = lds + (((cc / CS) & 1) * CS + cc % CS) * a_bytes;
-        bf16x8_t a[3][TM];
+        if (chunk + 1 < n_chunks) {
+            if (!CONV_DBG(4)) load_w(ncc, nkk);
+            if (nkk == 0 && !CONV_DBG(32)) load_a(ncc);
+        }
+        const char *Ab = lds + abuf * a_bytes;
+        const char *Wb = lds + wbuf * w_bytes + w_rd;
+        bf16x8_t a[3][TM], w[3][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int row = a_row0 + i * 32 * p.stride + kk;
@@ -583,19 +611,25 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16x3_kernel(ConvParams p
 #pragma unroll
             for (int m = 0; m < 3; ++m)
                 if (!CONV_DBG(8)) a[m][i] = *reinterpret_cast<const bf16x8_t *>(src + 32 * m);
-                else a[m][i] = wc[m][0];
+                else a[m][i] = __builtin_bit_cast(bf16x8_t, wreg[m]);
         }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+                if (!CONV_DBG(8)) w[m][j] = *reinterpret_cast<const bf16x8_t *>(Wb + (j * 3 + m) * 1024);
+                else w[m][j] = __builtin_bit_cast(bf16x8_t, wreg[m]);
         // smallest terms first; the TM x TN accumulators interleave so dependent MFMAs are TM * TN apart
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0};      // window image (0 hi, 1 mid, 2 lo)
         constexpr int PW[6] = {0, 2, 1, 0, 1, 0};      // weight image
         if (!CONV_DBG(2)) {
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+            for (int t = 0; t < 6; ++t)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[PW[t]][j], a[PA[t]][i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[PW[t]][j], a[PA[t]][i], acc[i][j], 0, 0, 0);
         } else {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -603,16 +637,12 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16x3_kernel(ConvParams p
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int m = 0; m < 3; ++m)
-                        acc[i][j][m] += __builtin_bit_cast(v4u32_t, a[m][i]).x + __builtin_bit_cast(v4u32_t, wc[m][j]).x;
+                        acc[i][j][m] += __builtin_bit_cast(v4u32_t, a[m][i]).x + __builtin_bit_cast(v4u32_t, w[m][j]).x;
         }
         cc = ncc; kk = nkk;
-    };
-    for (int chunk = 0; chunk < n_chunks; chunk += 2) {
-        step(wA, wB, chunk + 1 < n_chunks);
-        if (chunk + 1 < n_chunks) step(wB, wA, chunk + 2 < n_chunks);
     }
     if (CONV_DBG(1) && acc[0][0][0] != 12345.678f) return;
-    conv_epilogue<TM, TN, WN>(p, acc, b, x0, n0, wm, wn, l31, kh);
+    conv_epilogue<TM, TN, WN>(p, acc, b, x0, n0, wm, wn, l31, kh, cst);
 }
 
 // Generic VALU kernel for shapes the MFMA tile does not cover (tiny K such as
@@ -661,20 +691,20 @@ extern "C" int nntk_shim_bn_derive(float *d_block, float eps, int C) {
     return 0;
 }
 
-template <int WM, int WN, int TM, int TN, bool A4, int SPLIT_CS = 0>
+template <int WM, int WN, int TM, int TN, bool A4, bool SPLIT = false>
 static int launch_mfma(const ConvParams &p) {
     constexpr int BN = WN * TN * 32;
-    constexpr bool SPLIT = SPLIT_CS > 0;
-    // 41 KB at BN = 128: three workgroups per CU, which is what hides the barrier / staging latency
-    size_t lds = SPLIT ? (size_t)2 * SPLIT_CS * p.rows_a * SPLIT_ROW
+    // 41 KB at BN = 128 (50 KB split): three workgroups per CU, which is what hides the barrier / staging latency
+    size_t lds = SPLIT ? (size_t)2 * (p.rows_a * SPLIT_ROW + (BN / 32) * 3 * 1024)
                        : (size_t)(2 * p.rows_a * CONV_LS + 2 * BN * CONV_LS) * sizeof(float);
+    lds += 6 * BN * sizeof(float);                    // epilogue constants
     ConvParams q = p;
     q.m_tiles = p.B * p.tiles_per_seq;
     q.n_tiles = p.Cout_p / BN;
     const long blocks = (long)((q.m_tiles + 7) / 8) * 8 * q.n_tiles;
     if ((long)p.B * p.tiles_per_seq > 0x7fffffffL / 8 || blocks > 0x7fffffffL)
         return nntk_fail_msg("conv1d: too many tiles for one launch");
-    auto kern = SPLIT ? conv1d_mfma_bf16x3_kernel<WM, WN, TM, TN, A4, SPLIT ? SPLIT_CS : 1> : conv1d_mfma_kernel<WM, WN, TM, TN, A4>;
+    auto kern = SPLIT ? conv1d_mfma_bf16x3_kernel<WM, WN, TM, TN, A4> : conv1d_mfma_kernel<WM, WN, TM, TN, A4>;
     if (lds > 64 * 1024) {
         if (nntk_set_max_dynamic_lds((const void *)kern, lds)) return -1;
     }
@@ -702,7 +732,7 @@ extern "C" int nntk_shim_conv1d(const float *d_in, const float *d_wp, const floa
     p.rows_a = (CONV_BM - 1) * stride + k;
     const NntkOptions &opt = nntk_options();
     p.bn_fast = opt.bn_fast == 1 ? 1 : 0;
-    p.store16 = Cout % 4 == 0 && (((size_t)d_out | (size_t)d_bias | (size_t)d_bn) & 15) == 0;
+    p.store16 = Cout % 4 == 0 && ((size_t)d_out & 15) == 0;
 #ifdef NNTK_CONV_DBG
     p.dbg = opt.conv_dbg;
 #endif
@@ -737,15 +767,13 @@ extern "C" int nntk_shim_conv1d(const float *d_in, const float *d_wp, const floa
         p.out_mode = 0;                               // row (t, b) -> t * B + b: exactly the time-major layout
         p.tiles_per_seq = (p.Tout + CONV_BM - 1) / CONV_BM;
     }
-    if (opt.gemm_split_bf16 == 1 && (long)p.Cout_p * k * p.Cin_p * 6 < (long)CONV_OOB) {
-        if (k == 1 && a4) {        // dense GEMMs: two channel chunks per barrier
-            if (p.Cout_p % 128 == 0) return launch_mfma<2, 2, 2, 2, true, 2>(p);
-            if (p.Cout_p % 64 == 0)  return launch_mfma<4, 1, 1, 2, true, 2>(p);
-            return launch_mfma<4, 1, 1, 1, true, 2>(p);
-        }
-        if (p.Cout_p % 128 == 0) return a4 ? launch_mfma<2, 2, 2, 2, true, 1>(p) : launch_mfma<2, 2, 2, 2, false, 1>(p);
-        if (p.Cout_p % 64 == 0)  return a4 ? launch_mfma<4, 1, 1, 2, true, 1>(p) : launch_mfma<4, 1, 1, 2, false, 1>(p);
-        return a4 ? launch_mfma<4, 1, 1, 1, true, 1>(p) : launch_mfma<4, 1, 1, 1, false, 1>(p);
+    // auto: every contraction except the recurrent input projection (out_mode 1), whose exact k-ordered chain the
+    // streaming kernel reproduces bit for bit (recurrent.hip rec_stream_step_kernel)
+    const bool split = opt.gemm_split_bf16 == 1 || (opt.gemm_split_bf16 < 0 && out_mode == 0);
+    if (split && (long)p.Cout_p * k * p.Cin_p * 6 < (long)CONV_OOB) {
+        if (p.Cout_p % 128 == 0) return a4 ? launch_mfma<2, 2, 2, 2, true, true>(p) : launch_mfma<2, 2, 2, 2, false, true>(p);
+        if (p.Cout_p % 64 == 0)  return a4 ? launch_mfma<4, 1, 1, 2, true, true>(p) : launch_mfma<4, 1, 1, 2, false, true>(p);
+        return a4 ? launch_mfma<4, 1, 1, 1, true, true>(p) : launch_mfma<4, 1, 1, 1, false, true>(p);
     }
     if (p.Cout_p % 128 == 0) return a4 ? launch_mfma<2, 2, 2, 2, true>(p) : launch_mfma<2, 2, 2, 2, false>(p);
     if (p.Cout_p % 64 == 0)  return a4 ? launch_mfma<4, 1, 1, 2, true>(p) : launch_mfma<4, 1, 1, 2, false>(p);

@@ -66,7 +66,7 @@ def test_conv1d_single_sequence(gpu, cin, cout, k, stride, T):
     (128, 1000, 1, 1, 140),    # TimeDistributedDense-like: Cout padded to 1024
 ])
 def test_split_bf16_contraction_matches_oracle(gpu, cin, cout, k, stride, T):
-    """Option gemm_split_bf16 = 1: the 3-way split-bf16 MFMA contraction (conv1d.hip).  It is an f32-accuracy
+    """Option gemm_split_bf16 (auto: on for conv / dense): the 3-way split-bf16 MFMA contraction (conv1d.hip).  It is an f32-accuracy
     contraction but not the exact k-ordered chain, so the check is the oracle tolerance, plus: it must differ from the
     exact path by no more than a few f32 roundings of the row's magnitude."""
     r = rng(cin * 7 + cout)
@@ -74,12 +74,12 @@ def test_split_bf16_contraction_matches_oracle(gpu, cin, cout, k, stride, T):
     x, W, b = u(r, B, T, cin), u(r, cout, cin, k, sc=(cin * k) ** -0.5), u(r, cout, sc=0.2)
     conv = NL.Conv1d(cin, cout, k, stride, T)
     conv.set_weights(W, b)
+    capi.set_option("gemm_split_bf16", "0")
     exact = conv.apply(x)
     capi.set_option("gemm_split_bf16", "1")
-    try:
-        split = conv.apply(x)
-    finally:
-        capi.set_option("gemm_split_bf16", "0")
+    split = conv.apply(x)
+    capi.set_option("gemm_split_bf16", "auto")
+    assert np.array_equal(conv.apply(x), split)                 # auto = split for conv / dense
     ref = O.conv1d(x, W, b, stride)
     close(split, ref)
     assert not np.array_equal(split, exact)                     # the option really selected the other kernel

@@ -29,6 +29,47 @@ def main():
         ("TimeDistributedDense (512->1000)", 256, 996, 512, 1000, 1),
         ("GRU-256 input projection (128->768)", 256, 1000, 128, 768, 1),
     ]
+    # stress distributions on one shape: error measured against the float64 contraction and normalised by the
+    # condition-free scale sum_k |x_k| |w_k| (the quantity any f32 summation's error bound is proportional to)
+    def lognormal(*s):
+        return torch.exp(4.0 * torch.randn(*s, generator=g, device="cuda")) * torch.sign(u(*s))
+    stress = [
+        ("uniform", lambda *s: u(*s), lambda *s: u(*s)),
+        ("lognormal sigma 4 (13 decades)", lognormal, lambda *s: u(*s)),
+        ("both lognormal", lognormal, lognormal),
+        ("cancellation: x = 1000 + noise, w alternating", lambda *s: 1000.0 + u(*s), None),
+        ("tiny 1e-30", lambda *s: 1e-30 * u(*s), lambda *s: u(*s)),
+        ("huge 1e30 x 1e-3", lambda *s: 1e30 * u(*s), lambda *s: 1e-3 * u(*s)),
+        ("denormal inputs 1e-40", lambda *s: 1e-40 * u(*s), lambda *s: u(*s)),
+    ]
+    if "--stress" in sys.argv:
+        B, T, Cin, Cout, k = 64, 500, 40, 128, 5
+        for name, fx, fw in stress:
+            x = fx(B, T, Cin)
+            if fw is None:
+                W = torch.ones(Cout, Cin, k, device="cuda")
+                W.view(Cout, -1)[:, 1::2] = -1.0
+                W = W * (1 + 1e-3 * u(Cout, Cin, k))
+            else:
+                W = fw(Cout, Cin, k)
+            bias = torch.zeros(Cout, device="cuda")
+            conv = NL.Conv1d(Cin, Cout, k, 1, T)
+            conv.set_weights(W.cpu().numpy(), bias.cpu().numpy())
+            xs = x.double().transpose(1, 2)
+            y64 = torch.nn.functional.conv1d(xs, W.double()).transpose(1, 2)
+            mag = torch.nn.functional.conv1d(xs.abs(), W.double().abs()).transpose(1, 2) + 1e-300
+            res = {}
+            for mode in ("0", "1"):
+                capi.set_option("gemm_split_bf16", mode)
+                out = torch.empty(B, T - k + 1, Cout, device="cuda")
+                conv.apply_device(x, out=out)
+                torch.cuda.synchronize()
+                e = (out.double() - y64).abs() / mag
+                res[mode] = dict(max=float(e.max()), mean=float(e.mean()), finite=bool(torch.isfinite(out).all()))
+            capi.set_option("gemm_split_bf16", "0")
+            conv.destroy()
+            print(json.dumps(dict(stress=name, units="error / sum|x||w|  (2^-24 = 5.96e-8)", exact=res["0"], split=res["1"])))
+        return 0
     rows = []
     for name, B, T, Cin, Cout, k in cases:
         x = u(B, T, Cin)
