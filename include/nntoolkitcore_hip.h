@@ -54,6 +54,14 @@ ActivationFunction ActivationFunctionCreate(int size, ActivationImplementerDestr
 void ActivationFunctionDestroy(ActivationFunction filter);
 /* host pointers; size fixed at create time (activation.c:23) */
 void ActivationFunctionApply(ActivationFunction filter, const float *input, float *output);
+/* activation.c:47-54: output = d_out * activation'(.) -- on the cached forward value `a` when the kind has a cached
+ * derivative (sigmoid, tanh, softmax) and a != NULL, else on z.  Reference quirks kept: ReLU's derivative is
+ * clamp(z, 0, 1) (activation_default.c:118-121), and inside ONE call every softmax vector reads d_out at the call's
+ * base (activation_default.c:183).  The Device form takes device pointers; size <= 0 means the handle's size. */
+void ActivationFunctionCalculateGradient(ActivationFunction filter, const float *z, const float *a, const float *d_out,
+                                         float *output);
+int  ActivationFunctionCalculateGradientDevice(ActivationFunction filter, const float *d_z, const float *d_a,
+                                               const float *d_dout, float *d_output, int size);
 
 /* ---- nntoolkitcore/layers/activation_default.h:19-27 ------------------- */
 ActivationFunction ActivationFunctionCreateIdentity(int input_size);
@@ -197,8 +205,20 @@ typedef struct DenseStruct *Dense;
 DenseConfig DenseConfigCreate(int input_size, int output_size, ActivationFunction activation);
 Dense DenseCreateForInference(DenseConfig config);
 DenseWeights *DenseGetWeights(Dense filter);             /* W [in,out] row-major then b [out] */
-int  DenseApplyInference(Dense filter, const float *input, float *output);
+int  DenseApplyInference(Dense filter, const float *input, float *output);     /* -1 on a training-mode handle (dense.c:136) */
 void DenseDestroy(Dense filter);
+
+/* training, second slice (dense.h:23-51, dense.c:85-119, :144-185): forward over the mini-batch keeping x, z, a on the
+ * device; DenseCalculateGradient ADDS d_W, d_b onto the block in mini-batch order and overwrites d_X [mini_batch, in].
+ * The activation must be built-in and sized to output_size (softmax: input_size * vector_size == output_size). */
+typedef DefaultGradient DenseGradient;
+typedef DefaultTrainingConfig DenseTrainingConfig;
+Dense DenseCreateForTraining(DenseConfig config, DenseTrainingConfig training_config);
+int  DenseApplyTrainingBatch(Dense filter, const float *input, float *output);  /* -1 on an inference-mode handle (dense.c:145) */
+DenseGradient *DenseGradientCreate(DenseConfig config, DenseTrainingConfig training_config);
+DenseGradient *DenseGradientCreateFromFilter(Dense dense);                      /* NULL on an inference-mode handle */
+void DenseGradientDestroy(DenseGradient *gradient);
+void DenseCalculateGradient(Dense filter, DenseGradient *gradient, float *d_out /*[mini_batch, out]*/);
 
 /* ---- nntoolkitcore/layers/time_distributed_dense.h:19-45 --------------- */
 typedef struct { DenseConfig dense; int ts; } TimeDistributedDenseConfig;
@@ -393,6 +413,23 @@ int RNNResetState(RNN filter);
 int GRUGetState(GRU filter, float *h_host);
 int RNNGetState(RNN filter, float *h_host);
 int LSTMGetState(LSTM filter, float *h_host, float *c_host);
+
+/* ---- nntoolkitcore/train/loss.h:17-23, train/optimizers.h:12-16 ------- */
+/* Host pointers, the reference's names and operation order (per-sample sums in order, batch sum in order).  One
+ * documented difference: categorical_crossentropy_derivative writes EVERY row; the reference's loop (loss.c:47-52)
+ * forgets the row offset and only ever writes row 0 (identical here). */
+float mean_squared_error(float *y, float *y_pred, int size, int batch);
+void  mean_squared_error_derivative(float *y, float *y_pred, float *d_y_pred, int size, int batch);
+float categorical_crossentropy(float *y, float *y_pred, int c, int batch);
+void  categorical_crossentropy_derivative(float *y, float *y_pred, float *d_y_pred, int c, int batch);
+typedef struct { float learning_rate; } SGD;
+int   sgd_optimize(SGD optimizer, float *gradient, float *weights, int size);    /* w -= g * lr, two roundings */
+/* device-pointer forms */
+int nntk_mean_squared_error_device(const float *d_y, const float *d_pred, int size, int batch, float *loss);
+int nntk_categorical_crossentropy_device(const float *d_y, const float *d_pred, int c, int batch, float *loss);
+int nntk_mean_squared_error_derivative_device(const float *d_y, const float *d_pred, float *d_out, int size, int batch);
+int nntk_categorical_crossentropy_derivative_device(const float *d_y, const float *d_pred, float *d_out, int c, int batch);
+int nntk_sgd_optimize_device(SGD optimizer, const float *d_gradient, float *d_weights, long size);
 
 #ifdef __cplusplus
 }

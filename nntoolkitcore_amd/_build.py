@@ -13,8 +13,8 @@ CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(PKG, "lib", "obj")
 LIB = os.path.join(PKG, "lib", "libnntoolkitcore_hip.so")
 
-HOST_SRC = ["runtime.c", "activation.c", "conv_1d.c", "recurrent.c", "dense.c", "spectrogram.c", "mel.c"]
-HIP_SRC = ["runtime.hip", "conv1d.hip", "recurrent.hip", "spectrogram.hip", "dist.hip", "conv1d_grad.hip"]
+HOST_SRC = ["runtime.c", "activation.c", "conv_1d.c", "recurrent.c", "dense.c", "spectrogram.c", "mel.c", "train.c"]
+HIP_SRC = ["runtime.hip", "conv1d.hip", "recurrent.hip", "spectrogram.hip", "dist.hip", "conv1d_grad.hip", "train.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 

@@ -31,6 +31,10 @@ class DefaultGradient(C.Structure):
     _fields_ = [("d_W", fp), ("d_b", fp), ("d_X", fp)]
 
 
+class SGD(C.Structure):
+    _fields_ = [("learning_rate", C.c_float)]
+
+
 class DefaultWeights(C.Structure):
     _fields_ = [("W", fp), ("b", fp)]
 
@@ -159,6 +163,25 @@ SIGNATURES = {
     "DenseCreateForInference": (vp, [DenseConfig]),
     "DenseGetWeights": (C.POINTER(DefaultWeights), [vp]),
     "DenseApplyInference": (C.c_int, [vp, fp, fp]),
+    # training, second slice
+    "DenseCreateForTraining": (vp, [DenseConfig, ConvTrainingConfig]),
+    "DenseApplyTrainingBatch": (C.c_int, [vp, fp, fp]),
+    "DenseGradientCreate": (C.POINTER(DefaultGradient), [DenseConfig, ConvTrainingConfig]),
+    "DenseGradientCreateFromFilter": (C.POINTER(DefaultGradient), [vp]),
+    "DenseGradientDestroy": (None, [C.POINTER(DefaultGradient)]),
+    "DenseCalculateGradient": (None, [vp, C.POINTER(DefaultGradient), fp]),
+    "ActivationFunctionCalculateGradient": (None, [vp, fp, fp, fp, fp]),
+    "ActivationFunctionCalculateGradientDevice": (C.c_int, [vp, vp, vp, vp, vp, C.c_int]),
+    "mean_squared_error": (C.c_float, [fp, fp, C.c_int, C.c_int]),
+    "mean_squared_error_derivative": (None, [fp, fp, fp, C.c_int, C.c_int]),
+    "categorical_crossentropy": (C.c_float, [fp, fp, C.c_int, C.c_int]),
+    "categorical_crossentropy_derivative": (None, [fp, fp, fp, C.c_int, C.c_int]),
+    "sgd_optimize": (C.c_int, [SGD, fp, fp, C.c_int]),
+    "nntk_mean_squared_error_device": (C.c_int, [vp, vp, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "nntk_categorical_crossentropy_device": (C.c_int, [vp, vp, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "nntk_mean_squared_error_derivative_device": (C.c_int, [vp, vp, vp, C.c_int, C.c_int]),
+    "nntk_categorical_crossentropy_derivative_device": (C.c_int, [vp, vp, vp, C.c_int, C.c_int]),
+    "nntk_sgd_optimize_device": (C.c_int, [SGD, vp, vp, C.c_long]),
     "DenseDestroy": (None, [vp]),
     "TimeDistributedDenseConfigCreate": (TimeDistributedDenseConfig, [C.c_int, DenseConfig]),
     "TimeDistributedDenseCreateForInference": (vp, [TimeDistributedDenseConfig]),

@@ -104,6 +104,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t conv_rsrc(const void *base, si
 // The per-channel constants come from LDS (conv_stage_constants, written before the K loop's first barrier): fetched
 // from global memory inside the epilogue they were eight serial load -> use round trips per tile, a quarter of the
 // fused Conv+BN+ReLU time.
+// a * b + c with TWO roundings (the instructions keep this mode when the helper is inlined)
+#pragma clang fp contract(off)
+__device__ __forceinline__ float nofma_muladd(float a, float b, float c) { return a * b + c; }
+#pragma clang fp contract(fast)
+
 template <int BN>
 __device__ __forceinline__ void conv_load_constants(const ConvParams &p, int n0, int tid, float (&c)[6]) {
     c[0] = 0.f; c[1] = 1.f; c[2] = 0.f; c[3] = 0.f; c[4] = 1.f; c[5] = 1.f;      // bias | gamma | beta | mean | sd | 1/sd
@@ -184,7 +189,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
                             const float d = v[e] - mu[e];
                             float qn = d * rsd[e];
                             qn = fmaf(fmaf(-qn, sd[e], d), rsd[e], qn);
-                            v[e] = p.bn_fast ? (d * rsd[e]) * ga[e] + be[e] : qn * ga[e] + be[e];
+                            // separately rounded multiply and add, as the reference's op_vec_mul / op_vec_add (and the
+                            // standalone BatchNorm kernel): the fused result equals the conv -> BatchNorm chain bit for bit
+                            v[e] = p.bn_fast ? (d * rsd[e]) * ga[e] + be[e] : nofma_muladd(qn, ga[e], be[e]);
                         }
                         v[e] = ACT == -1 ? nntk_act(p.act_kind, v[e], p.relu_a)
                              : ACT == NNTK_ACT_RELU ? nntk_act(NNTK_ACT_RELU, v[e], p.relu_a)

@@ -94,6 +94,14 @@ int nntk_shim_activation(int kind, float relu_a, int softmax_vector_size,
 /* ---- bidirectional helpers (layers/bidirectional.c): rows of [B, T, F] in reverse time order; row-wise
  *      concatenation [rows, C] | [rows, C] -> [rows, 2C]; elementwise sum */
 int nntk_shim_reverse_time(const float *d_in, float *d_out, long B, int T, int F);
+/* ---- training, second slice (train.hip): reference operation order throughout ---- */
+int nntk_shim_activation_grad(int kind, int vector_size, int vectors_per_call, const float *d_z, const float *d_a,
+                              const float *d_dout, float *d_out, long n);
+int nntk_shim_dense_grad(const float *d_x, const float *d_W /*[in,out] caller layout*/, const float *d_dz, float *d_gW,
+                         float *d_gb, float *d_dX, int B, int in, int out);
+int nntk_shim_loss_rows(int kind /*0 mse, 1 categorical ce*/, const float *d_y, const float *d_pred, float *d_per_row, int size, int batch);
+int nntk_shim_loss_grad(int kind, const float *d_y, const float *d_pred, float *d_out, int size, int batch);
+int nntk_shim_sgd(float lr, const float *d_grad, float *d_w, long n);
 int nntk_shim_concat2(const float *d_a, const float *d_b, float *d_out, long rows, int C);
 int nntk_shim_add2(const float *d_a, const float *d_b, float *d_out, long n);
 

@@ -326,6 +326,8 @@ int nntk_shim_memset(void *d_ptr, int value, size_t bytes) {
 // block stays in L1/L2.  Grid-stride over float elements; when C % 4 == 0 each
 // lane moves 16 B.
 // ----------------------------------------------------------------------------
+// (contraction off: the reference rounds the multiply by gamma and the add of beta separately; hipcc would fuse them)
+#pragma clang fp contract(off)
 __global__ __launch_bounds__(256) void bn_kernel_vec4(const float4 *in, const float *__restrict__ bn,
                                                       float eps, float4 *out, long n4, int C) {
     const float *gamma = bn, *beta = bn + C, *mean = bn + 2 * C, *var = bn + 3 * C;
@@ -351,6 +353,7 @@ __global__ __launch_bounds__(256) void bn_kernel(const float *in, const float *_
         out[i] = ((in[i] - mean[c]) / s) * gamma[c] + beta[c];
     }
 }
+#pragma clang fp contract(fast)
 
 // elementwise activations (activation_default.c), 16 B per lane where aligned
 __global__ __launch_bounds__(256) void act_kernel(int kind, float relu_a, const float *in,

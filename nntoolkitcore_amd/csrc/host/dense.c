@@ -16,6 +16,9 @@ struct DenseStruct {
     nntk_wblock wb;
     float *d_wp, *d_bias;
     nntk_devbuf d_in, d_out;
+    /* training (dense.c:18-48): x | z | a kept from DenseApplyTrainingBatch for DenseCalculateGradient */
+    int training, mini_batch;
+    nntk_devbuf d_x, d_z, d_a, d_dz, d_dout, d_grad, d_wraw, d_dx;
 };
 
 /* dense.c:67-73 */
@@ -51,6 +54,9 @@ void DenseDestroy(Dense filter) {
     nntk_shim_free(filter->d_bias);
     nntk_devbuf_free(&filter->d_in);
     nntk_devbuf_free(&filter->d_out);
+    nntk_devbuf_free(&filter->d_x); nntk_devbuf_free(&filter->d_z); nntk_devbuf_free(&filter->d_a);
+    nntk_devbuf_free(&filter->d_dz); nntk_devbuf_free(&filter->d_dout); nntk_devbuf_free(&filter->d_grad);
+    nntk_devbuf_free(&filter->d_wraw); nntk_devbuf_free(&filter->d_dx);
     nntk_wblock_free(&filter->wb);
     free(filter->weights);
     free(filter);
@@ -120,11 +126,109 @@ static int dense_rows_host(Dense f, const float *input, float *output, long rows
     return nntk_shim_download(output, d_out, n_out * sizeof(float));
 }
 
-/* dense.c:135-142 */
+/* dense.c:135-142 (-1 for a training-mode handle, :136-138) */
 int DenseApplyInference(Dense filter, const float *input, float *output) {
     nntk_shim_clear_error();
     if (!filter) NNTK_FAIL("DenseApplyInference: NULL handle");
+    if (filter->training) NNTK_FAIL("DenseApplyInference: the handle was created for training");
     return dense_rows_host(filter, input, output, 1);
+}
+
+/* ---- training, second slice: dense.c:85-119 (create, gradient block), :144-162 (forward over the
+ *      mini-batch keeping x, z, a), :164-185 (DenseCalculateGradient) ---- */
+Dense DenseCreateForTraining(DenseConfig config, DenseTrainingConfig training_config) {
+    Dense f = DenseCreateForInference(config);
+    if (!f) return NULL;
+    f->training = 1;
+    f->mini_batch = training_config.mini_batch_size;
+    return f;
+}
+
+/* one zeroed block d_W | d_b | d_X (weights_private.c:29-36) */
+DenseGradient *DenseGradientCreate(DenseConfig config, DenseTrainingConfig training_config) {
+    DenseGradient *g = (DenseGradient *)malloc(sizeof(DenseGradient));
+    if (!g) return NULL;
+    size_t w = (size_t)config.input_size * config.output_size;
+    size_t x = (size_t)training_config.mini_batch_size * config.input_size;
+    g->d_W = (float *)calloc(w + config.output_size + x + 1, sizeof(float));
+    if (!g->d_W) { free(g); return NULL; }
+    g->d_b = g->d_W + w;
+    g->d_X = g->d_b + config.output_size;
+    return g;
+}
+DenseGradient *DenseGradientCreateFromFilter(Dense dense) {
+    if (!dense || !dense->training) return NULL;                      /* dense.c:107-109 */
+    DenseTrainingConfig tc;
+    tc.mini_batch_size = dense->mini_batch;
+    return DenseGradientCreate(dense->config, tc);
+}
+void DenseGradientDestroy(DenseGradient *gradient) {
+    if (!gradient) return;
+    free(gradient->d_W);
+    free(gradient);
+}
+
+static int dense_act_matches(Dense f) {
+    ActivationFunction act = f->config.activation;
+    if (!act) return 1;
+    if (act->kind == NNTK_ACT_CUSTOM) return 0;
+    long n = act->kind == NNTK_ACT_SOFTMAX ? (long)act->input_size * act->vector_size : act->input_size;
+    return n == f->config.output_size;
+}
+
+int DenseApplyTrainingBatch(Dense filter, const float *input, float *output) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("DenseApplyTrainingBatch: NULL handle");
+    if (!filter->training) NNTK_FAIL("DenseApplyTrainingBatch: the handle was created for inference");      /* dense.c:145-147 */
+    if (!dense_act_matches(filter))
+        NNTK_FAIL("DenseApplyTrainingBatch: the activation must be built-in and sized to the dense output_size");
+    const int B = filter->mini_batch, in = filter->config.input_size, out = filter->config.output_size;
+    if (B <= 0) return 0;
+    if (dense_ensure(filter, 1)) return -1;
+    float *d_x = nntk_devbuf_reserve(&filter->d_x, (size_t)B * in);
+    float *d_z = nntk_devbuf_reserve(&filter->d_z, (size_t)B * out);
+    float *d_a = nntk_devbuf_reserve(&filter->d_a, (size_t)B * out);
+    if (!d_x || !d_z || !d_a) return -1;
+    if (nntk_shim_upload(d_x, input, (size_t)B * in * sizeof(float))) return -1;
+    /* z = x W + b for the whole mini-batch (one GEMM), then a = activation(z) as its own pass: z is needed later */
+    if (nntk_shim_conv1d(d_x, filter->d_wp, filter->d_bias, NULL, 0.f, NNTK_ACT_IDENTITY, 1.f, d_z, 1, B, in, out, 1, 1, B, 0))
+        return -1;
+    ActivationFunction act = filter->config.activation;
+    if (act) {
+        if (nntk_shim_activation(act->kind, act->relu_a, act->vector_size, d_z, d_a, (long)B * out)) return -1;
+    } else if (nntk_shim_copy_d2d(d_a, d_z, (size_t)B * out * sizeof(float))) {
+        return -1;
+    }
+    return nntk_shim_download(output, d_a, (size_t)B * out * sizeof(float));
+}
+
+/* d_W and d_b are accumulated onto the caller's block in mini-batch order (default_gradient_sum, weights_private.c:43-48),
+ * d_X is overwritten.  void in the reference; errors through nntk_last_error(). */
+void DenseCalculateGradient(Dense filter, DenseGradient *gradient, float *d_out) {
+    nntk_shim_clear_error();
+    if (!filter || !gradient || !d_out) { nntk_set_error("DenseCalculateGradient: NULL argument"); return; }
+    if (!filter->training || !filter->d_x.p) { nntk_set_error("DenseCalculateGradient: run DenseApplyTrainingBatch on a training handle first"); return; }
+    const int B = filter->mini_batch, in = filter->config.input_size, out = filter->config.output_size;
+    const size_t w = (size_t)in * out;
+    float *d_dout = nntk_devbuf_reserve(&filter->d_dout, (size_t)B * out);
+    float *d_dz = nntk_devbuf_reserve(&filter->d_dz, (size_t)B * out);
+    float *d_grad = nntk_devbuf_reserve(&filter->d_grad, w + out);
+    float *d_wraw = nntk_devbuf_reserve(&filter->d_wraw, w);
+    float *d_dx = nntk_devbuf_reserve(&filter->d_dx, (size_t)B * in);
+    if (!d_dout || !d_dz || !d_grad || !d_wraw || !d_dx) return;
+    if (nntk_shim_upload(d_dout, d_out, (size_t)B * out * sizeof(float))) return;
+    if (nntk_shim_upload(d_wraw, filter->weights->W, w * sizeof(float))) return;             /* caller layout [in, out] */
+    if (nntk_shim_upload(d_grad, gradient->d_W, (w + out) * sizeof(float))) return;          /* d_W | d_b are contiguous */
+    ActivationFunction act = filter->config.activation;
+    const float *dz = d_dout;
+    if (act) {      /* dz = d_out * activation'(z)  (per sample in the reference; the kernels are elementwise / per vector) */
+        int vpc = act->kind == NNTK_ACT_SOFTMAX ? act->input_size : 1;
+        if (nntk_shim_activation_grad(act->kind, act->vector_size, vpc, filter->d_z.p, filter->d_a.p, d_dout, d_dz, (long)B * out)) return;
+        dz = d_dz;
+    }
+    if (nntk_shim_dense_grad(filter->d_x.p, d_wraw, dz, d_grad, d_grad + w, d_dx, B, in, out)) return;
+    if (nntk_shim_download(gradient->d_W, d_grad, (w + out) * sizeof(float))) return;
+    nntk_shim_download(gradient->d_X, d_dx, (size_t)B * in * sizeof(float));
 }
 
 /* ========================= TimeDistributedDense =========================== */

@@ -92,6 +92,16 @@ void ref_conv1d_batch(const float *in, const float *W, const float *b, float *ou
 void ref_conv1d_gradient(const float *in, const float *W, const float *dout, float *dW, float *db, float *dX,
                          int B, int T, int Cin, int Cout, int k, int stride);
 
+/* training, second slice: activation gradients, Dense gradient, losses, SGD (see nnref_layers.c for file:line) */
+void ref_activation_gradient(int kind, int vector_size, const float *z, const float *a, const float *dout, float *out, int size);
+void ref_dense_gradient(const float *x, const float *W, const float *z, const float *a, const float *dout,
+                        int act_kind, int vector_size, int act_size, float *gW, float *gb, float *dX, int B, int in, int out);
+float ref_mean_squared_error(const float *y, const float *p, int size, int batch);
+void  ref_mean_squared_error_derivative(const float *y, const float *p, float *d, int size, int batch);
+float ref_categorical_crossentropy(const float *y, const float *p, int c, int batch);
+void  ref_categorical_crossentropy_derivative(const float *y, const float *p, float *d, int c, int batch);
+void  ref_sgd_optimize(float lr, const float *g, float *w, int size);
+
 void ref_batch_norm(const float *in, const float *gamma, const float *beta,
                     const float *mean, const float *variance, float *out,
                     float epsilon, int count, int C);

@@ -157,6 +157,74 @@ def conv1d_gradient(x, W, dout, stride=1):
     return dW, db, dX
 
 
+def activation_gradient(kind, z, a, dout, softmax_vector_size=0):
+    """ActivationFunctionCalculateGradient for ONE call of a handle sized to the arrays (a=None: non-cached form)."""
+    dout = _f32(dout)
+    z = None if z is None else _f32(z)
+    a = None if a is None else _f32(a)
+    out = np.empty_like(dout)
+    size = dout.size if kind != ACT_SOFTMAX else dout.size // softmax_vector_size
+    lib().ref_activation_gradient(C.c_int(kind), C.c_int(softmax_vector_size), _p(z) if z is not None else None,
+                                  _p(a) if a is not None else None, _p(dout), _p(out), C.c_int(size))
+    return out
+
+
+def dense_forward_training(x, W, b, act=None, softmax_vector_size=0):
+    """(z, a) [B,out] as DenseApplyTrainingBatch caches them."""
+    x = _f32(x)
+    z = time_distributed_dense(x, W, b)
+    a = z.copy() if act is None else np.stack([activation(act, z[i], softmax_vector_size=softmax_vector_size) for i in range(x.shape[0])])
+    return z, a
+
+
+def dense_gradient(x, W, z, a, dout, act=None, softmax_vector_size=0, gW=None, gb=None):
+    """DenseCalculateGradient: returns (gW [in,out], gb [out], dX [B,in]); gW / gb start from the given blocks (zeros)."""
+    x, W, z, a, dout = _f32(x), _f32(W), _f32(z), _f32(a), _f32(dout)
+    B, n_in = x.shape
+    n_out = W.shape[1]
+    gW = np.zeros_like(W) if gW is None else _f32(gW).copy()
+    gb = np.zeros(n_out, np.float32) if gb is None else _f32(gb).copy()
+    dX = np.empty_like(x)
+    kind = -1 if act is None else act
+    act_size = n_out if act != ACT_SOFTMAX else n_out // softmax_vector_size
+    lib().ref_dense_gradient(_p(x), _p(W), _p(z), _p(a), _p(dout), C.c_int(kind), C.c_int(softmax_vector_size),
+                             C.c_int(act_size), _p(gW), _p(gb), _p(dX), B, n_in, n_out)
+    return gW, gb, dX
+
+
+def mean_squared_error(y, p):
+    y, p = _f32(y), _f32(p)
+    lib().ref_mean_squared_error.restype = C.c_float
+    return float(lib().ref_mean_squared_error(_p(y), _p(p), C.c_int(y.shape[1]), C.c_int(y.shape[0])))
+
+
+def mean_squared_error_derivative(y, p):
+    y, p = _f32(y), _f32(p)
+    d = np.empty_like(y)
+    lib().ref_mean_squared_error_derivative(_p(y), _p(p), _p(d), C.c_int(y.shape[1]), C.c_int(y.shape[0]))
+    return d
+
+
+def categorical_crossentropy(y, p):
+    y, p = _f32(y), _f32(p)
+    lib().ref_categorical_crossentropy.restype = C.c_float
+    return float(lib().ref_categorical_crossentropy(_p(y), _p(p), C.c_int(y.shape[1]), C.c_int(y.shape[0])))
+
+
+def categorical_crossentropy_derivative(y, p, fill=np.nan):
+    """AS WRITTEN in the reference: only row 0 is computed; the other rows keep `fill`."""
+    y, p = _f32(y), _f32(p)
+    d = np.full_like(y, fill)
+    lib().ref_categorical_crossentropy_derivative(_p(y), _p(p), _p(d), C.c_int(y.shape[1]), C.c_int(y.shape[0]))
+    return d
+
+
+def sgd_optimize(lr, g, w):
+    g, w = _f32(g), _f32(w).copy()
+    lib().ref_sgd_optimize(C.c_float(lr), _p(g), _p(w), C.c_int(w.size))
+    return w
+
+
 def batch_norm(x, gamma, beta, mean, var, eps):
     x = _f32(x)
     C_ = x.shape[-1]

@@ -374,3 +374,109 @@ void ref_time_distributed_dense(const float *x, const float *W, const float *b, 
         ref_dense(x + (size_t)t * in, W, b, out + (size_t)t * out_size, in, out_size,
                   act_kind, relu_a, softmax_vector_size, act_size);
 }
+
+/* ======================= training, second slice ======================= */
+
+/* layers/activation.c:47-54 with activation_default.c:38-51 (sigmoid), :70-82 (tanh), :94-96 (identity), :118-121
+ * (ReLU), :169-190 (softmax).  a == NULL selects the non-cached derivative (forward recomputed from z); kinds without a
+ * cached derivative (identity, ReLU) always use z.  size = elements, or vectors for softmax.  The softmax loop reads
+ * d_out at the CALL's base for every vector (activation_default.c:183) -- restated as it is. */
+void ref_activation_gradient(int kind, int vector_size, const float *z, const float *a, const float *dout, float *out, int size) {
+    if (kind == REF_ACT_SOFTMAX) {
+        int v = vector_size;
+        float *fwd = NULL;
+        if (!a) {
+            fwd = (float *)malloc((size_t)size * v * sizeof(float));
+            ref_activation(REF_ACT_SOFTMAX, 1.0f, v, z, fwd, size);
+            a = fwd;
+        }
+        float *m = (float *)malloc((size_t)v * v * sizeof(float));
+        float *tmp = (float *)malloc((size_t)v * sizeof(float));
+        for (int index = 0; index < size; ++index) {
+            const float *in = a + (size_t)index * v;
+            for (int i = 0; i < v; ++i)
+                for (int j = 0; j < v; ++j)
+                    m[i * v + j] = i == j ? in[i] * (1 - in[i]) : -1 * in[i] * in[j];
+            ref_op_mat_mul(dout, m, tmp, 1, v, v);
+            memcpy(out + (size_t)index * v, tmp, (size_t)v * sizeof(float));
+        }
+        free(m); free(tmp); free(fwd);
+        return;
+    }
+    for (int i = 0; i < size; ++i) {
+        float r;
+        if (kind == REF_ACT_SIGMOID || kind == REF_ACT_TANH) {
+            float s;
+            if (a) s = a[i];
+            else ref_activation(kind, 1.0f, 0, z + i, &s, 1);
+            if (kind == REF_ACT_SIGMOID) { float t = -s; t = t + 1; t = s * t; r = t * dout[i]; }
+            else { float t = s * s; t = -t; t = t + 1; r = t * dout[i]; }
+        } else if (kind == REF_ACT_RELU) {
+            float c = fmaxf(fminf(z[i], 1.0f), 0.0f);
+            r = c * dout[i];
+        } else {
+            r = dout[i];
+        }
+        out[i] = r;
+    }
+}
+
+/* layers/dense.c:164-185 + weights_private.c:43-48.  act_kind < 0: no activation handle.  act_size = the handle's
+ * input_size (elements, or vectors for softmax) -- the reference calls the activation once per sample.  gW [in,out] and
+ * gb [out] are ADDED to in mini-batch order, dX [B,in] is overwritten.  z, a: [B,out] cached by the forward pass. */
+void ref_dense_gradient(const float *x, const float *W, const float *z, const float *a, const float *dout,
+                        int act_kind, int vector_size, int act_size, float *gW, float *gb, float *dX, int B, int in, int out) {
+    float *dz = (float *)malloc((size_t)out * sizeof(float));
+    float *dW = (float *)malloc((size_t)in * out * sizeof(float));
+    for (int b = 0; b < B; ++b) {
+        if (act_kind >= 0) {
+            int cached = act_kind == REF_ACT_SIGMOID || act_kind == REF_ACT_TANH || act_kind == REF_ACT_SOFTMAX;
+            ref_activation_gradient(act_kind, vector_size, z + (size_t)b * out, cached ? a + (size_t)b * out : NULL,
+                                    dout + (size_t)b * out, dz, act_size);
+        } else {
+            memcpy(dz, dout + (size_t)b * out, (size_t)out * sizeof(float));
+        }
+        ref_op_mat_mul(x + (size_t)b * in, dz, dW, in, out, 1);              /* d_W = x^T dz */
+        ref_op_mat_mul(W, dz, dX + (size_t)b * in, in, 1, out);              /* d_X = W dz */
+        for (size_t e = 0; e < (size_t)in * out; ++e) gW[e] = dW[e] + gW[e];
+        for (int o = 0; o < out; ++o) gb[o] = dz[o] + gb[o];
+    }
+    free(dz); free(dW);
+}
+
+/* train/loss.c:13-24 */
+float ref_mean_squared_error(const float *y, const float *p, int size, int batch) {
+    float loss = 0.0f;
+    for (int b = 0; b < batch; ++b) {
+        float one = 0.0f;
+        for (int i = 0; i < size; ++i) { float d = y[(size_t)b * size + i] - p[(size_t)b * size + i]; d = d * d; one = one + d; }
+        loss += one / (float)size;
+    }
+    return loss / (float)batch;
+}
+/* train/loss.c:26-32 */
+void ref_mean_squared_error_derivative(const float *y, const float *p, float *d, int size, int batch) {
+    for (int b = 0; b < batch; ++b) {
+        float k = -2.0f / (float)(size * batch);
+        for (int i = 0; i < size; ++i) { float t = y[(size_t)b * size + i] - p[(size_t)b * size + i]; d[(size_t)b * size + i] = t * k; }
+    }
+}
+/* train/loss.c:34-45 */
+float ref_categorical_crossentropy(const float *y, const float *p, int c, int batch) {
+    float loss = 0.0f;
+    for (int b = 0; b < batch; ++b) {
+        float one = 0.0f;
+        for (int i = 0; i < c; ++i) { float t = logf(p[(size_t)b * c + i]); t = t * y[(size_t)b * c + i]; one = one + t; }
+        loss += -one;
+    }
+    return loss / (float)batch;
+}
+/* train/loss.c:47-52 AS WRITTEN: the loop body ignores b, so only row 0 is ever written (batch times) */
+void ref_categorical_crossentropy_derivative(const float *y, const float *p, float *d, int c, int batch) {
+    for (int b = 0; b < batch; ++b)
+        for (int i = 0; i < c; ++i) { float t = y[i] / p[i]; d[i] = t * -1.0f; }
+}
+/* train/optimizers.c:13-19 */
+void ref_sgd_optimize(float lr, const float *g, float *w, int size) {
+    for (int i = 0; i < size; ++i) { float t = g[i] * lr; w[i] = w[i] - t; }
+}

@@ -1,0 +1,190 @@
+"""Training path, second slice through the C boundary: activation gradients, Dense training forward and
+DenseCalculateGradient, the losses and SGD -- against the oracle (reference operation order) and torch float64 autograd."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from nntoolkitcore_amd import capi
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+P = lambda a: a.ctypes.data_as(capi.fp)
+
+
+def rng(seed):
+    return np.random.default_rng(seed)
+
+
+def u(r, *shape, sc=1.0):
+    return r.uniform(-sc, sc, shape).astype(np.float32)
+
+
+ACTS = {"sigmoid": (O.ACT_SIGMOID, "ActivationFunctionCreateSigmoid"), "tanh": (O.ACT_TANH, "ActivationFunctionCreateTanh"),
+        "identity": (O.ACT_IDENTITY, "ActivationFunctionCreateIdentity"), "relu": (O.ACT_RELU, None), "softmax": (O.ACT_SOFTMAX, None)}
+
+
+def make_act(L, name, n, v=0):
+    if name == "relu":
+        return L.ActivationFunctionCreateReLU(n, 1.0)
+    if name == "softmax":
+        return L.ActivationFunctionCreateSoftmax(n // v, v)
+    return getattr(L, ACTS[name][1])(n)
+
+
+@pytest.mark.parametrize("name,n,v", [("sigmoid", 1000, 0), ("tanh", 777, 0), ("identity", 33, 0), ("relu", 4096, 0),
+                                      ("softmax", 60, 10), ("softmax", 7, 7)])
+@pytest.mark.parametrize("cached", [True, False])
+def test_activation_gradient_is_bit_exact(gpu, name, n, v, cached):
+    """ActivationFunctionCalculateGradient (activation.c:47-54): the derivative kernels mirror the reference's separately
+    rounded operations, so given the same z / a they agree with the oracle BIT FOR BIT (sigmoid / tanh / softmax forward
+    values recomputed on the device in the non-cached form are within the forward tolerance instead)."""
+    L = capi.load()
+    r = rng(n + 7 * cached)
+    z = u(r, n, sc=2.0)
+    kind = ACTS[name][0]
+    a = O.activation(kind, z, softmax_vector_size=v)
+    dout = u(r, n)
+    h = make_act(L, name, n, v)
+    out = np.empty(n, np.float32)
+    L.ActivationFunctionCalculateGradient(h, P(z), P(a) if cached else None, P(dout), P(out))
+    assert capi.last_error() == ""
+    ref = O.activation_gradient(kind, z, a if cached else None, dout, softmax_vector_size=v)
+    if cached or name in ("identity", "relu"):
+        np.testing.assert_array_equal(out, ref)
+    else:
+        np.testing.assert_allclose(out, ref, rtol=2e-6, atol=2e-7)
+    L.ActivationFunctionDestroy(h)
+
+
+def test_relu_gradient_is_the_reference_clamp_not_a_step(gpu):
+    L = capi.load()
+    z = np.array([-1.0, 0.0, 0.25, 0.5, 1.0, 3.0], np.float32)
+    dout = np.full(6, 2.0, np.float32)
+    h = L.ActivationFunctionCreateReLU(6, 1.0)
+    out = np.empty(6, np.float32)
+    L.ActivationFunctionCalculateGradient(h, P(z), None, P(dout), P(out))
+    np.testing.assert_array_equal(out, np.array([0, 0, 0.5, 1.0, 2.0, 2.0], np.float32))    # activation_default.c:118-121
+    L.ActivationFunctionDestroy(h)
+
+
+@pytest.mark.parametrize("B,n_in,n_out,act,v", [(5, 12, 7, None, 0), (16, 64, 32, "sigmoid", 0), (8, 33, 10, "softmax", 10),
+                                                (32, 512, 1000, "tanh", 0), (3, 20, 24, "relu", 0), (64, 256, 40, "softmax", 40)])
+def test_dense_training_forward_and_gradient(gpu, B, n_in, n_out, act, v):
+    import torch
+    L = capi.load()
+    r = rng(B * 13 + n_out)
+    x = u(r, B, n_in)
+    W, b = u(r, n_in, n_out, sc=n_in ** -0.5), u(r, n_out, sc=0.1)
+    ah = make_act(L, act, n_out, v) if act else None
+    kind = ACTS[act][0] if act else None
+    cfg = L.DenseConfigCreate(n_in, n_out, ah)
+    tc = capi.ConvTrainingConfig(B)
+    h = L.DenseCreateForTraining(cfg, tc)
+    w = L.DenseGetWeights(h).contents
+    C.memmove(w.W, W.ctypes.data, W.nbytes); C.memmove(w.b, b.ctypes.data, b.nbytes)
+    y = np.empty((B, n_out), np.float32)
+    assert L.DenseApplyInference(h, P(x), P(y)) == -1                     # dense.c:136-138
+    assert L.DenseApplyTrainingBatch(h, P(x), P(y)) == 0, capi.last_error()
+    z, a = O.dense_forward_training(x, W, b, act=kind, softmax_vector_size=v)
+    np.testing.assert_allclose(y, a, rtol=1e-5, atol=1e-6)
+    dout = u(r, B, n_out)
+    g = L.DenseGradientCreateFromFilter(h)
+    L.DenseCalculateGradient(h, g, P(dout))
+    assert capi.last_error() == ""
+    gW = np.ctypeslib.as_array(g.contents.d_W, shape=(n_in, n_out)).copy()
+    gb = np.ctypeslib.as_array(g.contents.d_b, shape=(n_out,)).copy()
+    gX = np.ctypeslib.as_array(g.contents.d_X, shape=(B, n_in)).copy()
+    oW, ob, oX = O.dense_gradient(x, W, z, a, dout, act=kind, softmax_vector_size=v)
+    # torch float64 autograd of the same forward (ReLU: the reference's clamp derivative, so skip autograd there)
+    refs = [("oracle", oW, ob, oX)]
+    if act != "relu":
+        xt, Wt, bt = (torch.tensor(t).double().requires_grad_(True) for t in (x, W, b))
+        zt = xt @ Wt + bt
+        at = {None: zt, "sigmoid": torch.sigmoid(zt), "tanh": torch.tanh(zt), "softmax": torch.softmax(zt, 1)}[act]
+        at.backward(torch.tensor(dout).double())
+        refs.append(("torch float64", Wt.grad.numpy(), bt.grad.numpy(), xt.grad.numpy()))
+    tol = 4e-6 * np.sqrt(max(B, n_out))
+    for nm, rW, rb, rX in refs:
+        for part, got, ref in (("dW", gW, rW), ("db", gb, rb), ("dX", gX, rX)):
+            sc = max(1.0, float(np.abs(ref).max()))
+            err = float(np.abs(got - ref).max())
+            print("dense grad %s vs %s (%d,%d,%d,%s): %.2e" % (part, nm, B, n_in, n_out, act, err))
+            assert err <= tol * sc, (part, nm, err)
+    # a second call accumulates d_W / d_b onto the block and rewrites d_X
+    L.DenseCalculateGradient(h, g, P(dout))
+    np.testing.assert_allclose(np.ctypeslib.as_array(g.contents.d_W, shape=(n_in, n_out)), 2 * gW, rtol=2e-6, atol=1e-6)
+    np.testing.assert_array_equal(np.ctypeslib.as_array(g.contents.d_X, shape=(B, n_in)), gX)
+    # mode checks like the reference
+    hi = L.DenseCreateForInference(cfg)
+    assert L.DenseApplyTrainingBatch(hi, P(x), P(y)) == -1                # dense.c:145-147
+    assert not L.DenseGradientCreateFromFilter(hi)                        # dense.c:107-109
+    L.DenseDestroy(hi); L.DenseGradientDestroy(g); L.DenseDestroy(h)
+    if ah: L.ActivationFunctionDestroy(ah)
+
+
+def test_losses_and_sgd_follow_the_reference(gpu):
+    L = capi.load()
+    r = rng(3)
+    B, c = 37, 19
+    y = np.eye(c, dtype=np.float32)[r.integers(0, c, B)]
+    p = O.activation(O.ACT_SOFTMAX, u(r, B, c, sc=2.0), softmax_vector_size=c).reshape(B, c)
+    # MSE: per-sample sums in order on the device, batch sum in order on the host -> the oracle's value bit for bit
+    assert L.mean_squared_error(P(y), P(p), c, B) == np.float32(O.mean_squared_error(y, p))
+    d = np.empty_like(y)
+    L.mean_squared_error_derivative(P(y), P(p), P(d), c, B)
+    np.testing.assert_array_equal(d, O.mean_squared_error_derivative(y, p))
+    # categorical cross-entropy: device logf is within 1 ulp of libm's
+    got, ref = L.categorical_crossentropy(P(y), P(p), c, B), O.categorical_crossentropy(y, p)
+    assert abs(got - ref) <= 2e-6 * abs(ref)
+    L.categorical_crossentropy_derivative(P(y), P(p), P(d), c, B)
+    o = O.categorical_crossentropy_derivative(y, p)                       # the reference only ever writes row 0
+    np.testing.assert_array_equal(d[0], o[0])
+    assert np.isnan(o[1:]).all()
+    np.testing.assert_array_equal(d, -(y / p))                             # every row here
+    # SGD: two roundings, no FMA
+    n = 100003
+    g, w = u(r, n), u(r, n)
+    w2 = w.copy()
+    assert L.sgd_optimize(capi.SGD(0.0371), P(g), P(w2), n) == 0, capi.last_error()
+    np.testing.assert_array_equal(w2, O.sgd_optimize(0.0371, g, w))
+
+
+def test_a_dense_softmax_head_trains_on_the_device_path(gpu):
+    """End to end: DenseApplyTrainingBatch -> categorical_crossentropy(+derivative) -> DenseCalculateGradient ->
+    sgd_optimize on the handle's own weight block (picked up by the next forward's edit check).  The loss must fall and
+    the weights must follow the same trajectory as the oracle's loop within float tolerance."""
+    L = capi.load()
+    r = rng(11)
+    B, n_in, c = 64, 20, 5
+    true_W = u(r, n_in, c)
+    x = u(r, B, n_in)
+    labels = (x @ true_W).argmax(1)
+    y = np.eye(c, dtype=np.float32)[labels]
+    W, b = u(r, n_in, c, sc=0.1), np.zeros(c, np.float32)
+    ah = L.ActivationFunctionCreateSoftmax(1, c)
+    cfg = L.DenseConfigCreate(n_in, c, ah)
+    h = L.DenseCreateForTraining(cfg, capi.ConvTrainingConfig(B))
+    w = L.DenseGetWeights(h).contents
+    C.memmove(w.W, W.ctypes.data, W.nbytes); C.memmove(w.b, b.ctypes.data, b.nbytes)
+    oW, ob = W.copy(), b.copy()
+    p, d = np.empty((B, c), np.float32), np.empty((B, c), np.float32)
+    losses = []
+    for it in range(30):
+        assert L.DenseApplyTrainingBatch(h, P(x), P(p)) == 0, capi.last_error()
+        losses.append(L.categorical_crossentropy(P(y), P(p), c, B))
+        L.categorical_crossentropy_derivative(P(y), P(p), P(d), c, B)
+        d /= B                                                             # mean over the batch (the caller's choice)
+        g = L.DenseGradientCreateFromFilter(h)
+        L.DenseCalculateGradient(h, g, P(d))
+        assert L.sgd_optimize(capi.SGD(0.5), g.contents.d_W, w.W, n_in * c + c) == 0        # d_W | d_b and W | b are contiguous
+        L.DenseGradientDestroy(g)
+        # the same step with the oracle
+        z_o, a_o = O.dense_forward_training(x, oW, ob, act=O.ACT_SOFTMAX, softmax_vector_size=c)
+        d_o = (-(y / a_o) / B).astype(np.float32)
+        gW, gb, _ = O.dense_gradient(x, oW, z_o, a_o, d_o, act=O.ACT_SOFTMAX, softmax_vector_size=c)
+        oW, ob = O.sgd_optimize(0.5, gW, oW), O.sgd_optimize(0.5, gb, ob)
+    assert losses[-1] < 0.6 * losses[0], losses
+    np.testing.assert_allclose(np.ctypeslib.as_array(w.W, shape=(n_in, c)), oW, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(np.ctypeslib.as_array(w.b, shape=(c,)), ob, rtol=1e-4, atol=1e-5)
+    L.DenseDestroy(h); L.ActivationFunctionDestroy(ah)

@@ -1,0 +1,28 @@
+"""Build-time ISA lint (no GPU): the compiled kernels must not contain the wide-store hazard the compiler does not
+cover on gfx950 (tools/check_store_hazard.py) -- found the hard way in conv1d.hip's epilogue, where it corrupted four
+lanes per 16 of some stores depending on timing."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_scanner_flags_the_hazard_pattern():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_store_hazard as L
+    bad = """_Z1kv:
+\tbuffer_store_dwordx4 v[64:67], v68, s[16:19], s10 offen
+\tv_or_b32_e32 v64, s12, v96
+"""
+    ok_imm = bad.replace("s10 offen", "0 offen")
+    ok_nop = bad.replace("\tv_or_b32", "\ts_nop 1\n\tv_or_b32")
+    ok_other = bad.replace("v_or_b32_e32 v64", "v_or_b32_e32 v70")
+    assert len(L.scan(bad)) == 1 and L.scan(bad)[0][0] == "_Z1kv"
+    assert L.scan(ok_imm) == [] and L.scan(ok_nop) == [] and L.scan(ok_other) == []
+
+
+def test_no_kernel_has_the_wide_store_sgpr_soffset_hazard():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_store_hazard.py")], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr

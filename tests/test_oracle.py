@@ -366,3 +366,78 @@ def test_conv1d_gradient_oracle_vs_torch_autograd(B, T, Cin, Cout, k, s):
         assert np.abs(got - want).max() <= 2e-6 * max(1.0, np.abs(want).max()) * np.sqrt(B * Tout)
     g = GOLD["conv1d_gradient_block"]          # the real reference's block layout: d_W | d_b | d_X, zeroed
     assert g == {"d_b_offset": 4 * 3 * 5, "d_X_offset": 4 * 3 * 5 + 4, "all_zero": 1}
+
+
+# ---- training, second slice: the oracle's restatements against torch float64 autograd (the reference ships no tests and
+#      its op layer cannot be built here, so independent implementations are the cross-check) ----
+@pytest.mark.parametrize("kind,name", [(O.ACT_SIGMOID, "sigmoid"), (O.ACT_TANH, "tanh"), (O.ACT_IDENTITY, "identity"), (O.ACT_SOFTMAX, "softmax")])
+def test_oracle_activation_gradient_matches_autograd(kind, name):
+    import torch
+    r = np.random.default_rng(5)
+    n, v = 60, 12
+    z = r.uniform(-2, 2, n).astype(np.float32)
+    dout = r.uniform(-1, 1, n).astype(np.float32)
+    a = O.activation(kind, z, softmax_vector_size=v)
+    if kind == O.ACT_SOFTMAX:
+        # one vector per call is what Dense does; inside ONE call of several vectors the reference reads d_out at the
+        # call's base for every vector (activation_default.c:183) -- restated, and visible here
+        got = np.concatenate([O.activation_gradient(kind, z[i:i + v], a[i:i + v], dout[i:i + v], softmax_vector_size=v) for i in range(0, n, v)])
+        multi = O.activation_gradient(kind, z, a, dout, softmax_vector_size=v)
+        np.testing.assert_array_equal(multi[:v], got[:v])
+        assert not np.allclose(multi[v:], got[v:])
+        np.testing.assert_array_equal(multi[v:2 * v], O.activation_gradient(kind, z[v:2 * v], a[v:2 * v], dout[:v], softmax_vector_size=v))
+    else:
+        got = O.activation_gradient(kind, z, a, dout)
+        np.testing.assert_array_equal(got, O.activation_gradient(kind, z, None, dout))      # non-cached form recomputes a
+    zt = torch.tensor(z, dtype=torch.float64, requires_grad=True)
+    at = {"sigmoid": torch.sigmoid, "tanh": torch.tanh, "identity": lambda t: t * 1.0,
+          "softmax": lambda t: torch.softmax(t.view(-1, v), 1).view(-1)}[name](zt)
+    at.backward(torch.tensor(dout, dtype=torch.float64))
+    assert np.abs(got - zt.grad.numpy()).max() < 3e-7
+
+
+def test_oracle_relu_gradient_is_the_reference_clamp():
+    z = np.array([-2, -0.0, 0.3, 1.0, 7.0], np.float32)
+    np.testing.assert_array_equal(O.activation_gradient(O.ACT_RELU, z, None, np.ones(5, np.float32)),
+                                  np.array([0, 0, 0.3, 1, 1], np.float32))            # activation_default.c:118-121
+
+
+@pytest.mark.parametrize("act,name,v", [(None, None, 0), (O.ACT_SIGMOID, "sigmoid", 0), (O.ACT_TANH, "tanh", 0), (O.ACT_SOFTMAX, "softmax", 9)])
+def test_oracle_dense_gradient_matches_autograd(act, name, v):
+    import torch
+    r = np.random.default_rng(8)
+    B, n_in, n_out = 7, 15, 9
+    x = r.uniform(-1, 1, (B, n_in)).astype(np.float32)
+    W, b = r.uniform(-0.3, 0.3, (n_in, n_out)).astype(np.float32), r.uniform(-0.1, 0.1, n_out).astype(np.float32)
+    dout = r.uniform(-1, 1, (B, n_out)).astype(np.float32)
+    z, a = O.dense_forward_training(x, W, b, act=act, softmax_vector_size=v)
+    g0W, g0b = r.uniform(-1, 1, W.shape).astype(np.float32), r.uniform(-1, 1, n_out).astype(np.float32)
+    gW, gb, dX = O.dense_gradient(x, W, z, a, dout, act=act, softmax_vector_size=v, gW=g0W, gb=g0b)
+    xt, Wt, bt = (torch.tensor(t, dtype=torch.float64, requires_grad=True) for t in (x, W, b))
+    zt = xt @ Wt + bt
+    at = {None: zt, "sigmoid": torch.sigmoid(zt), "tanh": torch.tanh(zt), "softmax": torch.softmax(zt, 1)}[name]
+    at.backward(torch.tensor(dout, dtype=torch.float64))
+    assert np.abs(gW - (g0W + Wt.grad.numpy())).max() < 2e-6          # accumulated ONTO the caller's block
+    assert np.abs(gb - (g0b + bt.grad.numpy())).max() < 2e-6
+    assert np.abs(dX - xt.grad.numpy()).max() < 2e-6
+
+
+def test_oracle_losses_and_sgd():
+    import torch
+    r = np.random.default_rng(9)
+    B, c = 11, 6
+    y = np.eye(c, dtype=np.float32)[r.integers(0, c, B)]
+    p = O.activation(O.ACT_SOFTMAX, r.uniform(-2, 2, B * c).astype(np.float32), softmax_vector_size=c).reshape(B, c)
+    pt = torch.tensor(p, dtype=torch.float64, requires_grad=True)
+    yt = torch.tensor(y, dtype=torch.float64)
+    mse = ((yt - pt) ** 2).mean()
+    mse.backward()
+    assert abs(O.mean_squared_error(y, p) - float(mse.detach())) < 1e-7
+    assert np.abs(O.mean_squared_error_derivative(y, p) - pt.grad.numpy()).max() < 1e-8
+    cce = -(yt * pt.log()).sum(1).mean()
+    assert abs(O.categorical_crossentropy(y, p) - float(cce.detach())) < 1e-6
+    d = O.categorical_crossentropy_derivative(y, p)
+    np.testing.assert_array_equal(d[0], -(y[0] / p[0]))
+    assert np.isnan(d[1:]).all()                                       # loss.c:47-52 never offsets by the row
+    g, w = r.uniform(-1, 1, 1000).astype(np.float32), r.uniform(-1, 1, 1000).astype(np.float32)
+    np.testing.assert_array_equal(O.sgd_optimize(0.01, g, w), w - (g * np.float32(0.01)).astype(np.float32))

@@ -45,11 +45,16 @@ def scan(asm_text):
 def main():
     files = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "nntoolkitcore_amd", "csrc", "hip", "*.hip")))
     bad = 0
+    from concurrent.futures import ThreadPoolExecutor
     with tempfile.TemporaryDirectory() as td:
-        for f in files:
+        def compile_one(f):
             out = os.path.join(td, os.path.basename(f) + ".s")
             subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-Wno-unused-function",
-                                   "--cuda-device-only", "-S", "-I", os.path.dirname(f), f, "-o", out])
+                                   "--cuda-device-only", "-S", "-I", os.path.dirname(f), f, "-o", out], stderr=subprocess.DEVNULL)
+            return out
+        with ThreadPoolExecutor(4) as ex:
+            outs = list(ex.map(compile_one, files))
+        for f, out in zip(files, outs):
             res = scan(open(out).read())
             print("%s: %d wide SGPR-soffset stores with a data register overwritten right behind them" % (os.path.basename(f), len(res)))
             for kern, ln, st, wr in res[:5]:
