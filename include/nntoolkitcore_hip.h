@@ -107,8 +107,19 @@ typedef struct BatchNormFilterStruct *BatchNorm;
 BatchNormConfig BatchNormConfigCreate(int feature_channels, float epsilon, int count);
 BatchNorm BatchNormCreateForInference(BatchNormConfig config);
 BatchNormWeights *BatchNormGetWeights(BatchNorm filter);
-int  BatchNormApplyInference(BatchNorm filter, const float *input, float *output);
+int  BatchNormApplyInference(BatchNorm filter, const float *input, float *output);    /* -1 on a training-mode handle (batch_norm.c:167) */
 void BatchNormDestroy(BatchNorm filter);
+/* training (batch_norm.h:27-62, batch_norm.c:96-126, :191-386): forward over N = count * mini_batch rows with the batch's
+ * own mean / biased variance, moving statistics updated in the weight block with `momentum`; the gradient OVERWRITES
+ * d_beta, d_gamma [feature_channels] and d_x [N, feature_channels]. */
+typedef struct { float momentum; int mini_batch_size; } BatchNormTrainingConfig;
+typedef struct { float *d_gamma; float *d_beta; float *d_x; } BatchNormGradient;        /* block order: d_beta | d_gamma | d_x */
+BatchNormTrainingConfig BatchNormTrainingConfigCreate(float momentum, int mini_batch_size);
+BatchNorm BatchNormCreateForTraining(BatchNormConfig config, BatchNormTrainingConfig training_config);
+BatchNormGradient *BatchNormGradientCreate(BatchNormConfig config, BatchNormTrainingConfig training_config);
+void BatchNormGradientDestroy(BatchNormGradient *grad);
+int  BatchNormApplyTrainingBatch(BatchNorm filter, const float *input, float *output);   /* -1 on an inference-mode handle */
+void BatchNormCalculateGradient(BatchNorm filter, BatchNormGradient *gradient, float *d_out);
 
 /* ---- nntoolkitcore/layers/recurrent.h:17-56 ---------------------------- */
 typedef struct { int w; int u; int b_i; int b_h; int sum; } RecurrentWeightsSize;

@@ -31,6 +31,14 @@ class DefaultGradient(C.Structure):
     _fields_ = [("d_W", fp), ("d_b", fp), ("d_X", fp)]
 
 
+class BatchNormTrainingConfig(C.Structure):
+    _fields_ = [("momentum", C.c_float), ("mini_batch_size", C.c_int)]
+
+
+class BatchNormGradient(C.Structure):
+    _fields_ = [("d_gamma", fp), ("d_beta", fp), ("d_x", fp)]
+
+
 class SGD(C.Structure):
     _fields_ = [("learning_rate", C.c_float)]
 
@@ -126,6 +134,12 @@ SIGNATURES = {
     "BatchNormCreateForInference": (vp, [BatchNormConfig]),
     "BatchNormGetWeights": (C.POINTER(BatchNormWeights), [vp]),
     "BatchNormApplyInference": (C.c_int, [vp, fp, fp]),
+    "BatchNormTrainingConfigCreate": (BatchNormTrainingConfig, [C.c_float, C.c_int]),
+    "BatchNormCreateForTraining": (vp, [BatchNormConfig, BatchNormTrainingConfig]),
+    "BatchNormGradientCreate": (C.POINTER(BatchNormGradient), [BatchNormConfig, BatchNormTrainingConfig]),
+    "BatchNormGradientDestroy": (None, [C.POINTER(BatchNormGradient)]),
+    "BatchNormApplyTrainingBatch": (C.c_int, [vp, fp, fp]),
+    "BatchNormCalculateGradient": (None, [vp, C.POINTER(BatchNormGradient), fp]),
     "BatchNormDestroy": (None, [vp]),
     # recurrent.h / gru.h
     "RecurrentConfigCreate": (RecurrentConfig, [C.c_int, C.c_int, C.c_bool, C.c_int]),

@@ -102,6 +102,11 @@ int nntk_shim_dense_grad(const float *d_x, const float *d_W /*[in,out] caller la
 int nntk_shim_loss_rows(int kind /*0 mse, 1 categorical ce*/, const float *d_y, const float *d_pred, float *d_per_row, int size, int batch);
 int nntk_shim_loss_grad(int kind, const float *d_y, const float *d_pred, float *d_out, int size, int batch);
 int nntk_shim_sgd(float lr, const float *d_grad, float *d_w, long n);
+/* BatchNorm training (batch_norm.c:191-386): x, d_out [N, F]; d_block = gamma | beta | ...; d_stats [8][F] = mean | variance |
+ * var_eps | sqrt_var | d_beta | d_gamma | d_var | d_mu; d_partial [slices][3][F] with slices from nntk_shim_bn_train_slices */
+int nntk_shim_bn_train_slices(long N, int *rows_per_slice);
+int nntk_shim_bn_train_forward(const float *d_x, const float *d_block, float eps, float *d_stats, float *d_partial, float *d_out, long N, int F);
+int nntk_shim_bn_train_backward(const float *d_x, const float *d_dout, const float *d_block, float *d_stats, float *d_partial, float *d_dx, long N, int F);
 int nntk_shim_concat2(const float *d_a, const float *d_b, float *d_out, long rows, int C);
 int nntk_shim_add2(const float *d_a, const float *d_b, float *d_out, long n);
 

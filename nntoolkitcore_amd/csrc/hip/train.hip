@@ -195,3 +195,156 @@ extern "C" int nntk_shim_sgd(float lr, const float *d_grad, float *d_w, long n) 
     NNTK_LAUNCH_CHECK("sgd_kernel");
     return 0;
 }
+
+// ---- BatchNorm training (layers/batch_norm.c:191-386) -----------------------------------------------------------
+// x, d_out are [N, F] (N = count * mini_batch rows).  Every per-feature quantity is a column sum over N.  The reference
+// transposes and sums each column in order; here a column is summed in R-row slices (one lane per feature, coalesced
+// across features, rows of a slice in order) and the slices are added in order by the finishing kernel: deterministic,
+// and different from the reference's single chain only in where the partial sums are cut (the reference's own NEON /
+// vDSP builds cut them differently again).  Elementwise operations keep the reference's order and separate roundings.
+//   mode 0: sum x                                    (mean, :203-207)
+//   mode 1: sum (x + -mean)^2                        (variance, :210-220)
+//   mode 2: sum d_out | sum d_out * x_norm | sum (d_out * gamma) * x_mu      (d_beta, d_gamma, d_ivar, :283-326)
+//   mode 3: sum d_x_mu,  d_x_mu = (d_out * gamma) / sqrt_var + (x_mu * 2) * d_var       (d_mu, :353-373)
+struct BnParams {
+    const float *x, *dout;       // [N, F]
+    const float *gamma;          // [F]
+    const float *mean, *sqrt_var, *dvar;   // [F] (as each mode needs)
+    float *partial;              // [slices][nsums][F]
+    long N;
+    int F, rows_per_slice;
+};
+template <int MODE>
+__global__ __launch_bounds__(64) void bn_colsum_kernel(BnParams p) {
+    const int f = blockIdx.y * 64 + threadIdx.x;
+    if (f >= p.F) return;
+    const long r0 = (long)blockIdx.x * p.rows_per_slice;
+    long r1 = r0 + p.rows_per_slice;
+    if (r1 > p.N) r1 = p.N;
+    constexpr int NS = MODE == 2 ? 3 : 1;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    const float mean = MODE >= 1 ? p.mean[f] : 0.f;
+    const float sv = MODE >= 2 ? p.sqrt_var[f] : 1.f;
+    const float g = MODE >= 2 ? p.gamma[f] : 1.f;
+    const float dvar = MODE == 3 ? p.dvar[f] : 0.f;
+    for (long r = r0; r < r1; ++r) {
+        const float x = p.x[r * p.F + f];
+        if (MODE == 0) {
+            s0 = add_rn(s0, x);
+        } else if (MODE == 1) {
+            const float d = add_rn(x, -mean);
+            s0 = add_rn(s0, mul_rn(d, d));
+        } else {
+            const float d = p.dout[r * p.F + f];
+            const float x_mu = sub_rn(x, mean);
+            const float dxn = mul_rn(d, g);
+            if (MODE == 2) {
+                const float x_norm = x_mu / sv;
+                s0 = add_rn(s0, d);
+                s1 = add_rn(s1, mul_rn(d, x_norm));
+                s2 = add_rn(s2, mul_rn(dxn, x_mu));
+            } else {
+                s0 = add_rn(s0, add_rn(dxn / sv, mul_rn(mul_rn(x_mu, 2.0f), dvar)));
+            }
+        }
+    }
+    float *out = p.partial + (size_t)blockIdx.x * NS * p.F;
+    out[f] = s0;
+    if (MODE == 2) { out[p.F + f] = s1; out[2 * p.F + f] = s2; }
+}
+// stats block (device, [8][F]): 0 mean | 1 variance | 2 var_eps | 3 sqrt_var | 4 d_beta | 5 d_gamma | 6 d_var | 7 d_mu
+// step 0: mean = sum / N            step 1: variance = sum / N, var_eps = variance + eps, sqrt_var = sqrtf(var_eps)
+// step 2: d_beta, d_gamma, d_var = (((d_ivar * -1) / var_eps) / sqrt_var) / 2 / N        step 3: d_mu = sum * (-1 / N)
+__global__ __launch_bounds__(256) void bn_finish_kernel(int step, const float *partial, int slices, float *stats, int F, long N, float eps) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const int ns = step == 2 ? 3 : 1;
+    float s[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < slices; ++k)
+        for (int q = 0; q < ns; ++q) s[q] = add_rn(s[q], partial[((size_t)k * ns + q) * F + f]);
+    const float n = (float)N;
+    if (step == 0) {
+        stats[f] = s[0] / n;
+    } else if (step == 1) {
+        const float var = s[0] / n;
+        const float ve = add_rn(var, eps);
+        stats[F + f] = var; stats[2 * F + f] = ve; stats[3 * F + f] = sqrtf(ve);
+    } else if (step == 2) {
+        stats[4 * F + f] = s[0];
+        stats[5 * F + f] = s[1];
+        float d = mul_rn(s[2], -1.0f) / stats[2 * F + f];      // d_sqrt_var
+        d = d / stats[3 * F + f];                              // d_var
+        d = d / 2.0f;
+        stats[6 * F + f] = d / n;
+    } else {
+        stats[7 * F + f] = mul_rn(s[0], -1.0f / n);
+    }
+}
+// forward: out = ((x - mean) / sqrt_var) * gamma + beta       backward: d_x = ((d_out * gamma) / sqrt_var + (x_mu * 2) * d_var) + d_mu
+__global__ __launch_bounds__(256) void bn_train_apply_kernel(int backward, const float *__restrict__ x, const float *__restrict__ dout,
+                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                             const float *__restrict__ stats, float *__restrict__ out, long n, int F) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int f = (int)(i % F);
+        const float x_mu = sub_rn(x[i], stats[f]);
+        const float sv = stats[3 * F + f];
+        if (!backward) {
+            out[i] = add_rn(mul_rn(x_mu / sv, gamma[f]), beta[f]);
+        } else {
+            const float dxn = mul_rn(dout[i], gamma[f]);
+            out[i] = add_rn(add_rn(dxn / sv, mul_rn(mul_rn(x_mu, 2.0f), stats[6 * F + f])), stats[7 * F + f]);
+        }
+    }
+}
+
+extern "C" int nntk_shim_bn_train_slices(long N, int *rows_per_slice) {
+    long r = (N + 1023) / 1024;
+    if (r < 32) r = 32;
+    *rows_per_slice = (int)r;
+    return (int)((N + r - 1) / r);
+}
+static int bn_colsum(int mode, const BnParams &p, int slices) {
+    dim3 grid((unsigned)slices, (unsigned)((p.F + 63) / 64));
+    switch (mode) {
+    case 0: hipLaunchKernelGGL(bn_colsum_kernel<0>, grid, dim3(64), 0, nntk_stream(), p); break;
+    case 1: hipLaunchKernelGGL(bn_colsum_kernel<1>, grid, dim3(64), 0, nntk_stream(), p); break;
+    case 2: hipLaunchKernelGGL(bn_colsum_kernel<2>, grid, dim3(64), 0, nntk_stream(), p); break;
+    default: hipLaunchKernelGGL(bn_colsum_kernel<3>, grid, dim3(64), 0, nntk_stream(), p); break;
+    }
+    NNTK_LAUNCH_CHECK("bn_colsum_kernel");
+    return 0;
+}
+// d_block: gamma | beta | ... (the BatchNorm device block); d_stats [8][F]; d_partial [slices][3][F]
+extern "C" int nntk_shim_bn_train_forward(const float *d_x, const float *d_block, float eps, float *d_stats, float *d_partial,
+                                          float *d_out, long N, int F) {
+    if (N <= 0 || F <= 0) return 0;
+    BnParams p{};
+    p.x = d_x; p.gamma = d_block; p.mean = d_stats; p.sqrt_var = d_stats + 3 * (size_t)F; p.partial = d_partial; p.N = N; p.F = F;
+    const int slices = nntk_shim_bn_train_slices(N, &p.rows_per_slice);
+    for (int step = 0; step < 2; ++step) {
+        if (bn_colsum(step, p, slices)) return -1;
+        hipLaunchKernelGGL(bn_finish_kernel, dim3((F + 255) / 256), dim3(256), 0, nntk_stream(), step, d_partial, slices, d_stats, F, N, eps);
+        NNTK_LAUNCH_CHECK("bn_finish_kernel");
+    }
+    hipLaunchKernelGGL(bn_train_apply_kernel, dim3(grid_for(N * F, 256)), dim3(256), 0, nntk_stream(), 0, d_x, (const float *)nullptr,
+                       d_block, d_block + F, d_stats, d_out, N * F, F);
+    NNTK_LAUNCH_CHECK("bn_train_apply_kernel");
+    return 0;
+}
+extern "C" int nntk_shim_bn_train_backward(const float *d_x, const float *d_dout, const float *d_block, float *d_stats,
+                                           float *d_partial, float *d_dx, long N, int F) {
+    if (N <= 0 || F <= 0) return 0;
+    BnParams p{};
+    p.x = d_x; p.dout = d_dout; p.gamma = d_block; p.mean = d_stats; p.sqrt_var = d_stats + 3 * (size_t)F;
+    p.dvar = d_stats + 6 * (size_t)F; p.partial = d_partial; p.N = N; p.F = F;
+    const int slices = nntk_shim_bn_train_slices(N, &p.rows_per_slice);
+    for (int step = 2; step < 4; ++step) {
+        if (bn_colsum(step, p, slices)) return -1;
+        hipLaunchKernelGGL(bn_finish_kernel, dim3((F + 255) / 256), dim3(256), 0, nntk_stream(), step, d_partial, slices, d_stats, F, N, 0.f);
+        NNTK_LAUNCH_CHECK("bn_finish_kernel");
+    }
+    hipLaunchKernelGGL(bn_train_apply_kernel, dim3(grid_for(N * F, 256)), dim3(256), 0, nntk_stream(), 1, d_x, d_dout,
+                       d_block, d_block + F, d_stats, d_dx, N * F, F);
+    NNTK_LAUNCH_CHECK("bn_train_apply_kernel");
+    return 0;
+}

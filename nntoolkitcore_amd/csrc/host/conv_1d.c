@@ -249,6 +249,10 @@ struct BatchNormFilterStruct {
     nntk_wblock wb;           /* gamma | beta | moving_mean | moving_variance (batch_norm.c:79-84) */
     float *d_block;
     nntk_devbuf d_io;
+    /* training (batch_norm.c:20-64): the mini-batch input is kept; x_mu, x_norm, ... are recomputed from it */
+    int training, mini_batch, have_batch;
+    float momentum;
+    nntk_devbuf d_x, d_dout, d_stats, d_partial, d_res;
 };
 
 /* batch_norm.c:65-71 */
@@ -283,6 +287,8 @@ void BatchNormDestroy(BatchNorm filter) {
     nntk_shim_synchronize();
     nntk_shim_free(filter->d_block);
     nntk_devbuf_free(&filter->d_io);
+    nntk_devbuf_free(&filter->d_x); nntk_devbuf_free(&filter->d_dout); nntk_devbuf_free(&filter->d_stats);
+    nntk_devbuf_free(&filter->d_partial); nntk_devbuf_free(&filter->d_res);
     nntk_wblock_free(&filter->wb);
     free(filter->weights);
     free(filter);
@@ -330,10 +336,103 @@ int BatchNormApplyDevice(BatchNorm filter, const float *d_input, float *d_output
     return nntk_shim_batch_norm(d_input, blk, filter->config.epsilon, d_output, rows, filter->config.feature_channels);
 }
 
-/* batch_norm.c:166-189: `count` rows of `feature_channels` */
+/* ---- training: batch_norm.c:96-126 (create), :191-262 (forward with batch statistics + moving
+ *      statistics update), :264-386 (gradient) ---- */
+BatchNormTrainingConfig BatchNormTrainingConfigCreate(float momentum, int mini_batch_size) {
+    BatchNormTrainingConfig c;
+    c.momentum = momentum;
+    c.mini_batch_size = mini_batch_size;
+    return c;
+}
+BatchNorm BatchNormCreateForTraining(BatchNormConfig config, BatchNormTrainingConfig training_config) {
+    BatchNorm f = BatchNormCreateForInference(config);
+    if (!f) return NULL;
+    f->training = 1;
+    f->momentum = training_config.momentum;
+    f->mini_batch = training_config.mini_batch_size;
+    return f;
+}
+/* ONE zeroed block d_beta | d_gamma | d_x (batch_norm.c:96-104: note the order) */
+BatchNormGradient *BatchNormGradientCreate(BatchNormConfig config, BatchNormTrainingConfig training_config) {
+    BatchNormGradient *g = (BatchNormGradient *)malloc(sizeof(BatchNormGradient));
+    if (!g) return NULL;
+    size_t F = (size_t)config.feature_channels;
+    size_t n = 2 * F + F * config.count * training_config.mini_batch_size;
+    g->d_beta = (float *)calloc(n + 1, sizeof(float));
+    if (!g->d_beta) { free(g); return NULL; }
+    g->d_gamma = g->d_beta + F;
+    g->d_x = g->d_gamma + F;
+    return g;
+}
+void BatchNormGradientDestroy(BatchNormGradient *grad) {
+    if (!grad) return;
+    free(grad->d_beta);
+    free(grad);
+}
+
+int BatchNormApplyTrainingBatch(BatchNorm filter, const float *input, float *output) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("BatchNormApplyTrainingBatch: NULL handle");
+    if (!filter->training) NNTK_FAIL("BatchNormApplyTrainingBatch: the handle was created for inference");   /* batch_norm.c:192-194 */
+    const int F = filter->config.feature_channels;
+    const long N = (long)filter->config.count * filter->mini_batch;
+    if (N <= 0 || F <= 0) return 0;
+    const float *blk = nntk_batch_norm_device_block(filter, 1);
+    if (!blk) return -1;
+    int rps, slices = nntk_shim_bn_train_slices(N, &rps);
+    float *d_x = nntk_devbuf_reserve(&filter->d_x, (size_t)N * F);
+    float *d_o = nntk_devbuf_reserve(&filter->d_res, (size_t)N * F);
+    float *d_stats = nntk_devbuf_reserve(&filter->d_stats, (size_t)8 * F);
+    float *d_part = nntk_devbuf_reserve(&filter->d_partial, (size_t)slices * 3 * F);
+    if (!d_x || !d_o || !d_stats || !d_part) return -1;
+    if (nntk_shim_upload(d_x, input, (size_t)N * F * sizeof(float))) return -1;
+    if (nntk_shim_bn_train_forward(d_x, blk, filter->config.epsilon, d_stats, d_part, d_o, N, F)) return -1;
+    if (nntk_shim_download(output, d_o, (size_t)N * F * sizeof(float))) return -1;
+    /* moving statistics (batch_norm.c:247-257), on the caller-visible weight block, in the reference's operation order;
+     * the next inference apply sees the edit and re-uploads */
+    float *ms = (float *)malloc((size_t)2 * F * sizeof(float));
+    if (!ms) NNTK_FAIL("out of host memory");
+    if (nntk_shim_download(ms, d_stats, (size_t)2 * F * sizeof(float))) { free(ms); return -1; }
+    const float m = filter->momentum;
+    const volatile float one_minus = 1 - m;
+    for (int f = 0; f < F; ++f) {
+        volatile float b = ms[f] * one_minus;
+        volatile float mm = filter->weights->moving_mean[f] * m;
+        filter->weights->moving_mean[f] = b + mm;
+        b = ms[F + f] * one_minus;
+        mm = filter->weights->moving_variance[f] * m;
+        filter->weights->moving_variance[f] = b + mm;
+    }
+    free(ms);
+    filter->have_batch = 1;
+    return 0;
+}
+
+/* d_beta, d_gamma, d_x are all OVERWRITTEN (op_vec_sum stores, batch_norm.c:286, :297, :384).  void in the reference;
+ * errors through nntk_last_error(). */
+void BatchNormCalculateGradient(BatchNorm filter, BatchNormGradient *gradient, float *d_out) {
+    nntk_shim_clear_error();
+    if (!filter || !gradient || !d_out) { nntk_set_error("BatchNormCalculateGradient: NULL argument"); return; }
+    if (!filter->training || !filter->have_batch) { nntk_set_error("BatchNormCalculateGradient: run BatchNormApplyTrainingBatch on a training handle first"); return; }
+    const int F = filter->config.feature_channels;
+    const long N = (long)filter->config.count * filter->mini_batch;
+    const float *blk = nntk_batch_norm_device_block(filter, 1);      /* gamma may have been edited (an optimizer step) */
+    if (!blk) return;
+    float *d_dout = nntk_devbuf_reserve(&filter->d_dout, (size_t)N * F);
+    float *d_dx = nntk_devbuf_reserve(&filter->d_res, (size_t)N * F);
+    if (!d_dout || !d_dx) return;
+    if (nntk_shim_upload(d_dout, d_out, (size_t)N * F * sizeof(float))) return;
+    if (nntk_shim_bn_train_backward(filter->d_x.p, d_dout, blk, filter->d_stats.p, filter->d_partial.p, d_dx, N, F)) return;
+    if (nntk_shim_download(gradient->d_beta, filter->d_stats.p + (size_t)4 * F, (size_t)F * sizeof(float))) return;
+    if (nntk_shim_download(gradient->d_gamma, filter->d_stats.p + (size_t)5 * F, (size_t)F * sizeof(float))) return;
+    nntk_shim_download(gradient->d_x, d_dx, (size_t)N * F * sizeof(float));
+}
+
+/* batch_norm.c:166-189: `count` rows of `feature_channels`; -1 for a training-mode handle (:167-169) */
 int BatchNormApplyInference(BatchNorm filter, const float *input, float *output) {
     nntk_shim_clear_error();
     if (!filter) NNTK_FAIL("BatchNormApplyInference: NULL handle");
+    if (filter->training) NNTK_FAIL("BatchNormApplyInference: the handle was created for training");
     const float *blk = nntk_batch_norm_device_block(filter, 1);
     if (!blk) return -1;
     size_t n = (size_t)filter->config.count * filter->config.feature_channels;

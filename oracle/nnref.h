@@ -101,6 +101,10 @@ void  ref_mean_squared_error_derivative(const float *y, const float *p, float *d
 float ref_categorical_crossentropy(const float *y, const float *p, int c, int batch);
 void  ref_categorical_crossentropy_derivative(const float *y, const float *p, float *d, int c, int batch);
 void  ref_sgd_optimize(float lr, const float *g, float *w, int size);
+void ref_batch_norm_training_forward(const float *x, const float *gamma, const float *beta, float eps, float momentum,
+                                     float *out, float *mean, float *var, float *moving_mean, float *moving_var, int N, int F);
+void ref_batch_norm_gradient(const float *x, const float *dout, const float *gamma, const float *mean, const float *var,
+                             float eps, float *d_beta, float *d_gamma, float *d_x, int N, int F);
 
 void ref_batch_norm(const float *in, const float *gamma, const float *beta,
                     const float *mean, const float *variance, float *out,

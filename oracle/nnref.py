@@ -225,6 +225,27 @@ def sgd_optimize(lr, g, w):
     return w
 
 
+def batch_norm_training_forward(x, gamma, beta, eps, momentum, moving_mean, moving_var):
+    """BatchNormApplyTrainingBatch on x [N, F]: returns (out, batch_mean, batch_var, new_moving_mean, new_moving_var)."""
+    x = _f32(x)
+    N, F = x.shape
+    out, mean, var = np.empty_like(x), np.empty(F, np.float32), np.empty(F, np.float32)
+    mm, mv = _f32(moving_mean).copy(), _f32(moving_var).copy()
+    lib().ref_batch_norm_training_forward(_p(x), _p(_f32(gamma)), _p(_f32(beta)), C.c_float(eps), C.c_float(momentum),
+                                          _p(out), _p(mean), _p(var), _p(mm), _p(mv), N, F)
+    return out, mean, var, mm, mv
+
+
+def batch_norm_gradient(x, dout, gamma, mean, var, eps):
+    """BatchNormCalculateGradient: returns (d_beta, d_gamma, d_x)."""
+    x, dout = _f32(x), _f32(dout)
+    N, F = x.shape
+    db, dg, dx = np.empty(F, np.float32), np.empty(F, np.float32), np.empty_like(x)
+    lib().ref_batch_norm_gradient(_p(x), _p(dout), _p(_f32(gamma)), _p(_f32(mean)), _p(_f32(var)), C.c_float(eps),
+                                  _p(db), _p(dg), _p(dx), N, F)
+    return db, dg, dx
+
+
 def batch_norm(x, gamma, beta, mean, var, eps):
     x = _f32(x)
     C_ = x.shape[-1]

@@ -480,3 +480,68 @@ void ref_categorical_crossentropy_derivative(const float *y, const float *p, flo
 void ref_sgd_optimize(float lr, const float *g, float *w, int size) {
     for (int i = 0; i < size; ++i) { float t = g[i] * lr; w[i] = w[i] - t; }
 }
+
+/* layers/batch_norm.c:191-262: batch mean / biased variance per feature (column sums in row order), batch_norm() with
+ * them, then the moving statistics: buffer = stat * (1 - momentum); moving = moving * momentum; moving = buffer + moving.
+ * x, out [N, F]; mean, var [F] are outputs; moving_mean / moving_var [F] are updated in place. */
+void ref_batch_norm_training_forward(const float *x, const float *gamma, const float *beta, float eps, float momentum,
+                                     float *out, float *mean, float *var, float *moving_mean, float *moving_var, int N, int F) {
+    for (int f = 0; f < F; ++f) {
+        float s = 0.0f;
+        for (int n = 0; n < N; ++n) s = s + x[(size_t)n * F + f];
+        mean[f] = s / (float)N;
+    }
+    for (int f = 0; f < F; ++f) {
+        float s = 0.0f;
+        for (int n = 0; n < N; ++n) { float d = x[(size_t)n * F + f] + -mean[f]; d = d * d; s = s + d; }
+        var[f] = s / (float)N;
+    }
+    ref_batch_norm(x, gamma, beta, mean, var, out, eps, N, F);
+    float one_minus = 1 - momentum;
+    for (int f = 0; f < F; ++f) {
+        float b = mean[f] * one_minus; float m = moving_mean[f] * momentum; moving_mean[f] = b + m;
+        b = var[f] * one_minus; m = moving_var[f] * momentum; moving_var[f] = b + m;
+    }
+}
+
+/* layers/batch_norm.c:264-386 in its operation order (mean, var = the batch statistics of the forward pass).
+ * d_beta, d_gamma [F] and d_x [N, F] are overwritten. */
+void ref_batch_norm_gradient(const float *x, const float *dout, const float *gamma, const float *mean, const float *var,
+                             float eps, float *d_beta, float *d_gamma, float *d_x, int N, int F) {
+    float *d_var = (float *)malloc((size_t)F * sizeof(float)), *d_mu = (float *)malloc((size_t)F * sizeof(float));
+    float *sqrt_var = (float *)malloc((size_t)F * sizeof(float));
+    for (int f = 0; f < F; ++f) {
+        float var_eps = var[f] + eps;
+        sqrt_var[f] = sqrtf(var_eps);
+        float sb = 0.0f, sg = 0.0f, si = 0.0f;
+        for (int n = 0; n < N; ++n) {
+            float d = dout[(size_t)n * F + f];
+            float x_mu = x[(size_t)n * F + f] - mean[f];
+            float x_norm = x_mu / sqrt_var[f];
+            float dxn = d * gamma[f];
+            sb = sb + d;
+            float t = d * x_norm; sg = sg + t;
+            t = dxn * x_mu; si = si + t;
+        }
+        d_beta[f] = sb; d_gamma[f] = sg;
+        float ds = si * -1.0f; ds = ds / var_eps;          /* d_sqrt_var */
+        float dv = ds / sqrt_var[f]; dv = dv / 2.0f; dv = dv / (float)N;
+        d_var[f] = dv;
+    }
+    for (int f = 0; f < F; ++f) {
+        float s = 0.0f;
+        for (int n = 0; n < N; ++n) {
+            float x_mu = x[(size_t)n * F + f] - mean[f];
+            float dxn = dout[(size_t)n * F + f] * gamma[f];
+            float a = dxn / sqrt_var[f];
+            float b = x_mu * 2; b = b * d_var[f];
+            float dxm = a + b;
+            d_x[(size_t)n * F + f] = dxm;
+            s = s + dxm;
+        }
+        d_mu[f] = s * (-1.0f / (float)N);
+    }
+    for (int n = 0; n < N; ++n)
+        for (int f = 0; f < F; ++f) d_x[(size_t)n * F + f] = d_x[(size_t)n * F + f] + d_mu[f];
+    free(d_var); free(d_mu); free(sqrt_var);
+}

@@ -188,3 +188,63 @@ def test_a_dense_softmax_head_trains_on_the_device_path(gpu):
     np.testing.assert_allclose(np.ctypeslib.as_array(w.W, shape=(n_in, c)), oW, rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(np.ctypeslib.as_array(w.b, shape=(c,)), ob, rtol=1e-4, atol=1e-5)
     L.DenseDestroy(h); L.ActivationFunctionDestroy(ah)
+
+
+@pytest.mark.parametrize("count,mb,F", [(1, 8, 5), (13, 4, 7), (50, 16, 128), (996, 8, 128), (3, 2, 300)])
+def test_batch_norm_training_forward_and_gradient(gpu, count, mb, F):
+    """BatchNormCreateForTraining / ApplyTrainingBatch / CalculateGradient (batch_norm.c:191-386) against the oracle and
+    torch float64 autograd.  Column sums are cut into slices here and are one chain in the scalar reference, so the
+    comparison is at summation tolerance; the moving statistics land in the caller-visible weight block."""
+    import torch
+    L = capi.load()
+    r = rng(count * 7 + F)
+    N = count * mb
+    x = (u(r, N, F, sc=2.0) + u(r, F, sc=1.0)).astype(np.float32)
+    g, be = 1 + u(r, F, sc=0.5), u(r, F, sc=0.5)
+    mm0, mv0 = u(r, F, sc=0.2), 1 + u(r, F, sc=0.3)
+    eps, mom = 1e-3, 0.9
+    cfg = L.BatchNormConfigCreate(F, eps, count)
+    tc = L.BatchNormTrainingConfigCreate(mom, mb)
+    h = L.BatchNormCreateForTraining(cfg, tc)
+    w = L.BatchNormGetWeights(h).contents
+    for dst, src in ((w.gamma, g), (w.beta, be), (w.moving_mean, mm0), (w.moving_variance, mv0)):
+        C.memmove(dst, src.ctypes.data, src.nbytes)
+    y = np.empty((N, F), np.float32)
+    assert L.BatchNormApplyInference(h, P(x), P(y)) == -1                  # batch_norm.c:167-169
+    assert L.BatchNormApplyTrainingBatch(h, P(x), P(y)) == 0, capi.last_error()
+    o_y, o_mean, o_var, o_mm, o_mv = O.batch_norm_training_forward(x, g, be, eps, mom, mm0, mv0)
+    tol = 2e-6 * max(1.0, np.sqrt(N) / 8)
+    np.testing.assert_allclose(y, o_y, rtol=tol, atol=tol * 4)
+    np.testing.assert_allclose(np.ctypeslib.as_array(w.moving_mean, shape=(F,)), o_mm, rtol=tol, atol=tol)
+    np.testing.assert_allclose(np.ctypeslib.as_array(w.moving_variance, shape=(F,)), o_mv, rtol=tol, atol=tol)
+    dout = u(r, N, F)
+    gr = L.BatchNormGradientCreate(cfg, tc)
+    L.BatchNormCalculateGradient(h, gr, P(dout))
+    assert capi.last_error() == ""
+    db = np.ctypeslib.as_array(gr.contents.d_beta, shape=(F,)).copy()
+    dg = np.ctypeslib.as_array(gr.contents.d_gamma, shape=(F,)).copy()
+    dx = np.ctypeslib.as_array(gr.contents.d_x, shape=(N, F)).copy()
+    o_db, o_dg, o_dx = O.batch_norm_gradient(x, dout, g, o_mean, o_var, eps)
+    xt, gt, bt = (torch.tensor(t).double().requires_grad_(True) for t in (x, g, be))
+    mu, var = xt.mean(0), xt.var(0, unbiased=False)
+    (((xt - mu) / torch.sqrt(var + eps)) * gt + bt).backward(torch.tensor(dout).double())
+    gtol = 6e-6 * np.sqrt(N)
+    for nm, got, ora, t64 in (("d_beta", db, o_db, bt.grad.numpy()), ("d_gamma", dg, o_dg, gt.grad.numpy()), ("d_x", dx, o_dx, xt.grad.numpy())):
+        sc = max(1.0, float(np.abs(t64).max()))
+        e_o, e_t = float(np.abs(got - ora).max()), float(np.abs(got - t64).max())
+        print("bn grad %s (%d,%d,%d): vs oracle %.2e, vs torch float64 %.2e" % (nm, count, mb, F, e_o, e_t))
+        assert e_o <= gtol * sc and e_t <= gtol * sc
+    # the block is laid out d_beta | d_gamma | d_x (batch_norm.c:96-104) and a second call overwrites
+    assert C.addressof(gr.contents.d_gamma.contents) - C.addressof(gr.contents.d_beta.contents) == 4 * F
+    L.BatchNormCalculateGradient(h, gr, P(dout))
+    np.testing.assert_array_equal(np.ctypeslib.as_array(gr.contents.d_beta, shape=(F,)), db)
+    # inference handles refuse the training call; the inference path of a handle fed the trained statistics matches
+    hi = L.BatchNormCreateForInference(cfg)
+    assert L.BatchNormApplyTrainingBatch(hi, P(x), P(y)) == -1
+    wi = L.BatchNormGetWeights(hi).contents
+    for dst, src in ((wi.gamma, g), (wi.beta, be), (wi.moving_mean, o_mean), (wi.moving_variance, o_var)):
+        C.memmove(dst, src.ctypes.data, src.nbytes)
+    y2 = np.empty((count, F), np.float32)
+    assert L.BatchNormApplyInference(hi, P(x[:count]), P(y2)) == 0
+    np.testing.assert_allclose(y2, o_y[:count], rtol=tol, atol=tol * 4)
+    L.BatchNormDestroy(hi); L.BatchNormGradientDestroy(gr); L.BatchNormDestroy(h)
