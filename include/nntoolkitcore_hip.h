@@ -150,6 +150,19 @@ void GRUActivationsDestroy(GRUActivations activations);
 GRUConfig GRUConfigCreate(int input_feature_channels, int output_feature_channels, bool return_sequences,
                           int timesteps, GRUActivations activations);
 GRUWeights *GRUGetWeights(GRU filter);                   /* W [in,3H] | U [H,3H] | b_i [3H] | b_h [3H]; gates z,r,h */
+/* training (gru.h:23-69, gru.c:232-512): forward over the mini-batch from a ZERO state per sequence keeping the gate
+ * caches on the device, then back-propagation through time.  GRUCalculateGradient ADDS d_W, d_U, d_b_i, d_b_h onto the
+ * block and overwrites d_X [mini_batch, timesteps, in]; d_out is [mini_batch, timesteps, out] if return_sequences else
+ * [mini_batch, out].  Gate activations: built-in identity / sigmoid / tanh / ReLU. */
+typedef struct { float *d_W; float *d_U; float *d_b_i; float *d_b_h; float *d_X; } RecurrentGradient;   /* one block, this order */
+typedef DefaultTrainingConfig RecurrentTrainingConfig;
+typedef RecurrentGradient GRUGradient;
+typedef RecurrentTrainingConfig GRUTrainingConfig;
+void RecurrentGradientDestroy(RecurrentGradient *gradient);
+GRU  GRUCreateForTraining(GRUConfig config, GRUTrainingConfig training_config);
+GRUGradient *GRUGradientCreate(GRUConfig config, GRUTrainingConfig training_config);
+int  GRUApplyTrainingBatch(GRU filter, const float *input, float *output);      /* -1 on an inference-mode handle (gru.c:247) */
+void GRUCalculateGradient(GRU filter, GRUGradient *gradients, float *d_out);
 GRU  GRUCreateForInference(GRUConfig config);
 int  GRUApplyInference(GRU filter, const float *input, float *output);  /* host, one sequence, STATEFUL */
 void GRUDestroy(GRU filter);

@@ -39,6 +39,10 @@ class BatchNormGradient(C.Structure):
     _fields_ = [("d_gamma", fp), ("d_beta", fp), ("d_x", fp)]
 
 
+class RecurrentGradient(C.Structure):
+    _fields_ = [("d_W", fp), ("d_U", fp), ("d_b_i", fp), ("d_b_h", fp), ("d_X", fp)]
+
+
 class SGD(C.Structure):
     _fields_ = [("learning_rate", C.c_float)]
 
@@ -150,6 +154,11 @@ SIGNATURES = {
     "GRUGetWeights": (C.POINTER(RecurrentWeights), [vp]),
     "GRUCreateForInference": (vp, [GRUConfig]),
     "GRUApplyInference": (C.c_int, [vp, fp, fp]),
+    "GRUCreateForTraining": (vp, [GRUConfig, ConvTrainingConfig]),
+    "GRUGradientCreate": (C.POINTER(RecurrentGradient), [GRUConfig, ConvTrainingConfig]),
+    "RecurrentGradientDestroy": (None, [C.POINTER(RecurrentGradient)]),
+    "GRUApplyTrainingBatch": (C.c_int, [vp, fp, fp]),
+    "GRUCalculateGradient": (None, [vp, C.POINTER(RecurrentGradient), fp]),
     "GRUDestroy": (None, [vp]),
     # rnn.h
     "RNNConfigCreate": (RNNConfig, [C.c_int, C.c_int, C.c_bool, C.c_int, C.c_bool, vp]),

@@ -104,6 +104,17 @@ int nntk_shim_loss_grad(int kind, const float *d_y, const float *d_pred, float *
 int nntk_shim_sgd(float lr, const float *d_grad, float *d_w, long n);
 /* BatchNorm training (batch_norm.c:191-386): x, d_out [N, F]; d_block = gamma | beta | ...; d_stats [8][F] = mean | variance |
  * var_eps | sqrt_var | d_beta | d_gamma | d_var | d_mu; d_partial [slices][3][F] with slices from nntk_shim_bn_train_slices */
+/* GRU training (gru.c:246-512): caller-layout weights W [in][3H], U [H][3H]; caches h [B][T][H], Zg [B][T][6H], hU [B][T][H];
+ * acts / scales in the order z, h, r */
+int nntk_shim_gru_train_forward(const float *d_x, const float *d_W, const float *d_U, const float *d_bi, const float *d_bh,
+                                float *d_h, float *d_Zg, float *d_hU, int B, int T, int in, int H, const int *acts, const float *scales);
+int nntk_shim_gru_train_backward(const float *d_dout, const float *d_U, const float *d_h, const float *d_Zg, const float *d_hU,
+                                 float *d_dxW, float *d_dhU, float *d_work /*5*B*H*/, int B, int T, int H, int return_sequences, const int *acts);
+/* C [I][K] += A^T B over `rows` rows, c [K] += column sums of B (a_shift_T > 0: A is h [B][T][I] and row (b,t) uses h_{t-1}) */
+size_t nntk_shim_outer_scratch_floats(int I, int K);
+int nntk_shim_outer_accumulate(const float *d_A, const float *d_B, float *d_C, float *d_c, float *d_scratch, long rows, int I, int K, int a_shift_T);
+/* out [rows][I] = d [rows][K] times M [I][K]^T, k-ordered */
+int nntk_shim_rows_times_rowmat(const float *d_d, const float *d_M, float *d_out, long rows, int I, int K);
 int nntk_shim_bn_train_slices(long N, int *rows_per_slice);
 int nntk_shim_bn_train_forward(const float *d_x, const float *d_block, float eps, float *d_stats, float *d_partial, float *d_out, long N, int F);
 int nntk_shim_bn_train_backward(const float *d_x, const float *d_dout, const float *d_block, float *d_stats, float *d_partial, float *d_dx, long N, int F);

@@ -348,3 +348,198 @@ extern "C" int nntk_shim_bn_train_backward(const float *d_x, const float *d_dout
     NNTK_LAUNCH_CHECK("bn_train_apply_kernel");
     return 0;
 }
+
+// ---- GRU training (layers/gru.c:246-512) ------------------------------------------------------------------------
+// Correct, deterministic, reference operation order; NOT tuned (one launch per timestep and direction, VALU dots).
+// Forward step t for the whole mini-batch: thread (b, j) computes GRUCellForward's three columns j, H + j, 2H + j
+// (gru.c:128-187; op_mat_mul as a k-ordered sum of separately rounded products) and stores what the backward pass
+// reads: Z_gates [B][T][6H] = Z_z | Z_r | Z_h~ | z | r | h~, h_pr_Uh [B][T][H] (= h_prev U_h + b_hh), h [B][T][H].
+struct GruTrainParams {
+    const float *x;              // [B][T][in]
+    const float *W, *U, *bi, *bh;    // caller layouts: W [in][3H], U [H][3H]
+    float *h, *Zg, *hU;          // caches
+    int B, T, in, H, t;
+    int act_z, act_h, act_r;
+    float sc_z, sc_h, sc_r;      // ReLU output scales
+};
+__global__ __launch_bounds__(256) void gru_train_fwd_step_kernel(GruTrainParams p) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.B * p.H) return;
+    const int b = e / p.H, j = e % p.H, H = p.H, G = 3 * p.H;
+    const float *x = p.x + ((size_t)b * p.T + p.t) * p.in;
+    const size_t row = (size_t)b * p.T + p.t;
+    const float *hp = p.t > 0 ? p.h + (row - 1) * H : nullptr;      // h_0 = 0 for every sequence (gru.c:262)
+    float xw[3] = {0.f, 0.f, 0.f}, hu[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < p.in; ++k) {
+        const float xv = x[k];
+        const float *w = p.W + (size_t)k * G;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) xw[g] = add_rn(xw[g], mul_rn(xv, w[g * H + j]));
+    }
+    if (hp)
+        for (int k = 0; k < H; ++k) {
+            const float hv = hp[k];
+            const float *u = p.U + (size_t)k * G;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) hu[g] = add_rn(hu[g], mul_rn(hv, u[g * H + j]));
+        }
+#pragma unroll
+    for (int g = 0; g < 3; ++g) { xw[g] = add_rn(xw[g], p.bi[g * H + j]); hu[g] = add_rn(hu[g], p.bh[g * H + j]); }
+    const float Zz = add_rn(xw[0], hu[0]), Zr = add_rn(xw[1], hu[1]);
+    const float z = nntk_gate_act(p.act_z, Zz, p.sc_z), r = nntk_gate_act(p.act_r, Zr, p.sc_r);
+    const float Zh = add_rn(mul_rn(r, hu[2]), xw[2]);
+    const float ht = nntk_gate_act(p.act_h, Zh, p.sc_h);
+    const float hprev = hp ? hp[j] : 0.0f;
+    const float hn = add_rn(mul_rn(add_rn(-z, 1.0f), ht), mul_rn(z, hprev));
+    float *Zg = p.Zg + row * 6 * H;
+    Zg[j] = Zz; Zg[H + j] = Zr; Zg[2 * H + j] = Zh; Zg[3 * H + j] = z; Zg[4 * H + j] = r; Zg[5 * H + j] = ht;
+    p.hU[row * H + j] = hu[2];
+    p.h[row * H + j] = hn;
+}
+
+__device__ __forceinline__ float gate_grad(int kind, float Z, float a, float d) {     // activation_default.c derivatives
+    if (kind == NNTK_ACT_SIGMOID) return mul_rn(mul_rn(a, add_rn(-a, 1.0f)), d);
+    if (kind == NNTK_ACT_TANH) return mul_rn(add_rn(-mul_rn(a, a), 1.0f), d);
+    if (kind == NNTK_ACT_RELU) return mul_rn(fmaxf(fminf(Z, 1.0f), 0.0f), d);
+    return d;
+}
+// Backward step t, elementwise part of GRUCellBackward (gru.c:314-430) for thread (b, j):
+//   d_h = (carry or 0) + d_out_t;  d_h_prev_1 = z d_h;  d_h~ = (-z) d_h + d_h;  d_z = (h_prev - h~) d_h;
+//   d_Zh = act_h'(.) d_h~;  d_r = h_pr_Uh d_Zh;  d_Zz = act_z'(.) d_z;  d_Zr = act_r'(.) d_r
+// writes d_xW [B][T][3H] = d_Zz | d_Zr | d_Zh, d_hU [B][T][3H] = d_Zz | d_Zr | r d_Zh, its copy for this step
+// d_hU_step [B][3H], and d_h_prev_1 [B][H].  carry = d_h_prev_1 + d_h_prev_2 of step t + 1 (gru.c:426).
+struct GruBwdParams {
+    const float *dout;           // [B][T][H] or [B][H]
+    const float *h, *Zg, *hU;    // forward caches
+    const float *dhp1, *dhp2;    // [B][H] of step t + 1
+    float *dxW, *dhU, *dhU_step, *dhp1_out;
+    int B, T, H, t, return_sequences;
+    int act_z, act_h, act_r;
+};
+__global__ __launch_bounds__(256) void gru_train_bwd_step_kernel(GruBwdParams p) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.B * p.H) return;
+    const int b = e / p.H, j = e % p.H, H = p.H;
+    const size_t row = (size_t)b * p.T + p.t;
+    float dout = 0.0f;
+    if (p.return_sequences) dout = p.dout[row * H + j];
+    else if (p.t == p.T - 1) dout = p.dout[(size_t)b * H + j];
+    const float carry = p.t == p.T - 1 ? 0.0f : add_rn(p.dhp1[e], p.dhp2[e]);
+    const float dh = add_rn(carry, dout);
+    const float *Zg = p.Zg + row * 6 * H;
+    const float z = Zg[3 * H + j], r = Zg[4 * H + j], ht = Zg[5 * H + j];
+    const float dhp1 = mul_rn(z, dh);
+    const float dht = add_rn(mul_rn(-z, dh), dh);
+    const float dz = mul_rn(p.t > 0 ? sub_rn(p.h[(row - 1) * H + j], ht) : -ht, dh);
+    const float dZh = gate_grad(p.act_h, Zg[2 * H + j], ht, dht);
+    const float dr = mul_rn(p.hU[row * H + j], dZh);
+    const float dZz = gate_grad(p.act_z, Zg[j], z, dz);
+    const float dZr = gate_grad(p.act_r, Zg[H + j], r, dr);
+    const float dhUh = mul_rn(r, dZh);
+    float *dxW = p.dxW + row * 3 * H, *dhU = p.dhU + row * 3 * H, *ds = p.dhU_step + (size_t)b * 3 * H;
+    dxW[j] = dZz; dxW[H + j] = dZr; dxW[2 * H + j] = dZh;
+    dhU[j] = dZz; dhU[H + j] = dZr; dhU[2 * H + j] = dhUh;
+    ds[j] = dZz; ds[H + j] = dZr; ds[2 * H + j] = dhUh;
+    p.dhp1_out[e] = dhp1;
+}
+// out[row][i] = sum_k M[i][k] * d[row][k] in k order (op_mat_mul(M, d, ., I, 1, K)): d_h_prev_2 = U d_hU per step, and
+// d_X = W d_xW for all rows at the end
+__global__ __launch_bounds__(256) void rows_times_rowmat_kernel(const float *__restrict__ d, const float *__restrict__ M,
+                                                                float *__restrict__ out, long rows, int I, int K) {
+    const long total = rows * I;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long row = e / I;
+        const int i = (int)(e % I);
+        const float *m = M + (size_t)i * K, *dv = d + row * K;
+        float acc = 0.0f;
+        for (int k = 0; k < K; ++k) acc = add_rn(acc, mul_rn(m[k], dv[k]));
+        out[e] = acc;
+    }
+}
+// C[i][k] += sum_rows A[row][i] * Bm[row][k] and c[k] += sum_rows Bm[row][k]: row slices summed in order inside a slice,
+// slices added in order onto C (the reference adds each (b, t) term onto the gradient block one by one, gru.c:508)
+#define OUTER_SLICES 32
+__global__ __launch_bounds__(256) void outer_partial_kernel(const float *__restrict__ A, const float *__restrict__ Bm,
+                                                            float *__restrict__ partial, long rows, int I, int K, int a_shift_T) {
+    // block (i, slice); thread k.  a_shift_T > 0: A is h [B][T][I] and row (b, t) uses h_{t-1} (zero at t = 0)
+    const int i = blockIdx.x;
+    const long r0 = rows * blockIdx.y / gridDim.y, r1 = rows * (blockIdx.y + 1) / gridDim.y;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        float acc = 0.0f;
+        for (long r = r0; r < r1; ++r) {
+            float a;
+            if (i == I) a = 1.0f;                                   // bias row: plain column sum
+            else if (a_shift_T > 0) a = (r % a_shift_T) ? A[(r - 1) * I + i] : 0.0f;
+            else a = A[r * I + i];
+            acc = i == I ? add_rn(acc, Bm[r * K + k]) : add_rn(acc, mul_rn(a, Bm[r * K + k]));
+        }
+        partial[((size_t)blockIdx.y * (I + 1) + i) * K + k] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void outer_reduce_kernel(const float *__restrict__ partial, float *__restrict__ C, float *__restrict__ c,
+                                                           int I, int K, int slices) {
+    const long total = (long)(I + 1) * K;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        float *dst = e < (long)I * K ? C + e : c + (e - (long)I * K);
+        float s = *dst;
+        for (int sl = 0; sl < slices; ++sl) s = add_rn(s, partial[(size_t)sl * (I + 1) * K + e]);
+        *dst = s;
+    }
+}
+
+extern "C" size_t nntk_shim_outer_scratch_floats(int I, int K) { return (size_t)OUTER_SLICES * (I + 1) * K; }
+extern "C" int nntk_shim_outer_accumulate(const float *d_A, const float *d_B, float *d_C, float *d_c, float *d_scratch,
+                                          long rows, int I, int K, int a_shift_T) {
+    if (rows <= 0 || I <= 0 || K <= 0) return 0;
+    hipLaunchKernelGGL(outer_partial_kernel, dim3((unsigned)(I + 1), OUTER_SLICES), dim3(K >= 256 ? 256 : ((K + 63) / 64) * 64), 0,
+                       nntk_stream(), d_A, d_B, d_scratch, rows, I, K, a_shift_T);
+    NNTK_LAUNCH_CHECK("outer_partial_kernel");
+    hipLaunchKernelGGL(outer_reduce_kernel, dim3(grid_for((long)(I + 1) * K, 256)), dim3(256), 0, nntk_stream(), d_scratch, d_C, d_c,
+                       I, K, OUTER_SLICES);
+    NNTK_LAUNCH_CHECK("outer_reduce_kernel");
+    return 0;
+}
+extern "C" int nntk_shim_rows_times_rowmat(const float *d_d, const float *d_M, float *d_out, long rows, int I, int K) {
+    if (rows <= 0 || I <= 0) return 0;
+    hipLaunchKernelGGL(rows_times_rowmat_kernel, dim3(grid_for(rows * I, 256)), dim3(256), 0, nntk_stream(), d_d, d_M, d_out, rows, I, K);
+    NNTK_LAUNCH_CHECK("rows_times_rowmat_kernel");
+    return 0;
+}
+// forward over all timesteps; caches: d_h [B][T][H], d_Zg [B][T][6H], d_hU [B][T][H]
+extern "C" int nntk_shim_gru_train_forward(const float *d_x, const float *d_W, const float *d_U, const float *d_bi, const float *d_bh,
+                                           float *d_h, float *d_Zg, float *d_hU, int B, int T, int in, int H,
+                                           const int *acts /*z,h,r*/, const float *scales) {
+    if (B <= 0 || T <= 0) return 0;
+    GruTrainParams p{};
+    p.x = d_x; p.W = d_W; p.U = d_U; p.bi = d_bi; p.bh = d_bh; p.h = d_h; p.Zg = d_Zg; p.hU = d_hU;
+    p.B = B; p.T = T; p.in = in; p.H = H;
+    p.act_z = acts[0]; p.act_h = acts[1]; p.act_r = acts[2];
+    p.sc_z = scales[0]; p.sc_h = scales[1]; p.sc_r = scales[2];
+    for (int t = 0; t < T; ++t) {
+        p.t = t;
+        hipLaunchKernelGGL(gru_train_fwd_step_kernel, dim3((B * H + 255) / 256), dim3(256), 0, nntk_stream(), p);
+    }
+    NNTK_LAUNCH_CHECK("gru_train_fwd_step_kernel");
+    return 0;
+}
+// backward recurrence; d_work: 2 x [B][H] (d_h_prev_1, d_h_prev_2) + [B][3H] (this step's d_hU)
+extern "C" int nntk_shim_gru_train_backward(const float *d_dout, const float *d_U, const float *d_h, const float *d_Zg,
+                                            const float *d_hU, float *d_dxW, float *d_dhU, float *d_work, int B, int T, int H,
+                                            int return_sequences, const int *acts) {
+    if (B <= 0 || T <= 0) return 0;
+    GruBwdParams p{};
+    p.dout = d_dout; p.h = d_h; p.Zg = d_Zg; p.hU = d_hU; p.dxW = d_dxW; p.dhU = d_dhU;
+    float *dhp1 = d_work, *dhp2 = d_work + (size_t)B * H, *step = d_work + (size_t)2 * B * H;
+    p.dhp1 = dhp1; p.dhp2 = dhp2; p.dhp1_out = dhp1; p.dhU_step = step;
+    p.B = B; p.T = T; p.H = H; p.return_sequences = return_sequences;
+    p.act_z = acts[0]; p.act_h = acts[1]; p.act_r = acts[2];
+    for (int t = T - 1; t >= 0; --t) {
+        p.t = t;
+        hipLaunchKernelGGL(gru_train_bwd_step_kernel, dim3((B * H + 255) / 256), dim3(256), 0, nntk_stream(), p);
+        if (t > 0)
+            hipLaunchKernelGGL(rows_times_rowmat_kernel, dim3(grid_for((long)B * H, 256)), dim3(256), 0, nntk_stream(),
+                               (const float *)step, d_U, dhp2, (long)B, H, 3 * H);
+    }
+    NNTK_LAUNCH_CHECK("gru_train_bwd_step_kernel");
+    return 0;
+}

@@ -266,9 +266,21 @@ static int gate_kind(ActivationFunction a, int *kind, float *scale) {
 
 /* ================================= GRU ==================================== */
 
+/* training state shared by the recurrent layers (gru.c:85-108): the mini-batch input and the forward caches on the device */
+typedef struct {
+    int on, mini_batch, have_batch;
+    nntk_devbuf d_x, d_h, d_Zg, d_hU, d_dxW, d_dhU, d_work, d_raw, d_grad, d_scr, d_dout, d_dX;
+} rec_train;
+static void train_free(rec_train *t) {
+    nntk_devbuf_free(&t->d_x); nntk_devbuf_free(&t->d_h); nntk_devbuf_free(&t->d_Zg); nntk_devbuf_free(&t->d_hU);
+    nntk_devbuf_free(&t->d_dxW); nntk_devbuf_free(&t->d_dhU); nntk_devbuf_free(&t->d_work); nntk_devbuf_free(&t->d_raw);
+    nntk_devbuf_free(&t->d_grad); nntk_devbuf_free(&t->d_scr); nntk_devbuf_free(&t->d_dout); nntk_devbuf_free(&t->d_dX);
+}
+
 struct GRUStruct {
     GRUConfig config;
     rec_core core;
+    rec_train train;
 };
 
 /* gru.c:13-19 */
@@ -316,6 +328,7 @@ GRUWeights *GRUGetWeights(GRU filter) { return filter->core.weights; }
 void GRUDestroy(GRU filter) {
     if (!filter) return;
     core_free(&filter->core);   /* activations stay with the caller (gru.c:116-126) */
+    train_free(&filter->train);
     free(filter);
 }
 
@@ -339,11 +352,108 @@ int GRUSyncWeights(GRU filter) {
 }
 
 /* gru.c:189-204 */
+/* ---- training: gru.c:232-244 (create), :246-293 (forward keeping Z_gates, h_pr_Uh, h), :295-512 (BPTT).
+ *      One launch per timestep and direction, VALU dots in the reference's operation order: correct and deterministic,
+ *      not tuned (csrc/hip/train.hip). ---- */
+GRU GRUCreateForTraining(GRUConfig config, GRUTrainingConfig training_config) {
+    GRU f = GRUCreateForInference(config);
+    if (!f) return NULL;
+    f->train.on = 1;
+    f->train.mini_batch = training_config.mini_batch_size;
+    return f;
+}
+/* ONE zeroed block d_W | d_U | d_b_i | d_b_h | d_X (recurrent_private.c:10-22) */
+GRUGradient *GRUGradientCreate(GRUConfig config, GRUTrainingConfig training_config) {
+    GRUGradient *g = (GRUGradient *)malloc(sizeof(GRUGradient));
+    if (!g) return NULL;
+    size_t in = (size_t)config.base.input_feature_channels, H = (size_t)config.base.output_feature_channels;
+    size_t w = in * 3 * H, u = H * 3 * H, b = 3 * H;
+    size_t x = (size_t)training_config.mini_batch_size * in * config.base.timesteps;
+    g->d_W = (float *)calloc(w + u + 2 * b + x + 1, sizeof(float));
+    if (!g->d_W) { free(g); return NULL; }
+    g->d_U = g->d_W + w;
+    g->d_b_i = g->d_U + u;
+    g->d_b_h = g->d_b_i + b;
+    g->d_X = g->d_b_h + b;
+    return g;
+}
+void RecurrentGradientDestroy(RecurrentGradient *gradient) {
+    if (!gradient) return;
+    free(gradient->d_W);
+    free(gradient);
+}
+
+int GRUApplyTrainingBatch(GRU filter, const float *input, float *output) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("GRUApplyTrainingBatch: NULL handle");
+    if (!filter->train.on) NNTK_FAIL("GRUApplyTrainingBatch: the handle was created for inference");      /* gru.c:247-249 */
+    int acts[3];
+    float sc[3];
+    if (gru_acts(filter, acts, sc)) return -1;
+    rec_core *c = &filter->core;
+    rec_train *t = &filter->train;
+    const int B = t->mini_batch, T = c->T, in = c->in, H = c->H;
+    if (B <= 0 || T <= 0) return 0;
+    const size_t nw = (size_t)in * 3 * H + (size_t)H * 3 * H + 6 * (size_t)H;
+    float *d_x = nntk_devbuf_reserve(&t->d_x, (size_t)B * T * in);
+    float *d_h = nntk_devbuf_reserve(&t->d_h, (size_t)B * T * H);
+    float *d_Zg = nntk_devbuf_reserve(&t->d_Zg, (size_t)B * T * 6 * H);
+    float *d_hU = nntk_devbuf_reserve(&t->d_hU, (size_t)B * T * H);
+    float *d_raw = nntk_devbuf_reserve(&t->d_raw, nw);
+    if (!d_x || !d_h || !d_Zg || !d_hU || !d_raw) return -1;
+    if (nntk_shim_upload(d_x, input, (size_t)B * T * in * sizeof(float))) return -1;
+    if (nntk_shim_upload(d_raw, c->wb.host, nw * sizeof(float))) return -1;          /* W | U | b_i | b_h, caller layout */
+    const float *dW = d_raw, *dU = dW + (size_t)in * 3 * H, *dbi = dU + (size_t)H * 3 * H, *dbh = dbi + 3 * (size_t)H;
+    if (nntk_shim_gru_train_forward(d_x, dW, dU, dbi, dbh, d_h, d_Zg, d_hU, B, T, in, H, acts, sc)) return -1;
+    t->have_batch = 1;
+    if (c->return_sequences) return nntk_shim_download(output, d_h, (size_t)B * T * H * sizeof(float));
+    for (int b = 0; b < B; ++b)         /* gru.c:286-291: the last step of every sequence */
+        if (nntk_shim_download(output + (size_t)b * H, d_h + ((size_t)b * T + (T - 1)) * H, (size_t)H * sizeof(float))) return -1;
+    return 0;
+}
+
+/* d_W, d_U, d_b_i, d_b_h are ADDED onto the caller's block (recurrent_gradient_sum per (b, t), gru.c:508), d_X is
+ * overwritten.  void in the reference; errors through nntk_last_error(). */
+void GRUCalculateGradient(GRU filter, GRUGradient *gradient, float *d_out) {
+    nntk_shim_clear_error();
+    if (!filter || !gradient || !d_out) { nntk_set_error("GRUCalculateGradient: NULL argument"); return; }
+    rec_core *c = &filter->core;
+    rec_train *t = &filter->train;
+    if (!t->on || !t->have_batch) { nntk_set_error("GRUCalculateGradient: run GRUApplyTrainingBatch on a training handle first"); return; }
+    int acts[3];
+    float sc[3];
+    if (gru_acts(filter, acts, sc)) return;
+    const int B = t->mini_batch, T = c->T, in = c->in, H = c->H;
+    const size_t w = (size_t)in * 3 * H, u = (size_t)H * 3 * H, b3 = 3 * (size_t)H, rows = (size_t)B * T;
+    const size_t n_do = c->return_sequences ? rows * H : (size_t)B * H;
+    size_t scr = nntk_shim_outer_scratch_floats(in > H ? in : H, 3 * H);
+    float *d_dout = nntk_devbuf_reserve(&t->d_dout, n_do);
+    float *d_dxW = nntk_devbuf_reserve(&t->d_dxW, rows * 3 * H);
+    float *d_dhU = nntk_devbuf_reserve(&t->d_dhU, rows * 3 * H);
+    float *d_work = nntk_devbuf_reserve(&t->d_work, (size_t)B * 5 * H);
+    float *d_grad = nntk_devbuf_reserve(&t->d_grad, w + u + 2 * b3);
+    float *d_scr = nntk_devbuf_reserve(&t->d_scr, scr);
+    float *d_dX = nntk_devbuf_reserve(&t->d_dX, rows * in);
+    if (!d_dout || !d_dxW || !d_dhU || !d_work || !d_grad || !d_scr || !d_dX) return;
+    const float *dW = t->d_raw.p, *dU = dW + w;
+    if (nntk_shim_upload(d_dout, d_out, n_do * sizeof(float))) return;
+    if (nntk_shim_upload(d_grad, gradient->d_W, (w + u + 2 * b3) * sizeof(float))) return;       /* the block is contiguous */
+    if (nntk_shim_gru_train_backward(d_dout, dU, t->d_h.p, t->d_Zg.p, t->d_hU.p, d_dxW, d_dhU, d_work, B, T, H,
+                                     c->return_sequences ? 1 : 0, acts)) return;
+    /* d_W += x^T d_xW, d_b_i += colsum d_xW;  d_U += h_prev^T d_hU, d_b_h += colsum d_hU;  d_X = d_xW W^T */
+    if (nntk_shim_outer_accumulate(t->d_x.p, d_dxW, d_grad, d_grad + w + u, d_scr, (long)rows, in, 3 * H, 0)) return;
+    if (nntk_shim_outer_accumulate(t->d_h.p, d_dhU, d_grad + w, d_grad + w + u + b3, d_scr, (long)rows, H, 3 * H, T)) return;
+    if (nntk_shim_rows_times_rowmat(d_dxW, dW, d_dX, (long)rows, in, 3 * H)) return;
+    if (nntk_shim_download(gradient->d_W, d_grad, (w + u + 2 * b3) * sizeof(float))) return;
+    nntk_shim_download(gradient->d_X, d_dX, rows * in * sizeof(float));
+}
+
 int GRUApplyInference(GRU filter, const float *input, float *output) {
     nntk_shim_clear_error();
     int acts[3];
     float sc[3];
     if (!filter) NNTK_FAIL("GRUApplyInference: NULL handle");
+    if (filter->train.on) NNTK_FAIL("GRUApplyInference: the handle was created for training");           /* gru.c:190-192 */
     if (gru_acts(filter, acts, sc)) return -1;
     return core_apply_host(&filter->core, 0, 1, acts, sc, input, output, 1, 1);
 }

@@ -101,6 +101,11 @@ void  ref_mean_squared_error_derivative(const float *y, const float *p, float *d
 float ref_categorical_crossentropy(const float *y, const float *p, int c, int batch);
 void  ref_categorical_crossentropy_derivative(const float *y, const float *p, float *d, int c, int batch);
 void  ref_sgd_optimize(float lr, const float *g, float *w, int size);
+void ref_gru_training_forward(const float *x, const float *W, const float *U, const float *b_i, const float *b_h,
+                              float *h, float *Zg, float *hU, int B, int T, int in, int H, int act_z, int act_h, int act_r);
+void ref_gru_gradient(const float *x, const float *W, const float *U, const float *h, const float *Zg, const float *hU,
+                      const float *dout, int return_sequences, float *gW, float *gU, float *gbi, float *gbh, float *dX,
+                      int B, int T, int in, int H, int act_z, int act_h, int act_r);
 void ref_batch_norm_training_forward(const float *x, const float *gamma, const float *beta, float eps, float momentum,
                                      float *out, float *mean, float *var, float *moving_mean, float *moving_var, int N, int F);
 void ref_batch_norm_gradient(const float *x, const float *dout, const float *gamma, const float *mean, const float *var,

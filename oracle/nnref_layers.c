@@ -545,3 +545,66 @@ void ref_batch_norm_gradient(const float *x, const float *dout, const float *gam
         for (int f = 0; f < F; ++f) d_x[(size_t)n * F + f] = d_x[(size_t)n * F + f] + d_mu[f];
     free(d_var); free(d_mu); free(sqrt_var);
 }
+
+/* layers/gru.c:246-293 (GRUApplyTrainingBatch): zero state per sequence; caches Z_gates [B][T][6H] = Z_z | Z_r | Z_h~ |
+ * z | r | h~, h_pr_Uh [B][T][H], h [B][T][H] */
+void ref_gru_training_forward(const float *x, const float *W, const float *U, const float *b_i, const float *b_h,
+                              float *h, float *Zg, float *hU, int B, int T, int in, int H, int act_z, int act_h, int act_r) {
+    float *buf = (float *)calloc((size_t)14 * H, sizeof(float)), *state = (float *)malloc((size_t)H * sizeof(float));
+    for (int b = 0; b < B; ++b) {
+        memset(state, 0, (size_t)H * sizeof(float));
+        for (int t = 0; t < T; ++t) {
+            size_t row = (size_t)b * T + t;
+            gru_cell(x + row * in, W, U, b_i, b_h, state, h + row * H, buf, in, H, act_z, act_h, act_r);
+            memcpy(Zg + row * 6 * H, buf, (size_t)6 * H * sizeof(float));
+            memcpy(hU + row * H, buf + 9 * H + 2 * H, (size_t)H * sizeof(float));      /* h_pr_U[2H..3H) */
+            memcpy(state, h + row * H, (size_t)H * sizeof(float));
+            memset(buf, 0, (size_t)14 * H * sizeof(float));
+        }
+    }
+    free(buf); free(state);
+}
+
+/* layers/gru.c:295-512 (GRUCellBackward + GRUCalculateGradient) in its operation order: for b, for t = T-1 .. 0, the
+ * cell's d_W_t, d_U_t, d_bi_t, d_bh_t are added onto gW [in][3H], gU [H][3H], gbi, gbh [3H]; dX [B][T][in] overwritten. */
+void ref_gru_gradient(const float *x, const float *W, const float *U, const float *h, const float *Zg, const float *hU,
+                      const float *dout, int return_sequences, float *gW, float *gU, float *gbi, float *gbh, float *dX,
+                      int B, int T, int in, int H, int act_z, int act_h, int act_r) {
+    int G = 3 * H;
+    float *dW = (float *)malloc((size_t)in * G * sizeof(float)), *dU = (float *)malloc((size_t)H * G * sizeof(float));
+    float *d_x_W = (float *)malloc((size_t)G * sizeof(float)), *d_h_pr_U = (float *)malloc((size_t)G * sizeof(float));
+    float *tmp = (float *)malloc((size_t)8 * H * sizeof(float)), *dh_carry = (float *)malloc((size_t)H * sizeof(float));
+    float *d_h_t = tmp, *d_h_prev_1 = tmp + H, *d_h_tilda = tmp + 2 * H, *d_z_t = tmp + 3 * H, *d_z_h = tmp + 4 * H,
+          *d_r_t = tmp + 5 * H, *d_h_prev_2 = tmp + 6 * H, *d_zr = tmp + 7 * H;
+    (void)d_zr;
+    for (int b = 0; b < B; ++b)
+        for (int t = T - 1; t >= 0; --t) {
+            size_t row = (size_t)b * T + t;
+            const float *Z = Zg + row * 6 * H, *z = Z + 3 * H, *r = Z + 4 * H, *ht = Z + 5 * H;
+            const float *h_prev = t == 0 ? NULL : h + (row - 1) * H;
+            for (int j = 0; j < H; ++j) {
+                float d_o = return_sequences ? dout[row * H + j] : (t == T - 1 ? dout[(size_t)b * H + j] : 0.0f);
+                d_h_t[j] = (t == T - 1 ? 0.0f : dh_carry[j]) + d_o;
+            }
+            vec_mul(z, d_h_t, d_h_prev_1, H);
+            for (int j = 0; j < H; ++j) { float m = -z[j]; m = m * d_h_t[j]; d_h_tilda[j] = m + d_h_t[j]; }
+            for (int j = 0; j < H; ++j) { float d = h_prev ? h_prev[j] - ht[j] : -ht[j]; d_z_t[j] = d * d_h_t[j]; }
+            ref_activation_gradient(act_h, 0, Z + 2 * H, ht, d_h_tilda, d_z_h, H);
+            vec_mul(hU + row * H, d_z_h, d_r_t, H);
+            memcpy(d_x_W + 2 * H, d_z_h, (size_t)H * sizeof(float));
+            vec_mul(r, d_z_h, d_h_pr_U + 2 * H, H);
+            ref_activation_gradient(act_z, 0, Z, z, d_z_t, d_x_W, H);
+            ref_activation_gradient(act_r, 0, Z + H, r, d_r_t, d_x_W + H, H);
+            memcpy(d_h_pr_U, d_x_W, (size_t)2 * H * sizeof(float));
+            ref_op_mat_mul(W, d_x_W, dX + row * in, in, 1, G);
+            ref_op_mat_mul(U, d_h_pr_U, d_h_prev_2, H, 1, G);
+            vec_add(d_h_prev_1, d_h_prev_2, dh_carry, H);
+            ref_op_mat_mul(x + row * in, d_x_W, dW, in, G, 1);
+            if (h_prev) ref_op_mat_mul(h_prev, d_h_pr_U, dU, H, G, 1);
+            else memset(dU, 0, (size_t)H * G * sizeof(float));
+            for (size_t e = 0; e < (size_t)in * G; ++e) gW[e] = gW[e] + dW[e];
+            for (size_t e = 0; e < (size_t)H * G; ++e) gU[e] = gU[e] + dU[e];
+            for (int e = 0; e < G; ++e) { gbi[e] = gbi[e] + d_x_W[e]; gbh[e] = gbh[e] + d_h_pr_U[e]; }
+        }
+    free(dW); free(dU); free(d_x_W); free(d_h_pr_U); free(tmp); free(dh_carry);
+}

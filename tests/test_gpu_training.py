@@ -248,3 +248,71 @@ def test_batch_norm_training_forward_and_gradient(gpu, count, mb, F):
     assert L.BatchNormApplyInference(hi, P(x[:count]), P(y2)) == 0
     np.testing.assert_allclose(y2, o_y[:count], rtol=tol, atol=tol * 4)
     L.BatchNormDestroy(hi); L.BatchNormGradientDestroy(gr); L.BatchNormDestroy(h)
+
+
+@pytest.mark.parametrize("B,T,n_in,H,seq,acts", [
+    (3, 7, 5, 4, True, ("sigmoid", "tanh", "sigmoid")),
+    (4, 12, 16, 32, False, ("sigmoid", "tanh", "sigmoid")),
+    (8, 50, 40, 64, True, ("sigmoid", "tanh", "sigmoid")),
+    (2, 9, 6, 8, True, ("sigmoid", "relu", "tanh")),
+    (16, 100, 128, 256, True, ("sigmoid", "tanh", "sigmoid")),
+])
+def test_gru_training_forward_and_bptt(gpu, B, T, n_in, H, seq, acts):
+    """GRUCreateForTraining / ApplyTrainingBatch / GradientCreate / CalculateGradient (gru.c:232-512) through the C boundary
+    against the oracle (the reference's loops) and, for the default activations, torch float64 autograd."""
+    import torch
+    L = capi.load()
+    r = rng(B * 100 + T)
+    x = u(r, B, T, n_in)
+    W, U = u(r, n_in, 3 * H, sc=n_in ** -0.5), u(r, H, 3 * H, sc=H ** -0.5)
+    bi, bh = u(r, 3 * H, sc=0.1), u(r, 3 * H, sc=0.1)
+    ah = [make_act(L, a, H) for a in acts]                                   # z, h, r
+    cfg = L.GRUConfigCreate(n_in, H, seq, T, L.GRUActivationsCreate(ah[0], ah[1], ah[2]))
+    tc = capi.ConvTrainingConfig(B)
+    h = L.GRUCreateForTraining(cfg, tc)
+    w = L.GRUGetWeights(h).contents
+    for dst, src in ((w.W, W), (w.U, U), (w.b_i, bi), (w.b_h, bh)):
+        C.memmove(dst, src.ctypes.data, src.nbytes)
+    n_out = (B, T, H) if seq else (B, H)
+    y = np.empty(n_out, np.float32)
+    assert L.GRUApplyInference(h, P(x), P(y)) == -1                          # gru.c:190-192
+    assert L.GRUApplyTrainingBatch(h, P(x), P(y)) == 0, capi.last_error()
+    dout = u(r, *n_out)
+    kinds = tuple(ACTS[a][0] for a in acts)
+    o_h, (oW, oU, obi, obh, oX) = O.gru_training(x, W, U, bi, bh, dout, return_sequences=seq, acts=kinds)
+    np.testing.assert_allclose(y, o_h if seq else o_h[:, -1], rtol=2e-5, atol=2e-6)
+    g = L.GRUGradientCreate(cfg, tc)
+    L.GRUCalculateGradient(h, g, P(dout))
+    assert capi.last_error() == ""
+    gc = g.contents
+    got = [np.ctypeslib.as_array(p_, shape=s).copy() for p_, s in ((gc.d_W, W.shape), (gc.d_U, U.shape), (gc.d_b_i, bi.shape),
+                                                                   (gc.d_b_h, bh.shape), (gc.d_X, x.shape))]
+    refs = [("oracle", (oW, oU, obi, obh, oX))]
+    if acts == ("sigmoid", "tanh", "sigmoid"):
+        xt, Wt, Ut, bit, bht = (torch.tensor(a).double().requires_grad_(True) for a in (x, W, U, bi, bh))
+        hp = torch.zeros(B, H, dtype=torch.float64)
+        outs = []
+        for t in range(T):
+            xw, hu = xt[:, t] @ Wt + bit, hp @ Ut + bht
+            z, rr = torch.sigmoid(xw[:, :H] + hu[:, :H]), torch.sigmoid(xw[:, H:2 * H] + hu[:, H:2 * H])
+            hp = (1 - z) * torch.tanh(rr * hu[:, 2 * H:] + xw[:, 2 * H:]) + z * hp
+            outs.append(hp)
+        hh = torch.stack(outs, 1)
+        (hh if seq else hh[:, -1]).backward(torch.tensor(dout).double())
+        refs.append(("torch float64", tuple(t_.grad.numpy() for t_ in (Wt, Ut, bit, bht, xt))))
+    tol = 5e-6 * np.sqrt(B * T)
+    for nm, ref in refs:
+        for part, a, b_ in zip(("dW", "dU", "dbi", "dbh", "dX"), got, ref):
+            sc = max(1.0, float(np.abs(b_).max()))
+            err = float(np.abs(a - b_).max())
+            print("gru grad %s vs %s (%d,%d,%d,%d): %.2e (scale %.1f)" % (part, nm, B, T, n_in, H, err, sc))
+            assert err <= tol * sc, (part, nm, err)
+    # the block is d_W | d_U | d_b_i | d_b_h | d_X, and a second call accumulates the weight gradients
+    assert C.addressof(gc.d_U.contents) - C.addressof(gc.d_W.contents) == 4 * W.size
+    L.GRUCalculateGradient(h, g, P(dout))
+    np.testing.assert_allclose(np.ctypeslib.as_array(gc.d_U, shape=U.shape), 2 * got[1], rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(got[1]).max())))
+    np.testing.assert_array_equal(np.ctypeslib.as_array(gc.d_X, shape=x.shape), got[4])
+    hi = L.GRUCreateForInference(cfg)
+    assert L.GRUApplyTrainingBatch(hi, P(x), P(y)) == -1                     # gru.c:247-249
+    L.GRUDestroy(hi); L.RecurrentGradientDestroy(g); L.GRUDestroy(h)
+    for a in ah: L.ActivationFunctionDestroy(a)
