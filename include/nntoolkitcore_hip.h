@@ -189,6 +189,14 @@ void LSTMActivationsDestroy(LSTMActivations activations);
 LSTMConfig LSTMConfigCreate(int input_feature_channels, int output_feature_channels, bool return_sequences,
                             int timesteps, bool v2, LSTMActivations activations);
 LSTMWeights *LSTMGetWeights(LSTM filter);                /* W [in,4H] | U [H,4H] | b_i | b_h; gates i,f,g,o */
+/* training (lstm.h:21-73, lstm.c:294-556): as for the GRU -- zero state per sequence, caches on the device, BPTT;
+ * LSTMCalculateGradient ADDS d_W, d_U, d_b_i, d_b_h onto the block and overwrites d_X */
+typedef RecurrentGradient LSTMGradient;
+typedef RecurrentTrainingConfig LSTMTrainingConfig;
+LSTM LSTMCreateForTraining(LSTMConfig config, LSTMTrainingConfig training_config);
+LSTMGradient *LSTMGradientCreate(LSTMConfig config, LSTMTrainingConfig training_config);
+int  LSTMApplyTrainingBatch(LSTM filter, const float *input, float *output);     /* -1 on an inference-mode handle (lstm.c:419) */
+void LSTMCalculateGradient(LSTM filter, LSTMGradient *gradient, float *d_out);
 LSTM LSTMCreateForInference(LSTMConfig config);
 int  LSTMApplyInference(LSTM filter, const float *input, float *output); /* host, one sequence, STATEFUL */
 void LSTMDestroy(LSTM filter);

@@ -154,6 +154,10 @@ SIGNATURES = {
     "GRUGetWeights": (C.POINTER(RecurrentWeights), [vp]),
     "GRUCreateForInference": (vp, [GRUConfig]),
     "GRUApplyInference": (C.c_int, [vp, fp, fp]),
+    "LSTMCreateForTraining": (vp, [LSTMConfig, ConvTrainingConfig]),
+    "LSTMGradientCreate": (C.POINTER(RecurrentGradient), [LSTMConfig, ConvTrainingConfig]),
+    "LSTMApplyTrainingBatch": (C.c_int, [vp, fp, fp]),
+    "LSTMCalculateGradient": (None, [vp, C.POINTER(RecurrentGradient), fp]),
     "GRUCreateForTraining": (vp, [GRUConfig, ConvTrainingConfig]),
     "GRUGradientCreate": (C.POINTER(RecurrentGradient), [GRUConfig, ConvTrainingConfig]),
     "RecurrentGradientDestroy": (None, [C.POINTER(RecurrentGradient)]),

@@ -543,3 +543,124 @@ extern "C" int nntk_shim_gru_train_backward(const float *d_dout, const float *d_
     NNTK_LAUNCH_CHECK("gru_train_bwd_step_kernel");
     return 0;
 }
+
+// ---- LSTM training (layers/lstm.c:185-239 forward cell, :294-556 BPTT) --------------------------------------------
+// Same structure as the GRU path.  Caches: zifgo [B][T][8H] = Z_i | Z_f | Z_g | Z_o | i | f | g | o, c [B][T][H], h [B][T][H].
+struct LstmTrainParams {
+    const float *x, *W, *U, *bi, *bh;      // W [in][4H], U [H][4H]
+    float *h, *c, *zifgo;
+    int B, T, in, H, t, v2;
+    int act[5];                            // i, f, g, o, out
+    float sc[5];
+};
+__global__ __launch_bounds__(256) void lstm_train_fwd_step_kernel(LstmTrainParams p) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.B * p.H) return;
+    const int b = e / p.H, j = e % p.H, H = p.H, G = 4 * p.H;
+    const size_t row = (size_t)b * p.T + p.t;
+    const float *x = p.x + row * p.in;
+    const float *hp = p.t > 0 ? p.h + (row - 1) * H : nullptr;      // zero state per sequence (lstm.c:441)
+    float Z[4] = {0.f, 0.f, 0.f, 0.f}, hu[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < p.in; ++k) {
+        const float xv = x[k];
+        const float *w = p.W + (size_t)k * G;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) Z[g] = add_rn(Z[g], mul_rn(xv, w[g * H + j]));
+    }
+    if (hp)
+        for (int k = 0; k < H; ++k) {
+            const float hv = hp[k];
+            const float *u = p.U + (size_t)k * G;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) hu[g] = add_rn(hu[g], mul_rn(hv, u[g * H + j]));
+        }
+    float a[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        Z[g] = add_rn(Z[g], p.bi[g * H + j]);
+        if (p.v2) hu[g] = add_rn(hu[g], p.bh[g * H + j]);
+        Z[g] = add_rn(Z[g], hu[g]);
+        a[g] = nntk_gate_act(p.act[g], Z[g], p.sc[g]);
+    }
+    const float cp = p.t > 0 ? p.c[(row - 1) * H + j] : 0.0f;
+    const float c = add_rn(mul_rn(a[1], cp), mul_rn(a[0], a[2]));         // f c_prev + i g
+    const float h = mul_rn(a[3], nntk_gate_act(p.act[4], c, p.sc[4]));
+    float *zg = p.zifgo + row * 8 * H;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { zg[g * H + j] = Z[g]; zg[(4 + g) * H + j] = a[g]; }
+    p.c[row * H + j] = c;
+    p.h[row * H + j] = h;
+}
+// elementwise part of LSTMCellBackward (lstm.c:294-416) for thread (b, j); d_c carry in place, d_h carry from the
+// previous step's U dgates product
+struct LstmBwdParams {
+    const float *dout, *c, *zifgo;
+    const float *dh_carry;       // [B][H] = U dgates of step t + 1
+    float *dc_carry;             // [B][H], read (t < T-1) and rewritten
+    float *dG, *dG_step;         // [B][T][4H], [B][4H]
+    int B, T, H, t, return_sequences;
+    int act[5];
+    float sc_out;
+};
+__global__ __launch_bounds__(256) void lstm_train_bwd_step_kernel(LstmBwdParams p) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.B * p.H) return;
+    const int b = e / p.H, j = e % p.H, H = p.H;
+    const size_t row = (size_t)b * p.T + p.t;
+    float dout = 0.0f;
+    if (p.return_sequences) dout = p.dout[row * H + j];
+    else if (p.t == p.T - 1) dout = p.dout[(size_t)b * H + j];
+    const bool last = p.t == p.T - 1;
+    const float dh = add_rn(last ? 0.0f : p.dh_carry[e], dout);
+    const float *zg = p.zifgo + row * 8 * H;
+    const float it = zg[4 * H + j], ft = zg[5 * H + j], gt = zg[6 * H + j], ot = zg[7 * H + j];
+    const float ct = p.c[row * H + j];
+    const float tc = nntk_gate_act(p.act[4], ct, p.sc_out);
+    const float d_o = gate_grad(p.act[3], zg[3 * H + j], ot, mul_rn(dh, tc));
+    // non-cached derivative of the output activation at c_t (activation.c:49-50): forward value recomputed, UNscaled
+    float dc = gate_grad(p.act[4], ct, nntk_gate_act(p.act[4], ct, 1.0f), mul_rn(dh, ot));
+    if (!last) dc = add_rn(dc, p.dc_carry[e]);
+    const float d_i = gate_grad(p.act[0], zg[j], it, mul_rn(dc, gt));
+    const float d_f = p.t == 0 ? 0.0f : gate_grad(p.act[1], zg[H + j], ft, mul_rn(p.c[(row - 1) * H + j], dc));
+    const float d_g = gate_grad(p.act[2], zg[2 * H + j], gt, mul_rn(dc, it));
+    p.dc_carry[e] = mul_rn(dc, ft);
+    float *dG = p.dG + row * 4 * H, *ds = p.dG_step + (size_t)b * 4 * H;
+    dG[j] = d_i; dG[H + j] = d_f; dG[2 * H + j] = d_g; dG[3 * H + j] = d_o;
+    ds[j] = d_i; ds[H + j] = d_f; ds[2 * H + j] = d_g; ds[3 * H + j] = d_o;
+}
+extern "C" int nntk_shim_lstm_train_forward(const float *d_x, const float *d_W, const float *d_U, const float *d_bi, const float *d_bh,
+                                            float *d_h, float *d_c, float *d_zifgo, int B, int T, int in, int H, int v2,
+                                            const int *acts /*i,f,g,o,out*/, const float *scales) {
+    if (B <= 0 || T <= 0) return 0;
+    LstmTrainParams p{};
+    p.x = d_x; p.W = d_W; p.U = d_U; p.bi = d_bi; p.bh = d_bh; p.h = d_h; p.c = d_c; p.zifgo = d_zifgo;
+    p.B = B; p.T = T; p.in = in; p.H = H; p.v2 = v2;
+    for (int g = 0; g < 5; ++g) { p.act[g] = acts[g]; p.sc[g] = scales[g]; }
+    for (int t = 0; t < T; ++t) {
+        p.t = t;
+        hipLaunchKernelGGL(lstm_train_fwd_step_kernel, dim3((B * H + 255) / 256), dim3(256), 0, nntk_stream(), p);
+    }
+    NNTK_LAUNCH_CHECK("lstm_train_fwd_step_kernel");
+    return 0;
+}
+// d_work: [B][H] d_h carry + [B][H] d_c carry + [B][4H] this step's dgates
+extern "C" int nntk_shim_lstm_train_backward(const float *d_dout, const float *d_U, const float *d_c, const float *d_zifgo,
+                                             float *d_dG, float *d_work, int B, int T, int H, int return_sequences,
+                                             const int *acts, const float *scales) {
+    if (B <= 0 || T <= 0) return 0;
+    LstmBwdParams p{};
+    float *dh = d_work, *dc = d_work + (size_t)B * H, *step = d_work + (size_t)2 * B * H;
+    p.dout = d_dout; p.c = d_c; p.zifgo = d_zifgo; p.dh_carry = dh; p.dc_carry = dc; p.dG = d_dG; p.dG_step = step;
+    p.B = B; p.T = T; p.H = H; p.return_sequences = return_sequences;
+    for (int g = 0; g < 5; ++g) p.act[g] = acts[g];
+    p.sc_out = scales[4];
+    for (int t = T - 1; t >= 0; --t) {
+        p.t = t;
+        hipLaunchKernelGGL(lstm_train_bwd_step_kernel, dim3((B * H + 255) / 256), dim3(256), 0, nntk_stream(), p);
+        if (t > 0)
+            hipLaunchKernelGGL(rows_times_rowmat_kernel, dim3(grid_for((long)B * H, 256)), dim3(256), 0, nntk_stream(),
+                               (const float *)step, d_U, dh, (long)B, H, 4 * H);
+    }
+    NNTK_LAUNCH_CHECK("lstm_train_bwd_step_kernel");
+    return 0;
+}

@@ -550,6 +550,7 @@ int GRUStack2ApplyInferenceBatch(GRU l1, GRU l2, const float *input, float *outp
 struct LSTMStruct {
     LSTMConfig config;
     rec_core core;
+    rec_train train;            /* d_Zg = zifgo [B][T][8H], d_hU = the cell state c [B][T][H] */
 };
 
 /* lstm.c:17-26: argument order (input, forget, candidate, output_gate, output) */
@@ -602,6 +603,7 @@ LSTMWeights *LSTMGetWeights(LSTM filter) { return filter->core.weights; }
 void LSTMDestroy(LSTM filter) {
     if (!filter) return;
     core_free(&filter->core);
+    train_free(&filter->train);
     free(filter);
 }
 
@@ -628,11 +630,97 @@ int LSTMSyncWeights(LSTM filter) {
 }
 
 /* lstm.c:241-268 */
+/* ---- training: lstm.c:418-475 (forward keeping zifgo, c, h), :294-416 + :477-556 (BPTT); same
+ *      structure and caveats as the GRU path ---- */
+LSTM LSTMCreateForTraining(LSTMConfig config, LSTMTrainingConfig training_config) {
+    LSTM f = LSTMCreateForInference(config);
+    if (!f) return NULL;
+    f->train.on = 1;
+    f->train.mini_batch = training_config.mini_batch_size;
+    return f;
+}
+LSTMGradient *LSTMGradientCreate(LSTMConfig config, LSTMTrainingConfig training_config) {
+    LSTMGradient *g = (LSTMGradient *)malloc(sizeof(LSTMGradient));
+    if (!g) return NULL;
+    size_t in = (size_t)config.base.input_feature_channels, H = (size_t)config.base.output_feature_channels;
+    size_t w = in * 4 * H, u = H * 4 * H, b = 4 * H;
+    size_t x = (size_t)training_config.mini_batch_size * in * config.base.timesteps;
+    g->d_W = (float *)calloc(w + u + 2 * b + x + 1, sizeof(float));
+    if (!g->d_W) { free(g); return NULL; }
+    g->d_U = g->d_W + w;
+    g->d_b_i = g->d_U + u;
+    g->d_b_h = g->d_b_i + b;
+    g->d_X = g->d_b_h + b;
+    return g;
+}
+
+int LSTMApplyTrainingBatch(LSTM filter, const float *input, float *output) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("LSTMApplyTrainingBatch: NULL handle");
+    if (!filter->train.on) NNTK_FAIL("LSTMApplyTrainingBatch: the handle was created for inference");    /* lstm.c:419-421 */
+    int acts[5];
+    float sc[5];
+    if (lstm_acts(filter, acts, sc)) return -1;
+    rec_core *c = &filter->core;
+    rec_train *t = &filter->train;
+    const int B = t->mini_batch, T = c->T, in = c->in, H = c->H;
+    if (B <= 0 || T <= 0) return 0;
+    const size_t nw = (size_t)in * 4 * H + (size_t)H * 4 * H + 8 * (size_t)H;
+    float *d_x = nntk_devbuf_reserve(&t->d_x, (size_t)B * T * in);
+    float *d_h = nntk_devbuf_reserve(&t->d_h, (size_t)B * T * H);
+    float *d_z = nntk_devbuf_reserve(&t->d_Zg, (size_t)B * T * 8 * H);
+    float *d_c = nntk_devbuf_reserve(&t->d_hU, (size_t)B * T * H);
+    float *d_raw = nntk_devbuf_reserve(&t->d_raw, nw);
+    if (!d_x || !d_h || !d_z || !d_c || !d_raw) return -1;
+    if (nntk_shim_upload(d_x, input, (size_t)B * T * in * sizeof(float))) return -1;
+    if (nntk_shim_upload(d_raw, c->wb.host, nw * sizeof(float))) return -1;          /* W | U | b_i | b_h, caller layout */
+    const float *dW = d_raw, *dU = dW + (size_t)in * 4 * H, *dbi = dU + (size_t)H * 4 * H, *dbh = dbi + 4 * (size_t)H;
+    if (nntk_shim_lstm_train_forward(d_x, dW, dU, dbi, dbh, d_h, d_c, d_z, B, T, in, H, filter->config.v2 ? 1 : 0, acts, sc)) return -1;
+    t->have_batch = 1;
+    if (c->return_sequences) return nntk_shim_download(output, d_h, (size_t)B * T * H * sizeof(float));
+    for (int b = 0; b < B; ++b)
+        if (nntk_shim_download(output + (size_t)b * H, d_h + ((size_t)b * T + (T - 1)) * H, (size_t)H * sizeof(float))) return -1;
+    return 0;
+}
+
+void LSTMCalculateGradient(LSTM filter, LSTMGradient *gradient, float *d_out) {
+    nntk_shim_clear_error();
+    if (!filter || !gradient || !d_out) { nntk_set_error("LSTMCalculateGradient: NULL argument"); return; }
+    rec_core *c = &filter->core;
+    rec_train *t = &filter->train;
+    if (!t->on || !t->have_batch) { nntk_set_error("LSTMCalculateGradient: run LSTMApplyTrainingBatch on a training handle first"); return; }
+    int acts[5];
+    float sc[5];
+    if (lstm_acts(filter, acts, sc)) return;
+    const int B = t->mini_batch, T = c->T, in = c->in, H = c->H;
+    const size_t w = (size_t)in * 4 * H, u = (size_t)H * 4 * H, b4 = 4 * (size_t)H, rows = (size_t)B * T;
+    const size_t n_do = c->return_sequences ? rows * H : (size_t)B * H;
+    size_t scr = nntk_shim_outer_scratch_floats(in > H ? in : H, 4 * H);
+    float *d_dout = nntk_devbuf_reserve(&t->d_dout, n_do);
+    float *d_dG = nntk_devbuf_reserve(&t->d_dxW, rows * 4 * H);
+    float *d_work = nntk_devbuf_reserve(&t->d_work, (size_t)B * 6 * H);
+    float *d_grad = nntk_devbuf_reserve(&t->d_grad, w + u + 2 * b4);
+    float *d_scr = nntk_devbuf_reserve(&t->d_scr, scr);
+    float *d_dX = nntk_devbuf_reserve(&t->d_dX, rows * in);
+    if (!d_dout || !d_dG || !d_work || !d_grad || !d_scr || !d_dX) return;
+    const float *dW = t->d_raw.p, *dU = dW + w;
+    if (nntk_shim_upload(d_dout, d_out, n_do * sizeof(float))) return;
+    if (nntk_shim_upload(d_grad, gradient->d_W, (w + u + 2 * b4) * sizeof(float))) return;
+    if (nntk_shim_lstm_train_backward(d_dout, dU, t->d_hU.p, t->d_Zg.p, d_dG, d_work, B, T, H, c->return_sequences ? 1 : 0, acts, sc)) return;
+    /* d_W += x^T dgates, d_U += h_prev^T dgates, d_b_i += colsum, d_b_h += colsum (lstm.c:412-415), d_X = dgates W^T */
+    if (nntk_shim_outer_accumulate(t->d_x.p, d_dG, d_grad, d_grad + w + u, d_scr, (long)rows, in, 4 * H, 0)) return;
+    if (nntk_shim_outer_accumulate(t->d_h.p, d_dG, d_grad + w, d_grad + w + u + b4, d_scr, (long)rows, H, 4 * H, T)) return;
+    if (nntk_shim_rows_times_rowmat(d_dG, dW, d_dX, (long)rows, in, 4 * H)) return;
+    if (nntk_shim_download(gradient->d_W, d_grad, (w + u + 2 * b4) * sizeof(float))) return;
+    nntk_shim_download(gradient->d_X, d_dX, rows * in * sizeof(float));
+}
+
 int LSTMApplyInference(LSTM filter, const float *input, float *output) {
     nntk_shim_clear_error();
     int acts[5];
     float sc[5];
     if (!filter) NNTK_FAIL("LSTMApplyInference: NULL handle");
+    if (filter->train.on) NNTK_FAIL("LSTMApplyInference: the handle was created for training");         /* lstm.c:242-244 */
     if (lstm_acts(filter, acts, sc)) return -1;
     return core_apply_host(&filter->core, 1, filter->config.v2, acts, sc, input, output, 1, 1);
 }

@@ -608,3 +608,65 @@ void ref_gru_gradient(const float *x, const float *W, const float *U, const floa
         }
     free(dW); free(dU); free(d_x_W); free(d_h_pr_U); free(tmp); free(dh_carry);
 }
+
+/* layers/lstm.c:418-475 (LSTMApplyTrainingBatch): zero state per sequence; caches zifgo [B][T][8H], c [B][T][H], h [B][T][H] */
+void ref_lstm_training_forward(const float *x, const float *W, const float *U, const float *b_i, const float *b_h,
+                               float *h, float *c, float *zifgo, int B, int T, int in, int H, int v2,
+                               int act_i, int act_f, int act_g, int act_o, int act_out) {
+    float *buf = (float *)calloc((size_t)15 * H, sizeof(float));
+    float *hs = (float *)malloc((size_t)H * sizeof(float)), *cs = (float *)malloc((size_t)H * sizeof(float));
+    for (int b = 0; b < B; ++b) {
+        memset(hs, 0, (size_t)H * sizeof(float)); memset(cs, 0, (size_t)H * sizeof(float));
+        for (int t = 0; t < T; ++t) {
+            size_t row = (size_t)b * T + t;
+            lstm_cell(x + row * in, W, U, b_i, b_h, cs, hs, c + row * H, h + row * H, buf, in, H, v2, act_i, act_f, act_g, act_o, act_out);
+            memcpy(zifgo + row * 8 * H, buf, (size_t)8 * H * sizeof(float));
+            memcpy(hs, h + row * H, (size_t)H * sizeof(float));
+            memcpy(cs, c + row * H, (size_t)H * sizeof(float));
+        }
+    }
+    free(buf); free(hs); free(cs);
+}
+
+/* layers/lstm.c:294-416 (LSTMCellBackward) + :477-556 (LSTMCalculateGradient) in its operation order */
+void ref_lstm_gradient(const float *x, const float *W, const float *U, const float *h, const float *c, const float *zifgo,
+                       const float *dout, int return_sequences, float *gW, float *gU, float *gbi, float *gbh, float *dX,
+                       int B, int T, int in, int H, int act_i, int act_f, int act_g, int act_o, int act_out) {
+    int G = 4 * H;
+    float *dW = (float *)malloc((size_t)in * G * sizeof(float)), *dU = (float *)malloc((size_t)H * G * sizeof(float));
+    float *dg = (float *)malloc((size_t)G * sizeof(float)), *tmp = (float *)malloc((size_t)8 * H * sizeof(float));
+    float *dh = (float *)malloc((size_t)H * sizeof(float)), *dc_carry = (float *)malloc((size_t)H * sizeof(float));
+    float *d_h_t = tmp, *d_a_O = tmp + H, *d_a_C = tmp + 2 * H, *d_c_t = tmp + 3 * H, *d_a = tmp + 4 * H, *tc = tmp + 5 * H;
+    for (int b = 0; b < B; ++b)
+        for (int t = T - 1; t >= 0; --t) {
+            size_t row = (size_t)b * T + t;
+            const float *Z = zifgo + row * 8 * H, *it = Z + 4 * H, *ft = Z + 5 * H, *gt = Z + 6 * H, *ot = Z + 7 * H;
+            const float *c_t = c + row * H, *c_prev = t == 0 ? NULL : c + (row - 1) * H, *h_prev = t == 0 ? NULL : h + (row - 1) * H;
+            for (int j = 0; j < H; ++j) {
+                float d_o = return_sequences ? dout[row * H + j] : (t == T - 1 ? dout[(size_t)b * H + j] : 0.0f);
+                d_h_t[j] = (t == T - 1 ? 0.0f : dh[j]) + d_o;
+            }
+            ref_activation(act_out, g_gate_a[4], 0, c_t, tc, H);
+            vec_mul(d_h_t, tc, d_a_O, H);
+            ref_activation_gradient(act_o, 0, Z + 3 * H, ot, d_a_O, dg + 3 * H, H);
+            vec_mul(d_h_t, ot, d_a_C, H);
+            ref_activation_gradient(act_out, 0, c_t, NULL, d_a_C, d_c_t, H);
+            if (t != T - 1) vec_add(d_c_t, dc_carry, d_c_t, H);
+            vec_mul(d_c_t, gt, d_a, H);
+            ref_activation_gradient(act_i, 0, Z, it, d_a, dg, H);
+            if (!c_prev) memset(dg + H, 0, (size_t)H * sizeof(float));
+            else { vec_mul(c_prev, d_c_t, d_a, H); ref_activation_gradient(act_f, 0, Z + H, ft, d_a, dg + H, H); }
+            vec_mul(d_c_t, it, d_a, H);
+            ref_activation_gradient(act_g, 0, Z + 2 * H, gt, d_a, dg + 2 * H, H);
+            vec_mul(d_c_t, ft, dc_carry, H);
+            ref_op_mat_mul(W, dg, dX + row * in, in, 1, G);
+            ref_op_mat_mul(U, dg, dh, H, 1, G);
+            ref_op_mat_mul(x + row * in, dg, dW, in, G, 1);
+            if (h_prev) ref_op_mat_mul(h_prev, dg, dU, H, G, 1);
+            else memset(dU, 0, (size_t)H * G * sizeof(float));
+            for (size_t e = 0; e < (size_t)in * G; ++e) gW[e] = gW[e] + dW[e];
+            for (size_t e = 0; e < (size_t)H * G; ++e) gU[e] = gU[e] + dU[e];
+            for (int e = 0; e < G; ++e) { gbi[e] = gbi[e] + dg[e]; gbh[e] = gbh[e] + dg[e]; }
+        }
+    free(dW); free(dU); free(dg); free(tmp); free(dh); free(dc_carry);
+}

@@ -316,3 +316,72 @@ def test_gru_training_forward_and_bptt(gpu, B, T, n_in, H, seq, acts):
     assert L.GRUApplyTrainingBatch(hi, P(x), P(y)) == -1                     # gru.c:247-249
     L.GRUDestroy(hi); L.RecurrentGradientDestroy(g); L.GRUDestroy(h)
     for a in ah: L.ActivationFunctionDestroy(a)
+
+
+@pytest.mark.parametrize("B,T,n_in,H,seq,v2,acts", [
+    (3, 7, 5, 4, True, True, None),
+    (4, 12, 16, 32, False, True, None),
+    (8, 50, 40, 64, True, False, None),
+    (2, 9, 6, 8, True, True, ("sigmoid", "tanh", "relu", "sigmoid", "sigmoid")),
+    (16, 100, 128, 256, True, True, None),
+])
+def test_lstm_training_forward_and_bptt(gpu, B, T, n_in, H, seq, v2, acts):
+    """LSTMCreateForTraining / ApplyTrainingBatch / GradientCreate / CalculateGradient (lstm.c:294-556) against the oracle
+    and, for the default activations, torch float64 autograd."""
+    import torch
+    L = capi.load()
+    r = rng(B * 100 + T + 1)
+    default = acts is None
+    acts = acts or ("sigmoid", "sigmoid", "tanh", "sigmoid", "tanh")           # input, forget, candidate, output gate, output
+    x = u(r, B, T, n_in)
+    W, U = u(r, n_in, 4 * H, sc=n_in ** -0.5), u(r, H, 4 * H, sc=H ** -0.5)
+    bi, bh = u(r, 4 * H, sc=0.1), u(r, 4 * H, sc=0.1)
+    ah = [make_act(L, a, H) for a in acts]
+    cfg = L.LSTMConfigCreate(n_in, H, seq, T, v2, L.LSTMActivationsCreate(*ah))
+    tc = capi.ConvTrainingConfig(B)
+    h = L.LSTMCreateForTraining(cfg, tc)
+    w = L.LSTMGetWeights(h).contents
+    for dst, src in ((w.W, W), (w.U, U), (w.b_i, bi), (w.b_h, bh)):
+        C.memmove(dst, src.ctypes.data, src.nbytes)
+    n_out = (B, T, H) if seq else (B, H)
+    y = np.empty(n_out, np.float32)
+    assert L.LSTMApplyInference(h, P(x), P(y)) == -1                         # lstm.c:242-244
+    assert L.LSTMApplyTrainingBatch(h, P(x), P(y)) == 0, capi.last_error()
+    dout = u(r, *n_out)
+    kinds = tuple(ACTS[a][0] for a in acts)
+    o_h, oref = O.lstm_training(x, W, U, bi, bh, dout, return_sequences=seq, v2=v2, acts=kinds)
+    np.testing.assert_allclose(y, o_h if seq else o_h[:, -1], rtol=2e-5, atol=2e-6)
+    g = L.LSTMGradientCreate(cfg, tc)
+    L.LSTMCalculateGradient(h, g, P(dout))
+    assert capi.last_error() == ""
+    gc = g.contents
+    got = [np.ctypeslib.as_array(p_, shape=s).copy() for p_, s in ((gc.d_W, W.shape), (gc.d_U, U.shape), (gc.d_b_i, bi.shape),
+                                                                   (gc.d_b_h, bh.shape), (gc.d_X, x.shape))]
+    refs = [("oracle", oref)]
+    if default:
+        xt, Wt, Ut, bit, bht = (torch.tensor(a).double().requires_grad_(True) for a in (x, W, U, bi, bh))
+        hp, cp, outs = torch.zeros(B, H, dtype=torch.float64), torch.zeros(B, H, dtype=torch.float64), []
+        for t in range(T):
+            Z = xt[:, t] @ Wt + bit + hp @ Ut + (bht if v2 else 0)
+            i, f, g_, o = torch.sigmoid(Z[:, :H]), torch.sigmoid(Z[:, H:2 * H]), torch.tanh(Z[:, 2 * H:3 * H]), torch.sigmoid(Z[:, 3 * H:])
+            cp = f * cp + i * g_
+            hp = o * torch.tanh(cp)
+            outs.append(hp)
+        hh = torch.stack(outs, 1)
+        (hh if seq else hh[:, -1]).backward(torch.tensor(dout).double())
+        # without v2 the forward never reads b_h, but the reference still reports d_b_h = dgates (lstm.c:415)
+        refs.append(("torch float64", (Wt.grad.numpy(), Ut.grad.numpy(), bit.grad.numpy(), bht.grad.numpy() if v2 else bit.grad.numpy(), xt.grad.numpy())))
+    tol = 5e-6 * np.sqrt(B * T)
+    for nm, ref in refs:
+        for part, a, b_ in zip(("dW", "dU", "dbi", "dbh", "dX"), got, ref):
+            sc = max(1.0, float(np.abs(b_).max()))
+            err = float(np.abs(a - b_).max())
+            print("lstm grad %s vs %s (%d,%d,%d,%d): %.2e (scale %.1f)" % (part, nm, B, T, n_in, H, err, sc))
+            assert err <= tol * sc, (part, nm, err)
+    L.LSTMCalculateGradient(h, g, P(dout))
+    np.testing.assert_allclose(np.ctypeslib.as_array(gc.d_U, shape=U.shape), 2 * got[1], rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(got[1]).max())))
+    np.testing.assert_array_equal(np.ctypeslib.as_array(gc.d_X, shape=x.shape), got[4])
+    hi = L.LSTMCreateForInference(cfg)
+    assert L.LSTMApplyTrainingBatch(hi, P(x), P(y)) == -1                    # lstm.c:419-421
+    L.LSTMDestroy(hi); L.RecurrentGradientDestroy(g); L.LSTMDestroy(h)
+    for a in ah: L.ActivationFunctionDestroy(a)
