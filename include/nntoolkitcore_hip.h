@@ -211,6 +211,13 @@ typedef struct RNNStruct *RNN;
 RNNConfig RNNConfigCreate(int input_feature_channels, int output_feature_channels, bool return_sequences,
                           int timesteps, bool v2, ActivationFunction activation);
 RNNWeights *RNNGetWeights(RNN filter);
+/* training (rnn.h:16-48, rnn.c:184-221, :249-351): as for GRU / LSTM */
+typedef RecurrentGradient RNNGradient;
+typedef RecurrentTrainingConfig RNNTrainingConfig;
+RNN  RNNCreateForTraining(RNNConfig config, RNNTrainingConfig training_config);
+RNNGradient *RNNGradientCreate(RNNConfig config, RNNTrainingConfig training_config);
+int  RNNApplyTrainingBatch(RNN filter, const float *input, float *output);
+void RNNCalculateGradient(RNN filter, RNNGradient *gradients, float *d_out);
 RNN  RNNCreateForInference(RNNConfig config);
 /* host, one sequence, STATEFUL: T cells from the handle's h, output [T,out] or the last [out].  The
  * reference's loop (rnn.c:228-247) addresses its output at i * (i * out) and reloads h from the wrong row;
@@ -260,6 +267,13 @@ TimeDistributedDenseConfig TimeDistributedDenseConfigCreate(int ts, DenseConfig 
 TimeDistributedDense TimeDistributedDenseCreateForInference(TimeDistributedDenseConfig config);
 DenseWeights *TimeDistributedDenseGetWeights(TimeDistributedDense filter);
 int  TimeDistributedDenseApplyInference(TimeDistributedDense filter, const float *input, float *output);
+/* training (time_distributed_dense.h:24-43): a Dense trained on mini_batch * ts rows */
+typedef DefaultTrainingConfig TimeDistributedDenseTrainingConfig;
+TimeDistributedDense TimeDistributedDenseCreateForTraining(TimeDistributedDenseConfig config,
+                                                           TimeDistributedDenseTrainingConfig training_config);
+DenseGradient *TimeDistributedDenseGradientCreate(TimeDistributedDense filter);
+int  TimeDistributedDenseApplyTrainingBatch(TimeDistributedDense filter, const float *input, float *output);
+void TimeDistributedDenseCalculateGradient(TimeDistributedDense filter, DenseGradient *gradient, float *d_out);
 void TimeDistributedDenseDestroy(TimeDistributedDense filter);
 
 /* ---- nntoolkitcore/signal/window.h:17-29 ------------------------------- */

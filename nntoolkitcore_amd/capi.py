@@ -154,6 +154,14 @@ SIGNATURES = {
     "GRUGetWeights": (C.POINTER(RecurrentWeights), [vp]),
     "GRUCreateForInference": (vp, [GRUConfig]),
     "GRUApplyInference": (C.c_int, [vp, fp, fp]),
+    "RNNCreateForTraining": (vp, [RNNConfig, ConvTrainingConfig]),
+    "RNNGradientCreate": (C.POINTER(RecurrentGradient), [RNNConfig, ConvTrainingConfig]),
+    "RNNApplyTrainingBatch": (C.c_int, [vp, fp, fp]),
+    "RNNCalculateGradient": (None, [vp, C.POINTER(RecurrentGradient), fp]),
+    "TimeDistributedDenseCreateForTraining": (vp, [TimeDistributedDenseConfig, ConvTrainingConfig]),
+    "TimeDistributedDenseGradientCreate": (C.POINTER(DefaultGradient), [vp]),
+    "TimeDistributedDenseApplyTrainingBatch": (C.c_int, [vp, fp, fp]),
+    "TimeDistributedDenseCalculateGradient": (None, [vp, C.POINTER(DefaultGradient), fp]),
     "LSTMCreateForTraining": (vp, [LSTMConfig, ConvTrainingConfig]),
     "LSTMGradientCreate": (C.POINTER(RecurrentGradient), [LSTMConfig, ConvTrainingConfig]),
     "LSTMApplyTrainingBatch": (C.c_int, [vp, fp, fp]),

@@ -115,6 +115,11 @@ int nntk_shim_lstm_train_forward(const float *d_x, const float *d_W, const float
                                  float *d_h, float *d_c, float *d_zifgo, int B, int T, int in, int H, int v2, const int *acts, const float *scales);
 int nntk_shim_lstm_train_backward(const float *d_dout, const float *d_U, const float *d_c, const float *d_zifgo, float *d_dG,
                                   float *d_work /*6*B*H*/, int B, int T, int H, int return_sequences, const int *acts, const float *scales);
+/* RNN training (rnn.c:144-221, :249-351): W [in][H], U [H][H]; caches h, gate [B][T][H] */
+int nntk_shim_rnn_train_forward(const float *d_x, const float *d_W, const float *d_U, const float *d_bi, const float *d_bh,
+                                float *d_h, float *d_gate, int B, int T, int in, int H, int v2, int act, float scale);
+int nntk_shim_rnn_train_backward(const float *d_dout, const float *d_U, const float *d_h, const float *d_gate, float *d_dG,
+                                 float *d_work /*2*B*H*/, int B, int T, int H, int return_sequences, int act);
 /* C [I][K] += A^T B over `rows` rows, c [K] += column sums of B (a_shift_T > 0: A is h [B][T][I] and row (b,t) uses h_{t-1}) */
 size_t nntk_shim_outer_scratch_floats(int I, int K);
 int nntk_shim_outer_accumulate(const float *d_A, const float *d_B, float *d_C, float *d_c, float *d_scratch, long rows, int I, int K, int a_shift_T);

@@ -664,3 +664,71 @@ extern "C" int nntk_shim_lstm_train_backward(const float *d_dout, const float *d
     NNTK_LAUNCH_CHECK("lstm_train_bwd_step_kernel");
     return 0;
 }
+
+// ---- RNN training (layers/rnn.c:144-166 forward cell, :184-221 backward cell, :249-351) ---------------------------
+// caches: gate [B][T][H] (pre-activation), h [B][T][H]
+struct RnnTrainParams {
+    const float *x, *W, *U, *bi, *bh;      // W [in][H], U [H][H]
+    float *h, *gate;
+    int B, T, in, H, t, v2, act;
+    float sc;
+};
+__global__ __launch_bounds__(256) void rnn_train_fwd_step_kernel(RnnTrainParams p) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.B * p.H) return;
+    const int b = e / p.H, j = e % p.H, H = p.H;
+    const size_t row = (size_t)b * p.T + p.t;
+    const float *x = p.x + row * p.in;
+    const float *hp = p.t > 0 ? p.h + (row - 1) * H : nullptr;
+    float xw = 0.f, hu = 0.f;
+    for (int k = 0; k < p.in; ++k) xw = add_rn(xw, mul_rn(x[k], p.W[(size_t)k * H + j]));
+    if (hp) for (int k = 0; k < H; ++k) hu = add_rn(hu, mul_rn(hp[k], p.U[(size_t)k * H + j]));
+    xw = add_rn(xw, p.bi[j]);
+    if (p.v2) hu = add_rn(hu, p.bh[j]);
+    const float g = add_rn(hu, xw);
+    p.gate[row * H + j] = g;
+    p.h[row * H + j] = nntk_gate_act(p.act, g, p.sc);
+}
+__global__ __launch_bounds__(256) void rnn_train_bwd_step_kernel(const float *dout, const float *h, const float *gate,
+                                                                 const float *dh_carry, float *dG, float *dG_step,
+                                                                 int B, int T, int H, int t, int return_sequences, int act) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B * H) return;
+    const int b = e / H, j = e % H;
+    const size_t row = (size_t)b * T + t;
+    float d_o = 0.0f;
+    if (return_sequences) d_o = dout[row * H + j];
+    else if (t == T - 1) d_o = dout[(size_t)b * H + j];
+    const float dh = add_rn(t == T - 1 ? 0.0f : dh_carry[e], d_o);
+    const float dg = gate_grad(act, gate[row * H + j], h[row * H + j], dh);
+    dG[row * H + j] = dg;
+    dG_step[e] = dg;
+}
+extern "C" int nntk_shim_rnn_train_forward(const float *d_x, const float *d_W, const float *d_U, const float *d_bi, const float *d_bh,
+                                           float *d_h, float *d_gate, int B, int T, int in, int H, int v2, int act, float scale) {
+    if (B <= 0 || T <= 0) return 0;
+    RnnTrainParams p{};
+    p.x = d_x; p.W = d_W; p.U = d_U; p.bi = d_bi; p.bh = d_bh; p.h = d_h; p.gate = d_gate;
+    p.B = B; p.T = T; p.in = in; p.H = H; p.v2 = v2; p.act = act; p.sc = scale;
+    for (int t = 0; t < T; ++t) {
+        p.t = t;
+        hipLaunchKernelGGL(rnn_train_fwd_step_kernel, dim3((B * H + 255) / 256), dim3(256), 0, nntk_stream(), p);
+    }
+    NNTK_LAUNCH_CHECK("rnn_train_fwd_step_kernel");
+    return 0;
+}
+// d_work: [B][H] d_h carry + [B][H] this step's d_gate
+extern "C" int nntk_shim_rnn_train_backward(const float *d_dout, const float *d_U, const float *d_h, const float *d_gate,
+                                            float *d_dG, float *d_work, int B, int T, int H, int return_sequences, int act) {
+    if (B <= 0 || T <= 0) return 0;
+    float *dh = d_work, *step = d_work + (size_t)B * H;
+    for (int t = T - 1; t >= 0; --t) {
+        hipLaunchKernelGGL(rnn_train_bwd_step_kernel, dim3((B * H + 255) / 256), dim3(256), 0, nntk_stream(), d_dout, d_h, d_gate,
+                           (const float *)dh, d_dG, step, B, T, H, t, return_sequences, act);
+        if (t > 0)
+            hipLaunchKernelGGL(rows_times_rowmat_kernel, dim3(grid_for((long)B * H, 256)), dim3(256), 0, nntk_stream(),
+                               (const float *)step, d_U, dh, (long)B, H, H);
+    }
+    NNTK_LAUNCH_CHECK("rnn_train_bwd_step_kernel");
+    return 0;
+}

@@ -256,6 +256,29 @@ TimeDistributedDense TimeDistributedDenseCreateForInference(TimeDistributedDense
     if (!f->dense) { free(f); return NULL; }
     return f;
 }
+/* training (time_distributed_dense.c:38-67): a Dense trained on mini_batch * ts rows */
+TimeDistributedDense TimeDistributedDenseCreateForTraining(TimeDistributedDenseConfig config,
+                                                           TimeDistributedDenseTrainingConfig training_config) {
+    TimeDistributedDense f = (TimeDistributedDense)calloc(1, sizeof(struct TimeDistributedDenseStruct));
+    if (!f) return NULL;
+    f->config = config;
+    DenseTrainingConfig dc;
+    dc.mini_batch_size = training_config.mini_batch_size * config.ts;
+    f->dense = DenseCreateForTraining(config.dense, dc);
+    if (!f->dense) { free(f); return NULL; }
+    return f;
+}
+DenseGradient *TimeDistributedDenseGradientCreate(TimeDistributedDense filter) {
+    return filter ? DenseGradientCreateFromFilter(filter->dense) : NULL;
+}
+int TimeDistributedDenseApplyTrainingBatch(TimeDistributedDense filter, const float *input, float *output) {
+    if (!filter) { nntk_shim_clear_error(); NNTK_FAIL("TimeDistributedDenseApplyTrainingBatch: NULL handle"); }
+    return DenseApplyTrainingBatch(filter->dense, input, output);
+}
+void TimeDistributedDenseCalculateGradient(TimeDistributedDense filter, DenseGradient *gradient, float *d_out) {
+    if (!filter) { nntk_shim_clear_error(); nntk_set_error("TimeDistributedDenseCalculateGradient: NULL handle"); return; }
+    DenseCalculateGradient(filter->dense, gradient, d_out);
+}
 DenseWeights *TimeDistributedDenseGetWeights(TimeDistributedDense filter) { return DenseGetWeights(filter->dense); }
 void TimeDistributedDenseDestroy(TimeDistributedDense filter) {
     if (!filter) return;
@@ -278,6 +301,7 @@ int TimeDistributedDenseBroadcastWeights(TimeDistributedDense filter, int root) 
 int TimeDistributedDenseApplyInference(TimeDistributedDense filter, const float *input, float *output) {
     nntk_shim_clear_error();
     if (!filter) NNTK_FAIL("TimeDistributedDenseApplyInference: NULL handle");
+    if (filter->dense->training) NNTK_FAIL("TimeDistributedDenseApplyInference: the handle was created for training");
     return dense_rows_host(filter->dense, input, output, filter->config.ts);
 }
 int TimeDistributedDenseApplyInferenceBatch(TimeDistributedDense filter, const float *input, float *output, int batch) {

@@ -764,6 +764,7 @@ int LSTMGetState(LSTM filter, float *h_host, float *c_host) {
 struct RNNStruct {
     RNNConfig config;
     rec_core core;
+    rec_train train;            /* d_Zg = gate [B][T][H] */
 };
 
 /* rnn.c:48-61 */
@@ -789,6 +790,7 @@ RNNWeights *RNNGetWeights(RNN filter) { return filter->core.weights; }
 void RNNDestroy(RNN filter) {
     if (!filter) return;
     core_free(&filter->core);   /* the activation stays with the caller, as in GRU/LSTM */
+    train_free(&filter->train);
     free(filter);
 }
 
@@ -805,11 +807,91 @@ int RNNSyncWeights(RNN filter) {
 }
 
 /* rnn.c:228-247 (intended semantics, see the header) */
+/* ---- training: rnn.c:249-291 (forward keeping gate, h), :184-221 + :293-351 (BPTT) ---- */
+RNN RNNCreateForTraining(RNNConfig config, RNNTrainingConfig training_config) {
+    RNN f = RNNCreateForInference(config);
+    if (!f) return NULL;
+    f->train.on = 1;
+    f->train.mini_batch = training_config.mini_batch_size;
+    return f;
+}
+RNNGradient *RNNGradientCreate(RNNConfig config, RNNTrainingConfig training_config) {
+    RNNGradient *g = (RNNGradient *)malloc(sizeof(RNNGradient));
+    if (!g) return NULL;
+    size_t in = (size_t)config.base.input_feature_channels, H = (size_t)config.base.output_feature_channels;
+    size_t x = (size_t)training_config.mini_batch_size * in * config.base.timesteps;
+    g->d_W = (float *)calloc(in * H + H * H + 2 * H + x + 1, sizeof(float));
+    if (!g->d_W) { free(g); return NULL; }
+    g->d_U = g->d_W + in * H;
+    g->d_b_i = g->d_U + H * H;
+    g->d_b_h = g->d_b_i + H;
+    g->d_X = g->d_b_h + H;
+    return g;
+}
+int RNNApplyTrainingBatch(RNN filter, const float *input, float *output) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("RNNApplyTrainingBatch: NULL handle");
+    if (!filter->train.on) NNTK_FAIL("RNNApplyTrainingBatch: the handle was created for inference");      /* rnn.c:250-252 */
+    int act;
+    float sc;
+    if (gate_kind(filter->config.activation, &act, &sc)) return -1;
+    rec_core *c = &filter->core;
+    rec_train *t = &filter->train;
+    const int B = t->mini_batch, T = c->T, in = c->in, H = c->H;
+    if (B <= 0 || T <= 0) return 0;
+    const size_t nw = (size_t)in * H + (size_t)H * H + 2 * (size_t)H;
+    float *d_x = nntk_devbuf_reserve(&t->d_x, (size_t)B * T * in);
+    float *d_h = nntk_devbuf_reserve(&t->d_h, (size_t)B * T * H);
+    float *d_g = nntk_devbuf_reserve(&t->d_Zg, (size_t)B * T * H);
+    float *d_raw = nntk_devbuf_reserve(&t->d_raw, nw);
+    if (!d_x || !d_h || !d_g || !d_raw) return -1;
+    if (nntk_shim_upload(d_x, input, (size_t)B * T * in * sizeof(float))) return -1;
+    if (nntk_shim_upload(d_raw, c->wb.host, nw * sizeof(float))) return -1;
+    const float *dW = d_raw, *dU = dW + (size_t)in * H, *dbi = dU + (size_t)H * H, *dbh = dbi + H;
+    if (nntk_shim_rnn_train_forward(d_x, dW, dU, dbi, dbh, d_h, d_g, B, T, in, H, filter->config.v2 ? 1 : 0, act, sc)) return -1;
+    t->have_batch = 1;
+    if (c->return_sequences) return nntk_shim_download(output, d_h, (size_t)B * T * H * sizeof(float));
+    for (int b = 0; b < B; ++b)
+        if (nntk_shim_download(output + (size_t)b * H, d_h + ((size_t)b * T + (T - 1)) * H, (size_t)H * sizeof(float))) return -1;
+    return 0;
+}
+void RNNCalculateGradient(RNN filter, RNNGradient *gradient, float *d_out) {
+    nntk_shim_clear_error();
+    if (!filter || !gradient || !d_out) { nntk_set_error("RNNCalculateGradient: NULL argument"); return; }
+    rec_core *c = &filter->core;
+    rec_train *t = &filter->train;
+    if (!t->on || !t->have_batch) { nntk_set_error("RNNCalculateGradient: run RNNApplyTrainingBatch on a training handle first"); return; }
+    int act;
+    float sc;
+    if (gate_kind(filter->config.activation, &act, &sc)) return;
+    const int B = t->mini_batch, T = c->T, in = c->in, H = c->H;
+    const size_t w = (size_t)in * H, u = (size_t)H * H, rows = (size_t)B * T;
+    const size_t n_do = c->return_sequences ? rows * H : (size_t)B * H;
+    size_t scr = nntk_shim_outer_scratch_floats(in > H ? in : H, H);
+    float *d_dout = nntk_devbuf_reserve(&t->d_dout, n_do);
+    float *d_dG = nntk_devbuf_reserve(&t->d_dxW, rows * H);
+    float *d_work = nntk_devbuf_reserve(&t->d_work, (size_t)B * 2 * H);
+    float *d_grad = nntk_devbuf_reserve(&t->d_grad, w + u + 2 * (size_t)H);
+    float *d_scr = nntk_devbuf_reserve(&t->d_scr, scr);
+    float *d_dX = nntk_devbuf_reserve(&t->d_dX, rows * in);
+    if (!d_dout || !d_dG || !d_work || !d_grad || !d_scr || !d_dX) return;
+    const float *dW = t->d_raw.p, *dU = dW + w;
+    if (nntk_shim_upload(d_dout, d_out, n_do * sizeof(float))) return;
+    if (nntk_shim_upload(d_grad, gradient->d_W, (w + u + 2 * (size_t)H) * sizeof(float))) return;
+    if (nntk_shim_rnn_train_backward(d_dout, dU, t->d_h.p, t->d_Zg.p, d_dG, d_work, B, T, H, c->return_sequences ? 1 : 0, act)) return;
+    if (nntk_shim_outer_accumulate(t->d_x.p, d_dG, d_grad, d_grad + w + u, d_scr, (long)rows, in, H, 0)) return;
+    if (nntk_shim_outer_accumulate(t->d_h.p, d_dG, d_grad + w, d_grad + w + u + H, d_scr, (long)rows, H, H, T)) return;
+    if (nntk_shim_rows_times_rowmat(d_dG, dW, d_dX, (long)rows, in, H)) return;
+    if (nntk_shim_download(gradient->d_W, d_grad, (w + u + 2 * (size_t)H) * sizeof(float))) return;
+    nntk_shim_download(gradient->d_X, d_dX, rows * in * sizeof(float));
+}
+
 int RNNApplyInference(RNN filter, const float *input, float *output) {
     nntk_shim_clear_error();
     int act;
     float sc;
     if (!filter) NNTK_FAIL("RNNApplyInference: NULL handle");
+    if (filter->train.on) NNTK_FAIL("RNNApplyInference: the handle was created for training");           /* rnn.c:223-225 */
     if (gate_kind(filter->config.activation, &act, &sc)) return -1;
     return core_apply_host(&filter->core, 0, filter->config.v2, &act, &sc, input, output, 1, 1);
 }

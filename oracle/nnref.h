@@ -112,6 +112,11 @@ void ref_lstm_training_forward(const float *x, const float *W, const float *U, c
 void ref_lstm_gradient(const float *x, const float *W, const float *U, const float *h, const float *c, const float *zifgo,
                        const float *dout, int return_sequences, float *gW, float *gU, float *gbi, float *gbh, float *dX,
                        int B, int T, int in, int H, int act_i, int act_f, int act_g, int act_o, int act_out);
+void ref_rnn_training_forward(const float *x, const float *W, const float *U, const float *b_i, const float *b_h,
+                              float *h, float *gate, int B, int T, int in, int H, int v2, int act);
+void ref_rnn_gradient(const float *x, const float *W, const float *U, const float *h, const float *gate, const float *dout,
+                      int return_sequences, float *gW, float *gU, float *gbi, float *gbh, float *dX,
+                      int B, int T, int in, int H, int act);
 void ref_batch_norm_training_forward(const float *x, const float *gamma, const float *beta, float eps, float momentum,
                                      float *out, float *mean, float *var, float *moving_mean, float *moving_var, int N, int F);
 void ref_batch_norm_gradient(const float *x, const float *dout, const float *gamma, const float *mean, const float *var,

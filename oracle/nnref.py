@@ -334,6 +334,19 @@ def lstm_training(x, W, U, b_i, b_h, dout, return_sequences=True, v2=True,
     return h, (gW, gU, gbi, gbh, dX)
 
 
+def rnn_training(x, W, U, b_i, b_h, dout, return_sequences=True, v2=True, act=ACT_TANH):
+    """RNNApplyTrainingBatch + RNNCalculateGradient: returns (h [B,T,H], (gW, gU, gbi, gbh, dX))."""
+    x, W, U, b_i, b_h, dout = (_f32(a) for a in (x, W, U, b_i, b_h, dout))
+    B, T, n_in = x.shape
+    H = U.shape[0]
+    h, gate = np.empty((B, T, H), np.float32), np.empty((B, T, H), np.float32)
+    lib().ref_rnn_training_forward(_p(x), _p(W), _p(U), _p(b_i), _p(b_h), _p(h), _p(gate), B, T, n_in, H, C.c_int(1 if v2 else 0), C.c_int(act))
+    gW, gU, gbi, gbh, dX = np.zeros_like(W), np.zeros_like(U), np.zeros_like(b_i), np.zeros_like(b_h), np.empty_like(x)
+    lib().ref_rnn_gradient(_p(x), _p(W), _p(U), _p(h), _p(gate), _p(dout), C.c_int(1 if return_sequences else 0),
+                           _p(gW), _p(gU), _p(gbi), _p(gbh), _p(dX), B, T, n_in, H, C.c_int(act))
+    return h, (gW, gU, gbi, gbh, dX)
+
+
 def rnn(x, W, U, b_i, b_h, h0=None, return_sequences=True, v2=True, act=ACT_TANH, relu_a=None):
     """One-gate RNN.  x: [T,in] (stateful single sequence; returns (out, h_final)) or [B,T,in] (zero state)."""
     _gate_scales(None if relu_a is None else [relu_a])

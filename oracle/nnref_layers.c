@@ -670,3 +670,46 @@ void ref_lstm_gradient(const float *x, const float *W, const float *U, const flo
         }
     free(dW); free(dU); free(dg); free(tmp); free(dh); free(dc_carry);
 }
+
+/* layers/rnn.c:249-291 (RNNApplyTrainingBatch) + :184-221, :293-351 (RNNCellBackward, RNNCalculateGradient) */
+void ref_rnn_training_forward(const float *x, const float *W, const float *U, const float *b_i, const float *b_h,
+                              float *h, float *gate, int B, int T, int in, int H, int v2, int act) {
+    float *buf = (float *)calloc((size_t)3 * H, sizeof(float)), *hs = (float *)malloc((size_t)H * sizeof(float));
+    for (int b = 0; b < B; ++b) {
+        memset(hs, 0, (size_t)H * sizeof(float));
+        for (int t = 0; t < T; ++t) {
+            size_t row = (size_t)b * T + t;
+            rnn_cell(x + row * in, W, U, b_i, b_h, hs, h + row * H, buf, in, H, v2, act);
+            memcpy(gate + row * H, buf + 2 * H, (size_t)H * sizeof(float));
+            memcpy(hs, h + row * H, (size_t)H * sizeof(float));
+        }
+    }
+    free(buf); free(hs);
+}
+void ref_rnn_gradient(const float *x, const float *W, const float *U, const float *h, const float *gate, const float *dout,
+                      int return_sequences, float *gW, float *gU, float *gbi, float *gbh, float *dX,
+                      int B, int T, int in, int H, int act) {
+    float *dW = (float *)malloc((size_t)in * H * sizeof(float)), *dU = (float *)malloc((size_t)H * H * sizeof(float));
+    float *dg = (float *)malloc((size_t)H * sizeof(float)), *dh = (float *)malloc((size_t)H * sizeof(float));
+    float *d_h_t = (float *)malloc((size_t)H * sizeof(float));
+    for (int b = 0; b < B; ++b)
+        for (int t = T - 1; t >= 0; --t) {
+            size_t row = (size_t)b * T + t;
+            const float *h_prev = t == 0 ? NULL : h + (row - 1) * H;
+            for (int j = 0; j < H; ++j) {
+                float d_o = return_sequences ? dout[row * H + j] : (t == T - 1 ? dout[(size_t)b * H + j] : 0.0f);
+                d_h_t[j] = (t == T - 1 ? 0.0f : dh[j]) + d_o;
+            }
+            int cached = act == REF_ACT_SIGMOID || act == REF_ACT_TANH;
+            ref_activation_gradient(act, 0, gate + row * H, cached ? h + row * H : NULL, d_h_t, dg, H);
+            ref_op_mat_mul(W, dg, dX + row * in, in, 1, H);
+            ref_op_mat_mul(U, dg, dh, H, 1, H);
+            ref_op_mat_mul(x + row * in, dg, dW, in, H, 1);
+            if (h_prev) ref_op_mat_mul(h_prev, dg, dU, H, H, 1);
+            else memset(dU, 0, (size_t)H * H * sizeof(float));
+            for (size_t e = 0; e < (size_t)in * H; ++e) gW[e] = gW[e] + dW[e];
+            for (size_t e = 0; e < (size_t)H * H; ++e) gU[e] = gU[e] + dU[e];
+            for (int e = 0; e < H; ++e) { gbi[e] = gbi[e] + dg[e]; gbh[e] = gbh[e] + dg[e]; }
+        }
+    free(dW); free(dU); free(dg); free(dh); free(d_h_t);
+}

@@ -385,3 +385,81 @@ def test_lstm_training_forward_and_bptt(gpu, B, T, n_in, H, seq, v2, acts):
     assert L.LSTMApplyTrainingBatch(hi, P(x), P(y)) == -1                    # lstm.c:419-421
     L.LSTMDestroy(hi); L.RecurrentGradientDestroy(g); L.LSTMDestroy(h)
     for a in ah: L.ActivationFunctionDestroy(a)
+
+
+@pytest.mark.parametrize("B,T,n_in,H,seq,v2,act", [(3, 7, 5, 4, True, True, "tanh"), (4, 20, 16, 32, False, False, "tanh"),
+                                                   (8, 60, 40, 64, True, True, "sigmoid"), (2, 9, 6, 8, True, True, "relu")])
+def test_rnn_training_forward_and_bptt(gpu, B, T, n_in, H, seq, v2, act):
+    """RNNCreateForTraining / ApplyTrainingBatch / GradientCreate / CalculateGradient (rnn.c:184-351)."""
+    import torch
+    L = capi.load()
+    r = rng(B * 10 + T)
+    x = u(r, B, T, n_in)
+    W, U, bi, bh = u(r, n_in, H, sc=n_in ** -0.5), u(r, H, H, sc=H ** -0.5), u(r, H, sc=0.1), u(r, H, sc=0.1)
+    ah = make_act(L, act, H)
+    cfg = L.RNNConfigCreate(n_in, H, seq, T, v2, ah)
+    tc = capi.ConvTrainingConfig(B)
+    h = L.RNNCreateForTraining(cfg, tc)
+    w = L.RNNGetWeights(h).contents
+    for dst, src in ((w.W, W), (w.U, U), (w.b_i, bi), (w.b_h, bh)):
+        C.memmove(dst, src.ctypes.data, src.nbytes)
+    n_out = (B, T, H) if seq else (B, H)
+    y = np.empty(n_out, np.float32)
+    assert L.RNNApplyInference(h, P(x), P(y)) == -1
+    assert L.RNNApplyTrainingBatch(h, P(x), P(y)) == 0, capi.last_error()
+    dout = u(r, *n_out)
+    o_h, oref = O.rnn_training(x, W, U, bi, bh, dout, return_sequences=seq, v2=v2, act=ACTS[act][0])
+    np.testing.assert_allclose(y, o_h if seq else o_h[:, -1], rtol=2e-5, atol=2e-6)
+    g = L.RNNGradientCreate(cfg, tc)
+    L.RNNCalculateGradient(h, g, P(dout))
+    assert capi.last_error() == ""
+    gc = g.contents
+    got = [np.ctypeslib.as_array(p_, shape=s).copy() for p_, s in ((gc.d_W, W.shape), (gc.d_U, U.shape), (gc.d_b_i, bi.shape),
+                                                                   (gc.d_b_h, bh.shape), (gc.d_X, x.shape))]
+    refs = [("oracle", oref)]
+    if act != "relu":
+        xt, Wt, Ut, bit, bht = (torch.tensor(a).double().requires_grad_(True) for a in (x, W, U, bi, bh))
+        f = torch.tanh if act == "tanh" else torch.sigmoid
+        hp, outs = torch.zeros(B, H, dtype=torch.float64), []
+        for t in range(T):
+            hp = f(xt[:, t] @ Wt + bit + hp @ Ut + (bht if v2 else 0))
+            outs.append(hp)
+        hh = torch.stack(outs, 1)
+        (hh if seq else hh[:, -1]).backward(torch.tensor(dout).double())
+        refs.append(("torch float64", (Wt.grad.numpy(), Ut.grad.numpy(), bit.grad.numpy(), bht.grad.numpy() if v2 else bit.grad.numpy(), xt.grad.numpy())))
+    tol = 5e-6 * np.sqrt(B * T)
+    for nm, ref in refs:
+        for part, a, b_ in zip(("dW", "dU", "dbi", "dbh", "dX"), got, ref):
+            sc = max(1.0, float(np.abs(b_).max()))
+            err = float(np.abs(a - b_).max())
+            assert err <= tol * sc, (part, nm, err)
+    hi = L.RNNCreateForInference(cfg)
+    assert L.RNNApplyTrainingBatch(hi, P(x), P(y)) == -1
+    L.RNNDestroy(hi); L.RecurrentGradientDestroy(g); L.RNNDestroy(h); L.ActivationFunctionDestroy(ah)
+
+
+def test_time_distributed_dense_training_is_dense_over_all_rows(gpu):
+    """time_distributed_dense.c:38-67: a Dense trained on mini_batch * ts rows."""
+    L = capi.load()
+    r = rng(77)
+    B, ts, n_in, n_out = 4, 9, 12, 10
+    x, W, b = u(r, B * ts, n_in), u(r, n_in, n_out, sc=0.3), u(r, n_out, sc=0.1)
+    ah = L.ActivationFunctionCreateSoftmax(1, n_out)
+    cfg = L.TimeDistributedDenseConfigCreate(ts, L.DenseConfigCreate(n_in, n_out, ah))
+    h = L.TimeDistributedDenseCreateForTraining(cfg, capi.ConvTrainingConfig(B))
+    w = L.TimeDistributedDenseGetWeights(h).contents
+    C.memmove(w.W, W.ctypes.data, W.nbytes); C.memmove(w.b, b.ctypes.data, b.nbytes)
+    y = np.empty((B * ts, n_out), np.float32)
+    assert L.TimeDistributedDenseApplyInference(h, P(x), P(y)) == -1
+    assert L.TimeDistributedDenseApplyTrainingBatch(h, P(x), P(y)) == 0, capi.last_error()
+    z, a = O.dense_forward_training(x, W, b, act=O.ACT_SOFTMAX, softmax_vector_size=n_out)
+    np.testing.assert_allclose(y, a, rtol=1e-5, atol=1e-6)
+    dout = u(r, B * ts, n_out)
+    g = L.TimeDistributedDenseGradientCreate(h)
+    L.TimeDistributedDenseCalculateGradient(h, g, P(dout))
+    assert capi.last_error() == ""
+    oW, ob, oX = O.dense_gradient(x, W, z, a, dout, act=O.ACT_SOFTMAX, softmax_vector_size=n_out)
+    np.testing.assert_allclose(np.ctypeslib.as_array(g.contents.d_W, shape=W.shape), oW, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(np.ctypeslib.as_array(g.contents.d_b, shape=b.shape), ob, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(np.ctypeslib.as_array(g.contents.d_X, shape=x.shape), oX, rtol=1e-5, atol=2e-6)
+    L.DenseGradientDestroy(g); L.TimeDistributedDenseDestroy(h); L.ActivationFunctionDestroy(ah)
