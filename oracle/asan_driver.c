@@ -87,6 +87,54 @@ int main(void) {
       ref_bd_reverse_batch(y, r, 3, 3, V); ref_bd_merge_concat(y, r, cat, 3, 3, V); ref_bd_merge_sum(y, r, cat, 3, 3, V);
       float *t = buf((size_t)I * V); ref_op_mat_transp(W, t, V, I); (void)ref_op_vec_dot(W, W, I * V);
       free(x); free(W); free(b); free(y); free(r); free(cat); free(t); }
+    /* training restatements: activation gradients, dense / batch-norm gradients, losses, SGD, GRU / LSTM / RNN BPTT
+     * (exact-size buffers; T = 1 and return_sequences = 0 included) */
+    { int B = 3, I = 5, V = 6;
+      float *x = rnd((size_t)B * I, 1), *W = rnd((size_t)I * V, 2), *z = rnd((size_t)B * V, 3), *a = buf((size_t)B * V), *d = rnd((size_t)B * V, 4);
+      float *gW = rnd((size_t)I * V, 5), *gb = rnd(V, 6), *dX = buf((size_t)B * I), *o = buf((size_t)B * V);
+      const int kinds[] = {REF_ACT_IDENTITY, REF_ACT_SIGMOID, REF_ACT_TANH, REF_ACT_RELU};
+      for (int k = 0; k < 4; ++k) {
+          ref_activation(kinds[k], 1.f, 0, z, a, B * V);
+          ref_activation_gradient(kinds[k], 0, z, a, d, o, B * V);
+          ref_activation_gradient(kinds[k], 0, z, NULL, d, o, B * V);
+          ref_dense_gradient(x, W, z, a, d, kinds[k], 0, V, gW, gb, dX, B, I, V);
+      }
+      ref_activation(REF_ACT_SOFTMAX, 1.f, V, z, a, B);
+      ref_activation_gradient(REF_ACT_SOFTMAX, V, z, a, d, o, B);
+      ref_activation_gradient(REF_ACT_SOFTMAX, V, z, NULL, d, o, B);
+      ref_dense_gradient(x, W, z, a, d, REF_ACT_SOFTMAX, V, 1, gW, gb, dX, B, I, V);
+      ref_dense_gradient(x, W, z, a, d, -1, 0, V, gW, gb, dX, B, I, V);
+      (void)ref_mean_squared_error(a, z, V, B); ref_mean_squared_error_derivative(a, z, o, V, B);
+      (void)ref_categorical_crossentropy(a, a, V, B); ref_categorical_crossentropy_derivative(a, a, o, V, B);
+      ref_sgd_optimize(0.1f, gW, W, I * V);
+      float *mean = buf(V), *var = buf(V), *mm = rnd(V, 7), *mv = rnd(V, 8), *g = rnd(V, 9), *be = rnd(V, 10);
+      for (int i = 0; i < V; ++i) mv[i] = mv[i] * mv[i] + 0.1f;
+      ref_batch_norm_training_forward(z, g, be, 1e-3f, 0.9f, o, mean, var, mm, mv, B, V);
+      ref_batch_norm_gradient(z, d, g, mean, var, 1e-3f, gb, be, a, B, V);
+      free(x); free(W); free(z); free(a); free(d); free(gW); free(gb); free(dX); free(o); free(mean); free(var); free(mm); free(mv); free(g); free(be); }
+    for (int T = 1; T <= 4; T += 3)
+        for (int seq = 0; seq < 2; ++seq) {
+            int B = 2, I = 3, H = 4;
+            size_t rows = (size_t)B * T;
+            float *x = rnd(rows * I, 1), *dout = rnd(seq ? rows * H : (size_t)B * H, 2), *dX = buf(rows * I);
+            float *h = buf(rows * H), *c = buf(rows * H), *Z = buf(rows * 8 * H), *hU = buf(rows * H);
+            for (int G = 1; G <= 4; G += (G == 1 ? 2 : 1)) {
+                float *W = rnd((size_t)I * G * H, 3), *U = rnd((size_t)H * G * H, 4), *bi = rnd((size_t)G * H, 5), *bh = rnd((size_t)G * H, 6);
+                float *gW = rnd((size_t)I * G * H, 7), *gU = rnd((size_t)H * G * H, 8), *gbi = rnd((size_t)G * H, 9), *gbh = rnd((size_t)G * H, 10);
+                if (G == 3) {
+                    ref_gru_training_forward(x, W, U, bi, bh, h, Z, hU, B, T, I, H, REF_ACT_SIGMOID, REF_ACT_TANH, REF_ACT_SIGMOID);
+                    ref_gru_gradient(x, W, U, h, Z, hU, dout, seq, gW, gU, gbi, gbh, dX, B, T, I, H, REF_ACT_SIGMOID, REF_ACT_TANH, REF_ACT_SIGMOID);
+                } else if (G == 4) {
+                    ref_lstm_training_forward(x, W, U, bi, bh, h, c, Z, B, T, I, H, seq, REF_ACT_SIGMOID, REF_ACT_SIGMOID, REF_ACT_TANH, REF_ACT_SIGMOID, REF_ACT_TANH);
+                    ref_lstm_gradient(x, W, U, h, c, Z, dout, seq, gW, gU, gbi, gbh, dX, B, T, I, H, REF_ACT_SIGMOID, REF_ACT_SIGMOID, REF_ACT_TANH, REF_ACT_SIGMOID, REF_ACT_RELU);
+                } else {
+                    ref_rnn_training_forward(x, W, U, bi, bh, h, hU, B, T, I, H, seq, REF_ACT_TANH);
+                    ref_rnn_gradient(x, W, U, h, hU, dout, seq, gW, gU, gbi, gbh, dX, B, T, I, H, REF_ACT_TANH);
+                }
+                free(W); free(U); free(bi); free(bh); free(gW); free(gU); free(gbi); free(gbh);
+            }
+            free(x); free(dout); free(dX); free(h); free(c); free(Z); free(hU);
+        }
     puts("oracle asan driver: ok");
     return 0;
 }
