@@ -235,6 +235,11 @@ void bd_merge_concat(const float *forward_result, const float *backward_result, 
                      RecurrentConfig config, int batch, float *buffer);
 void bd_merge_sum(const float *forward_result, const float *backward_result, float *output,
                   RecurrentConfig config, int batch);
+/* gradient helpers (bidirectional.h, bidirectional.c:58-74, :87-108); buffer unused */
+void bd_merge_concat_gradient(const float *d_out, float *d_forward_out, float *d_backward_out, RecurrentConfig config,
+                              int batch, float *buffer);
+void bd_merge_sum_gradient(const float *d_out, float *d_forward_out, float *d_backward_out, RecurrentConfig config, int batch);
+void bd_accumulate_d_x(const float *forward_dx, const float *backward_dx, float *output, RecurrentConfig config, int batch);
 
 /* ---- nntoolkitcore/layers/dense.h:21-55 -------------------------------- */
 typedef DefaultWeights DenseWeights;

@@ -154,6 +154,9 @@ SIGNATURES = {
     "GRUGetWeights": (C.POINTER(RecurrentWeights), [vp]),
     "GRUCreateForInference": (vp, [GRUConfig]),
     "GRUApplyInference": (C.c_int, [vp, fp, fp]),
+    "bd_merge_concat_gradient": (None, [fp, fp, fp, RecurrentConfig, C.c_int, fp]),
+    "bd_merge_sum_gradient": (None, [fp, fp, fp, RecurrentConfig, C.c_int]),
+    "bd_accumulate_d_x": (None, [fp, fp, fp, RecurrentConfig, C.c_int]),
     "RNNCreateForTraining": (vp, [RNNConfig, ConvTrainingConfig]),
     "RNNGradientCreate": (C.POINTER(RecurrentGradient), [RNNConfig, ConvTrainingConfig]),
     "RNNApplyTrainingBatch": (C.c_int, [vp, fp, fp]),

@@ -130,6 +130,7 @@ int nntk_shim_bn_train_forward(const float *d_x, const float *d_block, float eps
 int nntk_shim_bn_train_backward(const float *d_x, const float *d_dout, const float *d_block, float *d_stats, float *d_partial, float *d_dx, long N, int F);
 int nntk_shim_concat2(const float *d_a, const float *d_b, float *d_out, long rows, int C);
 int nntk_shim_add2(const float *d_a, const float *d_b, float *d_out, long n);
+int nntk_shim_split2(const float *d_in, float *d_a, float *d_b, long rows, int C);
 
 /* ---- K4: recurrent layers -------------------------------------------------
  * d_xw   [T, B, G*H] time-major input projections INCLUDING b_i (from nntk_shim_conv1d out_mode 1)

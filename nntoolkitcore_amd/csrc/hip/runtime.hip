@@ -422,6 +422,16 @@ __global__ __launch_bounds__(256) void concat2_kernel(const float *a, const floa
     }
 }
 
+// a[r][:] = in[r][0:C], b[r][:] = in[r][C:2C]   (bd_merge_concat_gradient, bidirectional.c:58-74, without its transposes)
+__global__ __launch_bounds__(256) void split2_kernel(const float *in, float *a, float *b, long rows, int C) {
+    const long total = rows * 2L * C;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % (2 * C));
+        const long r = e / (2 * C);
+        if (c < C) a[r * C + c] = in[e]; else b[r * C + (c - C)] = in[e];
+    }
+}
+
 __global__ __launch_bounds__(256) void add2_kernel(const float *a, const float *b, float *out, long n) {
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
         out[e] = a[e] + b[e];                                  // bd_merge_sum: op_vec_add (bidirectional.c:76-85)
@@ -462,6 +472,13 @@ int nntk_shim_concat2(const float *d_a, const float *d_b, float *d_out, long row
     if (rows <= 0 || C <= 0) return 0;
     hipLaunchKernelGGL(concat2_kernel, dim3(grid_for(rows * 2 * C, 256)), dim3(256), 0, nntk_stream(), d_a, d_b, d_out, rows, C);
     NNTK_LAUNCH_CHECK("concat2_kernel");
+    return 0;
+}
+
+int nntk_shim_split2(const float *d_in, float *d_a, float *d_b, long rows, int C) {
+    if (rows <= 0 || C <= 0) return 0;
+    hipLaunchKernelGGL(split2_kernel, dim3(grid_for(rows * 2 * C, 256)), dim3(256), 0, nntk_stream(), d_in, d_a, d_b, rows, C);
+    NNTK_LAUNCH_CHECK("split2_kernel");
     return 0;
 }
 

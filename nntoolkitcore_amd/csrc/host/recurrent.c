@@ -990,6 +990,39 @@ void bd_merge_concat(const float *forward_result, const float *backward_result, 
     (void)buffer;
     bd_merge_host(forward_result, backward_result, output, config, batch, 1);
 }
+/* ---- gradient helpers (bidirectional.c:58-74, :87-108): pure data movement, as their forward counterparts ---- */
+void bd_merge_concat_gradient(const float *d_out, float *d_forward_out, float *d_backward_out, RecurrentConfig config,
+                              int batch, float *buffer) {
+    (void)buffer;
+    nntk_shim_clear_error();
+    int rows = config.return_sequences ? config.timesteps : 1, C = config.output_feature_channels;
+    size_t n = (size_t)batch * rows * C;
+    if (!n) return;
+    float *d_in = nntk_devbuf_reserve(&g_bd_out, 2 * n);
+    float *d_a = nntk_devbuf_reserve(&g_bd_a, n), *d_b = nntk_devbuf_reserve(&g_bd_b, n);
+    if (!d_in || !d_a || !d_b) return;
+    if (nntk_shim_upload(d_in, d_out, 2 * n * sizeof(float))) return;
+    if (nntk_shim_split2(d_in, d_a, d_b, (long)batch * rows, C)) return;
+    if (nntk_shim_download(d_forward_out, d_a, n * sizeof(float))) return;
+    (void)nntk_shim_download(d_backward_out, d_b, n * sizeof(float));
+}
+void bd_merge_sum_gradient(const float *d_out, float *d_forward_out, float *d_backward_out, RecurrentConfig config, int batch) {
+    size_t n = (size_t)batch * (config.return_sequences ? config.timesteps : 1) * config.output_feature_channels;
+    memcpy(d_forward_out, d_out, n * sizeof(float));        /* f_copy twice (bidirectional.c:95-96): no arithmetic */
+    memcpy(d_backward_out, d_out, n * sizeof(float));
+}
+/* output = forward_dx + time-reversed backward_dx (bidirectional.c:99-108) */
+void bd_accumulate_d_x(const float *forward_dx, const float *backward_dx, float *output, RecurrentConfig config, int batch) {
+    nntk_shim_clear_error();
+    size_t n = (size_t)batch * config.timesteps * config.input_feature_channels;
+    if (!n) return;
+    float *d_a = nntk_devbuf_reserve(&g_bd_a, n), *d_b = nntk_devbuf_reserve(&g_bd_b, n), *d_o = nntk_devbuf_reserve(&g_bd_out, n);
+    if (!d_a || !d_b || !d_o) return;
+    if (nntk_shim_upload(d_a, forward_dx, n * sizeof(float)) || nntk_shim_upload(d_b, backward_dx, n * sizeof(float))) return;
+    if (nntk_shim_reverse_time(d_b, d_o, batch, config.timesteps, config.input_feature_channels)) return;
+    if (nntk_shim_add2(d_a, d_o, d_o, (long)n)) return;
+    (void)nntk_shim_download(output, d_o, n * sizeof(float));
+}
 /* bidirectional.c:76-85 */
 void bd_merge_sum(const float *forward_result, const float *backward_result, float *output,
                   RecurrentConfig config, int batch) {

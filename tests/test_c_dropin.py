@@ -110,3 +110,32 @@ def test_dist_c_caller_broadcasts_weights_and_shards(tmp_path, built_lib, gpu):
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     got = np.concatenate([np.fromfile(str(tmp_path / ("out_%d.bin" % rk)), np.float32) for rk in range(world)]).reshape(B, T, H)
     assert np.abs(got - O.gru(x, W, U, bi, bh)).max() < 1e-5
+
+
+# ---- a training loop written against the reference's API (gru.h, dense.h, train/loss.h, train/optimizers.h) ----
+TRAIN_SRC = os.path.join(ROOT, "tests", "c_api", "train_caller.c")
+
+
+def _build_train(tmp_path):
+    exe = str(tmp_path / "train_caller")
+    libdir = os.path.dirname(capi.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=gnu11", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), TRAIN_SRC,
+                           "-L", libdir, "-lnntoolkitcore_hip", "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined", "-lm", "-o", exe])
+    return exe
+
+
+def test_reference_style_training_loop_compiles_and_links(tmp_path, built_lib):
+    assert os.path.exists(_build_train(tmp_path))
+
+
+@pytest.mark.gpu
+def test_reference_style_training_loop_learns(tmp_path, built_lib, gpu):
+    """GRU -> Dense(softmax) -> categorical cross-entropy -> BPTT -> SGD, from C, on the reference's own API names."""
+    exe = _build_train(tmp_path)
+    env = dict(os.environ)
+    torch_lib = os.path.join(os.path.dirname(__import__("torch").__file__), "lib")
+    env["LD_LIBRARY_PATH"] = torch_lib + ":" + env.get("LD_LIBRARY_PATH", "")
+    out = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=300)
+    losses = [float(l.split()[-1]) for l in out.stdout.splitlines() if l.startswith("step")]
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert len(losses) == 40 and losses[-1] < 0.6 * losses[0]

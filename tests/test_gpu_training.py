@@ -463,3 +463,29 @@ def test_time_distributed_dense_training_is_dense_over_all_rows(gpu):
     np.testing.assert_allclose(np.ctypeslib.as_array(g.contents.d_b, shape=b.shape), ob, rtol=1e-5, atol=2e-6)
     np.testing.assert_allclose(np.ctypeslib.as_array(g.contents.d_X, shape=x.shape), oX, rtol=1e-5, atol=2e-6)
     L.DenseGradientDestroy(g); L.TimeDistributedDenseDestroy(h); L.ActivationFunctionDestroy(ah)
+
+
+def test_bidirectional_gradient_helpers(gpu):
+    """bd_merge_concat_gradient / bd_merge_sum_gradient / bd_accumulate_d_x (bidirectional.c:58-108): the inverses of the
+    forward helpers -- checked against them and against plain numpy."""
+    L = capi.load()
+    r = rng(5)
+    B, T, n_in, H = 3, 7, 4, 6
+    for seq in (True, False):
+        cfg = L.RecurrentConfigCreate(n_in, H, seq, T)
+        rows = T if seq else 1
+        d_out = u(r, B, rows, 2 * H)
+        f, b = np.empty((B, rows, H), np.float32), np.empty((B, rows, H), np.float32)
+        L.bd_merge_concat_gradient(P(d_out), P(f), P(b), cfg, B, None)
+        assert capi.last_error() == ""
+        np.testing.assert_array_equal(f, d_out[..., :H]); np.testing.assert_array_equal(b, d_out[..., H:])
+        back = np.empty_like(d_out)
+        L.bd_merge_concat(P(f), P(b), P(back), cfg, B, None)
+        np.testing.assert_array_equal(back, d_out)                         # gradient of concat = its inverse
+        d_sum = u(r, B, rows, H)
+        L.bd_merge_sum_gradient(P(d_sum), P(f), P(b), cfg, B)
+        np.testing.assert_array_equal(f, d_sum); np.testing.assert_array_equal(b, d_sum)
+    fx, bx = u(r, B, T, n_in), u(r, B, T, n_in)
+    out = np.empty_like(fx)
+    L.bd_accumulate_d_x(P(fx), P(bx), P(out), cfg, B)
+    np.testing.assert_array_equal(out, fx + bx[:, ::-1])
