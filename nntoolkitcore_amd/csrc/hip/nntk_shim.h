@@ -108,18 +108,23 @@ int nntk_shim_sgd(float lr, const float *d_grad, float *d_w, long n);
  * acts / scales in the order z, h, r */
 int nntk_shim_gru_train_forward(const float *d_x, const float *d_W, const float *d_U, const float *d_bi, const float *d_bh,
                                 float *d_h, float *d_Zg, float *d_hU, int B, int T, int in, int H, const int *acts, const float *scales);
-int nntk_shim_gru_train_backward(const float *d_dout, const float *d_U, const float *d_h, const float *d_Zg, const float *d_hU,
+int nntk_shim_gru_train_backward(const float *d_dout, const float *d_UT /*U transposed [3H][H]*/, const float *d_h, const float *d_Zg, const float *d_hU,
                                  float *d_dxW, float *d_dhU, float *d_work /*5*B*H*/, int B, int T, int H, int return_sequences, const int *acts);
 /* LSTM training (lstm.c:185-239, :294-556): W [in][4H], U [H][4H]; caches h, c [B][T][H], zifgo [B][T][8H]; acts i,f,g,o,out */
 int nntk_shim_lstm_train_forward(const float *d_x, const float *d_W, const float *d_U, const float *d_bi, const float *d_bh,
                                  float *d_h, float *d_c, float *d_zifgo, int B, int T, int in, int H, int v2, const int *acts, const float *scales);
-int nntk_shim_lstm_train_backward(const float *d_dout, const float *d_U, const float *d_c, const float *d_zifgo, float *d_dG,
+int nntk_shim_lstm_train_backward(const float *d_dout, const float *d_UT /*U transposed [4H][H]*/, const float *d_c, const float *d_zifgo, float *d_dG,
                                   float *d_work /*6*B*H*/, int B, int T, int H, int return_sequences, const int *acts, const float *scales);
 /* RNN training (rnn.c:144-221, :249-351): W [in][H], U [H][H]; caches h, gate [B][T][H] */
 int nntk_shim_rnn_train_forward(const float *d_x, const float *d_W, const float *d_U, const float *d_bi, const float *d_bh,
                                 float *d_h, float *d_gate, int B, int T, int in, int H, int v2, int act, float scale);
-int nntk_shim_rnn_train_backward(const float *d_dout, const float *d_U, const float *d_h, const float *d_gate, float *d_dG,
+int nntk_shim_rnn_train_backward(const float *d_dout, const float *d_UT /*U transposed [H][H]*/, const float *d_h, const float *d_gate, float *d_dG,
                                  float *d_work /*2*B*H*/, int B, int T, int H, int return_sequences, int act);
+/* MFMA forms of the large training products: C [M][N] (+)= A [M][K] x Bw [N][K]^T through the inference GEMM kernel (Bw is
+ * packed per call into d_pack >= nntk_shim_gemm_nt_scratch_floats(N, K) floats; accumulate uses d_tmp [M][N]) */
+size_t nntk_shim_gemm_nt_scratch_floats(int N, int K);
+int nntk_shim_gemm_nt(const float *d_A, const float *d_Bw, float *d_C, float *d_pack, float *d_tmp, long M, int N, int K, int accumulate);
+int nntk_shim_transpose(const float *d_src, float *d_dst, long R, int C, int shift_T);
 /* C [I][K] += A^T B over `rows` rows, c [K] += column sums of B (a_shift_T > 0: A is h [B][T][I] and row (b,t) uses h_{t-1}) */
 size_t nntk_shim_outer_scratch_floats(int I, int K);
 int nntk_shim_outer_accumulate(const float *d_A, const float *d_B, float *d_C, float *d_c, float *d_scratch, long rows, int I, int K, int a_shift_T);

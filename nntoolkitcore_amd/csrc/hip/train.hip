@@ -456,6 +456,20 @@ __global__ __launch_bounds__(256) void rows_times_rowmat_kernel(const float *__r
         out[e] = acc;
     }
 }
+// the same product and the same k order with the matrix given TRANSPOSED (MT [K][I]): lanes i read consecutive floats.
+// Used inside the per-timestep loops (U^T is built once per gradient call); bit-identical to the form above.
+__global__ __launch_bounds__(256) void rows_times_colmat_kernel(const float *__restrict__ d, const float *__restrict__ MT,
+                                                                float *__restrict__ out, long rows, int I, int K) {
+    const long total = rows * I;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long row = e / I;
+        const int i = (int)(e % I);
+        const float *dv = d + row * K;
+        float acc = 0.0f;
+        for (int k = 0; k < K; ++k) acc = add_rn(acc, mul_rn(MT[(size_t)k * I + i], dv[k]));
+        out[e] = acc;
+    }
+}
 // C[i][k] += sum_rows A[row][i] * Bm[row][k] and c[k] += sum_rows Bm[row][k]: row slices summed in order inside a slice,
 // slices added in order onto C (the reference adds each (b, t) term onto the gradient block one by one, gru.c:508)
 #define OUTER_SLICES 32
@@ -490,7 +504,7 @@ __global__ __launch_bounds__(256) void outer_reduce_kernel(const float *__restri
 extern "C" size_t nntk_shim_outer_scratch_floats(int I, int K) { return (size_t)OUTER_SLICES * (I + 1) * K; }
 extern "C" int nntk_shim_outer_accumulate(const float *d_A, const float *d_B, float *d_C, float *d_c, float *d_scratch,
                                           long rows, int I, int K, int a_shift_T) {
-    if (rows <= 0 || I <= 0 || K <= 0) return 0;
+    if (rows <= 0 || I < 0 || K <= 0) return 0;             // I == 0: only the column sums c
     hipLaunchKernelGGL(outer_partial_kernel, dim3((unsigned)(I + 1), OUTER_SLICES), dim3(K >= 256 ? 256 : ((K + 63) / 64) * 64), 0,
                        nntk_stream(), d_A, d_B, d_scratch, rows, I, K, a_shift_T);
     NNTK_LAUNCH_CHECK("outer_partial_kernel");
@@ -523,7 +537,7 @@ extern "C" int nntk_shim_gru_train_forward(const float *d_x, const float *d_W, c
     return 0;
 }
 // backward recurrence; d_work: 2 x [B][H] (d_h_prev_1, d_h_prev_2) + [B][3H] (this step's d_hU)
-extern "C" int nntk_shim_gru_train_backward(const float *d_dout, const float *d_U, const float *d_h, const float *d_Zg,
+extern "C" int nntk_shim_gru_train_backward(const float *d_dout, const float *d_UT /*[3H][H]*/, const float *d_h, const float *d_Zg,
                                             const float *d_hU, float *d_dxW, float *d_dhU, float *d_work, int B, int T, int H,
                                             int return_sequences, const int *acts) {
     if (B <= 0 || T <= 0) return 0;
@@ -537,8 +551,8 @@ extern "C" int nntk_shim_gru_train_backward(const float *d_dout, const float *d_
         p.t = t;
         hipLaunchKernelGGL(gru_train_bwd_step_kernel, dim3((B * H + 255) / 256), dim3(256), 0, nntk_stream(), p);
         if (t > 0)
-            hipLaunchKernelGGL(rows_times_rowmat_kernel, dim3(grid_for((long)B * H, 256)), dim3(256), 0, nntk_stream(),
-                               (const float *)step, d_U, dhp2, (long)B, H, 3 * H);
+            hipLaunchKernelGGL(rows_times_colmat_kernel, dim3(grid_for((long)B * H, 256)), dim3(256), 0, nntk_stream(),
+                               (const float *)step, d_UT, dhp2, (long)B, H, 3 * H);
     }
     NNTK_LAUNCH_CHECK("gru_train_bwd_step_kernel");
     return 0;
@@ -644,7 +658,7 @@ extern "C" int nntk_shim_lstm_train_forward(const float *d_x, const float *d_W, 
     return 0;
 }
 // d_work: [B][H] d_h carry + [B][H] d_c carry + [B][4H] this step's dgates
-extern "C" int nntk_shim_lstm_train_backward(const float *d_dout, const float *d_U, const float *d_c, const float *d_zifgo,
+extern "C" int nntk_shim_lstm_train_backward(const float *d_dout, const float *d_UT /*[4H][H]*/, const float *d_c, const float *d_zifgo,
                                              float *d_dG, float *d_work, int B, int T, int H, int return_sequences,
                                              const int *acts, const float *scales) {
     if (B <= 0 || T <= 0) return 0;
@@ -658,8 +672,8 @@ extern "C" int nntk_shim_lstm_train_backward(const float *d_dout, const float *d
         p.t = t;
         hipLaunchKernelGGL(lstm_train_bwd_step_kernel, dim3((B * H + 255) / 256), dim3(256), 0, nntk_stream(), p);
         if (t > 0)
-            hipLaunchKernelGGL(rows_times_rowmat_kernel, dim3(grid_for((long)B * H, 256)), dim3(256), 0, nntk_stream(),
-                               (const float *)step, d_U, dh, (long)B, H, 4 * H);
+            hipLaunchKernelGGL(rows_times_colmat_kernel, dim3(grid_for((long)B * H, 256)), dim3(256), 0, nntk_stream(),
+                               (const float *)step, d_UT, dh, (long)B, H, 4 * H);
     }
     NNTK_LAUNCH_CHECK("lstm_train_bwd_step_kernel");
     return 0;
@@ -718,7 +732,7 @@ extern "C" int nntk_shim_rnn_train_forward(const float *d_x, const float *d_W, c
     return 0;
 }
 // d_work: [B][H] d_h carry + [B][H] this step's d_gate
-extern "C" int nntk_shim_rnn_train_backward(const float *d_dout, const float *d_U, const float *d_h, const float *d_gate,
+extern "C" int nntk_shim_rnn_train_backward(const float *d_dout, const float *d_UT /*[H][H]*/, const float *d_h, const float *d_gate,
                                             float *d_dG, float *d_work, int B, int T, int H, int return_sequences, int act) {
     if (B <= 0 || T <= 0) return 0;
     float *dh = d_work, *step = d_work + (size_t)B * H;
@@ -726,9 +740,80 @@ extern "C" int nntk_shim_rnn_train_backward(const float *d_dout, const float *d_
         hipLaunchKernelGGL(rnn_train_bwd_step_kernel, dim3((B * H + 255) / 256), dim3(256), 0, nntk_stream(), d_dout, d_h, d_gate,
                            (const float *)dh, d_dG, step, B, T, H, t, return_sequences, act);
         if (t > 0)
-            hipLaunchKernelGGL(rows_times_rowmat_kernel, dim3(grid_for((long)B * H, 256)), dim3(256), 0, nntk_stream(),
-                               (const float *)step, d_U, dh, (long)B, H, H);
+            hipLaunchKernelGGL(rows_times_colmat_kernel, dim3(grid_for((long)B * H, 256)), dim3(256), 0, nntk_stream(),
+                               (const float *)step, d_UT, dh, (long)B, H, H);
     }
     NNTK_LAUNCH_CHECK("rnn_train_bwd_step_kernel");
+    return 0;
+}
+
+// ---- MFMA forms of the large training products -------------------------------------------------------------------
+// C [M][N] (+)= A [M][K] x Bw [N][K]^T with both operands K-contiguous: the inference GEMM kernel (conv1d.hip, k = 1)
+// with Bw packed as its weights each call (zero padded to whole tiles, bf16 split images behind it).  Used where a
+// training product is big enough that the VALU dots above would dominate (rows x I x K past a threshold); the small
+// cases keep the reference-ordered VALU kernels.  d_X = dgates W^T needs no transpose (W [in][G*H] IS Bw); d_W = x^T dgates
+// and d_U = h_prev^T dgates transpose both operands first (rows become K).
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float *__restrict__ src, float *__restrict__ dst, int N, int K, int N_p, int K_p) {
+    const long total = (long)N_p * K_p;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(e / K_p), k = (int)(e % K_p);
+        dst[e] = (n < N && k < K) ? src[(size_t)n * K + k] : 0.0f;
+    }
+}
+// dst [C][R] = src [R][C]^T through a 32 x 33 LDS tile; shift_T > 0: source row r is replaced by row r - 1, and by zeros
+// where r % shift_T == 0 (h_prev of the recurrent layers: row (b, t) -> h[b][t - 1], zero state at t = 0)
+__global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ src, float *__restrict__ dst, long R, int Cc, int shift_T) {
+    __shared__ float tile[32][33];
+    const long r0 = (long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const long r = r0 + j;
+        const int c = c0 + tx;
+        float v = 0.0f;
+        if (r < R && c < Cc) {
+            if (shift_T > 0) v = (r % shift_T) ? src[(r - 1) * Cc + c] : 0.0f;
+            else v = src[r * Cc + c];
+        }
+        tile[j][tx] = v;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j;
+        const long r = r0 + tx;
+        if (c < Cc && r < R) dst[(size_t)c * R + r] = tile[tx][j];
+    }
+}
+__global__ __launch_bounds__(256) void add_into_kernel(float *__restrict__ dst, const float *__restrict__ src, long n) {
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) dst[e] = add_rn(dst[e], src[e]);
+}
+extern "C" int nntk_shim_transpose(const float *d_src, float *d_dst, long R, int Cc, int shift_T) {
+    if (R <= 0 || Cc <= 0) return 0;
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((R + 31) / 32), (unsigned)((Cc + 31) / 32)), dim3(256), 0, nntk_stream(),
+                       d_src, d_dst, R, Cc, shift_T);
+    NNTK_LAUNCH_CHECK("transpose_kernel");
+    return 0;
+}
+extern "C" size_t nntk_shim_gemm_nt_scratch_floats(int N, int K) {
+    int K_p, N_p;
+    nntk_shim_conv_pack_sizes(K, N, 1, &K_p, &N_p);
+    return (size_t)N_p * K_p * 5 / 2 + 16;            // f32 matrix + three bf16 images
+}
+// d_C [M][N] = d_A [M][K] x d_Bw [N][K]^T  (accumulate != 0: d_C += that, through d_tmp [M][N])
+extern "C" int nntk_shim_gemm_nt(const float *d_A, const float *d_Bw, float *d_C, float *d_pack, float *d_tmp,
+                                 long M, int N, int K, int accumulate) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    if (M > 0x7fffffffL) return nntk_fail_msg("gemm_nt: too many rows");
+    int K_p, N_p;
+    nntk_shim_conv_pack_sizes(K, N, 1, &K_p, &N_p);
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(grid_for((long)N_p * K_p, 256)), dim3(256), 0, nntk_stream(), d_Bw, d_pack, N, K, N_p, K_p);
+    NNTK_LAUNCH_CHECK("pack_rows_kernel");
+    if (nntk_shim_split_bf16x3(d_pack, d_pack + (size_t)N_p * K_p, N_p, K_p)) return -1;
+    float *out = accumulate ? d_tmp : d_C;
+    if (nntk_shim_conv1d(d_A, d_pack, nullptr, nullptr, 0.f, NNTK_ACT_IDENTITY, 1.f, out, 1, (int)M, K, N, 1, 1, (int)M, 0)) return -1;
+    if (accumulate) {
+        hipLaunchKernelGGL(add_into_kernel, dim3(grid_for(M * N, 256)), dim3(256), 0, nntk_stream(), d_C, (const float *)d_tmp, M * N);
+        NNTK_LAUNCH_CHECK("add_into_kernel");
+    }
     return 0;
 }

@@ -226,7 +226,12 @@ void DenseCalculateGradient(Dense filter, DenseGradient *gradient, float *d_out)
         if (nntk_shim_activation_grad(act->kind, act->vector_size, vpc, filter->d_z.p, filter->d_a.p, d_dout, d_dz, (long)B * out)) return;
         dz = d_dz;
     }
-    if (nntk_shim_dense_grad(filter->d_x.p, d_wraw, dz, d_grad, d_grad + w, d_dx, B, in, out)) return;
+    if ((double)B * in * out < (double)(1 << 27)) {       /* small: the reference's mini-batch order exactly */
+        if (nntk_shim_dense_grad(filter->d_x.p, d_wraw, dz, d_grad, d_grad + w, d_dx, B, in, out)) return;
+    } else {                                              /* large: the MFMA GEMM (train.c) */
+        if (nntk_train_outer_accumulate(filter->d_x.p, dz, d_grad, d_grad + w, B, in, out, 0)) return;
+        if (nntk_train_rows_times_rowmat(dz, d_wraw, d_dx, B, in, out)) return;
+    }
     if (nntk_shim_download(gradient->d_W, d_grad, (w + out) * sizeof(float))) return;
     nntk_shim_download(gradient->d_X, d_dx, (size_t)B * in * sizeof(float));
 }

@@ -37,6 +37,9 @@ int nntk_upload_floats(float **d_dst, const float *h_src, size_t n);
 
 /* pack a row-major [K, N] matrix into the conv/GEMM kernel's [N_p][K_p] (K-contiguous) layout and upload */
 int nntk_upload_gemm_weights(float **d_wp, const float *W, int K, int N);
+/* training products (train.c): VALU in the reference's order when small, the MFMA GEMM when large */
+int nntk_train_outer_accumulate(const float *d_A, const float *d_B, float *d_C, float *d_c, long rows, int I, int K, int a_shift_T);
+int nntk_train_rows_times_rowmat(const float *d_d, const float *d_M, float *d_out, long rows, int I, int K);
 int nntk_upload_packed_weights(float **d_wp, const float *h_packed, int rows, int ktot);
 
 struct ActivationFunctionStruct {

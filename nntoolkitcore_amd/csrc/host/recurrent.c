@@ -426,24 +426,24 @@ void GRUCalculateGradient(GRU filter, GRUGradient *gradient, float *d_out) {
     const int B = t->mini_batch, T = c->T, in = c->in, H = c->H;
     const size_t w = (size_t)in * 3 * H, u = (size_t)H * 3 * H, b3 = 3 * (size_t)H, rows = (size_t)B * T;
     const size_t n_do = c->return_sequences ? rows * H : (size_t)B * H;
-    size_t scr = nntk_shim_outer_scratch_floats(in > H ? in : H, 3 * H);
     float *d_dout = nntk_devbuf_reserve(&t->d_dout, n_do);
     float *d_dxW = nntk_devbuf_reserve(&t->d_dxW, rows * 3 * H);
     float *d_dhU = nntk_devbuf_reserve(&t->d_dhU, rows * 3 * H);
     float *d_work = nntk_devbuf_reserve(&t->d_work, (size_t)B * 5 * H);
     float *d_grad = nntk_devbuf_reserve(&t->d_grad, w + u + 2 * b3);
-    float *d_scr = nntk_devbuf_reserve(&t->d_scr, scr);
+    float *d_UT = nntk_devbuf_reserve(&t->d_scr, u);
     float *d_dX = nntk_devbuf_reserve(&t->d_dX, rows * in);
-    if (!d_dout || !d_dxW || !d_dhU || !d_work || !d_grad || !d_scr || !d_dX) return;
+    if (!d_dout || !d_dxW || !d_dhU || !d_work || !d_grad || !d_UT || !d_dX) return;
     const float *dW = t->d_raw.p, *dU = dW + w;
     if (nntk_shim_upload(d_dout, d_out, n_do * sizeof(float))) return;
     if (nntk_shim_upload(d_grad, gradient->d_W, (w + u + 2 * b3) * sizeof(float))) return;       /* the block is contiguous */
-    if (nntk_shim_gru_train_backward(d_dout, dU, t->d_h.p, t->d_Zg.p, t->d_hU.p, d_dxW, d_dhU, d_work, B, T, H,
+    if (nntk_shim_transpose(dU, d_UT, H, 3 * H, 0)) return;                     /* U^T [3H][H]: coalesced per-step product */
+    if (nntk_shim_gru_train_backward(d_dout, d_UT, t->d_h.p, t->d_Zg.p, t->d_hU.p, d_dxW, d_dhU, d_work, B, T, H,
                                      c->return_sequences ? 1 : 0, acts)) return;
     /* d_W += x^T d_xW, d_b_i += colsum d_xW;  d_U += h_prev^T d_hU, d_b_h += colsum d_hU;  d_X = d_xW W^T */
-    if (nntk_shim_outer_accumulate(t->d_x.p, d_dxW, d_grad, d_grad + w + u, d_scr, (long)rows, in, 3 * H, 0)) return;
-    if (nntk_shim_outer_accumulate(t->d_h.p, d_dhU, d_grad + w, d_grad + w + u + b3, d_scr, (long)rows, H, 3 * H, T)) return;
-    if (nntk_shim_rows_times_rowmat(d_dxW, dW, d_dX, (long)rows, in, 3 * H)) return;
+    if (nntk_train_outer_accumulate(t->d_x.p, d_dxW, d_grad, d_grad + w + u, (long)rows, in, 3 * H, 0)) return;
+    if (nntk_train_outer_accumulate(t->d_h.p, d_dhU, d_grad + w, d_grad + w + u + b3, (long)rows, H, 3 * H, T)) return;
+    if (nntk_train_rows_times_rowmat(d_dxW, dW, d_dX, (long)rows, in, 3 * H)) return;
     if (nntk_shim_download(gradient->d_W, d_grad, (w + u + 2 * b3) * sizeof(float))) return;
     nntk_shim_download(gradient->d_X, d_dX, rows * in * sizeof(float));
 }
@@ -695,22 +695,22 @@ void LSTMCalculateGradient(LSTM filter, LSTMGradient *gradient, float *d_out) {
     const int B = t->mini_batch, T = c->T, in = c->in, H = c->H;
     const size_t w = (size_t)in * 4 * H, u = (size_t)H * 4 * H, b4 = 4 * (size_t)H, rows = (size_t)B * T;
     const size_t n_do = c->return_sequences ? rows * H : (size_t)B * H;
-    size_t scr = nntk_shim_outer_scratch_floats(in > H ? in : H, 4 * H);
     float *d_dout = nntk_devbuf_reserve(&t->d_dout, n_do);
     float *d_dG = nntk_devbuf_reserve(&t->d_dxW, rows * 4 * H);
     float *d_work = nntk_devbuf_reserve(&t->d_work, (size_t)B * 6 * H);
     float *d_grad = nntk_devbuf_reserve(&t->d_grad, w + u + 2 * b4);
-    float *d_scr = nntk_devbuf_reserve(&t->d_scr, scr);
+    float *d_UT = nntk_devbuf_reserve(&t->d_scr, u);
     float *d_dX = nntk_devbuf_reserve(&t->d_dX, rows * in);
-    if (!d_dout || !d_dG || !d_work || !d_grad || !d_scr || !d_dX) return;
+    if (!d_dout || !d_dG || !d_work || !d_grad || !d_UT || !d_dX) return;
     const float *dW = t->d_raw.p, *dU = dW + w;
     if (nntk_shim_upload(d_dout, d_out, n_do * sizeof(float))) return;
     if (nntk_shim_upload(d_grad, gradient->d_W, (w + u + 2 * b4) * sizeof(float))) return;
-    if (nntk_shim_lstm_train_backward(d_dout, dU, t->d_hU.p, t->d_Zg.p, d_dG, d_work, B, T, H, c->return_sequences ? 1 : 0, acts, sc)) return;
+    if (nntk_shim_transpose(dU, d_UT, H, 4 * H, 0)) return;
+    if (nntk_shim_lstm_train_backward(d_dout, d_UT, t->d_hU.p, t->d_Zg.p, d_dG, d_work, B, T, H, c->return_sequences ? 1 : 0, acts, sc)) return;
     /* d_W += x^T dgates, d_U += h_prev^T dgates, d_b_i += colsum, d_b_h += colsum (lstm.c:412-415), d_X = dgates W^T */
-    if (nntk_shim_outer_accumulate(t->d_x.p, d_dG, d_grad, d_grad + w + u, d_scr, (long)rows, in, 4 * H, 0)) return;
-    if (nntk_shim_outer_accumulate(t->d_h.p, d_dG, d_grad + w, d_grad + w + u + b4, d_scr, (long)rows, H, 4 * H, T)) return;
-    if (nntk_shim_rows_times_rowmat(d_dG, dW, d_dX, (long)rows, in, 4 * H)) return;
+    if (nntk_train_outer_accumulate(t->d_x.p, d_dG, d_grad, d_grad + w + u, (long)rows, in, 4 * H, 0)) return;
+    if (nntk_train_outer_accumulate(t->d_h.p, d_dG, d_grad + w, d_grad + w + u + b4, (long)rows, H, 4 * H, T)) return;
+    if (nntk_train_rows_times_rowmat(d_dG, dW, d_dX, (long)rows, in, 4 * H)) return;
     if (nntk_shim_download(gradient->d_W, d_grad, (w + u + 2 * b4) * sizeof(float))) return;
     nntk_shim_download(gradient->d_X, d_dX, rows * in * sizeof(float));
 }
@@ -867,21 +867,21 @@ void RNNCalculateGradient(RNN filter, RNNGradient *gradient, float *d_out) {
     const int B = t->mini_batch, T = c->T, in = c->in, H = c->H;
     const size_t w = (size_t)in * H, u = (size_t)H * H, rows = (size_t)B * T;
     const size_t n_do = c->return_sequences ? rows * H : (size_t)B * H;
-    size_t scr = nntk_shim_outer_scratch_floats(in > H ? in : H, H);
     float *d_dout = nntk_devbuf_reserve(&t->d_dout, n_do);
     float *d_dG = nntk_devbuf_reserve(&t->d_dxW, rows * H);
     float *d_work = nntk_devbuf_reserve(&t->d_work, (size_t)B * 2 * H);
     float *d_grad = nntk_devbuf_reserve(&t->d_grad, w + u + 2 * (size_t)H);
-    float *d_scr = nntk_devbuf_reserve(&t->d_scr, scr);
+    float *d_UT = nntk_devbuf_reserve(&t->d_scr, u);
     float *d_dX = nntk_devbuf_reserve(&t->d_dX, rows * in);
-    if (!d_dout || !d_dG || !d_work || !d_grad || !d_scr || !d_dX) return;
+    if (!d_dout || !d_dG || !d_work || !d_grad || !d_UT || !d_dX) return;
     const float *dW = t->d_raw.p, *dU = dW + w;
     if (nntk_shim_upload(d_dout, d_out, n_do * sizeof(float))) return;
     if (nntk_shim_upload(d_grad, gradient->d_W, (w + u + 2 * (size_t)H) * sizeof(float))) return;
-    if (nntk_shim_rnn_train_backward(d_dout, dU, t->d_h.p, t->d_Zg.p, d_dG, d_work, B, T, H, c->return_sequences ? 1 : 0, act)) return;
-    if (nntk_shim_outer_accumulate(t->d_x.p, d_dG, d_grad, d_grad + w + u, d_scr, (long)rows, in, H, 0)) return;
-    if (nntk_shim_outer_accumulate(t->d_h.p, d_dG, d_grad + w, d_grad + w + u + H, d_scr, (long)rows, H, H, T)) return;
-    if (nntk_shim_rows_times_rowmat(d_dG, dW, d_dX, (long)rows, in, H)) return;
+    if (nntk_shim_transpose(dU, d_UT, H, H, 0)) return;
+    if (nntk_shim_rnn_train_backward(d_dout, d_UT, t->d_h.p, t->d_Zg.p, d_dG, d_work, B, T, H, c->return_sequences ? 1 : 0, act)) return;
+    if (nntk_train_outer_accumulate(t->d_x.p, d_dG, d_grad, d_grad + w + u, (long)rows, in, H, 0)) return;
+    if (nntk_train_outer_accumulate(t->d_h.p, d_dG, d_grad + w, d_grad + w + u + H, (long)rows, H, H, T)) return;
+    if (nntk_train_rows_times_rowmat(d_dG, dW, d_dX, (long)rows, in, H)) return;
     if (nntk_shim_download(gradient->d_W, d_grad, (w + u + 2 * (size_t)H) * sizeof(float))) return;
     nntk_shim_download(gradient->d_X, d_dX, rows * in * sizeof(float));
 }

@@ -69,7 +69,8 @@ def test_relu_gradient_is_the_reference_clamp_not_a_step(gpu):
 
 
 @pytest.mark.parametrize("B,n_in,n_out,act,v", [(5, 12, 7, None, 0), (16, 64, 32, "sigmoid", 0), (8, 33, 10, "softmax", 10),
-                                                (32, 512, 1000, "tanh", 0), (3, 20, 24, "relu", 0), (64, 256, 40, "softmax", 40)])
+                                                (32, 512, 1000, "tanh", 0), (3, 20, 24, "relu", 0), (64, 256, 40, "softmax", 40),
+                                                (2048, 256, 320, "sigmoid", 0)])       # last: large enough for the MFMA forms
 def test_dense_training_forward_and_gradient(gpu, B, n_in, n_out, act, v):
     import torch
     L = capi.load()
