@@ -9,6 +9,11 @@ cd $R
 for w in stack gru conv spectrogram; do
   timeout -k 10 300 python bench.py --workload $w > $O/bench_$w.json 2> $O/bench_$w.err; tail -c 300 $O/bench_$w.json; echo
 done
+NNTK_GEMM_SPLIT_BF16=0 timeout -k 10 300 python bench.py --workload conv --no-cpu-baseline > $O/bench_conv_exact.json 2> $O/bench_conv_exact.err; tail -c 300 $O/bench_conv_exact.json; echo
+NNTK_GEMM_SPLIT_BF16=0 timeout -k 10 300 python bench.py --no-cpu-baseline > $O/bench_stack_exact.json 2> $O/bench_stack_exact.err; tail -c 300 $O/bench_stack_exact.json; echo
+timeout -k 10 300 python tools/split_error.py 2>&1 | grep -v amdgpu.ids > $O/split_error.log; timeout -k 10 200 python tools/split_error.py --stress 2>&1 | grep -v amdgpu.ids >> $O/split_error.log; echo split_error $?
+timeout -k 10 300 python tools/conv_probe.py gemm_split_bf16=0,1 2>&1 | grep -v amdgpu.ids > $O/conv_probe_ab.log; cat $O/conv_probe_ab.log
+timeout -k 10 300 python tools/train_bench.py 2>&1 | grep -v amdgpu.ids > $O/train_bench.log; cat $O/train_bench.log
 cd /tmp && export TMPDIR=/tmp
 for w in stack gru conv spectrogram; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$w -- python3 $R/bench.py --workload $w --no-cpu-baseline --steps 5 > $O/prof_$w.log 2>&1

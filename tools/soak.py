@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Random-shape soak of the conv / dense / recurrent kernels against the oracle (~580 cases incl. spectrogram geometries, the RNN, and round 2's streaming / fused-GRU / mixed-radix / log-mel paths, ~1 min on the GPU):
+"""Random-shape soak of the conv / dense / recurrent kernels against the oracle (~580 cases incl. spectrogram geometries, the RNN, and round 2's streaming / fused-GRU / mixed-radix / log-mel paths and the training path, ~1.5 min on the GPU):
 python tools/soak.py [seed]"""
 import os, sys
 import numpy as np
@@ -113,4 +113,73 @@ for _ in range(15):
     assert L.LogMelSpectrogramApplyBatch(lm, x.ctypes.data_as(capi.fp), out.ctypes.data_as(capi.fp), B) == 0
     assert np.abs(out - ref).max() < 5e-5, (n_mels, N)
     L.LogMelSpectrogramDestroy(lm); sp.destroy(); n += 1
+# ---- training path: random small shapes (incl. T = 1, mini-batch 1, return_sequences = False) against the oracle ----
+P = lambda a: a.ctypes.data_as(capi.fp)
+def fill(dst, src): C.memmove(dst, src.ctypes.data, src.nbytes)
+def rel(a, b): return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+for _ in range(40):
+    G = int(r.choice([1, 3, 4]))
+    B, T, I, H = int(r.integers(1, 7)), int(r.integers(1, 12)), int(r.integers(1, 40)), int(r.integers(1, 48))
+    seq, v2 = bool(r.integers(0, 2)), bool(r.integers(0, 2))
+    x, dout = u(B, T, I), (u(B, T, H) if seq else u(B, H))
+    W, U, bi, bh = u(I, G * H, sc=I ** -0.5), u(H, G * H, sc=H ** -0.5), u(G * H, sc=0.1), u(G * H, sc=0.1)
+    tc = capi.ConvTrainingConfig(B)
+    if G == 3:
+        acts = L.GRUActivationsCreateDefault(H); cfg = L.GRUConfigCreate(I, H, seq, T, acts)
+        h = L.GRUCreateForTraining(cfg, tc); w = L.GRUGetWeights(h).contents; g = L.GRUGradientCreate(cfg, tc)
+        fw, bw, de = L.GRUApplyTrainingBatch, L.GRUCalculateGradient, L.GRUDestroy
+        oh, ref = O.gru_training(x, W, U, bi, bh, dout, return_sequences=seq)
+    elif G == 4:
+        acts = L.LSTMActivationsCreateDefault(H); cfg = L.LSTMConfigCreate(I, H, seq, T, v2, acts)
+        h = L.LSTMCreateForTraining(cfg, tc); w = L.LSTMGetWeights(h).contents; g = L.LSTMGradientCreate(cfg, tc)
+        fw, bw, de = L.LSTMApplyTrainingBatch, L.LSTMCalculateGradient, L.LSTMDestroy
+        oh, ref = O.lstm_training(x, W, U, bi, bh, dout, return_sequences=seq, v2=v2)
+    else:
+        act = L.ActivationFunctionCreateTanh(H); cfg = L.RNNConfigCreate(I, H, seq, T, v2, act)
+        h = L.RNNCreateForTraining(cfg, tc); w = L.RNNGetWeights(h).contents; g = L.RNNGradientCreate(cfg, tc)
+        fw, bw, de = L.RNNApplyTrainingBatch, L.RNNCalculateGradient, L.RNNDestroy
+        oh, ref = O.rnn_training(x, W, U, bi, bh, dout, return_sequences=seq, v2=v2)
+    for dst, src in ((w.W, W), (w.U, U), (w.b_i, bi), (w.b_h, bh)): fill(dst, src)
+    y = np.empty((B, T, H) if seq else (B, H), np.float32)
+    assert fw(h, P(x), P(y)) == 0, capi.last_error()
+    assert rel(y, oh if seq else oh[:, -1]) < 2e-5
+    bw(h, g, P(dout)); assert capi.last_error() == ""
+    gc = g.contents
+    for ptr, rf in zip((gc.d_W, gc.d_U, gc.d_b_i, gc.d_b_h, gc.d_X), ref):
+        assert rel(np.ctypeslib.as_array(ptr, shape=rf.shape), rf) < 3e-5, (G, B, T, I, H, seq, v2)
+    L.RecurrentGradientDestroy(g); de(h); n += 1
+for _ in range(30):
+    B, n_in, n_out = int(r.integers(1, 40)), int(r.integers(1, 70)), int(r.integers(1, 60))
+    kind = int(r.choice([-1, O.ACT_SIGMOID, O.ACT_TANH, O.ACT_RELU, O.ACT_SOFTMAX]))
+    ah = {-1: None, O.ACT_SIGMOID: L.ActivationFunctionCreateSigmoid(n_out), O.ACT_TANH: L.ActivationFunctionCreateTanh(n_out),
+          O.ACT_RELU: L.ActivationFunctionCreateReLU(n_out, 1.0), O.ACT_SOFTMAX: L.ActivationFunctionCreateSoftmax(1, n_out)}[kind]
+    x, W, b, dout = u(B, n_in), u(n_in, n_out, sc=n_in ** -0.5), u(n_out, sc=0.1), u(B, n_out)
+    cfg = L.DenseConfigCreate(n_in, n_out, ah); h = L.DenseCreateForTraining(cfg, capi.ConvTrainingConfig(B))
+    w = L.DenseGetWeights(h).contents; fill(w.W, W); fill(w.b, b)
+    y = np.empty((B, n_out), np.float32)
+    assert L.DenseApplyTrainingBatch(h, P(x), P(y)) == 0, capi.last_error()
+    act = None if kind < 0 else kind
+    z, a = O.dense_forward_training(x, W, b, act=act, softmax_vector_size=n_out)
+    assert rel(y, a) < 2e-5
+    g = L.DenseGradientCreateFromFilter(h); L.DenseCalculateGradient(h, g, P(dout)); assert capi.last_error() == ""
+    for ptr, rf in zip((g.contents.d_W, g.contents.d_b, g.contents.d_X), O.dense_gradient(x, W, z, a, dout, act=act, softmax_vector_size=n_out)):
+        assert rel(np.ctypeslib.as_array(ptr, shape=rf.shape), rf) < 2e-5, (B, n_in, n_out, kind)
+    L.DenseGradientDestroy(g); L.DenseDestroy(h); n += 1
+for _ in range(20):
+    count, mb, F = int(r.integers(1, 30)), int(r.integers(1, 9)), int(r.integers(1, 200))
+    N = count * mb
+    if N < 2: continue
+    x, dout = u(N, F, sc=2.0), u(N, F)
+    gam, be, mm0, mv0 = 1 + u(F, sc=0.5), u(F, sc=0.5), u(F, sc=0.2), 1 + u(F, sc=0.3)
+    cfg = L.BatchNormConfigCreate(F, 1e-3, count); tc = L.BatchNormTrainingConfigCreate(0.9, mb)
+    h = L.BatchNormCreateForTraining(cfg, tc); w = L.BatchNormGetWeights(h).contents
+    for dst, src in ((w.gamma, gam), (w.beta, be), (w.moving_mean, mm0), (w.moving_variance, mv0)): fill(dst, src)
+    y = np.empty((N, F), np.float32)
+    assert L.BatchNormApplyTrainingBatch(h, P(x), P(y)) == 0, capi.last_error()
+    oy, om, ov, omm, omv = O.batch_norm_training_forward(x, gam, be, 1e-3, 0.9, mm0, mv0)
+    assert rel(y, oy) < 3e-5 and rel(np.ctypeslib.as_array(w.moving_variance, shape=(F,)), omv) < 1e-5
+    g = L.BatchNormGradientCreate(cfg, tc); L.BatchNormCalculateGradient(h, g, P(dout)); assert capi.last_error() == ""
+    for ptr, rf in zip((g.contents.d_beta, g.contents.d_gamma, g.contents.d_x), O.batch_norm_gradient(x, dout, gam, om, ov, 1e-3)):
+        assert rel(np.ctypeslib.as_array(ptr, shape=rf.shape), rf) < 1e-4, (count, mb, F)
+    L.BatchNormGradientDestroy(g); L.BatchNormDestroy(h); n += 1
 print("soak ok:", n, "cases")
