@@ -65,6 +65,7 @@ struct ConvParams {
     int rows_a;          // (BM-1)*stride + k window rows per tile
     int bn_fast;         // A/B: multiply by 1/sd instead of the reference's divide
     int store16;         // Cout % 4 == 0 and out 16-byte aligned: 16-byte stores of channel quads
+    int quad;            // which accumulator orientation / epilogue (host choice, see conv_epilogue_rows)
 #ifdef NNTK_CONV_DBG
     int dbg;             // timing experiments only: 1 no stores, 2 no MFMAs, 4 no global loads in the loop
 #endif
@@ -229,9 +230,83 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
     }
 }
 
+// The other orientation (window as the MFMA's A operand): a lane owns one CHANNEL and register r holds row
+// (r & 3) + 8 (r >> 2) + 4 kh, stored with 64 buffer_store_b32 per wavefront, each writing two rows x 128 contiguous
+// bytes.  Kept for the epilogue-heavy time-major input projection (K = 128, rows 8 KB apart), where the quad form's 16
+// stores touch 32 rows x 32 bytes each (four times as many cache lines per tile) and measured 1 % slower (LSTM phase
+// 10.94 vs 11.05 ms, tools/ab.py stack conv_store=0,1); the quad form is the faster one everywhere else (config 3:
+// 0.62 -> 0.55 ms exact, 0.50 -> 0.41 ms split; TimeDistributedDense 2.82 -> 2.74 ms).  Option conv_store forces either.
+// Identical values either way: swapping the MFMA's operands changes no product and no summation order.
+template <int TM, int TN, int WN>
+__device__ __forceinline__ void conv_epilogue_rows(const ConvParams &p, f32x16 (&acc)[TM][TN], int b, int x0, int n0,
+                                                   int wm, int wn, int l31, int kh, const float *cst) {
+    constexpr int BN = WN * TN * 32;
+    const size_t row_elems = (size_t)(p.out_mode ? p.B : 1) * p.Cout;
+    const size_t row_bytes = row_elems * 4;
+    const size_t obase = (p.out_mode ? (size_t)b * p.Cout : (size_t)b * p.Tout * p.Cout) + (size_t)x0 * row_elems;
+    const size_t oend = p.out_mode ? (size_t)p.Tout * p.B * p.Cout : ((size_t)b + 1) * p.Tout * p.Cout;
+    const __amdgpu_buffer_rsrc_t rs_out = conv_rsrc(p.out + obase, (oend - obase) * 4);
+    const bool fast_store = x0 + CONV_BM <= p.Tout && row_bytes * (size_t)(CONV_BM + 4) < (size_t)CONV_OOB;
+    const int rb = (int)row_bytes;
+    auto epilogue = [&](auto bn_tag, auto act_tag, auto fast_tag) {
+        constexpr bool HAS_BN = decltype(bn_tag)::value;
+        constexpr int ACT = decltype(act_tag)::value;
+        constexpr bool FAST = decltype(fast_tag)::value;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int cl = (wn * TN + j) * 32 + l31;
+            const int o = n0 + cl;
+            const bool col_ok = o < p.Cout;
+            const float bias = cst[cl];
+            const float g = cst[BN + cl], be = cst[2 * BN + cl], mu = cst[3 * BN + cl], sd = cst[4 * BN + cl], rsd = cst[5 * BN + cl];
+            const int voff = col_ok ? o * 4 + kh * 4 * rb : CONV_OOB;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int xr = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    float v = acc[i][j][r] + bias;
+                    if (HAS_BN) {
+                        const float d = v - mu;
+                        float qn = d * rsd;
+                        qn = fmaf(fmaf(-qn, sd, d), rsd, qn);
+                        v = p.bn_fast ? (d * rsd) * g + be : nofma_muladd(qn, g, be);
+                    }
+                    v = ACT == -1 ? nntk_act(p.act_kind, v, p.relu_a)
+                      : ACT == NNTK_ACT_RELU ? nntk_act(NNTK_ACT_RELU, v, p.relu_a)
+                      : v;
+                    if (FAST) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, voff, xr * rb, 0);
+                    } else {
+                        const int x = x0 + xr + 4 * kh;
+                        if (x < p.Tout && col_ok) {
+                            const size_t orow = p.out_mode ? ((size_t)x * p.B + b) : ((size_t)b * p.Tout + x);
+                            p.out[orow * p.Cout + o] = v;
+                        }
+                    }
+                }
+            }
+        }
+    };
+    using T_ = std::true_type; using F_ = std::false_type;
+    using AId = std::integral_constant<int, NNTK_ACT_IDENTITY>;
+    using ARelu = std::integral_constant<int, NNTK_ACT_RELU>;
+    using AAny = std::integral_constant<int, -1>;
+    if (fast_store) {
+        if (!p.bn && p.act_kind == NNTK_ACT_IDENTITY) epilogue(F_{}, AId{}, T_{});
+        else if (p.bn && p.act_kind == NNTK_ACT_RELU) epilogue(T_{}, ARelu{}, T_{});
+        else if (p.bn)                                epilogue(T_{}, AAny{}, T_{});
+        else                                          epilogue(F_{}, AAny{}, T_{});
+    } else {
+        if (p.bn) epilogue(T_{}, AAny{}, F_{});
+        else      epilogue(F_{}, AAny{}, F_{});
+    }
+}
+
 // WM x WN wavefronts, each computing TM x TN MFMA tiles of 32x32.
 // A4 = the window can be fetched with 16-byte loads (Cin % 4 == 0, 16-B aligned base).
-template <int WM, int WN, int TM, int TN, bool A4>
+// QUAD: weights as the MFMA's A operand and the 16-byte quad epilogue; else window as A and the row epilogue.
+template <int WM, int WN, int TM, int TN, bool A4, bool QUAD>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
     constexpr int BN = WN * TN * 32;
     constexpr int KC = CONV_KC, LS = CONV_LS;
@@ -393,7 +468,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
                     for (int j = 0; j < TN; ++j) {
                         const float av = u == 0 ? a[i].x : u == 1 ? a[i].y : u == 2 ? a[i].z : a[i].w;
                         const float wv = u == 0 ? w[j].x : u == 1 ? w[j].y : u == 2 ? w[j].z : w[j].w;
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, av, acc[i][j], 0, 0, 0);   // D = W x window^T
+                        acc[i][j] = QUAD ? __builtin_amdgcn_mfma_f32_32x32x2f32(wv, av, acc[i][j], 0, 0, 0)    // D = W x window^T
+                                         : __builtin_amdgcn_mfma_f32_32x32x2f32(av, wv, acc[i][j], 0, 0, 0);
                     }
         };
         if (!CONV_DBG(2)) {
@@ -405,7 +481,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
     }
 
     if (CONV_DBG(1) && acc[0][0][0] != 12345.678f) return;
-    conv_epilogue<TM, TN, WN>(p, acc, b, x0, n0, wm, wn, l31, kh, cst);
+    if constexpr (QUAD) conv_epilogue<TM, TN, WN>(p, acc, b, x0, n0, wm, wn, l31, kh, cst);
+    else conv_epilogue_rows<TM, TN, WN>(p, acc, b, x0, n0, wm, wn, l31, kh, cst);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -477,7 +554,7 @@ extern "C" int nntk_shim_split_bf16x3(const float *d_src, void *d_dst, int rows,
 
 #define SPLIT_ROW 96              // LDS bytes per window row: 3 images x 16 bf16
 
-template <int WM, int WN, int TM, int TN, bool A4>
+template <int WM, int WN, int TM, int TN, bool A4, bool QUAD>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16x3_kernel(ConvParams p) {
     constexpr int BN = WN * TN * 32;
     constexpr int KC = CONV_KC;
@@ -640,7 +717,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16x3_kernel(ConvParams p
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[PW[t]][j], a[PA[t]][i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = QUAD ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[PW[t]][j], a[PA[t]][i], acc[i][j], 0, 0, 0)
+                                         : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]][i], w[PW[t]][j], acc[i][j], 0, 0, 0);
         } else {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -653,7 +731,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16x3_kernel(ConvParams p
         cc = ncc; kk = nkk;
     }
     if (CONV_DBG(1) && acc[0][0][0] != 12345.678f) return;
-    conv_epilogue<TM, TN, WN>(p, acc, b, x0, n0, wm, wn, l31, kh, cst);
+    if constexpr (QUAD) conv_epilogue<TM, TN, WN>(p, acc, b, x0, n0, wm, wn, l31, kh, cst);
+    else conv_epilogue_rows<TM, TN, WN>(p, acc, b, x0, n0, wm, wn, l31, kh, cst);
 }
 
 // Generic VALU kernel for shapes the MFMA tile does not cover (tiny K such as
@@ -702,8 +781,8 @@ extern "C" int nntk_shim_bn_derive(float *d_block, float eps, int C) {
     return 0;
 }
 
-template <int WM, int WN, int TM, int TN, bool A4, bool SPLIT = false>
-static int launch_mfma(const ConvParams &p) {
+template <int WM, int WN, int TM, int TN, bool A4, bool SPLIT, bool QUAD>
+static int launch_mfma_o(const ConvParams &p) {
     constexpr int BN = WN * TN * 32;
     // 41 KB at BN = 128 (50 KB split): three workgroups per CU, which is what hides the barrier / staging latency
     size_t lds = SPLIT ? (size_t)2 * (p.rows_a * SPLIT_ROW + (BN / 32) * 3 * 1024)
@@ -715,7 +794,7 @@ static int launch_mfma(const ConvParams &p) {
     const long blocks = (long)((q.m_tiles + 7) / 8) * 8 * q.n_tiles;
     if ((long)p.B * p.tiles_per_seq > 0x7fffffffL / 8 || blocks > 0x7fffffffL)
         return nntk_fail_msg("conv1d: too many tiles for one launch");
-    auto kern = SPLIT ? conv1d_mfma_bf16x3_kernel<WM, WN, TM, TN, A4> : conv1d_mfma_kernel<WM, WN, TM, TN, A4>;
+    auto kern = SPLIT ? conv1d_mfma_bf16x3_kernel<WM, WN, TM, TN, A4, QUAD> : conv1d_mfma_kernel<WM, WN, TM, TN, A4, QUAD>;
     if (lds > 64 * 1024) {
         if (nntk_set_max_dynamic_lds((const void *)kern, lds)) return -1;
     }
@@ -723,6 +802,11 @@ static int launch_mfma(const ConvParams &p) {
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, nntk_stream(), q);
     NNTK_LAUNCH_CHECK("conv1d_mfma_kernel");
     return 0;
+}
+
+template <int WM, int WN, int TM, int TN, bool A4, bool SPLIT = false>
+static int launch_mfma(const ConvParams &p) {
+    return p.quad ? launch_mfma_o<WM, WN, TM, TN, A4, SPLIT, true>(p) : launch_mfma_o<WM, WN, TM, TN, A4, SPLIT, false>(p);
 }
 
 extern "C" int nntk_shim_conv1d(const float *d_in, const float *d_wp, const float *d_bias, const float *d_bn,
@@ -744,6 +828,7 @@ extern "C" int nntk_shim_conv1d(const float *d_in, const float *d_wp, const floa
     const NntkOptions &opt = nntk_options();
     p.bn_fast = opt.bn_fast == 1 ? 1 : 0;
     p.store16 = Cout % 4 == 0 && ((size_t)d_out & 15) == 0;
+    p.quad = opt.conv_store >= 0 ? opt.conv_store != 0 : out_mode == 0;      // the time-major projection keeps the row form
 #ifdef NNTK_CONV_DBG
     p.dbg = opt.conv_dbg;
 #endif

@@ -48,6 +48,7 @@ static const OptDesc g_opt_table[] = {
     {"bn_fast", "NNTK_BN_FAST", &NntkOptions::bn_fast},
     {"gemm_tm_batch", "NNTK_GEMM_TM_BATCH", &NntkOptions::gemm_tm_batch},
     {"gemm_split_bf16", "NNTK_GEMM_SPLIT_BF16", &NntkOptions::gemm_split_bf16},
+    {"conv_store", "NNTK_CONV_STORE", &NntkOptions::conv_store},
     {"conv_dbg", "NNTK_CONV_DBG", &NntkOptions::conv_dbg},
     {"weights_check", "NNTK_WEIGHTS_CHECK", &NntkOptions::weights_check},
 };
