@@ -105,6 +105,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t conv_rsrc(const void *base, si
 // The per-channel constants come from LDS (conv_stage_constants, written before the K loop's first barrier): fetched
 // from global memory inside the epilogue they were eight serial load -> use round trips per tile, a quarter of the
 // fused Conv+BN+ReLU time.
+// zero the components of a 4-channel piece that lie past the row's last channel (ragged last chunk, 16-byte loads)
+__device__ __forceinline__ v4u32_t mask_channels(v4u32_t v, int nvalid) {
+    if (nvalid < 4) v.w = 0;
+    if (nvalid < 3) v.z = 0;
+    if (nvalid < 2) v.y = 0;
+    if (nvalid < 1) v.x = 0;
+    return v;
+}
+
 // a * b + c with TWO roundings (the instructions keep this mode when the helper is inlined)
 #pragma clang fp contract(off)
 __device__ __forceinline__ float nofma_muladd(float a, float b, float c) { return a * b + c; }
@@ -304,7 +313,7 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvParams &p, f32x16 (
 }
 
 // WM x WN wavefronts, each computing TM x TN MFMA tiles of 32x32.
-// A4 = the window can be fetched with 16-byte loads (Cin % 4 == 0, 16-B aligned base).
+// A4 = the window is fetched with 16-byte loads (always, unless option conv_a4 = 0 and the rows are not 16-byte multiples).
 // QUAD: weights as the MFMA's A operand and the 16-byte quad epilogue; else window as A and the row epilogue.
 template <int WM, int WN, int TM, int TN, bool A4, bool QUAD>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
@@ -432,7 +441,10 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
             for (int q = 0; q < A_PT; ++q) {
                 const int r = ar + q * AR_STEP;
                 if (r < p.rows_a) {
-                    if (A4) *reinterpret_cast<v4u32_t *>(As + r * LS + ac) = areg4[q];
+                    // 16-byte loads of a row whose channel count is not a multiple of 4 pick up the next row's first
+                    // channels in the ragged last chunk: zeroed here (their weights are zero padding, but 0 x NaN is not 0)
+                    if (A4) *reinterpret_cast<v4u32_t *>(As + r * LS + ac) =
+                                (cin_ragged && cc == n_cchunks - 1) ? mask_channels(areg4[q], p.Cin - (cc * KC + ac)) : areg4[q];
                     else    *reinterpret_cast<unsigned *>(As + r * LS + ac) = areg[q];
                 }
             }
@@ -621,13 +633,13 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16x3_kernel(ConvParams p
             else    areg[q] = __builtin_amdgcn_raw_buffer_load_b32(rs_in, vo, cc * KC * 4, 0);
         }
     };
-    auto stage_a = [&](char *As) {                    // registers -> three bf16 images in LDS
+    auto stage_a = [&](char *As, int nvalid) {        // registers -> three bf16 images in LDS (nvalid: channels left in the row)
 #pragma unroll
         for (int q = 0; q < A_PT; q += (A4 ? 1 : 2)) {
             const int r = ar + q * AR_STEP;
             if (A4) {
                 if (r < p.rows_a) {
-                    const v4u32_t x = areg4[q];
+                    const v4u32_t x = nvalid < 4 ? mask_channels(areg4[q], nvalid) : areg4[q];
                     unsigned h0, m0, l0, h1, m1, l1;
                     split3_pair(__uint_as_float(x.x), __uint_as_float(x.y), h0, m0, l0);
                     split3_pair(__uint_as_float(x.z), __uint_as_float(x.w), h1, m1, l1);
@@ -676,7 +688,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16x3_kernel(ConvParams p
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         const int wbuf = chunk & 1;
         const int abuf = cc & 1;
-        if (kk == 0 && !CONV_DBG(16)) stage_a(lds + abuf * a_bytes);
+        if (kk == 0 && !CONV_DBG(16)) stage_a(lds + abuf * a_bytes, (cin_ragged && cc == n_cchunks - 1) ? p.Cin - (cc * KC + ac) : 4);
         if (w_thread) {
             char *dst = lds + wbuf * w_bytes + w_wr;
 #pragma unroll
@@ -847,7 +859,9 @@ extern "C" int nntk_shim_conv1d(const float *d_in, const float *d_wp, const floa
         NNTK_LAUNCH_CHECK("conv1d_valu_kernel");
         return 0;
     }
-    const bool a4 = (Cin % 4 == 0) && ((size_t)d_in % 16 == 0);
+    // 16-byte window loads need only 4-byte alignment (MUBUF dwordx4), so odd channel counts take them too; the pieces
+    // that run past a row's end are masked at staging time (conv_a4 = 0: 4-byte loads for those shapes, as before)
+    const bool a4 = ((Cin % 4 == 0) && ((size_t)d_in % 16 == 0)) || opt.conv_a4 != 0;
     // Time-major output of a dense GEMM (the recurrent input projection): tile over the BATCH at a
     // fixed timestep instead of over time within a sequence.  A tile then writes 128 rows of one
     // [B, Cout] slab (8 KB apart for LSTM-512) instead of 128 rows that are B * Cout * 4 bytes = 4 MB

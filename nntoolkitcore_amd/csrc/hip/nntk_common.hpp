@@ -25,6 +25,7 @@ struct NntkOptions {
     int spec_variant = -1;       // K1 kernel variant (A/B runs)
     int bn_fast = 0;             // reciprocal-multiply BatchNorm (not the reference's divide)
     int gemm_tm_batch = -1;      // tile time-major GEMM outputs over the batch
+    int conv_a4 = 1;             // 16-byte window loads also for channel counts that are not multiples of 4 (0: 4-byte loads there)
     int conv_store = -1;         // GEMM epilogue: -1 auto, 0 row form (4-byte stores), 1 quad form (16-byte stores); bit-identical
     int gemm_split_bf16 = -1;    // 3-way split-bf16 contraction: -1 auto (conv / dense / TDD / mel, not the recurrent xW), 0 never, 1 all
     int conv_dbg = 0;            // diagnostics build only

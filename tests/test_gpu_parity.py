@@ -87,6 +87,34 @@ def test_split_bf16_contraction_matches_oracle(gpu, cin, cout, k, stride, T):
     conv.destroy()
 
 
+@pytest.mark.parametrize("cin,cout,k", [(33, 32, 3), (257, 128, 5), (7, 64, 4), (5, 40, 1), (129, 96, 1), (18, 32, 2)])
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_odd_channel_counts_take_16_byte_window_loads(gpu, cin, cout, k, split):
+    """Rows whose length is not a multiple of 16 bytes are fetched with 16-byte loads all the same (conv_a4, default on);
+    the pieces that run into the next row are masked.  Same bits as the 4-byte-load form, the very last row of the tensor
+    included, and a NaN at the start of the FOLLOWING row must not reach a row that does not own it."""
+    r = rng(cin * 31 + k)
+    B, T = 2, 150
+    x, W, b = u(r, B, T, cin), u(r, cout, cin, k, sc=(cin * k) ** -0.5), u(r, cout, sc=0.2)
+    conv = NL.Conv1d(cin, cout, k, 1, T)
+    conv.set_weights(W, b)
+    capi.set_option("gemm_split_bf16", split)
+    capi.set_option("conv_a4", "0")
+    ref4 = conv.apply(x)
+    capi.set_option("conv_a4", "1")
+    got = conv.apply(x)
+    np.testing.assert_array_equal(got, ref4)
+    close(got, O.conv1d(x, W, b, 1))
+    xn = x.copy()
+    xn[1, 40, :3] = np.nan                                   # row 40 of sequence 1: windows of outputs 40-k+1 .. 40 own it
+    gn = conv.apply(xn)
+    own = np.zeros(gn.shape[:2], bool)
+    own[1, max(0, 40 - k + 1):41] = True
+    assert np.isnan(gn[own]).all() and np.isfinite(gn[~own]).all()
+    np.testing.assert_array_equal(gn[~own], got[~own])
+    conv.destroy()
+
+
 def test_conv1d_output_shorter_than_kernel_is_empty(gpu):
     conv = NL.Conv1d(2, 3, 5, 1, 4)        # output_size = 0 (conv_1d.c:84)
     assert conv.cfg.output_size == 0
