@@ -99,7 +99,7 @@ extern "C" int nntk_shim_conv1d_grad(const float *d_in, const float *d_W, const 
     hipLaunchKernelGGL(conv1d_grad_reduce_kernel, dim3((unsigned)((tot + 255) / 256 > 2048 ? 2048 : (tot + 255) / 256)), dim3(256), 0, st,
                        pw, pb, d_dW, d_db, Cin, Cout, k, GRAD_SLICES);
     const long nx = (long)B * T * Cin;
-    if (nx > 0)
+    if (nx > 0 && d_dX)                       // d_dX == NULL: the caller computes d_X itself (MFMA form, train.hip)
         hipLaunchKernelGGL(conv1d_dx_kernel, dim3((unsigned)((nx + 255) / 256 > 8192 ? 8192 : (nx + 255) / 256)), dim3(256), 0, st,
                            d_dout, d_W, d_dX, B, T, Cin, Cout, k, stride, Tout > 0 ? Tout : 0);
     NNTK_LAUNCH_CHECK("conv1d_grad kernels");

@@ -57,6 +57,7 @@ int   nntk_shim_upload(void *d_dst, const void *h_src, size_t bytes);     /* blo
 int   nntk_shim_upload_async(void *d_dst, const void *h_src, size_t bytes);        /* async on stream (pinned source) */
 int   nntk_shim_download(void *h_dst, const void *d_src, size_t bytes);   /* blocking; -1 if a recurrent launch faulted */
 int   nntk_shim_download_nocheck(void *h_dst, const void *d_src, size_t bytes);    /* blocking; leaves a fault for nntk_shim_take_fault */
+int   nntk_shim_download_rows(void *h_dst, const void *d_src, size_t spitch, size_t width, size_t height);   /* strided rows, packed at the destination */
 int   nntk_shim_copy_d2d(void *d_dst, const void *d_src, size_t bytes);   /* async on stream */
 int   nntk_shim_memset(void *d_ptr, int value, size_t bytes);             /* async on stream */
 
@@ -125,6 +126,10 @@ int nntk_shim_rnn_train_backward(const float *d_dout, const float *d_UT /*U tran
 size_t nntk_shim_gemm_nt_scratch_floats(int N, int K);
 int nntk_shim_gemm_nt(const float *d_A, const float *d_Bw, float *d_C, float *d_pack, float *d_tmp, long M, int N, int K, int accumulate);
 int nntk_shim_transpose(const float *d_src, float *d_dst, long R, int C, int shift_T);
+/* MFMA form of the Conv1d input gradient (stride 1): the forward kernel on zero-padded d_out with flipped weights (train.hip) */
+size_t nntk_shim_conv_dx_pack_floats(int Cin, int Cout, int k);
+int nntk_shim_conv_dx_mfma(const float *d_dout, const float *d_W, float *d_dX, float *d_pad, float *d_wpack,
+                           int B, int T, int Cin, int Cout, int k, int Tout);
 /* C [I][K] += A^T B over `rows` rows, c [K] += column sums of B (a_shift_T > 0: A is h [B][T][I] and row (b,t) uses h_{t-1}) */
 size_t nntk_shim_outer_scratch_floats(int I, int K);
 int nntk_shim_outer_accumulate(const float *d_A, const float *d_B, float *d_C, float *d_c, float *d_scratch, long rows, int I, int K, int a_shift_T);

@@ -291,6 +291,14 @@ int nntk_shim_upload(void *d_dst, const void *h_src, size_t bytes) {
     NNTK_HIP_TRY(hipStreamSynchronize(t_stream));
     return 0;
 }
+/* `height` rows of `width` bytes, source rows `spitch` bytes apart, packed at the destination (the last timestep of every
+ * sequence of a [B][T][H] tensor in one copy) */
+int nntk_shim_download_rows(void *h_dst, const void *d_src, size_t spitch, size_t width, size_t height) {
+    if (!width || !height) return 0;
+    NNTK_HIP_TRY(hipMemcpy2DAsync(h_dst, width, d_src, spitch, width, height, hipMemcpyDeviceToHost, t_stream));
+    NNTK_HIP_TRY(hipStreamSynchronize(t_stream));
+    return post_sync();
+}
 int nntk_shim_upload_async(void *d_dst, const void *h_src, size_t bytes) {
     if (!bytes) return 0;
     NNTK_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, t_stream));

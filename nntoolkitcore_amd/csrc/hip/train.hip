@@ -817,3 +817,53 @@ extern "C" int nntk_shim_gemm_nt(const float *d_A, const float *d_Bw, float *d_C
     }
     return 0;
 }
+
+// ---- MFMA form of the Conv1d input gradient (stride 1; large shapes) ----------------------------------------------
+// d_X: the forward kernel itself on d_out padded with k - 1 zero rows on both sides, with the weights flipped in time and
+//      transposed in channels: d_X[b][t][i] = sum_o sum_j dout'[b][t + j][o] W[o][i][k - 1 - j].
+// (d_W stays on conv1d_grad.hip's sliced VALU dots: its output is only [Cout][Cin * k] -- two MFMA tiles at config 3 --
+// with K = B * Tout rows, a shape the tile kernel cannot spread over the chip; measured as an im2col GEMM: slower.)
+__global__ __launch_bounds__(256) void pad_time_kernel(const float *__restrict__ in, float *__restrict__ out, int B, int Tin, int pad, int C) {
+    const int Tp = Tin + 2 * pad;
+    const long total = (long)B * Tp * C;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        const long bt = e / C;
+        const int t = (int)(bt % Tp) - pad;
+        const long b = bt / Tp;
+        out[e] = (t >= 0 && t < Tin) ? in[((size_t)b * Tin + t) * C + c] : 0.0f;
+    }
+}
+// packed forward-kernel weights of the d_X convolution: wp [Cin_p32][k][Cout_p16], wp[i][j][o] = W[o][i][k - 1 - j]
+__global__ __launch_bounds__(256) void conv_flip_pack_kernel(const float *__restrict__ W, float *__restrict__ wp, int Cout, int Cin, int k,
+                                                             int rows_p /*Cin padded to 32*/, int cols_p /*Cout padded to 16*/) {
+    const long total = (long)rows_p * k * cols_p;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int o = (int)(e % cols_p);
+        const long ij = e / cols_p;
+        const int j = (int)(ij % k);
+        const int i = (int)(ij / k);
+        wp[e] = (i < Cin && o < Cout) ? W[((size_t)o * Cin + i) * k + (k - 1 - j)] : 0.0f;
+    }
+}
+// d_X [B][T][Cin] from d_dout [B][Tout][Cout] (stride 1, T = Tout + k - 1); d_pad >= B * (Tout + 2k - 2) * Cout floats,
+// d_wpack >= nntk_shim_conv_dx_pack_floats(Cin, Cout, k) floats
+extern "C" size_t nntk_shim_conv_dx_pack_floats(int Cin, int Cout, int k) {
+    int cols_p, rows_p;
+    nntk_shim_conv_pack_sizes(Cout, Cin, k, &cols_p, &rows_p);
+    return (size_t)rows_p * k * cols_p * 5 / 2 + 16;
+}
+extern "C" int nntk_shim_conv_dx_mfma(const float *d_dout, const float *d_W, float *d_dX, float *d_pad, float *d_wpack,
+                                      int B, int T, int Cin, int Cout, int k, int Tout) {
+    if (B <= 0 || Tout <= 0) return 0;
+    int cols_p, rows_p;
+    nntk_shim_conv_pack_sizes(Cout, Cin, k, &cols_p, &rows_p);       // the d_X convolution has Cin' = Cout, Cout' = Cin
+    const int Tp = Tout + 2 * (k - 1);
+    hipLaunchKernelGGL(pad_time_kernel, dim3(grid_for((long)B * Tp * Cout, 256)), dim3(256), 0, nntk_stream(), d_dout, d_pad, B, Tout, k - 1, Cout);
+    NNTK_LAUNCH_CHECK("pad_time_kernel");
+    hipLaunchKernelGGL(conv_flip_pack_kernel, dim3(grid_for((long)rows_p * k * cols_p, 256)), dim3(256), 0, nntk_stream(), d_W, d_wpack,
+                       Cout, Cin, k, rows_p, cols_p);
+    NNTK_LAUNCH_CHECK("conv_flip_pack_kernel");
+    if (nntk_shim_split_bf16x3(d_wpack, d_wpack + (size_t)rows_p * k * cols_p, rows_p, k * cols_p)) return -1;
+    return nntk_shim_conv1d(d_pad, d_wpack, nullptr, nullptr, 0.f, NNTK_ACT_IDENTITY, 1.f, d_dX, B, Tp, Cout, Cin, k, 1, T, 0);
+}

@@ -19,7 +19,7 @@ struct Conv1dStruct {
     /* training mode (conv_1d.c:104-108): mini-batch size, the last forward pass's input kept on the device for the
      * gradient, and the gradient scratch */
     int training, mini_batch;
-    nntk_devbuf d_cache, d_dout, d_grad, d_wraw, d_scratch;
+    nntk_devbuf d_cache, d_dout, d_grad, d_wraw, d_scratch, d_pad, d_wpk;
 };
 
 /* conv_1d.c:77-87 */
@@ -69,6 +69,7 @@ void Conv1dDestroy(Conv1d filter) {
     nntk_devbuf_free(&filter->d_out);
     nntk_devbuf_free(&filter->d_cache); nntk_devbuf_free(&filter->d_dout); nntk_devbuf_free(&filter->d_grad);
     nntk_devbuf_free(&filter->d_wraw); nntk_devbuf_free(&filter->d_scratch);
+    nntk_devbuf_free(&filter->d_pad); nntk_devbuf_free(&filter->d_wpk);
     nntk_wblock_free(&filter->wb);
     free(filter->weights);
     free(filter);
@@ -229,8 +230,18 @@ void Conv1dCalculateGradient(Conv1d filter, ConvGradient *gradient, const float 
     if (!d_dout || !d_grad || !d_wraw || !d_scr) return;
     if (nntk_shim_upload(d_dout, d_out, n_do * sizeof(float))) return;
     if (nntk_shim_upload(d_wraw, filter->weights->W, w * sizeof(float))) return;         /* caller layout [Cout][Cin][k] */
-    if (nntk_shim_conv1d_grad(filter->d_cache.p, d_wraw, d_dout, d_grad, d_grad + w, d_grad + w + Cout, d_scr,
-                              B, c->input_size, Cin, Cout, k, c->stride, c->output_size)) return;
+    const long rows = (long)B * c->output_size;
+    if (c->stride == 1 && c->output_size > 0 && (double)rows * Cout * k * Cin >= (double)(1 << 27) && Cin >= 32 && Cout >= 16) {
+        /* large, stride 1: d_X on the MFMA forward kernel (train.hip); d_W, d_b on the sliced dots (few output tiles) */
+        const int T = c->input_size, Tout = c->output_size;
+        float *d_pad = nntk_devbuf_reserve(&filter->d_pad, (size_t)B * (Tout + 2 * (k - 1)) * Cout);
+        float *d_wpk = nntk_devbuf_reserve(&filter->d_wpk, nntk_shim_conv_dx_pack_floats(Cin, Cout, k));
+        if (!d_pad || !d_wpk) return;
+        if (nntk_shim_conv1d_grad(filter->d_cache.p, d_wraw, d_dout, d_grad, d_grad + w, NULL, d_scr,
+                                  B, T, Cin, Cout, k, 1, Tout)) return;
+        if (nntk_shim_conv_dx_mfma(d_dout, d_wraw, d_grad + w + Cout, d_pad, d_wpk, B, T, Cin, Cout, k, Tout)) return;
+    } else if (nntk_shim_conv1d_grad(filter->d_cache.p, d_wraw, d_dout, d_grad, d_grad + w, d_grad + w + Cout, d_scr,
+                                     B, c->input_size, Cin, Cout, k, c->stride, c->output_size)) return;
     float *tmp = (float *)malloc((w + Cout) * sizeof(float));
     if (!tmp) { nntk_set_error("out of host memory"); return; }
     if (nntk_shim_download(tmp, d_grad, (w + Cout) * sizeof(float)) == 0 &&

@@ -407,9 +407,8 @@ int GRUApplyTrainingBatch(GRU filter, const float *input, float *output) {
     if (nntk_shim_gru_train_forward(d_x, dW, dU, dbi, dbh, d_h, d_Zg, d_hU, B, T, in, H, acts, sc)) return -1;
     t->have_batch = 1;
     if (c->return_sequences) return nntk_shim_download(output, d_h, (size_t)B * T * H * sizeof(float));
-    for (int b = 0; b < B; ++b)         /* gru.c:286-291: the last step of every sequence */
-        if (nntk_shim_download(output + (size_t)b * H, d_h + ((size_t)b * T + (T - 1)) * H, (size_t)H * sizeof(float))) return -1;
-    return 0;
+    /* the last step of every sequence (gru.c:286-291, lstm.c:466-471, rnn.c:283-288): one strided copy */
+    return nntk_shim_download_rows(output, d_h + (size_t)(T - 1) * H, (size_t)T * H * sizeof(float), (size_t)H * sizeof(float), (size_t)B);
 }
 
 /* d_W, d_U, d_b_i, d_b_h are ADDED onto the caller's block (recurrent_gradient_sum per (b, t), gru.c:508), d_X is
@@ -678,9 +677,8 @@ int LSTMApplyTrainingBatch(LSTM filter, const float *input, float *output) {
     if (nntk_shim_lstm_train_forward(d_x, dW, dU, dbi, dbh, d_h, d_c, d_z, B, T, in, H, filter->config.v2 ? 1 : 0, acts, sc)) return -1;
     t->have_batch = 1;
     if (c->return_sequences) return nntk_shim_download(output, d_h, (size_t)B * T * H * sizeof(float));
-    for (int b = 0; b < B; ++b)
-        if (nntk_shim_download(output + (size_t)b * H, d_h + ((size_t)b * T + (T - 1)) * H, (size_t)H * sizeof(float))) return -1;
-    return 0;
+    /* the last step of every sequence (gru.c:286-291, lstm.c:466-471, rnn.c:283-288): one strided copy */
+    return nntk_shim_download_rows(output, d_h + (size_t)(T - 1) * H, (size_t)T * H * sizeof(float), (size_t)H * sizeof(float), (size_t)B);
 }
 
 void LSTMCalculateGradient(LSTM filter, LSTMGradient *gradient, float *d_out) {
@@ -851,9 +849,8 @@ int RNNApplyTrainingBatch(RNN filter, const float *input, float *output) {
     if (nntk_shim_rnn_train_forward(d_x, dW, dU, dbi, dbh, d_h, d_g, B, T, in, H, filter->config.v2 ? 1 : 0, act, sc)) return -1;
     t->have_batch = 1;
     if (c->return_sequences) return nntk_shim_download(output, d_h, (size_t)B * T * H * sizeof(float));
-    for (int b = 0; b < B; ++b)
-        if (nntk_shim_download(output + (size_t)b * H, d_h + ((size_t)b * T + (T - 1)) * H, (size_t)H * sizeof(float))) return -1;
-    return 0;
+    /* the last step of every sequence (gru.c:286-291, lstm.c:466-471, rnn.c:283-288): one strided copy */
+    return nntk_shim_download_rows(output, d_h + (size_t)(T - 1) * H, (size_t)T * H * sizeof(float), (size_t)H * sizeof(float), (size_t)B);
 }
 void RNNCalculateGradient(RNN filter, RNNGradient *gradient, float *d_out) {
     nntk_shim_clear_error();

@@ -18,7 +18,10 @@ static _Thread_local nntk_devbuf t_at, t_bt, t_pack, t_tmp, t_scr;
 /* C [I][K] += A [rows][I]^T B [rows][K];  c [K] += column sums of B.  a_shift_T > 0: A is h [B][T][I], row (b,t) uses h_{t-1} */
 int nntk_train_outer_accumulate(const float *d_A, const float *d_B, float *d_C, float *d_c, long rows, int I, int K, int a_shift_T) {
     if (rows <= 0 || K <= 0) return 0;
-    const int mfma = (double)rows * I * K >= NNTK_TRAIN_MFMA_MACS && I >= 16 && K >= 32 && rows >= 16;
+    /* the product is only [I][K]: it needs enough 128 x 128 output tiles to occupy the chip, else the 32-slice VALU dots
+     * ((I + 1) * 32 workgroups) spread better */
+    const int tiles = ((I + 127) / 128) * ((K + 127) / 128);
+    const int mfma = (double)rows * I * K >= NNTK_TRAIN_MFMA_MACS && I >= 16 && K >= 32 && rows >= 16 && tiles >= 6;
     if (!mfma) {
         float *scr = nntk_devbuf_reserve(&t_scr, nntk_shim_outer_scratch_floats(I, K));
         if (!scr) return -1;
