@@ -115,6 +115,41 @@ def test_odd_channel_counts_take_16_byte_window_loads(gpu, cin, cout, k, split):
     conv.destroy()
 
 
+@pytest.mark.parametrize("cin,cout,k,T", [(40, 128, 5, 300), (257, 128, 5, 200), (64, 192, 1, 257), (128, 1000, 1, 140), (33, 32, 3, 130)])
+def test_gemm_option_matrix_is_bit_identical_where_promised(gpu, cin, cout, k, T):
+    """conv_store (accumulator orientation / store width) and conv_a4 (window load width) change how the kernel moves
+    data, never what it computes: for each contraction (exact f32, split bf16x3) all four combinations must agree bit
+    for bit, fused BatchNorm + ReLU included; the two contractions agree to a few f32 roundings."""
+    import torch
+    r = rng(cin + cout + k)
+    B = 3
+    x, W, b = u(r, B, T, cin), u(r, cout, cin, k, sc=(cin * k) ** -0.5), u(r, cout, sc=0.2)
+    g, be, mu, var = 1 + u(r, cout, sc=0.5), u(r, cout, sc=0.5), u(r, cout, sc=0.1), 1 + u(r, cout, sc=0.5)
+    conv = NL.Conv1d(cin, cout, k, 1, T)
+    conv.set_weights(W, b)
+    Tc = conv.out_shape[0]
+    bn, relu = NL.BatchNorm(cout, 1e-3, B * Tc), NL.Activation("relu", B * Tc * cout, 1.0)
+    bn.set_weights(g, be, mu, var)
+    xd = torch.from_numpy(x).cuda()
+    res = {}
+    for split in ("0", "1"):
+        capi.set_option("gemm_split_bf16", split)
+        outs = []
+        for store in ("0", "1"):
+            for a4 in ("0", "1"):
+                capi.set_option("conv_store", store)
+                capi.set_option("conv_a4", a4)
+                outs.append((conv.apply_device(xd).cpu().numpy(), conv.apply_device(xd, bn=bn, act=relu).cpu().numpy()))
+        for plain, fused in outs[1:]:
+            np.testing.assert_array_equal(plain, outs[0][0])
+            np.testing.assert_array_equal(fused, outs[0][1])
+        res[split] = outs[0]
+    assert np.abs(res["0"][0] - res["1"][0]).max() < 4e-6
+    close(res["1"][1], O.activation(O.ACT_RELU, O.batch_norm(O.conv1d(x, W, b, 1), g, be, mu, var, 1e-3)))
+    for o in (conv, bn, relu):
+        o.destroy()
+
+
 def test_conv1d_output_shorter_than_kernel_is_empty(gpu):
     conv = NL.Conv1d(2, 3, 5, 1, 4)        # output_size = 0 (conv_1d.c:84)
     assert conv.cfg.output_size == 0
