@@ -879,7 +879,9 @@ extern "C" int nntk_shim_conv1d(const float *d_in, const float *d_wp, const floa
     }
     // auto: every contraction except the recurrent input projection (out_mode 1), whose exact k-ordered chain the
     // streaming kernel reproduces bit for bit (recurrent.hip rec_stream_step_kernel)
-    const bool split = opt.gemm_split_bf16 == 1 || (opt.gemm_split_bf16 < 0 && out_mode == 0);
+    const bool split = opt.gemm_split_bf16 == 1 || (opt.gemm_split_bf16 < 0 && out_mode == 0) ||
+                       (opt.gemm_split_bf16 == 2 && out_mode == 0 && k > 1) ||        // 2 / 3: convolutions only / dense only (A/B)
+                       (opt.gemm_split_bf16 == 3 && out_mode == 0 && k == 1);
     if (split && (long)p.Cout_p * k * p.Cin_p * 6 < (long)CONV_OOB) {
         if (p.Cout_p % 128 == 0) return a4 ? launch_mfma<2, 2, 2, 2, true, true>(p) : launch_mfma<2, 2, 2, 2, false, true>(p);
         if (p.Cout_p % 64 == 0)  return a4 ? launch_mfma<4, 1, 1, 2, true, true>(p) : launch_mfma<4, 1, 1, 2, false, true>(p);

@@ -56,7 +56,7 @@ static const OptDesc g_opt_table[] = {
 static void opt_init() {
     for (const OptDesc &d : g_opt_table) {
         const char *e = getenv(d.env);
-        if (e && *e) g_opt.*(d.field) = atoi(e);
+        if (e && *e && strcmp(e, "auto") != 0 && strcmp(e, "default") != 0) g_opt.*(d.field) = atoi(e);    // "auto" keeps the default
     }
 }
 const NntkOptions &nntk_options() {
