@@ -281,6 +281,21 @@ int  TimeDistributedDenseApplyTrainingBatch(TimeDistributedDense filter, const f
 void TimeDistributedDenseCalculateGradient(TimeDistributedDense filter, DenseGradient *gradient, float *d_out);
 void TimeDistributedDenseDestroy(TimeDistributedDense filter);
 
+/* ---- nntoolkitcore/signal/dft.h:15-47 ---------------------------------- */
+/* One complex DFT of any size on host split-complex buffers (un-normalised; forward = exp(-2 pi i k j / n)); the
+ * reference runs kissfft (dft.c:34-47), here a direct transform with double accumulation on the device.  The
+ * spectrogram kernels do not go through it. */
+typedef struct DFTSetupStruct *DFTSetup;
+typedef struct { int nfft; bool forward; bool complex; } DFTConfig;
+typedef struct { float real; float imag; } ComplexFloat;
+typedef struct { float *real_p; float *imag_p; } ComplexFloatSplit;
+DFTConfig DFTConfigCreate(int nfft, bool forward, bool complex);
+DFTSetup DFTSetupCreate(DFTConfig config);
+void DFTPerform(DFTSetup setup, ComplexFloatSplit *input, ComplexFloatSplit *output);
+void DFTSetupDestroy(DFTSetup setup);
+void split_complex(const ComplexFloat *complex, ComplexFloatSplit *split, int size);
+void join_complex_split(const ComplexFloatSplit *split, ComplexFloat *complex, int size);
+
 /* ---- nntoolkitcore/signal/window.h:17-29 ------------------------------- */
 typedef void (*window_fn)(float *, int);
 void hamming_window(float *vector, int size);

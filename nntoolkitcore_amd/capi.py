@@ -43,6 +43,14 @@ class RecurrentGradient(C.Structure):
     _fields_ = [("d_W", fp), ("d_U", fp), ("d_b_i", fp), ("d_b_h", fp), ("d_X", fp)]
 
 
+class DFTConfig(C.Structure):
+    _fields_ = [("nfft", C.c_int), ("forward", C.c_bool), ("complex", C.c_bool)]
+
+
+class ComplexFloatSplit(C.Structure):
+    _fields_ = [("real_p", fp), ("imag_p", fp)]
+
+
 class SGD(C.Structure):
     _fields_ = [("learning_rate", C.c_float)]
 
@@ -154,6 +162,12 @@ SIGNATURES = {
     "GRUGetWeights": (C.POINTER(RecurrentWeights), [vp]),
     "GRUCreateForInference": (vp, [GRUConfig]),
     "GRUApplyInference": (C.c_int, [vp, fp, fp]),
+    "DFTConfigCreate": (DFTConfig, [C.c_int, C.c_bool, C.c_bool]),
+    "DFTSetupCreate": (vp, [DFTConfig]),
+    "DFTPerform": (None, [vp, C.POINTER(ComplexFloatSplit), C.POINTER(ComplexFloatSplit)]),
+    "DFTSetupDestroy": (None, [vp]),
+    "split_complex": (None, [vp, C.POINTER(ComplexFloatSplit), C.c_int]),
+    "join_complex_split": (None, [C.POINTER(ComplexFloatSplit), vp, C.c_int]),
     "bd_merge_concat_gradient": (None, [fp, fp, fp, RecurrentConfig, C.c_int, fp]),
     "bd_merge_sum_gradient": (None, [fp, fp, fp, RecurrentConfig, C.c_int]),
     "bd_accumulate_d_x": (None, [fp, fp, fp, RecurrentConfig, C.c_int]),

@@ -140,6 +140,9 @@ int nntk_shim_bn_train_forward(const float *d_x, const float *d_block, float eps
 int nntk_shim_bn_train_backward(const float *d_x, const float *d_dout, const float *d_block, float *d_stats, float *d_partial, float *d_dx, long N, int F);
 int nntk_shim_concat2(const float *d_a, const float *d_b, float *d_out, long rows, int C);
 int nntk_shim_add2(const float *d_a, const float *d_b, float *d_out, long n);
+/* signal/dft.h: complex DFT of any size n (direct, double accumulation); d_tw = 2n floats from nntk_shim_dft_twiddles */
+int nntk_shim_dft_twiddles(float *d_tw, int n);
+int nntk_shim_dft(const float *d_re, const float *d_im, const float *d_tw, float *d_ore, float *d_oim, int n, int inverse);
 int nntk_shim_split2(const float *d_in, float *d_a, float *d_b, long rows, int C);
 
 /* ---- K4: recurrent layers -------------------------------------------------

@@ -447,6 +447,38 @@ __global__ __launch_bounds__(256) void add2_kernel(const float *a, const float *
         out[e] = a[e] + b[e];                                  // bd_merge_sum: op_vec_add (bidirectional.c:76-85)
 }
 
+// ---- signal/dft.h: one complex DFT of any size (signal/dft.c:34-47 runs kissfft; un-normalised, inverse = conjugate
+// kernel).  A direct O(n^2) transform: the public DFT API is a building block the spectrogram kernels do not go through
+// (they carry their own FFTs), so this favours exactness over speed -- twiddles from a table filled with sincospi in
+// double, accumulation in double, one output bin per thread.
+__global__ __launch_bounds__(256) void dft_twiddle_kernel(float2 *tw, int n) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < n) {
+        double sv, cv;
+        sincospi(2.0 * (double)m / (double)n, &sv, &cv);
+        tw[m] = make_float2((float)cv, (float)sv);
+    }
+}
+__global__ __launch_bounds__(256) void dft_direct_kernel(const float *__restrict__ re, const float *__restrict__ im,
+                                                         const float2 *__restrict__ tw, float *__restrict__ ore,
+                                                         float *__restrict__ oim, int n, int inverse) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double ar = 0.0, ai = 0.0;
+    int m = 0;                                   // (k * j) mod n
+    for (int j = 0; j < n; ++j) {
+        const float2 w = tw[m];
+        const double c = w.x, s = inverse ? (double)w.y : -(double)w.y;       // forward: exp(-2 pi i k j / n)
+        const double xr = re[j], xi = im[j];
+        ar += xr * c - xi * s;
+        ai += xr * s + xi * c;
+        m += k;
+        if (m >= n) m -= n;
+    }
+    ore[k] = (float)ar;
+    oim[k] = (float)ai;
+}
+
 static int grid_for(long work_items, int block) {
     long g = (work_items + block - 1) / block;
     if (g < 1) g = 1;
@@ -496,6 +528,20 @@ int nntk_shim_add2(const float *d_a, const float *d_b, float *d_out, long n) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(add2_kernel, dim3(grid_for(n, 256)), dim3(256), 0, nntk_stream(), d_a, d_b, d_out, n);
     NNTK_LAUNCH_CHECK("add2_kernel");
+    return 0;
+}
+
+int nntk_shim_dft_twiddles(float *d_tw /*2n floats*/, int n) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(dft_twiddle_kernel, dim3((n + 255) / 256), dim3(256), 0, nntk_stream(), (float2 *)d_tw, n);
+    NNTK_LAUNCH_CHECK("dft_twiddle_kernel");
+    return 0;
+}
+int nntk_shim_dft(const float *d_re, const float *d_im, const float *d_tw, float *d_ore, float *d_oim, int n, int inverse) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(dft_direct_kernel, dim3((n + 255) / 256), dim3(256), 0, nntk_stream(), d_re, d_im, (const float2 *)d_tw,
+                       d_ore, d_oim, n, inverse);
+    NNTK_LAUNCH_CHECK("dft_direct_kernel");
     return 0;
 }
 

@@ -174,3 +174,56 @@ int SpectrogramApplyBatch(Spectrogram filter, const float *input, float *output,
 void SpectrogramApply(Spectrogram filter, const float *input, float *output) {
     (void)SpectrogramApplyBatch(filter, input, output, 1);
 }
+
+
+/* ============================== signal/dft.h ==============================
+ * The reference's public complex DFT (dft.h:15-47, dft.c:23-92: kissfft of size nfft, un-normalised; `complex` is
+ * carried in the config and not used there either).  Host split-complex buffers in and out, as the reference. */
+struct DFTSetupStruct {
+    DFTConfig config;
+    float *d_tw;              /* [nfft] (cos, sin) */
+    float *d_io;              /* re | im | out re | out im */
+};
+DFTConfig DFTConfigCreate(int nfft, bool forward, bool complex) {
+    DFTConfig c;
+    memset(&c, 0, sizeof(c));
+    c.nfft = nfft;
+    c.forward = forward;
+    c.complex = complex;
+    return c;
+}
+DFTSetup DFTSetupCreate(DFTConfig config) {
+    nntk_shim_clear_error();
+    if (config.nfft <= 0) { nntk_set_error("DFTSetupCreate: nfft must be positive"); return NULL; }
+    DFTSetup s = (DFTSetup)calloc(1, sizeof(struct DFTSetupStruct));
+    if (!s) return NULL;
+    s->config = config;
+    s->d_tw = (float *)nntk_shim_malloc((size_t)2 * config.nfft * sizeof(float));
+    s->d_io = (float *)nntk_shim_malloc((size_t)4 * config.nfft * sizeof(float));
+    if (!s->d_tw || !s->d_io || nntk_shim_dft_twiddles(s->d_tw, config.nfft)) { DFTSetupDestroy(s); return NULL; }
+    return s;
+}
+void DFTSetupDestroy(DFTSetup setup) {
+    if (!setup) return;
+    nntk_shim_synchronize();
+    nntk_shim_free(setup->d_tw);
+    nntk_shim_free(setup->d_io);
+    free(setup);
+}
+void DFTPerform(DFTSetup setup, ComplexFloatSplit *input, ComplexFloatSplit *output) {
+    nntk_shim_clear_error();
+    if (!setup || !input || !output) { nntk_set_error("DFTPerform: NULL argument"); return; }
+    const size_t n = (size_t)setup->config.nfft;
+    float *d = setup->d_io;
+    if (nntk_shim_upload(d, input->real_p, n * sizeof(float)) || nntk_shim_upload(d + n, input->imag_p, n * sizeof(float))) return;
+    if (nntk_shim_dft(d, d + n, setup->d_tw, d + 2 * n, d + 3 * n, (int)n, setup->config.forward ? 0 : 1)) return;
+    if (nntk_shim_download(output->real_p, d + 2 * n, n * sizeof(float))) return;
+    (void)nntk_shim_download(output->imag_p, d + 3 * n, n * sizeof(float));
+}
+/* dft.c:62-75, :85-92: pure data movement between the interleaved and the split layout */
+void split_complex(const ComplexFloat *complex, ComplexFloatSplit *split, int size) {
+    for (int i = 0; i < size; ++i) { split->real_p[i] = complex[i].real; split->imag_p[i] = complex[i].imag; }
+}
+void join_complex_split(const ComplexFloatSplit *split, ComplexFloat *complex, int size) {
+    for (int i = 0; i < size; ++i) { complex[i].real = split->real_p[i]; complex[i].imag = split->imag_p[i]; }
+}

@@ -215,3 +215,26 @@ def test_boundary_behaviour_pinned_by_the_real_reference_round2(built_lib):
     # recorded for INTEGRATION.md: the reference returns -1 from *ApplyInference on a training-mode handle; the
     # product has no training-mode handles (out of scope), its -1 cases are NULL handles and device errors
     assert set(gold["wrong_mode_apply_inference"].values()) == {-1}
+
+
+def test_every_function_of_the_reference_headers_is_declared_and_exported(built_lib):
+    """Drop-in completeness: every function the reference's layers/, signal/ and train/ headers declare is declared in
+    include/nntoolkitcore_hip.h and exported by the library (the reference is only present in the build container)."""
+    import glob
+    import re
+    ref_root = "/root/reference/nntoolkitcore"
+    if not os.path.isdir(ref_root):
+        pytest.skip("reference tree not present")
+    names = set()
+    for sub in ("layers", "signal", "train"):
+        for f in glob.glob(os.path.join(ref_root, sub, "*.h")):
+            t = re.sub(r"/\*.*?\*/", "", open(f).read(), flags=re.S)
+            t = re.sub(r"//.*", "", t)
+            names |= {m.group(1) for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", t)}
+    names -= {"defined", "sizeof", "void", "float", "int"}           # typedef'd function pointers: `void (*Name)(...)`
+    assert len(names) > 100
+    header = open(os.path.join(ROOT, "include", "nntoolkitcore_hip.h")).read()
+    undeclared = sorted(n for n in names if not re.search(r"\b" + n + r"\s*\(", header))
+    assert not undeclared, undeclared
+    missing = sorted(n for n in names if not hasattr(built_lib, n))
+    assert not missing, missing

@@ -952,3 +952,39 @@ def test_random_dense_shapes(gpu):
         tdd.set_weights(W, b)
         close(tdd.apply(x), O.time_distributed_dense(x, W, b))
         tdd.destroy()
+
+
+@pytest.mark.parametrize("n", [1, 2, 8, 60, 512, 1000, 4096])
+@pytest.mark.parametrize("forward", [True, False])
+def test_public_dft_api_matches_kissfft_restatement_and_numpy(gpu, n, forward):
+    """signal/dft.h: DFTSetupCreate / DFTPerform / split_complex / join_complex_split on host split-complex buffers --
+    against the oracle's kissfft restatement (the sizes it factors) and numpy's float64 FFT."""
+    import ctypes as C
+    L = capi.load()
+    r = rng(n + forward)
+    z = (u(r, n) + 1j * u(r, n)).astype(np.complex64)
+    inter = np.ascontiguousarray(np.stack([z.real, z.imag], -1).astype(np.float32))
+    re, im = np.empty(n, np.float32), np.empty(n, np.float32)
+    sp_in = capi.ComplexFloatSplit(re.ctypes.data_as(capi.fp), im.ctypes.data_as(capi.fp))
+    L.split_complex(inter.ctypes.data, C.byref(sp_in), n)
+    np.testing.assert_array_equal(re, z.real); np.testing.assert_array_equal(im, z.imag)
+    ore, oim = np.empty(n, np.float32), np.empty(n, np.float32)
+    sp_out = capi.ComplexFloatSplit(ore.ctypes.data_as(capi.fp), oim.ctypes.data_as(capi.fp))
+    s = L.DFTSetupCreate(L.DFTConfigCreate(n, forward, True))
+    assert s, capi.last_error()
+    L.DFTPerform(s, C.byref(sp_in), C.byref(sp_out))
+    assert capi.last_error() == ""
+    ref64 = np.fft.fft(z.astype(np.complex128)) if forward else np.fft.ifft(z.astype(np.complex128)) * n
+    got = ore + 1j * oim
+    scale = max(1.0, float(np.abs(ref64).max()))
+    assert np.abs(got - ref64).max() <= 3e-7 * scale
+    try:
+        ok = O.kiss_fft(z, inverse=not forward)
+    except Exception:
+        ok = None                                   # sizes the restated kissfft does not take
+    if ok is not None:
+        assert np.abs(got - ok).max() <= 2e-6 * scale * max(1.0, np.log2(n))
+    back = np.empty((n, 2), np.float32)
+    L.join_complex_split(C.byref(sp_out), back.ctypes.data, n)
+    np.testing.assert_array_equal(back[:, 0], ore); np.testing.assert_array_equal(back[:, 1], oim)
+    L.DFTSetupDestroy(s)
