@@ -354,6 +354,49 @@ extern "C" int nntk_shim_bn_train_backward(const float *d_x, const float *d_dout
 // Forward step t for the whole mini-batch: thread (b, j) computes GRUCellForward's three columns j, H + j, 2H + j
 // (gru.c:128-187; op_mat_mul as a k-ordered sum of separately rounded products) and stores what the backward pass
 // reads: Z_gates [B][T][6H] = Z_z | Z_r | Z_h~ | z | r | h~, h_pr_Uh [B][T][H] (= h_prev U_h + b_hh), h [B][T][H].
+// The per-timestep forward dots, cut the same way as rows_times_colmat_kernel below: a workgroup is one batch row x 32
+// hidden units x 8 K-chunks of the concatenated [x_t | h_{t-1}] walk; chunk sums are added in chunk order through LDS.
+// Returns (in the threads with chunk index 0) xw[g] = x_t . W[:, g H + j] and hu[g] = h_{t-1} . U[:, g H + j].
+#define CELL_CHUNKS 8
+template <int G>
+__device__ __forceinline__ bool cell_dots_chunked(const float *__restrict__ x, const float *__restrict__ hp, const float *__restrict__ W,
+                                                  const float *__restrict__ U, int in, int H, int j, float (&xw)[G], float (&hu)[G]) {
+    __shared__ float part[CELL_CHUNKS][2 * G][32];
+    const int il = threadIdx.x & 31, c = threadIdx.x >> 5;
+    const int Kt = in + (hp ? H : 0);
+    const int per = (Kt + CELL_CHUNKS - 1) / CELL_CHUNKS;
+    const int k0 = c * per, k1 = k0 + per < Kt ? k0 + per : Kt;
+    const int GH = G * H;
+#pragma unroll
+    for (int g = 0; g < G; ++g) { xw[g] = 0.f; hu[g] = 0.f; }
+    if (j < H) {
+        for (int k = k0; k < k1 && k < in; ++k) {
+            const float xv = x[k];
+            const float *w = W + (size_t)k * GH + j;
+#pragma unroll
+            for (int g = 0; g < G; ++g) xw[g] = add_rn(xw[g], mul_rn(xv, w[g * H]));
+        }
+        for (int k = (k0 > in ? k0 : in); k < k1; ++k) {
+            const float hv = hp[k - in];
+            const float *u = U + (size_t)(k - in) * GH + j;
+#pragma unroll
+            for (int g = 0; g < G; ++g) hu[g] = add_rn(hu[g], mul_rn(hv, u[g * H]));
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) { part[c][g][il] = xw[g]; part[c][G + g][il] = hu[g]; }
+    __syncthreads();
+    if (c != 0 || j >= H) return false;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float a = part[0][g][il], b = part[0][G + g][il];
+#pragma unroll
+        for (int q = 1; q < CELL_CHUNKS; ++q) { a = add_rn(a, part[q][g][il]); b = add_rn(b, part[q][G + g][il]); }
+        xw[g] = a; hu[g] = b;
+    }
+    return true;
+}
+
 struct GruTrainParams {
     const float *x;              // [B][T][in]
     const float *W, *U, *bi, *bh;    // caller layouts: W [in][3H], U [H][3H]
@@ -363,26 +406,11 @@ struct GruTrainParams {
     float sc_z, sc_h, sc_r;      // ReLU output scales
 };
 __global__ __launch_bounds__(256) void gru_train_fwd_step_kernel(GruTrainParams p) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= p.B * p.H) return;
-    const int b = e / p.H, j = e % p.H, H = p.H, G = 3 * p.H;
-    const float *x = p.x + ((size_t)b * p.T + p.t) * p.in;
+    const int b = blockIdx.y, j = blockIdx.x * 32 + (threadIdx.x & 31), H = p.H;
     const size_t row = (size_t)b * p.T + p.t;
     const float *hp = p.t > 0 ? p.h + (row - 1) * H : nullptr;      // h_0 = 0 for every sequence (gru.c:262)
-    float xw[3] = {0.f, 0.f, 0.f}, hu[3] = {0.f, 0.f, 0.f};
-    for (int k = 0; k < p.in; ++k) {
-        const float xv = x[k];
-        const float *w = p.W + (size_t)k * G;
-#pragma unroll
-        for (int g = 0; g < 3; ++g) xw[g] = add_rn(xw[g], mul_rn(xv, w[g * H + j]));
-    }
-    if (hp)
-        for (int k = 0; k < H; ++k) {
-            const float hv = hp[k];
-            const float *u = p.U + (size_t)k * G;
-#pragma unroll
-            for (int g = 0; g < 3; ++g) hu[g] = add_rn(hu[g], mul_rn(hv, u[g * H + j]));
-        }
+    float xw[3], hu[3];
+    if (!cell_dots_chunked<3>(p.x + row * p.in, hp, p.W, p.U, p.in, H, j, xw, hu)) return;
 #pragma unroll
     for (int g = 0; g < 3; ++g) { xw[g] = add_rn(xw[g], p.bi[g * H + j]); hu[g] = add_rn(hu[g], p.bh[g * H + j]); }
     const float Zz = add_rn(xw[0], hu[0]), Zr = add_rn(xw[1], hu[1]);
@@ -458,16 +486,32 @@ __global__ __launch_bounds__(256) void rows_times_rowmat_kernel(const float *__r
 }
 // the same product and the same k order with the matrix given TRANSPOSED (MT [K][I]): lanes i read consecutive floats.
 // Used inside the per-timestep loops (U^T is built once per gradient call); bit-identical to the form above.
+// One workgroup = one row x 32 outputs x 8 K-chunks: at mini-batch 64 a (row, i) thread grid is only 16-32 k threads, each
+// walking all of K -- latency-bound.  The K range is cut into 8 contiguous chunks summed in order inside a chunk and then
+// chunk 0 .. 7 in order through LDS: deterministic, eight times the parallelism (LSTM-512 backward step 250 -> ~60 us);
+// the sum is no longer the reference's single chain (the difference is a few f32 roundings; small shapes and every other
+// product keep the exact order).
+#define COLMAT_CHUNKS 8
 __global__ __launch_bounds__(256) void rows_times_colmat_kernel(const float *__restrict__ d, const float *__restrict__ MT,
                                                                 float *__restrict__ out, long rows, int I, int K) {
-    const long total = rows * I;
-    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long row = e / I;
-        const int i = (int)(e % I);
+    __shared__ float part[COLMAT_CHUNKS][32];
+    const int il = threadIdx.x & 31, c = threadIdx.x >> 5;
+    const long row = blockIdx.y;
+    const int i = blockIdx.x * 32 + il;
+    const int per = (K + COLMAT_CHUNKS - 1) / COLMAT_CHUNKS;
+    const int k0 = c * per, k1 = k0 + per < K ? k0 + per : K;
+    float acc = 0.0f;
+    if (i < I) {
         const float *dv = d + row * K;
-        float acc = 0.0f;
-        for (int k = 0; k < K; ++k) acc = add_rn(acc, mul_rn(MT[(size_t)k * I + i], dv[k]));
-        out[e] = acc;
+        for (int k = k0; k < k1; ++k) acc = add_rn(acc, mul_rn(MT[(size_t)k * I + i], dv[k]));
+    }
+    part[c][il] = acc;
+    __syncthreads();
+    if (c == 0 && i < I) {
+        float s = part[0][il];
+#pragma unroll
+        for (int q = 1; q < COLMAT_CHUNKS; ++q) s = add_rn(s, part[q][il]);
+        out[row * I + i] = s;
     }
 }
 // C[i][k] += sum_rows A[row][i] * Bm[row][k] and c[k] += sum_rows Bm[row][k]: row slices summed in order inside a slice,
@@ -531,7 +575,7 @@ extern "C" int nntk_shim_gru_train_forward(const float *d_x, const float *d_W, c
     p.sc_z = scales[0]; p.sc_h = scales[1]; p.sc_r = scales[2];
     for (int t = 0; t < T; ++t) {
         p.t = t;
-        hipLaunchKernelGGL(gru_train_fwd_step_kernel, dim3((B * H + 255) / 256), dim3(256), 0, nntk_stream(), p);
+        hipLaunchKernelGGL(gru_train_fwd_step_kernel, dim3((unsigned)((H + 31) / 32), (unsigned)B), dim3(256), 0, nntk_stream(), p);
     }
     NNTK_LAUNCH_CHECK("gru_train_fwd_step_kernel");
     return 0;
@@ -551,7 +595,7 @@ extern "C" int nntk_shim_gru_train_backward(const float *d_dout, const float *d_
         p.t = t;
         hipLaunchKernelGGL(gru_train_bwd_step_kernel, dim3((B * H + 255) / 256), dim3(256), 0, nntk_stream(), p);
         if (t > 0)
-            hipLaunchKernelGGL(rows_times_colmat_kernel, dim3(grid_for((long)B * H, 256)), dim3(256), 0, nntk_stream(),
+            hipLaunchKernelGGL(rows_times_colmat_kernel, dim3((unsigned)((H + 31) / 32), (unsigned)B), dim3(256), 0, nntk_stream(),
                                (const float *)step, d_UT, dhp2, (long)B, H, 3 * H);
     }
     NNTK_LAUNCH_CHECK("gru_train_bwd_step_kernel");
@@ -568,26 +612,11 @@ struct LstmTrainParams {
     float sc[5];
 };
 __global__ __launch_bounds__(256) void lstm_train_fwd_step_kernel(LstmTrainParams p) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= p.B * p.H) return;
-    const int b = e / p.H, j = e % p.H, H = p.H, G = 4 * p.H;
+    const int b = blockIdx.y, j = blockIdx.x * 32 + (threadIdx.x & 31), H = p.H;
     const size_t row = (size_t)b * p.T + p.t;
-    const float *x = p.x + row * p.in;
     const float *hp = p.t > 0 ? p.h + (row - 1) * H : nullptr;      // zero state per sequence (lstm.c:441)
-    float Z[4] = {0.f, 0.f, 0.f, 0.f}, hu[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < p.in; ++k) {
-        const float xv = x[k];
-        const float *w = p.W + (size_t)k * G;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) Z[g] = add_rn(Z[g], mul_rn(xv, w[g * H + j]));
-    }
-    if (hp)
-        for (int k = 0; k < H; ++k) {
-            const float hv = hp[k];
-            const float *u = p.U + (size_t)k * G;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) hu[g] = add_rn(hu[g], mul_rn(hv, u[g * H + j]));
-        }
+    float Z[4], hu[4];
+    if (!cell_dots_chunked<4>(p.x + row * p.in, hp, p.W, p.U, p.in, H, j, Z, hu)) return;
     float a[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -652,7 +681,7 @@ extern "C" int nntk_shim_lstm_train_forward(const float *d_x, const float *d_W, 
     for (int g = 0; g < 5; ++g) { p.act[g] = acts[g]; p.sc[g] = scales[g]; }
     for (int t = 0; t < T; ++t) {
         p.t = t;
-        hipLaunchKernelGGL(lstm_train_fwd_step_kernel, dim3((B * H + 255) / 256), dim3(256), 0, nntk_stream(), p);
+        hipLaunchKernelGGL(lstm_train_fwd_step_kernel, dim3((unsigned)((H + 31) / 32), (unsigned)B), dim3(256), 0, nntk_stream(), p);
     }
     NNTK_LAUNCH_CHECK("lstm_train_fwd_step_kernel");
     return 0;
@@ -672,7 +701,7 @@ extern "C" int nntk_shim_lstm_train_backward(const float *d_dout, const float *d
         p.t = t;
         hipLaunchKernelGGL(lstm_train_bwd_step_kernel, dim3((B * H + 255) / 256), dim3(256), 0, nntk_stream(), p);
         if (t > 0)
-            hipLaunchKernelGGL(rows_times_colmat_kernel, dim3(grid_for((long)B * H, 256)), dim3(256), 0, nntk_stream(),
+            hipLaunchKernelGGL(rows_times_colmat_kernel, dim3((unsigned)((H + 31) / 32), (unsigned)B), dim3(256), 0, nntk_stream(),
                                (const float *)step, d_UT, dh, (long)B, H, 4 * H);
     }
     NNTK_LAUNCH_CHECK("lstm_train_bwd_step_kernel");
@@ -688,18 +717,14 @@ struct RnnTrainParams {
     float sc;
 };
 __global__ __launch_bounds__(256) void rnn_train_fwd_step_kernel(RnnTrainParams p) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= p.B * p.H) return;
-    const int b = e / p.H, j = e % p.H, H = p.H;
+    const int b = blockIdx.y, j = blockIdx.x * 32 + (threadIdx.x & 31), H = p.H;
     const size_t row = (size_t)b * p.T + p.t;
-    const float *x = p.x + row * p.in;
     const float *hp = p.t > 0 ? p.h + (row - 1) * H : nullptr;
-    float xw = 0.f, hu = 0.f;
-    for (int k = 0; k < p.in; ++k) xw = add_rn(xw, mul_rn(x[k], p.W[(size_t)k * H + j]));
-    if (hp) for (int k = 0; k < H; ++k) hu = add_rn(hu, mul_rn(hp[k], p.U[(size_t)k * H + j]));
-    xw = add_rn(xw, p.bi[j]);
-    if (p.v2) hu = add_rn(hu, p.bh[j]);
-    const float g = add_rn(hu, xw);
+    float xw[1], hu[1];
+    if (!cell_dots_chunked<1>(p.x + row * p.in, hp, p.W, p.U, p.in, H, j, xw, hu)) return;
+    const float xv = add_rn(xw[0], p.bi[j]);
+    const float hv = p.v2 ? add_rn(hu[0], p.bh[j]) : hu[0];
+    const float g = add_rn(hv, xv);
     p.gate[row * H + j] = g;
     p.h[row * H + j] = nntk_gate_act(p.act, g, p.sc);
 }
@@ -726,7 +751,7 @@ extern "C" int nntk_shim_rnn_train_forward(const float *d_x, const float *d_W, c
     p.B = B; p.T = T; p.in = in; p.H = H; p.v2 = v2; p.act = act; p.sc = scale;
     for (int t = 0; t < T; ++t) {
         p.t = t;
-        hipLaunchKernelGGL(rnn_train_fwd_step_kernel, dim3((B * H + 255) / 256), dim3(256), 0, nntk_stream(), p);
+        hipLaunchKernelGGL(rnn_train_fwd_step_kernel, dim3((unsigned)((H + 31) / 32), (unsigned)B), dim3(256), 0, nntk_stream(), p);
     }
     NNTK_LAUNCH_CHECK("rnn_train_fwd_step_kernel");
     return 0;
@@ -740,7 +765,7 @@ extern "C" int nntk_shim_rnn_train_backward(const float *d_dout, const float *d_
         hipLaunchKernelGGL(rnn_train_bwd_step_kernel, dim3((B * H + 255) / 256), dim3(256), 0, nntk_stream(), d_dout, d_h, d_gate,
                            (const float *)dh, d_dG, step, B, T, H, t, return_sequences, act);
         if (t > 0)
-            hipLaunchKernelGGL(rows_times_colmat_kernel, dim3(grid_for((long)B * H, 256)), dim3(256), 0, nntk_stream(),
+            hipLaunchKernelGGL(rows_times_colmat_kernel, dim3((unsigned)((H + 31) / 32), (unsigned)B), dim3(256), 0, nntk_stream(),
                                (const float *)step, d_UT, dh, (long)B, H, H);
     }
     NNTK_LAUNCH_CHECK("rnn_train_bwd_step_kernel");
