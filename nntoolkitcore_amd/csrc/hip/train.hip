@@ -352,7 +352,7 @@ extern "C" int nntk_shim_bn_train_backward(const float *d_x, const float *d_dout
 // ---- GRU training (layers/gru.c:246-512) ------------------------------------------------------------------------
 // Correct, deterministic, reference operation order; NOT tuned (one launch per timestep and direction, VALU dots).
 // Forward step t for the whole mini-batch: thread (b, j) computes GRUCellForward's three columns j, H + j, 2H + j
-// (gru.c:128-187; op_mat_mul as a k-ordered sum of separately rounded products) and stores what the backward pass
+// (gru.c:128-187; op_mat_mul as sums of separately rounded products, in eight k-ordered chunks -- cell_dots_chunked) and stores what the backward pass
 // reads: Z_gates [B][T][6H] = Z_z | Z_r | Z_h~ | z | r | h~, h_pr_Uh [B][T][H] (= h_prev U_h + b_hh), h [B][T][H].
 // The per-timestep forward dots, cut the same way as rows_times_colmat_kernel below: a workgroup is one batch row x 32
 // hidden units x 8 K-chunks of the concatenated [x_t | h_{t-1}] walk; chunk sums are added in chunk order through LDS.
@@ -484,8 +484,8 @@ __global__ __launch_bounds__(256) void rows_times_rowmat_kernel(const float *__r
         out[e] = acc;
     }
 }
-// the same product and the same k order with the matrix given TRANSPOSED (MT [K][I]): lanes i read consecutive floats.
-// Used inside the per-timestep loops (U^T is built once per gradient call); bit-identical to the form above.
+// the same product with the matrix given TRANSPOSED (MT [K][I]) so that lanes i read consecutive floats; used inside the
+// per-timestep loops (U^T is built once per gradient call).
 // One workgroup = one row x 32 outputs x 8 K-chunks: at mini-batch 64 a (row, i) thread grid is only 16-32 k threads, each
 // walking all of K -- latency-bound.  The K range is cut into 8 contiguous chunks summed in order inside a chunk and then
 // chunk 0 .. 7 in order through LDS: deterministic, eight times the parallelism (LSTM-512 backward step 250 -> ~60 us);
