@@ -549,7 +549,10 @@ def main():
             "parallelism": "utterance shards, dp%d, no data-path collective" % world,
             "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
             "ranks_seen": ranks_seen,
-            "gemm": gemm_mode() + " for conv / TDD" + ("; exact-f32 for the recurrent input projection and recurrences" if a.workload in ("stack", "gru") else "")},
+            "gemm": gemm_mode() + " for conv / TDD" + ("; exact-f32 for the recurrent input projection and recurrences" if a.workload in ("stack", "gru") else ""),
+            "gemm_accuracy": ("f32 results: error vs a float64 contraction <= the exact-f32 MFMA chain's on every BASELINE shape "
+                              "(profiles/r02_split_error.log, tools/split_error.py); NNTK_GEMM_SPLIT_BF16=0 selects the exact chain")
+                             if gemm_mode() != "exact-f32" else "exact-f32 MFMA chain"},
         "phase_ms": {k: round(v, 4) for k, v in phase_ms.items()},
     }
     if rank == 0:
