@@ -568,6 +568,7 @@ extern "C" int nntk_shim_gru_train_forward(const float *d_x, const float *d_W, c
                                            float *d_h, float *d_Zg, float *d_hU, int B, int T, int in, int H,
                                            const int *acts /*z,h,r*/, const float *scales) {
     if (B <= 0 || T <= 0) return 0;
+    if (B > 65535) return nntk_fail_msg("recurrent training: mini-batch above 65535 (one grid row per batch entry)");
     GruTrainParams p{};
     p.x = d_x; p.W = d_W; p.U = d_U; p.bi = d_bi; p.bh = d_bh; p.h = d_h; p.Zg = d_Zg; p.hU = d_hU;
     p.B = B; p.T = T; p.in = in; p.H = H;
@@ -585,6 +586,7 @@ extern "C" int nntk_shim_gru_train_backward(const float *d_dout, const float *d_
                                             const float *d_hU, float *d_dxW, float *d_dhU, float *d_work, int B, int T, int H,
                                             int return_sequences, const int *acts) {
     if (B <= 0 || T <= 0) return 0;
+    if (B > 65535) return nntk_fail_msg("recurrent training: mini-batch above 65535 (one grid row per batch entry)");
     GruBwdParams p{};
     p.dout = d_dout; p.h = d_h; p.Zg = d_Zg; p.hU = d_hU; p.dxW = d_dxW; p.dhU = d_dhU;
     float *dhp1 = d_work, *dhp2 = d_work + (size_t)B * H, *step = d_work + (size_t)2 * B * H;
@@ -675,6 +677,7 @@ extern "C" int nntk_shim_lstm_train_forward(const float *d_x, const float *d_W, 
                                             float *d_h, float *d_c, float *d_zifgo, int B, int T, int in, int H, int v2,
                                             const int *acts /*i,f,g,o,out*/, const float *scales) {
     if (B <= 0 || T <= 0) return 0;
+    if (B > 65535) return nntk_fail_msg("recurrent training: mini-batch above 65535 (one grid row per batch entry)");
     LstmTrainParams p{};
     p.x = d_x; p.W = d_W; p.U = d_U; p.bi = d_bi; p.bh = d_bh; p.h = d_h; p.c = d_c; p.zifgo = d_zifgo;
     p.B = B; p.T = T; p.in = in; p.H = H; p.v2 = v2;
@@ -691,6 +694,7 @@ extern "C" int nntk_shim_lstm_train_backward(const float *d_dout, const float *d
                                              float *d_dG, float *d_work, int B, int T, int H, int return_sequences,
                                              const int *acts, const float *scales) {
     if (B <= 0 || T <= 0) return 0;
+    if (B > 65535) return nntk_fail_msg("recurrent training: mini-batch above 65535 (one grid row per batch entry)");
     LstmBwdParams p{};
     float *dh = d_work, *dc = d_work + (size_t)B * H, *step = d_work + (size_t)2 * B * H;
     p.dout = d_dout; p.c = d_c; p.zifgo = d_zifgo; p.dh_carry = dh; p.dc_carry = dc; p.dG = d_dG; p.dG_step = step;
@@ -746,6 +750,7 @@ __global__ __launch_bounds__(256) void rnn_train_bwd_step_kernel(const float *do
 extern "C" int nntk_shim_rnn_train_forward(const float *d_x, const float *d_W, const float *d_U, const float *d_bi, const float *d_bh,
                                            float *d_h, float *d_gate, int B, int T, int in, int H, int v2, int act, float scale) {
     if (B <= 0 || T <= 0) return 0;
+    if (B > 65535) return nntk_fail_msg("recurrent training: mini-batch above 65535 (one grid row per batch entry)");
     RnnTrainParams p{};
     p.x = d_x; p.W = d_W; p.U = d_U; p.bi = d_bi; p.bh = d_bh; p.h = d_h; p.gate = d_gate;
     p.B = B; p.T = T; p.in = in; p.H = H; p.v2 = v2; p.act = act; p.sc = scale;
@@ -760,6 +765,7 @@ extern "C" int nntk_shim_rnn_train_forward(const float *d_x, const float *d_W, c
 extern "C" int nntk_shim_rnn_train_backward(const float *d_dout, const float *d_UT /*[H][H]*/, const float *d_h, const float *d_gate,
                                             float *d_dG, float *d_work, int B, int T, int H, int return_sequences, int act) {
     if (B <= 0 || T <= 0) return 0;
+    if (B > 65535) return nntk_fail_msg("recurrent training: mini-batch above 65535 (one grid row per batch entry)");
     float *dh = d_work, *step = d_work + (size_t)B * H;
     for (int t = T - 1; t >= 0; --t) {
         hipLaunchKernelGGL(rnn_train_bwd_step_kernel, dim3((B * H + 255) / 256), dim3(256), 0, nntk_stream(), d_dout, d_h, d_gate,
