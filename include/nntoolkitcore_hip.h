@@ -369,8 +369,10 @@ const char *nntk_version(void);
  * Tuning / diagnostics knobs by name; environment variables NNTK_<NAME> give the initial values (read once).
  *   "rec_persistent" 0 = per-timestep recurrent kernels only     "rec_pingpong" 0/1 = ping-pong halves off/on
  *   "rec_spin_us"    budget of the persistent kernel's spins     "gemm_tm_batch" 0/1
- *   "weights_check"  2 = host-pointer Apply compares the whole weight block with the uploaded copy each call,
- *                    1 = sampled probes (default), 0 = never (use <Layer>SyncWeights)
+ *   "weights_check"  host-pointer calls look for in-place edits of the weight block before they launch:
+ *                    1 (default) = the whole block is compared with the uploaded copy on every call, except the
+ *                    single-sequence streaming GRU/LSTM/RNNApplyInference (T <= 32), which checks 257 probes of 64 B;
+ *                    2 = the whole block everywhere, 0 = never (use <Layer>SyncWeights)
  * value "auto" restores the default.  0 ok, -1 unknown option. */
 int         nntk_hip_set_option(const char *name, const char *value);
 int         nntk_hip_get_option(const char *name, int *value);

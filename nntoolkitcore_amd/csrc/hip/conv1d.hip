@@ -564,6 +564,39 @@ extern "C" int nntk_shim_split_bf16x3(const float *d_src, void *d_dst, int rows,
     return 0;
 }
 
+// ---- weight sets the split contraction must not take ------------------------------------------------------------
+// bf16 has f32's exponent range but the bf16 MFMA flushes denormals, bf16(|w| > 3.39e38) is infinite and inf - inf is
+// NaN: a weight matrix holding a non-finite, huge or denormal value cannot be split exactly.  The host scans a weight
+// block when it packs it (runtime.c nntk_upload_packed_weights, free: it touches every value anyway) and registers the
+// device pointer here; "auto" then takes the exact-f32 kernel for that block, whose chain treats such values exactly as
+// the reference's (core/default_ops.cc:224-231).  The list is normally empty: one relaxed atomic load per launch.
+#include <atomic>
+#include <mutex>
+#include <vector>
+static std::mutex g_exact_mu;
+static std::vector<const void *> g_exact_only;
+static std::atomic<int> g_exact_n{0};
+extern "C" void nntk_shim_weights_exact_only(const void *d_wp, int on) {
+    if (!d_wp) return;
+    if (!on && g_exact_n.load(std::memory_order_relaxed) == 0) return;
+    std::lock_guard<std::mutex> lk(g_exact_mu);
+    for (size_t i = 0; i < g_exact_only.size(); ++i)
+        if (g_exact_only[i] == d_wp) {
+            if (on) return;
+            g_exact_only[i] = g_exact_only.back();
+            g_exact_only.pop_back();
+            g_exact_n.store((int)g_exact_only.size(), std::memory_order_relaxed);
+            return;
+        }
+    if (on) { g_exact_only.push_back(d_wp); g_exact_n.store((int)g_exact_only.size(), std::memory_order_relaxed); }
+}
+static bool weights_exact_only(const void *d_wp) {
+    if (g_exact_n.load(std::memory_order_relaxed) == 0) return false;
+    std::lock_guard<std::mutex> lk(g_exact_mu);
+    for (const void *q : g_exact_only) if (q == d_wp) return true;
+    return false;
+}
+
 #define SPLIT_ROW 96              // LDS bytes per window row: 3 images x 16 bf16
 
 template <int WM, int WN, int TM, int TN, bool A4, bool QUAD>
@@ -879,9 +912,10 @@ extern "C" int nntk_shim_conv1d(const float *d_in, const float *d_wp, const floa
     }
     // auto: every contraction except the recurrent input projection (out_mode 1), whose exact k-ordered chain the
     // streaming kernel reproduces bit for bit (recurrent.hip rec_stream_step_kernel)
-    const bool split = opt.gemm_split_bf16 == 1 || (opt.gemm_split_bf16 < 0 && out_mode == 0) ||
+    bool split = opt.gemm_split_bf16 == 1 || (opt.gemm_split_bf16 < 0 && out_mode == 0) ||
                        (opt.gemm_split_bf16 == 2 && out_mode == 0 && k > 1) ||        // 2 / 3: convolutions only / dense only (A/B)
                        (opt.gemm_split_bf16 == 3 && out_mode == 0 && k == 1);
+    if (split && opt.gemm_split_bf16 < 0 && weights_exact_only(d_wp)) split = false;      // "auto" only: 1 / 2 / 3 force the split (A/B runs)
     if (split && (long)p.Cout_p * k * p.Cin_p * 6 < (long)CONV_OOB) {
         if (p.Cout_p % 128 == 0) return a4 ? launch_mfma<2, 2, 2, 2, true, true>(p) : launch_mfma<2, 2, 2, 2, false, true>(p);
         if (p.Cout_p % 64 == 0)  return a4 ? launch_mfma<4, 1, 1, 2, true, true>(p) : launch_mfma<4, 1, 1, 2, false, true>(p);

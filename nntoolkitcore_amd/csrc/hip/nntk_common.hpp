@@ -29,8 +29,8 @@ struct NntkOptions {
     int conv_store = -1;         // GEMM epilogue: -1 auto, 0 row form (4-byte stores), 1 quad form (16-byte stores); bit-identical
     int gemm_split_bf16 = -1;    // 3-way split-bf16 contraction: -1 auto (conv / dense / TDD / mel, not the recurrent xW), 0 never, 1 all
     int conv_dbg = 0;            // diagnostics build only
-    int weights_check = -1;      // host-pointer Apply: 1 compare the whole weight block with its shadow each call (default),
-                                 // 0 trust *SyncWeights
+    int weights_check = -1;      // host-pointer Apply: 1 (default) whole-block compare with the shadow each call, sampled only on
+                                 // the streaming recurrent call; 2 whole block everywhere; 0 trust *SyncWeights
 };
 const NntkOptions &nntk_options();
 
@@ -41,6 +41,7 @@ void nntk_persistent_launch_begin();              // orders persistent launches 
 void nntk_persistent_launch_end();
 int nntk_cu_count();                              // cached per device
 int nntk_set_max_dynamic_lds(const void *kernel, size_t bytes);   // hipFuncSetAttribute once per (kernel, device)
+int nntk_resident_blocks(const void *kernel, int threads, size_t lds, int max_per_cu);   // occupancy x CUs (0: does not fit)
 
 #define NNTK_HIP_TRY(expr)                                             \
     do {                                                               \

@@ -29,6 +29,7 @@ enum {
 /* ---- runtime --------------------------------------------------------------- */
 int         nntk_shim_device_count(void);
 int         nntk_shim_set_device(int device);
+int         nntk_shim_get_device(void);            /* the calling thread's current device, -1 without one */
 void        nntk_shim_set_stream(void *stream);
 void       *nntk_shim_get_stream(void);
 int         nntk_shim_synchronize(void);
@@ -77,6 +78,9 @@ void nntk_shim_conv_pack_sizes(int Cin, int Cout, int k, int *Cin_p, int *Cout_p
  * nntk_shim_split_bf16x3(d_wp, d_wp + n, Cout_p, k * Cin_p); the images are read only by the split-bf16 kernel */
 int  nntk_shim_bn_derive(float *d_block, float eps, int C);
 int  nntk_shim_split_bf16x3(const float *d_src, void *d_dst, int rows, int ktot);
+/* on = 1: this packed weight block holds a non-finite, > 3.39e38 or denormal value, which the bf16 split cannot represent
+ * exactly -- the "auto" contraction takes the exact-f32 kernel for it.  on = 0 (re-upload of clean weights, free) clears. */
+void nntk_shim_weights_exact_only(const void *d_wp, int on);
 int  nntk_shim_conv1d(const float *d_in, const float *d_wp, const float *d_bias, const float *d_bn,
                       float bn_eps, int act_kind, float relu_a, float *d_out,
                       int B, int T, int Cin, int Cout, int k, int stride, int Tout, int out_mode);

@@ -974,9 +974,6 @@ extern "C" int nntk_shim_gru2(const float *d_xw1, const float *d_ut1, const floa
     const size_t lds = ((size_t)3 * 16 * (2 * (KP + 8) + (KP + 4)) + (size_t)4 * 2 * 3 * 2 * 64) * sizeof(float);
     if (lds > 160 * 1024) return 1;
     const int NCT = Hj_p / REC_HN;
-    const int cus = nntk_cu_count();
-    const int tiles_per_launch = NCT > 0 ? cus / NCT : 0;
-    if (tiles_per_launch < 1) return 1;
     unsigned *fault = nntk_fault_word();
     if (!fault) return 1;
     const size_t hbmax = rec_hb_floats_fwd(B, H);
@@ -984,6 +981,11 @@ extern "C" int nntk_shim_gru2(const float *d_xw1, const float *d_ut1, const floa
     if (hb_floats * 4 >= 0x3ffffff0ULL) return 1;
     auto kern = nch_p == 4 ? gru2_persistent_kernel<4> : gru2_persistent_kernel<8>;
     if (nntk_set_max_dynamic_lds((const void *)kern, lds)) return -1;
+    // every workgroup of a launch must be resident: the grid comes from the runtime's occupancy answer for THIS kernel
+    // at THIS LDS size (one per CU by design), not from the bare CU count
+    const int resident = nntk_resident_blocks((const void *)kern, 512, lds, 1);
+    const int tiles_per_launch = NCT > 0 ? resident / NCT : 0;
+    if (tiles_per_launch < 1) return 1;
     unsigned *cnt = reinterpret_cast<unsigned *>(d_work + 4 * hbmax);
     const int nbt_total = (B + REC_BM - 1) / REC_BM;
     if (nntk_shim_memset(d_work, 0, 4 * hbmax * 4 + (size_t)nbt_total * 2 * RECP_CNT_STRIDE * sizeof(unsigned))) return -1;
@@ -1267,12 +1269,10 @@ static int run_recurrent(const float *d_xw, const float *d_ut, const float *d_bh
         const int nch = p.Hk_p / REC_KC;
         const int nch_p = nch <= 4 ? 4 : nch <= 8 ? 8 : nch <= 12 ? 12 : 16;      // compiled K depths (x32)
         const size_t lds = ((size_t)G * 16 * (nch_p * REC_KC + 8) + (size_t)4 * 2 * G * 2 * 64 + 16) * sizeof(float);
-        const int cus = nntk_cu_count();
-        const int tiles_per_launch = NCT > 0 ? cus / NCT : 0;
         const size_t hb_floats = (size_t)((B + 63) & ~63) * (size_t)(nch_p * REC_KC);      // <= hbmax
         unsigned *fault = want ? nntk_fault_word() : nullptr;
-        if (want && fault && (H % 4) == 0 && lds <= 160 * 1024 && p.Hk_p <= RECP_MAXCH * REC_KC && tiles_per_launch >= 1 &&
-            hb_floats * 4 < 0x3ffffff0ULL) {
+        if (want && fault && (H % 4) == 0 && lds <= 160 * 1024 && p.Hk_p <= RECP_MAXCH * REC_KC && NCT >= 1 &&
+            NCT <= nntk_cu_count() && hb_floats * 4 < 0x3ffffff0ULL) {
             void (*kern)(RecPParams);
             int xwm = opt.rec_xw;
             const bool std_acts = G == 1 ? p.a0 == NNTK_ACT_TANH
@@ -1294,6 +1294,10 @@ static int run_recurrent(const float *d_xw, const float *d_ut, const float *d_bh
             else if (nch_p == 12) kern = REC_PICK(12);
             else                  kern = REC_PICK(16);
             if (nntk_set_max_dynamic_lds((const void *)kern, lds)) return -1;
+            // every workgroup of a launch must be resident: the grid comes from the runtime's occupancy answer for THIS
+            // kernel at THIS LDS size (one per CU by design), not from the bare CU count
+            const int tiles_per_launch = nntk_resident_blocks((const void *)kern, 512, lds, 1) / NCT;
+            if (tiles_per_launch >= 1) {
             unsigned *cnt = reinterpret_cast<unsigned *>(d_work + 2 * hbmax + BH);
             // tiled hand-off buffers: both parities cleared (the padding must stay zero), h_0 tiled into parity 0
             if (nntk_shim_memset(d_work, 0, 2 * hbmax * 4)) return -1;
@@ -1349,6 +1353,7 @@ static int run_recurrent(const float *d_xw, const float *d_ut, const float *d_bh
             NNTK_LAUNCH_CHECK("rec_persistent_kernel");
             if (IS_LSTM && d_cT) { if (nntk_shim_copy_d2d(d_cT, cbuf, BH * 4)) return -1; }
             return 0;
+            }
         }
     }
     if (d_h0) { if (nntk_shim_copy_d2d(hbuf[0], d_h0, BH * 4)) return -1; }

@@ -191,6 +191,34 @@ int nntk_set_max_dynamic_lds(const void *kernel, size_t bytes) {
     return 0;
 }
 
+// How many workgroups of `kernel` (threads per workgroup, dynamic LDS bytes) are resident at once on the current device:
+// the runtime's occupancy answer per CU (clamped to `max_per_cu`, the number the kernel's protocol was designed for)
+// times the CU count.  The persistent recurrent kernels size their grids from this instead of assuming "one per CU":
+// 0 means the kernel does not fit at all (another LDS carve-out, a different part) and the caller takes the per-step
+// path.  Cached per (kernel, device, LDS size).
+int nntk_resident_blocks(const void *kernel, int threads, size_t lds, int max_per_cu) {
+    struct Seen { const void *k; size_t lds; int dev, threads, per_cu; };
+    static std::vector<Seen> seen;
+    static std::mutex m;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int per_cu = -1;
+    {
+        std::lock_guard<std::mutex> lk(m);
+        for (const Seen &s : seen)
+            if (s.k == kernel && s.dev == dev && s.lds == lds && s.threads == threads) { per_cu = s.per_cu; break; }
+    }
+    if (per_cu < 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+        per_cu = n;
+        std::lock_guard<std::mutex> lk(m);
+        seen.push_back({kernel, lds, dev, threads, per_cu});
+    }
+    if (per_cu > max_per_cu) per_cu = max_per_cu;
+    return per_cu * nntk_cu_count();
+}
+
 extern "C" {
 
 int nntk_shim_set_option(const char *name, const char *value) {
@@ -252,6 +280,11 @@ int nntk_shim_set_device(int device) {
     NNTK_HIP_TRY(hipSetDevice(device));
     return 0;
 }
+int nntk_shim_get_device(void) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return dev;
+}
 void nntk_shim_set_stream(void *stream) { t_stream = (hipStream_t)stream; }
 void *nntk_shim_get_stream(void) { return (void *)t_stream; }
 int nntk_shim_synchronize(void) {
@@ -273,7 +306,11 @@ void *nntk_shim_malloc(size_t bytes) {
     if (e != hipSuccess) { nntk_fail("hipMalloc", e); return nullptr; }
     return p;
 }
-void nntk_shim_free(void *p) { if (p) (void)hipFree(p); }
+void nntk_shim_free(void *p) {
+    if (!p) return;
+    nntk_shim_weights_exact_only(p, 0);       // a later allocation may reuse the address
+    (void)hipFree(p);
+}
 
 void *nntk_shim_host_alloc(size_t bytes) {
     void *p = nullptr;

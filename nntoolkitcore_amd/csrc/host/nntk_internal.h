@@ -32,6 +32,14 @@ typedef struct { float *p; size_t cap; } nntk_devbuf;
 float *nntk_devbuf_reserve(nntk_devbuf *b, size_t n_floats);
 void   nntk_devbuf_free(nntk_devbuf *b);
 
+/* Scratch that belongs to no handle (losses, the optimiser, the gradient products, the bidirectional helpers): one set of
+ * growable buffers per host thread AND device -- a thread that switches devices gets that device's set, never a pointer
+ * into another GPU's memory -- released by a thread-exit hook (the former bare _Thread_local buffers leaked
+ * device memory with every thread that ever computed a gradient). */
+enum { NNTK_TS_A, NNTK_TS_B, NNTK_TS_C, NNTK_TS_AT, NNTK_TS_BT, NNTK_TS_PACK, NNTK_TS_TMP, NNTK_TS_SCR,
+       NNTK_TS_BD_A, NNTK_TS_BD_B, NNTK_TS_BD_OUT, NNTK_TS_SLOTS };
+nntk_devbuf *nntk_thread_scratch(int slot);
+
 /* upload a host array into a fresh/reused device buffer */
 int nntk_upload_floats(float **d_dst, const float *h_src, size_t n);
 

@@ -179,6 +179,13 @@ static int core_apply_device(rec_core *c, int is_lstm, int use_bh, const int *ac
  * lstm.c:241-268) -- is latency, not throughput: T launches of the streaming step kernel, x_t read from and h_t written
  * to pinned host memory by the kernels themselves, and the host waits on a pinned word the last workgroup raises
  * (a stream synchronisation alone costs more than the kernels).  Same bits as the batch path (recurrent.hip). */
+#if defined(__x86_64__) || defined(__i386__)
+#define NNTK_CPU_RELAX() __builtin_ia32_pause()
+#elif defined(__aarch64__)
+#define NNTK_CPU_RELAX() __asm__ __volatile__("yield")
+#else
+#define NNTK_CPU_RELAX() ((void)0)
+#endif
 static int core_apply_stream(rec_core *c, int is_lstm, int use_bh, const int *acts, const float *scales,
                              const float *input, float *output) {
     const size_t n_in = (size_t)c->T * c->in, n_out = c->return_sequences ? (size_t)c->T * c->H : (size_t)c->H;
@@ -213,12 +220,19 @@ static int core_apply_stream(rec_core *c, int is_lstm, int use_bh, const int *ac
         if ((spins & 1023) == 1023) {
             clock_gettime(CLOCK_MONOTONIC, &t1);
             if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 5000000L) {
-                if (nntk_shim_synchronize()) return -1;
-                if (*c->flag != seq) NNTK_FAIL("streaming recurrent kernel did not complete");
+                /* error paths: the last launch may not have counted every workgroup in, and only the workgroup that
+                 * counts in last resets the counter -- clear it here, or every later call on this handle would wait
+                 * for a count that is never reached */
+                if (nntk_shim_synchronize()) { (void)nntk_shim_memset(c->d_done, 0, 64); return -1; }
+                if (*c->flag != seq) {
+                    (void)nntk_shim_memset(c->d_done, 0, 64);
+                    (void)nntk_shim_synchronize();
+                    NNTK_FAIL("streaming recurrent kernel did not complete");
+                }
                 break;
             }
         }
-        __builtin_ia32_pause();
+        NNTK_CPU_RELAX();
     }
     memcpy(output, c->pin_out, n_out * sizeof(float));
     c->cur = (c->cur + c->T) & 1;
@@ -228,12 +242,15 @@ static int core_apply_stream(rec_core *c, int is_lstm, int use_bh, const int *ac
 static int core_apply_host(rec_core *c, int is_lstm, int use_bh, const int *acts, const float *scales,
                            const float *input, float *output, int B, int stateful) {
     if (B <= 0) return 0;
-    if (core_ensure(c, 1)) return -1;
     if (stateful && B == 1 && c->T >= 1 && c->T <= NNTK_STREAM_MAX_T) {
         int on = -1;
         (void)nntk_shim_get_option("rec_stream", &on);
-        if (on != 0) return core_apply_stream(c, is_lstm, use_bh, acts, scales, input, output);
+        if (on != 0) {
+            if (core_ensure(c, 2)) return -1;          /* latency path: sampled edit check (runtime.c) */
+            return core_apply_stream(c, is_lstm, use_bh, acts, scales, input, output);
+        }
     }
+    if (core_ensure(c, 1)) return -1;
     size_t n_in = (size_t)B * c->T * c->in;
     size_t n_out = c->return_sequences ? (size_t)B * c->T * c->H : (size_t)B * c->H;
     float *d_in = nntk_devbuf_reserve(&c->d_in, n_in);
@@ -926,7 +943,9 @@ int RNNGetState(RNN filter, float *h_host) {
  * reference's signatures (void, caller-owned host buffers) and stage through device scratch. */
 
 /* scratch of the host-pointer helpers: per calling thread (they have no handle to own it) */
-static _Thread_local nntk_devbuf g_bd_a, g_bd_b, g_bd_out;
+#define g_bd_a (*nntk_thread_scratch(NNTK_TS_BD_A))
+#define g_bd_b (*nntk_thread_scratch(NNTK_TS_BD_B))
+#define g_bd_out (*nntk_thread_scratch(NNTK_TS_BD_OUT))
 
 int bd_reverse_input_batch_device(const float *d_input, float *d_output, RecurrentConfig config, int batch) {
     nntk_shim_clear_error();

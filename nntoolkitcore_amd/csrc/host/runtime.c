@@ -62,13 +62,16 @@ void nntk_wblock_free(nntk_wblock *wb) {
     wb->host = wb->shadow = NULL;
 }
 /* The reference reads the caller's weight block on every Apply (no upload step), so a caller may edit it in
- * place without telling anyone.  The host-pointer Apply calls therefore look for edits before they launch:
- *   weights_check = 2  compare the whole block with its shadow (exact; 5 MB for LSTM-512 = ~0.2 ms per call)
- *   weights_check = 1  (default) compare 256 evenly spaced 64-byte probes plus the block's head and tail: a
- *                      replaced weight set (the realistic edit: memcpy of another model) always shows, a change
- *                      of a few floats may not -- call <Layer>SyncWeights after such an edit
- *   weights_check = 0  never look; <Layer>SyncWeights is the only way to re-upload
- * (the single-sequence streaming calls are latency-bound: the full compare was most of a T = 1 call) */
+ * place without telling anyone.  The host-pointer Apply calls therefore look for edits before they launch.
+ * check_edits: 0 = do not look (device-pointer calls: <Layer>SyncWeights is their contract),
+ *              1 = compare the WHOLE block with its shadow (every batch, training and ordinary inference call: the
+ *                  compare is noise next to the upload / launch it guards, and a missed edit of a few floats would
+ *                  make a training forward pass and its gradient use different weights -- ADVICE r02),
+ *              2 = latency path (the single-sequence streaming recurrent call, where the full compare of a 5 MB
+ *                  LSTM-512 block was most of a T = 1 call): 257 evenly spaced 64-byte probes incl. head and tail.
+ *                  A replaced weight set (the realistic edit: memcpy of another model) always shows; after an edit of
+ *                  a few floats call <Layer>SyncWeights, or set weights_check = 2.
+ * Option weights_check: 2 = always the whole block, 1 (default) = as above, 0 = never look. */
 #define NNTK_PROBE 16            /* floats per probe */
 int nntk_wblock_dirty(const nntk_wblock *wb, int check_edits) {
     if (!wb->uploaded) return 1;
@@ -77,7 +80,7 @@ int nntk_wblock_dirty(const nntk_wblock *wb, int check_edits) {
     (void)nntk_shim_get_option("weights_check", &mode);
     if (mode < 0) mode = 1;
     if (mode == 0) return 0;
-    if (mode >= 2 || wb->n <= 258 * NNTK_PROBE)
+    if (mode >= 2 || check_edits != 2 || wb->n <= 258 * NNTK_PROBE)
         return memcmp(wb->host, wb->shadow, wb->n * sizeof(float)) != 0;
     const size_t last = wb->n - NNTK_PROBE;
     for (int i = 0; i <= 256; ++i) {
@@ -110,6 +113,41 @@ void nntk_devbuf_free(nntk_devbuf *b) {
     b->cap = 0;
 }
 
+/* ---- per-thread, per-device scratch sets (nntk_internal.h) ---- */
+#include <pthread.h>
+#define NNTK_TS_MAX_DEV 64
+typedef struct { nntk_devbuf buf[NNTK_TS_MAX_DEV][NNTK_TS_SLOTS]; } nntk_tscratch;
+static pthread_key_t g_ts_key;
+static pthread_once_t g_ts_once = PTHREAD_ONCE_INIT;
+static void ts_destroy(void *p) {
+    nntk_tscratch *ts = (nntk_tscratch *)p;
+    if (!ts) return;
+    int cur = nntk_shim_get_device();
+    for (int d = 0; d < NNTK_TS_MAX_DEV; ++d) {
+        int any = 0;
+        for (int s = 0; s < NNTK_TS_SLOTS; ++s) any |= ts->buf[d][s].p != NULL;
+        if (!any) continue;
+        if (nntk_shim_set_device(d)) continue;      /* the runtime is shutting down: nothing left to free */
+        nntk_shim_synchronize();
+        for (int s = 0; s < NNTK_TS_SLOTS; ++s) nntk_devbuf_free(&ts->buf[d][s]);
+    }
+    if (cur >= 0) (void)nntk_shim_set_device(cur);
+    free(ts);
+}
+static void ts_make_key(void) { (void)pthread_key_create(&g_ts_key, ts_destroy); }
+nntk_devbuf *nntk_thread_scratch(int slot) {
+    static nntk_devbuf dead;                        /* no device / out of memory: reserve() on it fails cleanly */
+    (void)pthread_once(&g_ts_once, ts_make_key);
+    nntk_tscratch *ts = (nntk_tscratch *)pthread_getspecific(g_ts_key);
+    if (!ts) {
+        ts = (nntk_tscratch *)calloc(1, sizeof(*ts));
+        if (!ts || pthread_setspecific(g_ts_key, ts)) { free(ts); return &dead; }
+    }
+    int dev = nntk_shim_get_device();
+    if (dev < 0 || dev >= NNTK_TS_MAX_DEV || slot < 0 || slot >= NNTK_TS_SLOTS) return &dead;
+    return &ts->buf[dev][slot];
+}
+
 int nntk_upload_floats(float **d_dst, const float *h_src, size_t n) {
     if (!*d_dst) {
         *d_dst = (float *)nntk_shim_malloc(n * sizeof(float));
@@ -127,6 +165,15 @@ int nntk_upload_packed_weights(float **d_wp, const float *h_packed, int rows, in
         if (!*d_wp) return -1;
     }
     if (nntk_shim_upload(*d_wp, h_packed, n * sizeof(float))) return -1;
+    /* values the bf16 split cannot represent exactly (non-finite, beyond bf16's largest finite value, denormal): the
+     * "auto" contraction then keeps the exact-f32 kernel for this block (conv1d.hip) */
+    int odd = 0;
+    for (size_t i = 0; i < n && !odd; ++i) {
+        union { float f; unsigned u; } v = { h_packed[i] };
+        unsigned e = (v.u >> 23) & 0xffu, m = v.u & 0x7fffffu;
+        odd = e == 0xffu || (e == 0 && m != 0) || (v.u & 0x7fffffffu) > 0x7f7f0000u;
+    }
+    nntk_shim_weights_exact_only(*d_wp, odd);
     return nntk_shim_split_bf16x3(*d_wp, *d_wp + n, rows, ktot);
 }
 

@@ -8,11 +8,18 @@
 #include <string.h>
 #include "nntk_internal.h"
 
-static _Thread_local nntk_devbuf t_a, t_b, t_c;     /* scratch for the host-pointer forms */
+/* scratch for the host-pointer forms: per thread and device, freed at thread exit (nntk_thread_scratch, runtime.c) */
+#define t_a (*nntk_thread_scratch(NNTK_TS_A))
+#define t_b (*nntk_thread_scratch(NNTK_TS_B))
+#define t_c (*nntk_thread_scratch(NNTK_TS_C))
 
 /* ---- the three large products of every gradient: VALU kernels in the reference's order for small shapes, the MFMA GEMM
  *      (csrc/hip/train.hip "MFMA forms") once rows * I * K passes 2^27 multiply-adds ---- */
-static _Thread_local nntk_devbuf t_at, t_bt, t_pack, t_tmp, t_scr;
+#define t_at (*nntk_thread_scratch(NNTK_TS_AT))
+#define t_bt (*nntk_thread_scratch(NNTK_TS_BT))
+#define t_pack (*nntk_thread_scratch(NNTK_TS_PACK))
+#define t_tmp (*nntk_thread_scratch(NNTK_TS_TMP))
+#define t_scr (*nntk_thread_scratch(NNTK_TS_SCR))
 #define NNTK_TRAIN_MFMA_MACS ((double)(1 << 27))
 
 /* C [I][K] += A [rows][I]^T B [rows][K];  c [K] += column sums of B.  a_shift_T > 0: A is h [B][T][I], row (b,t) uses h_{t-1} */

@@ -586,9 +586,21 @@ def test_full_size_config4_two_layer_gru(gpu):
     g2.set_weights(W2, U2, bi2, bh2)
     y = g2.apply_device(g1.apply_device(x))
     assert y.shape == (B, T, H)
+    # the kernel behind bench.py's config-4 line: both layers in ONE persistent launch (gru2_persistent_kernel), at the
+    # benchmark's own size -- 16 batch tiles x 16 column tiles = all 256 CUs, 1000 steps
+    yf = NL.gru_stack2_apply_device(g1, g2, x)
+    assert yf.shape == (B, T, H)
+    assert capi.load().nntk_hip_device_status() == 0
     for i in (0, 700, 1023):
         ref = O.gru(O.gru(x[i:i + 1].cpu().numpy(), W1, U1, bi1, bh1), W2, U2, bi2, bh2)[0]
         close(y[i].cpu().numpy(), ref, atol=1e-4, rtol=1e-4)
+        close(yf[i].cpu().numpy(), ref, atol=1e-4, rtol=1e-4)
+        e = float(np.abs(yf[i].cpu().numpy() - ref).max())
+        print("fused 2xGRU-256 B=1024 T=1000 row %d: max abs err vs oracle %.2e (last step %.2e)"
+              % (i, e, float(np.abs(yf[i, -1].cpu().numpy() - ref[-1]).max())))
+        assert e < 3e-6
+    # the two forms differ only in layer 2's projection order, over the WHOLE batch
+    assert float((y - yf).abs().max()) < 1e-5
     g1.destroy()
     g2.destroy()
 

@@ -249,6 +249,12 @@ def test_achieved_error_two_layer_gru256_T1000(gpu):
     e_or, e_64 = float(np.abs(got - ref).max()), float(np.abs(got - r64).max())
     print("HIP GRU 128->256->256 T=1000: max abs err vs oracle %.2e, vs torch float64 %.2e" % (e_or, e_64))
     assert e_or < 3e-6 and e_64 < 3e-6
+    # the fused single-launch form (the config-4 bench kernel) on the same inputs
+    fused = NL.gru_stack2_apply(g1, g2, x)
+    f_or, f_64 = float(np.abs(fused - ref).max()), float(np.abs(fused - r64).max())
+    print("HIP fused GRU stack (gru2_persistent_kernel) T=1000: max abs err vs oracle %.2e, vs torch float64 %.2e, "
+          "vs the two calls %.2e" % (f_or, f_64, float(np.abs(fused - got).max())))
+    assert f_or < 3e-6 and f_64 < 3e-6
     g1.destroy(); g2.destroy()
 
 
@@ -328,6 +334,31 @@ def test_fused_two_layer_gru_matches_two_calls_and_oracle(gpu, B, I, H, T, seq):
     assert np.array_equal(a, fused)                            # reproducible
     lo = NL.gru_stack2_apply_device(g1, g2, xd[: B // 2 + 1].contiguous()).cpu().numpy()
     assert np.array_equal(lo, fused[: B // 2 + 1])             # a shard gives the same bits as the whole batch
+    g1.destroy(); g2.destroy()
+
+
+def test_fused_two_layer_gru_several_launches_and_ragged_batch(gpu):
+    """B = 1100 at H = 256: 18 batch tiles of 64 rows (the last one holds 12) x 16 column tiles = 288 workgroups > 256
+    CUs, so the call is TWO persistent launches (16 + 2 batch tiles) sharing one counter / hand-off area -- against the
+    oracle on rows of both launches and of the ragged tile, and bit-identical to the same rows run as smaller batches."""
+    import torch
+    r = rng(1100)
+    B, I, H, T = 1100, 40, 256, 48
+    x = u(r, B, T, I)
+    W1, U1, bi1, bh1 = u(r, I, 3 * H, sc=I ** -0.5), u(r, H, 3 * H, sc=H ** -0.5), u(r, 3 * H, sc=0.1), u(r, 3 * H, sc=0.1)
+    W2, U2, bi2, bh2 = u(r, H, 3 * H, sc=H ** -0.5), u(r, H, 3 * H, sc=H ** -0.5), u(r, 3 * H, sc=0.1), u(r, 3 * H, sc=0.1)
+    g1, g2 = NL.GRU(I, H, True, T), NL.GRU(H, H, True, T)
+    g1.set_weights(W1, U1, bi1, bh1); g2.set_weights(W2, U2, bi2, bh2)
+    xd = torch.from_numpy(x).cuda()
+    y = NL.gru_stack2_apply_device(g1, g2, xd)
+    assert capi.load().nntk_hip_device_status() == 0
+    rows = [0, 63, 64, 1023, 1024, 1087, 1088, 1099]
+    ref = O.gru(O.gru(x[rows], W1, U1, bi1, bh1), W2, U2, bi2, bh2)
+    got = y[rows].cpu().numpy()
+    print("fused GRU stack B=1100 (2 launches): max abs err vs oracle %.2e" % float(np.abs(got - ref).max()))
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
+    tail = NL.gru_stack2_apply_device(g1, g2, xd[1000:].contiguous())           # rows 1000..1099 as their own batch
+    assert torch.equal(tail, y[1000:])
     g1.destroy(); g2.destroy()
 
 
