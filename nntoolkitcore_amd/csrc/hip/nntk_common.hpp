@@ -21,6 +21,7 @@ struct NntkOptions {
     int rec_spin_us = 1000000;   // budget of every in-kernel spin before it gives up and raises the fault word
     int rec_stream = -1;         // small-batch streaming kernel (0 off)
     int rec_fused2 = -1;         // fused two-layer GRU kernel (0 off)
+    int rec_rr = -1;             // register-resident split-bf16 LSTM kernel with the fused input projection (0 off, 1 also for small batches)
     int spec_ppw = 0;            // frame pairs per wavefront in K1 (0 = auto)
     int spec_variant = -1;       // K1 kernel variant (A/B runs)
     int bn_fast = 0;             // reciprocal-multiply BatchNorm (not the reference's divide)

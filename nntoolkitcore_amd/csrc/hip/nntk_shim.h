@@ -172,6 +172,17 @@ int nntk_shim_lstm(const float *d_xw, const float *d_ut, const float *d_bh,
                    const float *d_h0, const float *d_c0, float *d_out, float *d_hT, float *d_cT,
                    float *d_work, int B, int T, int H, int return_sequences, const int acts[5], const float act_scales[5]);
 
+/* Register-resident split-bf16 LSTM with the input projection fused into the step (recurrent_rr.hip): standard
+ * activations, H % 16 == 0, 64 <= H <= 512, in % 8 == 0, in <= 256.  d_x [B][T][in]; d_img = weight images made by
+ * nntk_shim_lstm_rr_pack from the per-gate U^T (d_ut) and the packed W^T (d_wp); d_bh NULL for the one-bias form.
+ * nntk_shim_lstm_rr returns 1 when the shape / configuration is not taken (nothing launched). */
+size_t nntk_shim_lstm_rr_image_floats(int H, int in);           /* 0: shape not taken */
+size_t nntk_shim_lstm_rr_work_floats(int B, int H);
+int nntk_shim_lstm_rr_pack(const float *d_ut, const float *d_wp, float *d_img, int H, int in);
+int nntk_shim_lstm_rr(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,
+                      const float *d_h0, const float *d_c0, float *d_out, float *d_hT, float *d_cT,
+                      float *d_work, int B, int T, int in, int H, int return_sequences);
+
 /* fused two-layer GRU (standard activations, zero initial state, both layers H units): layer 2's input projection and
  * recurrence run inside layer 1's persistent launch, one step behind.  d_wt2 = W2^T packed like U^T.  Returns 1 when
  * the shape is not taken (nothing launched). */

@@ -1,0 +1,593 @@
+// recurrent_rr.hip -- K4b: persistent LSTM on the bf16 MFMA with the weights REGISTER-RESIDENT and the input
+// projection fused into the step.  Reference semantics: layers/lstm.c:185-239 (cell), :426-475 (batch forward,
+// zero or carried state).
+//
+// Why another LSTM kernel.  rec_persistent_kernel (recurrent.hip) keeps a [64 x H] f32 slice of U^T in LDS and
+// multiplies on the exact-f32 MFMA: 0.74 of that pipe's 157 TFLOP/s, and the pipe is the bound (9.2 us per step at
+// LSTM-512, B = 512), with the x W projection as a separate 2.5 ms GEMM whose [T, B, 4H] result (4.2 GB) makes a round
+// trip through HBM.  The split-bf16 x 3 contraction (conv1d.hip: every f32 operand = hi + mid + lo in bf16 exactly,
+// six bf16 products accumulated in f32 -- f32 accuracy, 2.67x less MFMA time) does not fit that design: three bf16
+// images of the U^T slice are 196 KB, more than the CU's 160 KB of LDS.  What does hold them is the REGISTER FILE:
+// one wavefront per SIMD may own 512 VGPRs, 512 KB per CU.  So:
+//
+//   * workgroup = 4 wavefronts (one per SIMD), 16 hidden units x 4 gates = 64 gate columns (two 32-row MFMA tiles) for a
+//     64-row batch tile, for the whole sequence; K = [h (H) | x_t (in)] is split over the 4 wavefronts, and each keeps the
+//     hi / mid images of its K range of U^T in REGISTERS as ready-made MFMA A fragments (LSTM-512: 128 VGPRs), loaded
+//     once per launch; the lo image (used by one product in six) and the three images of W^T sit in LDS (112 KB).
+//   * h travels between workgroups ALREADY SPLIT: the producer of h_t[b][j] writes its three bf16 images in the order
+//     the consumers' MFMA B fragments want them (1 KB blocks = 64 lanes x 16 B), so a consumer's operand is 24 16-byte
+//     loads per lane straight into registers, no LDS, no conversion.  Splitting once at the producer costs 6 bytes per
+//     element on the wire instead of 4, and 32x fewer VALU instructions than splitting at every consumer.
+//   * x_t W is computed inside the step on the same accumulators (x_t is split by its consumer: it does not depend on
+//     the recurrence and is fetched one half-step ahead).  No projection launch, no [T, B, 4H] tensor.
+//   * the 64 batch rows are two independent 32-row halves with their own hand-off chains, worked in strict alternation
+//     by ONE instruction stream per SIMD: while half A multiplies, half B's publication -> arrival -> poll -> operand
+//     fetch elapses, and the other way round.  The events of the idle half (drain + arrival of what it published, poll
+//     for its next operand, operand loads) are placed INSIDE the multiplying half's MFMA sequence.
+//
+// Hand-off protocol: the placement-independent recipe of the CDNA4 guide (Guideline 16 R1, sc1 row): write-through
+// (sc1) 16-byte stores, every storing wave waits vmcnt(0), the waves meet (here: an LDS counter, the wave whose add is
+// last signals), ONE lane adds to an agent-scope counter; the consumer polls from one lane (relaxed, s_sleep) and every
+// load of handed-off bytes is an sc1 buffer load.  Spins are bounded and poison the counter (runtime.hip fault word).
+//
+// Numerics: the contraction is the split form of conv1d.hip (error <= the f32 chain's against float64); gates are the
+// exp2 / rcp forms of nntk_common.hpp.  Not bit-identical to rec_persistent_kernel (another summation order), same
+// tolerance; results do not depend on the batch tile a row lands in, so shards equal the whole batch bit for bit.
+#include "nntk_common.hpp"
+#include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
+
+typedef __bf16 rr_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 rr_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float rr_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned rr_v4u __attribute__((ext_vector_type(4)));
+
+#define RR_CNT_STRIDE 64          // uints between arrival counters (256 B: atomics execute at the memory side)
+#define RR_HX_LD 20               // floats per row of the h exchange image (16-byte aligned rows)
+
+__device__ __forceinline__ unsigned rr_cvt_pk(float a, float b) {       // RNE, a in the low half
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((rr_f32x2){a, b}, rr_bf16x2));
+}
+// x = hi + mid + lo exactly (8 + 8 + 8 significand bits), two elements at a time
+__device__ __forceinline__ void rr_split_pair(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo) {
+    hi = rr_cvt_pk(x0, x1);
+    const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+    mid = rr_cvt_pk(r0, r1);
+    const float s0 = r0 - __uint_as_float(mid << 16), s1 = r1 - __uint_as_float(mid & 0xffff0000u);
+    lo = rr_cvt_pk(s0, s1);
+}
+// eight consecutive f32 -> the three 16-byte bf16 fragments
+__device__ __forceinline__ void rr_split8(const float (&v)[8], rr_v4u &hi, rr_v4u &mid, rr_v4u &lo) {
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rr_split_pair(v[2 * i], v[2 * i + 1], h[i], m[i], l[i]);
+    hi = (rr_v4u){h[0], h[1], h[2], h[3]};
+    mid = (rr_v4u){m[0], m[1], m[2], m[3]};
+    lo = (rr_v4u){l[0], l[1], l[2], l[3]};
+}
+
+// ---- weight images ------------------------------------------------------------------------------------------------
+// Tile row c (0..63) of column tile ct  <->  gate g = (c >> 3) & 3, hidden unit j = 16 ct + 8 ((c >> 2) & 1) + 4 (c >> 5) + (c & 3):
+// with the 32x32 MFMA's D layout (lane (n, kh) holds rows 8 q + 4 kh + e of a tile, q = 0..3, e = 0..3) a lane then owns
+// all four gates of hidden units 8 kh + 4 mt + e -- and lane (n, kh) of the publishing wave owns EIGHT CONSECUTIVE
+// hidden units of batch row n, which is exactly one B fragment (8 consecutive k) of the consumers.
+// Blocks of 1 KB = the A fragment of one (32-row tile mt, 16-deep k step): lane l holds row (l & 31), k = 8 (l >> 5) .. + 7.
+// Per column tile, in this order (KH / KX = k steps per wavefront of the h / x part):
+//   UH [w][i < KH][mt][m = hi, mid]       -> registers
+//   UL [w][i < KH][mt]                    -> LDS
+//   WX [w][ix < KX][mt][m = hi, mid, lo]  -> LDS
+__host__ __device__ inline int rr_blocks_per_ct(int KH, int KX) { return 4 * KH * 2 * 2 + 4 * KH * 2 + 4 * KX * 2 * 3; }
+
+// ut [4][Hj_p][Hk_p] f32 (U^T per gate), wp [4H padded][Kin_p] f32 (W^T, K-contiguous) -> images
+__global__ __launch_bounds__(256) void rr_pack_kernel(const float *__restrict__ ut, const float *__restrict__ wp,
+                                                      rr_v4u *__restrict__ img, int H, int in, int Hj_p, int Hk_p, int Kin_p,
+                                                      int KH, int KX, int NCT) {
+    const int bpc = rr_blocks_per_ct(KH, KX);
+    const long total = (long)NCT * bpc * 64;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int l = (int)(e & 63);
+        const long blk = e >> 6;
+        const int ct = (int)(blk / bpc);
+        int r = (int)(blk % bpc);
+        int part, w, i, mt, m;                    // part 0 = UH, 1 = UL, 2 = WX
+        const int n_uh = 4 * KH * 4, n_ul = 4 * KH * 2;
+        if (r < n_uh) { part = 0; m = r & 1; mt = (r >> 1) & 1; i = (r >> 2) % KH; w = (r >> 2) / KH; }
+        else if (r < n_uh + n_ul) { r -= n_uh; part = 1; m = 2; mt = r & 1; i = (r >> 1) % KH; w = (r >> 1) / KH; }
+        else { r -= n_uh + n_ul; part = 2; m = r % 3; mt = (r / 3) & 1; i = (r / 6) % KX; w = (r / 6) / KX; }
+        const int c = 32 * mt + (l & 31);
+        const int g = (c >> 3) & 3;
+        const int j = 16 * ct + 8 * ((c >> 2) & 1) + 4 * (c >> 5) + (c & 3);
+        const int ks = part == 2 ? w * KX + i : w * KH + i;
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = 16 * ks + 8 * (l >> 5) + q;
+            float val = 0.0f;
+            if (j < H) {
+                if (part == 2) { if (k < in) val = wp[((size_t)g * H + j) * Kin_p + k]; }
+                else if (k < H) val = ut[((size_t)g * Hj_p + j) * Hk_p + k];
+            }
+            v[q] = val;
+        }
+        rr_v4u hi, mid, lo;
+        rr_split8(v, hi, mid, lo);
+        img[e] = m == 0 ? hi : m == 1 ? mid : lo;
+    }
+}
+
+// h_0 [B][H] f32 -> the split hand-off layout of parity 0: block (((bt * 2 + half) * NKS + ks) * 3 + m), lane (n, kh)
+__global__ __launch_bounds__(256) void rr_tile_h0_kernel(const float *__restrict__ h0, rr_v4u *__restrict__ hb, int B, int H, int NKS) {
+    const long total = (long)((B + 63) / 64) * 2 * (H / 16) * 64;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int l = (int)(e & 63);
+        long r = e >> 6;
+        const int ks = (int)(r % (H / 16)); r /= (H / 16);
+        const int half = (int)(r & 1);
+        const long bt = r >> 1;
+        const long row = bt * 64 + half * 32 + (l & 31);
+        if (row >= B) continue;
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = h0[row * H + 16 * ks + 8 * (l >> 5) + q];
+        rr_v4u hi, mid, lo;
+        rr_split8(v, hi, mid, lo);
+        rr_v4u *dst = hb + ((((size_t)bt * 2 + half) * NKS + ks) * 3) * 64 + l;
+        dst[0] = hi; dst[64] = mid; dst[128] = lo;
+    }
+}
+
+struct RRParams {
+    const float *x;            // [B][T][in]
+    const rr_v4u *img;         // weight images (rr_pack_kernel)
+    const float *bi, *bh;      // [4H]; bh NULL when !v2
+    char *hb;                  // [2 parities][hb_parity_bytes] split hand-off buffers; parity 0 holds h_0
+    size_t hb_parity_bytes;
+    const float *c0;           // [B][H] or NULL (zeros)
+    float *cT, *hT;            // [B][H] or NULL
+    float *out;                // [B][T][H] or [B][H]
+    unsigned *cnt;             // [NBT][2 halves] x RR_CNT_STRIDE, zeroed before the launch
+    unsigned *fault;
+    unsigned long long spin_ticks;
+    int B, T, H, in, NBT, NCT, b_base, return_sequences;
+#ifdef NNTK_REC_STAMPS
+    unsigned long long *stamp; // [T][2 halves][8] s_memtime of workgroup 0, wave 0 (diagnostics build only)
+#endif
+};
+#ifdef NNTK_REC_STAMPS
+#define RR_STAMP(half, t, i) do { if (p.stamp && blockIdx.x == 0 && w == 0 && lane == 0) \
+        p.stamp[((size_t)(t) * 2 + (half)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RR_STAMP(half, t, i) do {} while (0)
+#endif
+
+// raw barrier: LDS traffic ordered, vector-memory operations (the operand prefetch!) left in flight
+#define RR_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+__device__ __forceinline__ void rr_lds_wait_ge(const unsigned *wd, unsigned target) {
+    while (__hip_atomic_load(wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+
+// KH / KX: k steps (of 16) per wavefront for the h / x part: H <= 64 KH, in <= 64 KX (zero padded).
+// E1 / E2: k-step index inside a half's MFMA sequence (KX + KH steps) at which the OTHER half's arrival / poll + loads go.
+template <int KH, int KX, int E1, int E2>
+__global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
+    constexpr int NKS = 4 * KH;                       // k steps of the hand-off buffer (>= H / 16)
+    constexpr int NST = KX + KH;                      // k steps one wavefront multiplies per half
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    rr_v4u *ULs = reinterpret_cast<rr_v4u *>(smem);                       // [4][KH][2] blocks
+    rr_v4u *WXs = ULs + 4 * KH * 2 * 64;                                  // [4][KX][2][3] blocks
+    rr_v4u *red = WXs + 4 * KX * 6 * 64;                                  // [dst 4][src 4][2] blocks: split-K exchange
+    float *hx = reinterpret_cast<float *>(red + 32 * 64);                 // [32][RR_HX_LD] h exchange
+    unsigned *syncw = reinterpret_cast<unsigned *>(hx + 32 * RR_HX_LD);   // [0..1] drained waves, [2..3] poll passed (per half)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, kh = lane >> 5;
+    const int bt = blockIdx.x % p.NBT;
+    const int ct = blockIdx.x / p.NBT;
+    const int bt_abs = p.b_base / 64 + bt;
+    const int b0 = p.b_base + bt * 64;
+    const int H = p.H;
+
+    // ---- resident operands ----
+    const rr_v4u *img = p.img + (size_t)ct * rr_blocks_per_ct(KH, KX) * 64;
+    rr_bf16x8 uh[KH][2][2];
+#pragma unroll
+    for (int i = 0; i < KH; ++i)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                uh[i][mt][m] = __builtin_bit_cast(rr_bf16x8, img[((((size_t)w * KH + i) * 2 + mt) * 2 + m) * 64 + lane]);
+    {
+        const rr_v4u *src = img + (size_t)4 * KH * 4 * 64;                // UL then WX, contiguous, same order as in LDS
+        constexpr int n16 = (4 * KH * 2 + 4 * KX * 6) * 64;
+        for (int e = tid; e < n16; e += 256) ULs[e] = src[e];
+    }
+    if (tid < 4) syncw[tid] = 0u;
+    // this lane finishes hidden units jf, jf + 1 (all four gates) of batch row n of each half
+    const int jl = 8 * kh + 4 * (w >> 1) + 2 * (w & 1);
+    const int jf = 16 * ct + jl;
+    float bsum[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            bsum[g][e] = jf + e < H ? p.bi[g * H + jf + e] + (p.bh ? p.bh[g * H + jf + e] : 0.0f) : 0.0f;
+    float cst[2][2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int row = b0 + half * 32 + n;
+            cst[half][e] = (p.c0 && row < p.B && jf + e < H) ? p.c0[(size_t)row * H + jf + e] : 0.0f;
+        }
+    // publishing lanes: wave w takes rows 8 w .. 8 w + 7 of a half (16 lanes: 8 rows x 2 k halves)
+    const bool pub_lane = (n >> 3) == w;
+    const int hb_bytes = (int)p.hb_parity_bytes;
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void *)p.hb, 0, hb_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.hb + p.hb_parity_bytes), 0, hb_bytes, 0x00020000);
+    const int lane16 = lane * 16;
+    RR_BARRIER();
+
+    rr_v4u hf[2][KH][3];           // the h operand of each half: issued at E2 of the other half's sequence
+    rr_v4u xr[2][KX][2];           // raw x_t (f32) of each half, split right before use
+    float hkeep[2][8];             // the publishing lanes' last h row piece (final state / last output)
+
+    auto issue_h = [&](int half, int t) __attribute__((always_inline)) {
+        const int so = ((bt_abs * 2 + half) * NKS + w * KH) * 3 * 1024;
+#pragma unroll
+        for (int i = 0; i < KH; ++i)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                if (t & 1) hf[half][i][m] = __builtin_amdgcn_raw_buffer_load_b128(rs1, lane16, so + (i * 3 + m) * 1024, 16 /* sc1 */);
+                else       hf[half][i][m] = __builtin_amdgcn_raw_buffer_load_b128(rs0, lane16, so + (i * 3 + m) * 1024, 16 /* sc1 */);
+            }
+    };
+    auto issue_x = [&](int half, int t) __attribute__((always_inline)) {
+        const int row = b0 + half * 32 + n;
+        const float *xp = p.x + ((size_t)row * p.T + t) * p.in + (w * KX) * 16 + 8 * kh;
+#pragma unroll
+        for (int ix = 0; ix < KX; ++ix)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                rr_v4u v = (rr_v4u){0u, 0u, 0u, 0u};
+                if (row < p.B && (w * KX + ix) * 16 + 8 * kh + 4 * q < p.in) v = *reinterpret_cast<const rr_v4u *>(xp + ix * 16 + 4 * q);
+                xr[half][ix][q] = v;
+            }
+    };
+    // the OTHER half's arrival: its publishing stores (end of the previous half-step) have had a third of this MFMA
+    // sequence to drain; every wave waits for its own, counts in on an LDS word, the last one signals
+    auto arrive = [&](int half, unsigned seq /* arrivals of this half so far */) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            const unsigned old = __hip_atomic_fetch_add(&syncw[half], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (old == 4u * seq + 3u)
+                __hip_atomic_fetch_add(p.cnt + ((size_t)bt * 2 + half) * RR_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    // wait until every column tile of this batch tile has published h_{t-1} of `half`: one lane polls, the others follow
+    auto poll = [&](int half, int t) __attribute__((always_inline)) {
+        if (w == 0) {
+            if (lane == 0) {
+                unsigned *cnt = p.cnt + ((size_t)bt * 2 + half) * RR_CNT_STRIDE;
+                const unsigned target = (unsigned)p.NCT * (unsigned)t;
+                const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+                bool expired = p.spin_ticks == 0;                    // 0 = fault injection (tests)
+                while (!expired && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    expired = __builtin_amdgcn_s_memrealtime() - t_start > p.spin_ticks;
+                }
+                if (expired) {
+                    __hip_atomic_fetch_or(p.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_or(cnt, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __hip_atomic_store(&syncw[2 + half], (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        } else {
+            rr_lds_wait_ge(&syncw[2 + half], (unsigned)t);
+        }
+    };
+
+    // one half-step: multiply `half` at step t; inside the sequence serve the other half: `arr_seq` >= 0 -> arrive for its
+    // last publication; `nt` >= 0 -> poll for and fetch its operand of step nt
+    auto half_step = [&](auto half_tag, int t, int arr_seq, int nt) __attribute__((always_inline)) {
+        constexpr int half = decltype(half_tag)::value;
+        constexpr int other = 1 - half;
+        RR_STAMP(half, t, 0);
+        // ---- x_t of this half: split into the three bf16 images (fetched at E2 of the previous half-step) ----
+        rr_bf16x8 xf[KX][3];
+#pragma unroll
+        for (int ix = 0; ix < KX; ++ix) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                v[4 * q] = __uint_as_float(xr[half][ix][q].x); v[4 * q + 1] = __uint_as_float(xr[half][ix][q].y);
+                v[4 * q + 2] = __uint_as_float(xr[half][ix][q].z); v[4 * q + 3] = __uint_as_float(xr[half][ix][q].w);
+            }
+            rr_v4u a, b, c;
+            rr_split8(v, a, b, c);
+            xf[ix][0] = __builtin_bit_cast(rr_bf16x8, a); xf[ix][1] = __builtin_bit_cast(rr_bf16x8, b); xf[ix][2] = __builtin_bit_cast(rr_bf16x8, c);
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+        // six products per (k step, tile), smallest terms first: (A image, B image) = (hi,lo) (lo,hi) (mid,mid) (hi,mid) (mid,hi) (hi,hi)
+        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+        for (int s = 0; s < NST; ++s) {
+            if (s == E1 && arr_seq >= 0) arrive(other, (unsigned)arr_seq);
+            if (s == E2 && nt >= 0) {
+                if (nt > 0) poll(other, nt);
+                issue_h(other, nt);
+                issue_x(other, nt);
+            }
+            if (s < KX) {                         // x part: W^T fragments from LDS
+                rr_bf16x8 a[2][3];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int m = 0; m < 3; ++m)
+                        a[mt][m] = __builtin_bit_cast(rr_bf16x8, WXs[((((w * KX + s) * 2 + mt) * 3) + m) * 64 + lane]);
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][PA[pr]], xf[s][PB[pr]], acc[mt], 0, 0, 0);
+            } else {                              // h part: hi / mid from registers, lo from LDS
+                constexpr int dummy = 0; (void)dummy;
+                const int i = s - KX;
+                rr_bf16x8 ulo[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) ulo[mt] = __builtin_bit_cast(rr_bf16x8, ULs[((w * KH + i) * 2 + mt) * 64 + lane]);
+                rr_bf16x8 b[3];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) b[m] = __builtin_bit_cast(rr_bf16x8, hf[half][i][m]);
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const rr_bf16x8 av = PA[pr] == 2 ? ulo[mt] : uh[i][mt][PA[pr]];
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b[PB[pr]], acc[mt], 0, 0, 0);
+                    }
+            }
+        }
+        RR_STAMP(half, t, 1);
+        // ---- split-K exchange: wave `dst` finishes registers 4 g + 2 (dst & 1) + {0, 1} of tile dst >> 1 ----
+#pragma unroll
+        for (int dst = 0; dst < 4; ++dst) {
+            const int mt = dst >> 1, o = 2 * (dst & 1);
+            const rr_v4u q0 = {__float_as_uint(acc[mt][o]), __float_as_uint(acc[mt][o + 1]), __float_as_uint(acc[mt][4 + o]), __float_as_uint(acc[mt][5 + o])};
+            const rr_v4u q1 = {__float_as_uint(acc[mt][8 + o]), __float_as_uint(acc[mt][9 + o]), __float_as_uint(acc[mt][12 + o]), __float_as_uint(acc[mt][13 + o])};
+            red[((dst * 4 + w) * 2 + 0) * 64 + lane] = q0;
+            red[((dst * 4 + w) * 2 + 1) * 64 + lane] = q1;
+        }
+        RR_BARRIER();
+        float z[4][2];
+        {
+            rr_v4u s0[4], s1[4];
+#pragma unroll
+            for (int src = 0; src < 4; ++src) {
+                s0[src] = red[((w * 4 + src) * 2 + 0) * 64 + lane];
+                s1[src] = red[((w * 4 + src) * 2 + 1) * 64 + lane];
+            }
+            auto sum4 = [&](unsigned a, unsigned b, unsigned c, unsigned d) {     // fixed order: ((w0 + w1) + w2) + w3
+                return ((__uint_as_float(a) + __uint_as_float(b)) + __uint_as_float(c)) + __uint_as_float(d);
+            };
+            z[0][0] = sum4(s0[0].x, s0[1].x, s0[2].x, s0[3].x); z[0][1] = sum4(s0[0].y, s0[1].y, s0[2].y, s0[3].y);
+            z[1][0] = sum4(s0[0].z, s0[1].z, s0[2].z, s0[3].z); z[1][1] = sum4(s0[0].w, s0[1].w, s0[2].w, s0[3].w);
+            z[2][0] = sum4(s1[0].x, s1[1].x, s1[2].x, s1[3].x); z[2][1] = sum4(s1[0].y, s1[1].y, s1[2].y, s1[3].y);
+            z[3][0] = sum4(s1[0].z, s1[1].z, s1[2].z, s1[3].z); z[3][1] = sum4(s1[0].w, s1[1].w, s1[2].w, s1[3].w);
+        }
+        // ---- gates (lstm.c:201-238): Z = xW + b_i + hU (+ b_h); blocks i | f | g | o ----
+        float hn[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float ig = nntk_fast_sigmoid(z[0][e] + bsum[0][e]);
+            const float fg = nntk_fast_sigmoid(z[1][e] + bsum[1][e]);
+            const float gg = nntk_fast_tanh(z[2][e] + bsum[2][e]);
+            const float og = nntk_fast_sigmoid(z[3][e] + bsum[3][e]);
+            const float cn = fmaf(fg, cst[half][e], ig * gg);
+            cst[half][e] = cn;
+            hn[e] = og * nntk_fast_tanh(cn);
+        }
+        *reinterpret_cast<float2 *>(hx + n * RR_HX_LD + jl) = make_float2(hn[0], hn[1]);
+        RR_BARRIER();
+        RR_STAMP(half, t, 2);
+        // ---- publish: 16 lanes per wave assemble 8 consecutive hidden units of one row, split them, store write-through ----
+        if (pub_lane) {
+            const float4 h_lo = *reinterpret_cast<const float4 *>(hx + n * RR_HX_LD + 8 * kh);
+            const float4 h_hi = *reinterpret_cast<const float4 *>(hx + n * RR_HX_LD + 8 * kh + 4);
+            const float v[8] = {h_lo.x, h_lo.y, h_lo.z, h_lo.w, h_hi.x, h_hi.y, h_hi.z, h_hi.w};
+            const int row = b0 + half * 32 + n;
+            if (row < p.B) {
+                rr_v4u a, b, c;
+                rr_split8(v, a, b, c);
+                const int so = (((bt_abs * 2 + half) * NKS + ct) * 3) * 1024;
+                if ((t + 1) & 1) {
+                    __builtin_amdgcn_raw_buffer_store_b128(a, rs1, lane16, so, 16 /* sc1 */);
+                    __builtin_amdgcn_raw_buffer_store_b128(b, rs1, lane16, so + 1024, 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(c, rs1, lane16, so + 2048, 16);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(a, rs0, lane16, so, 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(b, rs0, lane16, so + 1024, 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(c, rs0, lane16, so + 2048, 16);
+                }
+                if (p.return_sequences) {
+                    float *o = p.out + ((size_t)row * p.T + t) * H + 16 * ct + 8 * kh;
+                    *reinterpret_cast<float4 *>(o) = h_lo;
+                    *reinterpret_cast<float4 *>(o + 4) = h_hi;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) hkeep[half][q] = v[q];
+        }
+        RR_STAMP(half, t, 3);
+    };
+
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+    // prologue: operands of step 0 (h_0 sits in parity 0: no poll)
+    issue_h(0, 0); issue_x(0, 0);
+    for (int t = 0; t < p.T; ++t) {
+        // half A multiplies step t; half B: arrival of its step t-1 publication, then poll + fetch for step t
+        half_step(H0{}, t, t > 0 ? t - 1 : -1, t);
+        // half B multiplies step t; half A: arrival of the step-t publication just made, then poll + fetch for step t+1
+        half_step(H1{}, t, t, t + 1 < p.T ? t + 1 : -1);
+    }
+    // the very last publication of half B is never consumed; its stores only need to complete before the kernel ends
+    // ---- final state / last output ----
+    if (pub_lane) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int row = b0 + half * 32 + n;
+            if (row < p.B) {
+                const float4 a = make_float4(hkeep[half][0], hkeep[half][1], hkeep[half][2], hkeep[half][3]);
+                const float4 b = make_float4(hkeep[half][4], hkeep[half][5], hkeep[half][6], hkeep[half][7]);
+                if (!p.return_sequences) {
+                    float *o = p.out + (size_t)row * H + 16 * ct + 8 * kh;
+                    *reinterpret_cast<float4 *>(o) = a; *reinterpret_cast<float4 *>(o + 4) = b;
+                }
+                if (p.hT) {
+                    float *o = p.hT + (size_t)row * H + 16 * ct + 8 * kh;
+                    *reinterpret_cast<float4 *>(o) = a; *reinterpret_cast<float4 *>(o + 4) = b;
+                }
+            }
+        }
+    }
+    if (p.cT) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int row = b0 + half * 32 + n;
+            if (row < p.B && jf + 1 < H + 1) {
+                if (jf < H) p.cT[(size_t)row * H + jf] = cst[half][0];
+                if (jf + 1 < H) p.cT[(size_t)row * H + jf + 1] = cst[half][1];
+            }
+        }
+    }
+}
+
+// ---- host side --------------------------------------------------------------------------------------------------
+static bool rr_shape(int H, int in, int *KH, int *KX) {
+    if (H < 64 || H > 512 || (H % 16) != 0 || in < 8 || (in % 8) != 0) return false;
+    *KH = H <= 256 ? 4 : 8;
+    *KX = in <= 64 ? 1 : in <= 128 ? 2 : in <= 256 ? 4 : 0;
+    if (*KX == 0) return false;
+    if (*KH == 8 && *KX == 4) return false;             // 64 + 96 + 32 KB: past the CU's LDS
+    return true;
+}
+static size_t rr_lds_bytes(int KH, int KX) {
+    return (size_t)(4 * KH * 2 + 4 * KX * 6 + 32) * 1024 + 32 * RR_HX_LD * 4 + 64;
+}
+static size_t rr_parity_bytes(int B, int KH) { return (size_t)((B + 63) / 64) * 2 * (4 * KH) * 3 * 1024; }
+
+extern "C" size_t nntk_shim_lstm_rr_image_floats(int H, int in) {
+    int KH, KX;
+    if (!rr_shape(H, in, &KH, &KX)) return 0;
+    return (size_t)((H + 15) / 16) * rr_blocks_per_ct(KH, KX) * 256;        // 1 KB blocks, in floats
+}
+extern "C" size_t nntk_shim_lstm_rr_work_floats(int B, int H) {
+    const int KH = H <= 256 ? 4 : 8;
+    const size_t nbt = (size_t)(B + 63) / 64;
+    return 2 * rr_parity_bytes(B, KH) / 4 + (2 * nbt < 256 ? 256 : 2 * nbt) * RR_CNT_STRIDE;
+}
+// d_ut / d_wp: the per-gate U^T and packed W^T the other kernels use (host: core_upload); d_img: nntk_shim_lstm_rr_image_floats
+extern "C" int nntk_shim_lstm_rr_pack(const float *d_ut, const float *d_wp, float *d_img, int H, int in) {
+    int KH, KX;
+    if (!rr_shape(H, in, &KH, &KX)) return nntk_fail_msg("lstm_rr_pack: shape not taken by the register-resident kernel");
+    const int Hj_p = (H + 15) & ~15, Hk_p = (H + 31) & ~31;
+    int Kin_p, N_p;
+    nntk_shim_conv_pack_sizes(in, 4 * H, 1, &Kin_p, &N_p);
+    const int NCT = (H + 15) / 16;
+    const long total = (long)NCT * rr_blocks_per_ct(KH, KX) * 64;
+    long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(rr_pack_kernel, dim3((unsigned)g), dim3(256), 0, nntk_stream(), d_ut, d_wp, (rr_v4u *)d_img, H, in,
+                       Hj_p, Hk_p, Kin_p, KH, KX, NCT);
+    NNTK_LAUNCH_CHECK("rr_pack_kernel");
+    return 0;
+}
+
+// 0 = launched; 1 = shape / configuration not taken (the caller runs projection GEMM + rec_persistent_kernel); -1 = error
+extern "C" int nntk_shim_lstm_rr(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,
+                                 const float *d_h0, const float *d_c0, float *d_out, float *d_hT, float *d_cT,
+                                 float *d_work, int B, int T, int in, int H, int return_sequences) {
+    if (B <= 0 || T <= 0) return 0;
+    const NntkOptions &opt = nntk_options();
+    if (opt.rec_rr == 0 || opt.rec_persistent == 0 || nntk_persistent_disabled()) return 1;
+    int KH, KX;
+    if (!rr_shape(H, in, &KH, &KX)) return 1;
+    if ((((size_t)d_x) & 15) != 0 || (in % 4) != 0) return 1;
+    const int NCT = H / 16;
+    void (*kern)(RRParams) = nullptr;
+    // E1 / E2: a third / three quarters into the KX + KH steps of a half (see the kernel header)
+    if (KH == 8 && KX == 2) kern = lstm_rr_kernel<8, 2, 3, 7>;
+    else if (KH == 8 && KX == 1) kern = lstm_rr_kernel<8, 1, 3, 6>;
+    else if (KH == 4 && KX == 4) kern = lstm_rr_kernel<4, 4, 2, 5>;
+    else if (KH == 4 && KX == 2) kern = lstm_rr_kernel<4, 2, 2, 4>;
+    else if (KH == 4 && KX == 1) kern = lstm_rr_kernel<4, 1, 1, 3>;
+    if (!kern) return 1;
+    const size_t lds = rr_lds_bytes(KH, KX);
+    if (lds > 160 * 1024) return 1;
+    if (nntk_set_max_dynamic_lds((const void *)kern, lds)) return -1;
+    const int resident = nntk_resident_blocks((const void *)kern, 256, lds, 1);
+    const int tiles_per_launch = resident / NCT;
+    if (tiles_per_launch < 1) return 1;
+    unsigned *fault = nntk_fault_word();
+    if (!fault) return 1;
+    const size_t parity = rr_parity_bytes(B, KH);
+    if (parity >= 0x7ffffff0ULL) return 1;
+    const int nbt_total = (B + 63) / 64;
+    unsigned *cnt = reinterpret_cast<unsigned *>(d_work + 2 * parity / 4);
+    // both parities cleared (rows >= B and k steps >= H / 16 must stay zero), h_0 split into parity 0, counters zeroed
+    if (nntk_shim_memset(d_work, 0, 2 * parity + (size_t)nbt_total * 2 * RR_CNT_STRIDE * sizeof(unsigned))) return -1;
+    if (d_h0) {
+        long g = ((long)nbt_total * 2 * NCT * 64 + 255) / 256;
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(rr_tile_h0_kernel, dim3((unsigned)g), dim3(256), 0, nntk_stream(), d_h0, (rr_v4u *)d_work, B, H, 4 * KH);
+    }
+    RRParams q;
+    q.x = d_x; q.img = (const rr_v4u *)d_img; q.bi = d_bi; q.bh = d_bh;
+    q.hb = (char *)d_work; q.hb_parity_bytes = parity;
+    q.c0 = d_c0; q.cT = d_cT; q.hT = d_hT; q.out = d_out;
+    q.fault = fault;
+    q.spin_ticks = (unsigned long long)(opt.rec_spin_us > 0 ? opt.rec_spin_us : 0) * 100ull;
+    q.B = B; q.T = T; q.H = H; q.in = in; q.NCT = NCT; q.return_sequences = return_sequences;
+#ifdef NNTK_REC_STAMPS
+    q.stamp = nullptr;
+    const char *stamp_path = getenv("NNTK_REC_STAMP_FILE");
+    if (stamp_path) {
+        if (hipMalloc((void **)&q.stamp, (size_t)T * 16 * 8) != hipSuccess) return nntk_fail_msg("stamp alloc");
+        (void)hipMemset(q.stamp, 0, (size_t)T * 16 * 8);
+    }
+#endif
+    const int span = nntk_prof_span_begin(NNTK_SPAN_REC);
+    nntk_persistent_launch_begin();
+    for (int bt0 = 0; bt0 < nbt_total; bt0 += tiles_per_launch) {
+        const int nbt = nbt_total - bt0 < tiles_per_launch ? nbt_total - bt0 : tiles_per_launch;
+        q.NBT = nbt; q.b_base = bt0 * 64;
+        q.cnt = cnt + (size_t)bt0 * 2 * RR_CNT_STRIDE;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(nbt * NCT)), dim3(256), lds, nntk_stream(), q);
+    }
+    const int copy_rc = nntk_fault_enqueue_copy();
+    nntk_persistent_launch_end();
+    if (copy_rc) return -1;
+    nntk_prof_span_end(span, (nbt_total + tiles_per_launch - 1) / tiles_per_launch, T);
+#ifdef NNTK_REC_STAMPS
+    if (q.stamp) {
+        (void)hipStreamSynchronize(nntk_stream());
+        unsigned long long *hs = (unsigned long long *)malloc((size_t)T * 16 * 8);
+        (void)hipMemcpy(hs, q.stamp, (size_t)T * 16 * 8, hipMemcpyDeviceToHost);
+        FILE *f = fopen(stamp_path, "wb");
+        if (f) { fwrite(hs, 8, (size_t)T * 16, f); fclose(f); }
+        free(hs); (void)hipFree(q.stamp);
+    }
+#endif
+    NNTK_LAUNCH_CHECK("lstm_rr_kernel");
+    return 0;
+}

@@ -43,6 +43,7 @@ static const OptDesc g_opt_table[] = {
     {"rec_spin_us", "NNTK_REC_SPIN_US", &NntkOptions::rec_spin_us},
     {"rec_stream", "NNTK_REC_STREAM", &NntkOptions::rec_stream},
     {"rec_fused2", "NNTK_REC_FUSED2", &NntkOptions::rec_fused2},
+    {"rec_rr", "NNTK_REC_RR", &NntkOptions::rec_rr},
     {"spec_ppw", "NNTK_SPEC_PPW", &NntkOptions::spec_ppw},
     {"spec_variant", "NNTK_SPEC_VARIANT", &NntkOptions::spec_variant},
     {"bn_fast", "NNTK_BN_FAST", &NntkOptions::bn_fast},

@@ -42,6 +42,8 @@ typedef struct {
     float *d_wp, *d_bi, *d_ut, *d_bh;
     float *d_wt;                /* W^T packed like U^T (only when in == H): layer-2 operand of the fused two-layer GRU */
     int wt_valid;
+    float *d_rr;                /* LSTM: weight images of the register-resident split-bf16 kernel (recurrent_rr.hip), made on first use */
+    int rr_valid;
     /* persistent single-sequence state [H], double-buffered: a stateful call reads state[cur] and writes
      * state[cur ^ 1]; cur flips only once the call is known to be good, so a call that has to be repeated
      * (persistent-kernel fault, see core_apply_host) still finds its initial state intact */
@@ -54,7 +56,7 @@ typedef struct {
     unsigned *d_done;
     volatile unsigned *flag;
     unsigned seq;
-    nntk_devbuf d_in, d_out, d_xw, d_work;
+    nntk_devbuf d_in, d_out, d_xw, d_work, d_work_rr;
 } rec_core;
 
 static int core_init(rec_core *c, int G, RecurrentConfig base) {
@@ -84,10 +86,11 @@ static int core_init(rec_core *c, int G, RecurrentConfig base) {
 static void core_free(rec_core *c) {
     nntk_shim_synchronize();
     nntk_shim_free(c->d_wp); nntk_shim_free(c->d_bi); nntk_shim_free(c->d_ut); nntk_shim_free(c->d_bh); nntk_shim_free(c->d_wt);
+    nntk_shim_free(c->d_rr);
     nntk_shim_free(c->d_h[0]);
     nntk_shim_host_free(c->pin_in); nntk_shim_host_free(c->pin_out); nntk_shim_host_free((void *)c->flag);
     nntk_shim_free(c->d_done);
-    nntk_devbuf_free(&c->d_in); nntk_devbuf_free(&c->d_out); nntk_devbuf_free(&c->d_xw); nntk_devbuf_free(&c->d_work);
+    nntk_devbuf_free(&c->d_in); nntk_devbuf_free(&c->d_out); nntk_devbuf_free(&c->d_xw); nntk_devbuf_free(&c->d_work); nntk_devbuf_free(&c->d_work_rr);
     nntk_wblock_free(&c->wb);
     free(c->weights);
 }
@@ -112,6 +115,7 @@ static int core_upload(rec_core *c) {
     free(tmp);
     if (rc) return rc;
     c->wt_valid = 0;
+    c->rr_valid = 0;
     nntk_wblock_mark_uploaded(&c->wb);
     return 0;
 }
@@ -153,11 +157,46 @@ static int core_broadcast(rec_core *c, int root) {
     return core_upload(c);
 }
 
+/* LSTM batches of at least this many sequences take the register-resident split-bf16 kernel (recurrent_rr.hip: x W fused
+ * into the step, no [T, B, 4H] tensor); smaller ones are latency-bound on the hand-off chain, where the exact-f32
+ * kernel -- whose chain the streaming path reproduces bit for bit -- is as fast.  Option rec_rr = 1 takes it always. */
+#define NNTK_RR_MIN_BATCH 32
+
+static int lstm_std_acts(const int *acts) {
+    return acts[0] == NNTK_ACT_SIGMOID && acts[1] == NNTK_ACT_SIGMOID && acts[2] == NNTK_ACT_TANH &&
+           acts[3] == NNTK_ACT_SIGMOID && acts[4] == NNTK_ACT_TANH;
+}
+
+/* 0 = ran; 1 = not taken; -1 = error */
+static int core_try_lstm_rr(rec_core *c, int use_bh, const int *acts, const float *d_in, float *d_out, int B, int stateful) {
+    int on = -1;
+    (void)nntk_shim_get_option("rec_rr", &on);
+    if (on == 0 || c->G != 4 || !lstm_std_acts(acts)) return 1;
+    if (on != 1 && B < NNTK_RR_MIN_BATCH) return 1;
+    size_t img = nntk_shim_lstm_rr_image_floats(c->H, c->in);
+    if (!img) return 1;
+    if (!c->rr_valid) {
+        if (!c->d_rr && !(c->d_rr = (float *)nntk_shim_malloc(img * sizeof(float)))) return -1;
+        if (nntk_shim_lstm_rr_pack(c->d_ut, c->d_wp, c->d_rr, c->H, c->in)) return -1;
+        c->rr_valid = 1;
+    }
+    float *d_work = nntk_devbuf_reserve(&c->d_work_rr, nntk_shim_lstm_rr_work_floats(B, c->H));
+    if (!d_work) return -1;
+    const float *h0 = stateful ? c->d_h[c->cur] : NULL, *c0 = stateful ? c->d_c[c->cur] : NULL;
+    float *hT = stateful ? c->d_h[c->cur ^ 1] : NULL, *cT = stateful ? c->d_c[c->cur ^ 1] : NULL;
+    return nntk_shim_lstm_rr(d_in, c->d_rr, c->d_bi, use_bh ? c->d_bh : NULL, h0, c0, d_out, hT, cT, d_work,
+                             B, c->T, c->in, c->H, c->return_sequences);
+}
+
 /* stateful != 0: continue from / store into the handle's state (B must be 1) */
 static int core_apply_device(rec_core *c, int is_lstm, int use_bh, const int *acts, const float *scales,
                              const float *d_in, float *d_out, int B, int stateful) {
     int G = c->G, H = c->H, T = c->T;
     if (B <= 0 || T <= 0) return 0;
+    if (is_lstm) {
+        int rc = core_try_lstm_rr(c, use_bh, acts, d_in, d_out, B, stateful);
+        if (rc <= 0) return rc;
+    }
     float *d_xw = nntk_devbuf_reserve(&c->d_xw, (size_t)T * B * G * H);
     float *d_work = nntk_devbuf_reserve(&c->d_work, nntk_shim_recurrent_work_floats(B, H));
     if (!d_xw || !d_work) return -1;

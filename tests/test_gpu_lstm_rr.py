@@ -1,0 +1,190 @@
+"""GPU parity of the register-resident split-bf16 LSTM kernel (csrc/hip/recurrent_rr.hip: lstm_rr_kernel), the kernel
+behind the stack benchmark's LSTM phase: x W fused into the step, U^T in registers, h exchanged pre-split.
+
+Reference semantics: layers/lstm.c:185-239 (cell), :426-475 (batch forward).  Checked against the oracle (and torch
+float64 for the long recurrence), against the exact-f32 path (rec_rr = 0), and for the properties the path promises:
+a shard gives the same bits as the whole batch, rows do not contaminate each other, carried state works.
+"""
+import numpy as np
+import pytest
+
+import oracle as O
+from nntoolkitcore_amd import capi, layers as NL
+
+pytestmark = pytest.mark.gpu
+
+
+def rng(seed):
+    return np.random.default_rng(seed)
+
+
+def u(r, *shape, sc=1.0):
+    return r.uniform(-sc, sc, shape).astype(np.float32)
+
+
+def lstm_weights(r, I, H):
+    return u(r, I, 4 * H, sc=I ** -0.5), u(r, H, 4 * H, sc=H ** -0.5), u(r, 4 * H, sc=0.1), u(r, 4 * H, sc=0.1)
+
+
+def _took_rr(lstm, xd):
+    """True when the call ran on lstm_rr_kernel: the result then differs from the exact-f32 path in the last bits."""
+    a = lstm.apply_device(xd).clone()
+    capi.set_option("rec_rr", 0)
+    b = lstm.apply_device(xd).clone()
+    capi.set_option("rec_rr", "auto")
+    return not bool((a == b).all()), a, b
+
+
+@pytest.mark.parametrize("B,I,H,T,seq,v2", [
+    (64, 128, 512, 20, True, True),       # the stack's LSTM shape, one batch tile, KH = 8 / KX = 2
+    (70, 64, 256, 33, True, False),       # ragged second tile, Keras one-bias form, KH = 4 / KX = 1
+    (130, 40, 128, 9, False, True),       # last state only; in and H padded (40 -> 64, 128 -> 256 k steps)
+    (33, 256, 192, 12, True, True),       # KH = 4 / KX = 4; one row in the second half-tile
+    (96, 128, 320, 14, True, True),       # H between the compiled depths: 20 column tiles, padded k steps
+    (40, 8, 64, 25, True, True),          # smallest shapes the kernel takes
+    (200, 72, 512, 7, True, True),        # KH = 8 / KX = 2 with in = 72 (padded)
+])
+def test_lstm_rr_matches_oracle(gpu, B, I, H, T, seq, v2):
+    import torch
+    r = rng(B * 13 + H + T)
+    x = u(r, B, T, I)
+    W, U, bi, bh = lstm_weights(r, I, H)
+    lstm = NL.LSTM(I, H, seq, T, v2=v2)
+    lstm.set_weights(W, U, bi, bh)
+    xd = torch.from_numpy(x).cuda()
+    took, got, exact = _took_rr(lstm, xd)
+    assert took, "the call did not run on lstm_rr_kernel"
+    assert capi.load().nntk_hip_device_status() == 0
+    ref = O.lstm(x, W, U, bi, bh, v2=v2, return_sequences=seq)
+    ref = ref[0] if isinstance(ref, tuple) else ref
+    e_rr, e_ex = float(np.abs(got.cpu().numpy() - ref).max()), float(np.abs(exact.cpu().numpy() - ref).max())
+    print("lstm_rr B=%d I=%d H=%d T=%d: max abs err vs oracle %.2e (exact-f32 path %.2e)" % (B, I, H, T, e_rr, e_ex))
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    # host-pointer batch call: same kernel, same bits
+    assert np.array_equal(lstm.apply(x), got.cpu().numpy())
+    lstm.destroy()
+
+
+def test_lstm_rr_shards_are_bit_identical_and_rows_are_isolated(gpu):
+    import torch
+    r = rng(7)
+    B, I, H, T = 150, 128, 512, 11
+    x = u(r, B, T, I)
+    W, U, bi, bh = lstm_weights(r, I, H)
+    lstm = NL.LSTM(I, H, True, T, v2=True)
+    lstm.set_weights(W, U, bi, bh)
+    xd = torch.from_numpy(x).cuda()
+    whole = lstm.apply_device(xd).clone()
+    parts = torch.cat([lstm.apply_device(xd[:83].contiguous()).clone(), lstm.apply_device(xd[83:].contiguous()).clone()])
+    assert torch.equal(whole, parts)                   # a row's result does not depend on its tile / half / lane group
+    assert torch.equal(whole, lstm.apply_device(xd))   # reproducible
+    # one poisoned sequence (NaN and inf inputs) stays alone: every other row keeps its bits
+    xp = xd.clone()
+    xp[40, 3, 17] = float("nan")
+    xp[101, 0, 5] = float("inf")
+    bad = lstm.apply_device(xp)
+    keep = [i for i in range(B) if i not in (40, 101)]
+    assert torch.equal(bad[keep], whole[keep])
+    assert not torch.isfinite(bad[40, 3:]).all() and torch.equal(bad[40, :3], whole[40, :3])
+    lstm.destroy()
+
+
+def test_lstm_rr_carried_state_and_final_state(gpu):
+    """h_0 / c_0 taken from, and h_T / c_T left in, the handle (the reference's stateful single-sequence API, lstm.c:241-268)
+    through the register-resident kernel (rec_rr = 1 forces it for B = 1; rec_stream = 0 keeps the call off the streaming
+    kernel): three consecutive calls equal one long oracle run."""
+    r = rng(11)
+    I, H, T = 64, 128, 40
+    W, U, bi, bh = lstm_weights(r, I, H)
+    x = u(r, 3 * T, I)
+    capi.set_option("rec_rr", 1)
+    capi.set_option("rec_stream", 0)
+    lstm = NL.LSTM(I, H, True, T, v2=True)
+    lstm.set_weights(W, U, bi, bh)
+    got = np.concatenate([lstm.apply(x[i * T:(i + 1) * T]) for i in range(3)])
+    ref, hT, cT = O.lstm(x, W, U, bi, bh, v2=True)
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
+    h, c = lstm.state()
+    np.testing.assert_allclose(h, hT, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(c, cT, rtol=1e-5, atol=2e-5)
+    lstm.reset_state()
+    np.testing.assert_allclose(lstm.apply(x[:T]), ref[:T], rtol=1e-5, atol=1e-5)
+    lstm.destroy()
+
+
+def test_lstm_rr_nondefault_activations_fall_back(gpu):
+    import ctypes as C
+    L = capi.load()
+    r = rng(13)
+    B, I, H, T = 48, 64, 128, 6
+    x = u(r, B, T, I)
+    W, U, bi, bh = lstm_weights(r, I, H)
+    acts = L.LSTMActivationsCreate(L.ActivationFunctionCreateSigmoid(H), L.ActivationFunctionCreateSigmoid(H),
+                                   L.ActivationFunctionCreateReLU(H, C.c_float(0.5)), L.ActivationFunctionCreateSigmoid(H),
+                                   L.ActivationFunctionCreateTanh(H))
+    lstm = NL.LSTM(I, H, True, T, v2=True, acts=acts)
+    lstm.set_weights(W, U, bi, bh)
+    ref = O.lstm(x, W, U, bi, bh, v2=True, acts=(O.ACT_SIGMOID, O.ACT_SIGMOID, O.ACT_RELU, O.ACT_SIGMOID, O.ACT_TANH),
+                 relu_a=(1, 1, 0.5, 1, 1))
+    ref = ref[0] if isinstance(ref, tuple) else ref
+    np.testing.assert_allclose(lstm.apply(x), ref, rtol=1e-5, atol=1e-5)
+    lstm.destroy()
+
+
+def _torch64_lstm(x, W, U, bi, bh):
+    import torch
+    H = U.shape[0]
+    m = torch.nn.LSTM(W.shape[0], H, batch_first=True).double()
+    with torch.no_grad():
+        m.weight_ih_l0.copy_(torch.tensor(W).double().T); m.weight_hh_l0.copy_(torch.tensor(U).double().T)
+        m.bias_ih_l0.copy_(torch.tensor(bi).double()); m.bias_hh_l0.copy_(torch.tensor(bh).double())
+        return m(torch.tensor(x).double())[0].numpy()
+
+
+def test_achieved_error_lstm_rr_512_T996(gpu):
+    """The stack's LSTM(128 -> 512, v2) over 996 steps on the register-resident kernel, one full batch tile: the
+    deviation from the oracle (libm gates, scalar k order) and from torch float64 as NUMBERS, asserted at measured x 3."""
+    import torch
+    r = rng(501)
+    B, I, H, T = 64, 128, 512, 996
+    x = r.standard_normal((B, T, I)).astype(np.float32)
+    uw = lambda fan, *s: r.uniform(-fan ** -0.5, fan ** -0.5, s).astype(np.float32)
+    W, U, bi, bh = uw(I, I, 4 * H), uw(H, H, 4 * H), uw(H, 4 * H), uw(H, 4 * H)
+    lstm = NL.LSTM(I, H, True, T, v2=True)
+    lstm.set_weights(W, U, bi, bh)
+    xd = torch.from_numpy(x).cuda()
+    took, got, exact = _took_rr(lstm, xd)
+    assert took
+    rows = [0, 31, 32, 63]
+    got, exact = got[rows].cpu().numpy(), exact[rows].cpu().numpy()
+    ref = O.lstm(x[rows], W, U, bi, bh, v2=True)
+    ref = ref[0] if isinstance(ref, tuple) else ref
+    r64 = _torch64_lstm(x[rows], W, U, bi, bh)
+    e_or, e_64 = float(np.abs(got - ref).max()), float(np.abs(got - r64).max())
+    x_or, x_64 = float(np.abs(exact - ref).max()), float(np.abs(exact - r64).max())
+    print("lstm_rr LSTM(128->512, v2) T=996: max abs err vs oracle %.2e, vs torch float64 %.2e "
+          "(exact-f32 kernel: %.2e / %.2e; oracle vs float64 %.2e)" % (e_or, e_64, x_or, x_64, float(np.abs(ref - r64).max())))
+    assert e_or < 3e-6 and e_64 < 3e-6
+    lstm.destroy()
+
+
+def test_full_size_lstm_rr_stack_shard(gpu):
+    """B = 512 x T = 996: the bench's own launch (8 batch tiles x 32 column tiles = all 256 CUs), rows of the first and
+    last tile and of both halves against the oracle."""
+    import torch
+    r = rng(512)
+    B, I, H, T = 512, 128, 512, 996
+    x = torch.randn(B, T, I, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    uw = lambda fan, *s: r.uniform(-fan ** -0.5, fan ** -0.5, s).astype(np.float32)
+    W, U, bi, bh = uw(I, I, 4 * H), uw(H, H, 4 * H), uw(H, 4 * H), uw(H, 4 * H)
+    lstm = NL.LSTM(I, H, True, T, v2=True)
+    lstm.set_weights(W, U, bi, bh)
+    y = lstm.apply_device(x)
+    assert capi.load().nntk_hip_device_status() == 0
+    rows = [0, 40, 300, 479, 511]
+    ref = O.lstm(x[rows].cpu().numpy(), W, U, bi, bh, v2=True)
+    ref = ref[0] if isinstance(ref, tuple) else ref
+    e = float(np.abs(y[rows].cpu().numpy() - ref).max())
+    print("lstm_rr B=512 T=996: max abs err vs oracle %.2e" % e)
+    assert e < 3e-6
+    lstm.destroy()
