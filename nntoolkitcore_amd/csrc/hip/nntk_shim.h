@@ -173,7 +173,7 @@ int nntk_shim_lstm(const float *d_xw, const float *d_ut, const float *d_bh,
                    float *d_work, int B, int T, int H, int return_sequences, const int acts[5], const float act_scales[5]);
 
 /* Register-resident split-bf16 LSTM with the input projection fused into the step (recurrent_rr.hip): standard
- * activations, H % 16 == 0, 64 <= H <= 512, in % 8 == 0, in <= 256.  d_x [B][T][in]; d_img = weight images made by
+ * activations, H % 16 == 0, 64 <= H <= 512, in % 8 == 0, in <= 128.  d_x [B][T][in]; d_img = weight images made by
  * nntk_shim_lstm_rr_pack from the per-gate U^T (d_ut) and the packed W^T (d_wp); d_bh NULL for the one-bias form.
  * nntk_shim_lstm_rr returns 1 when the shape / configuration is not taken (nothing launched). */
 size_t nntk_shim_lstm_rr_image_floats(int H, int in);           /* 0: shape not taken */

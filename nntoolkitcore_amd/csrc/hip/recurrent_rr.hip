@@ -43,7 +43,17 @@ typedef __bf16 rr_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float rr_f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned rr_v4u __attribute__((ext_vector_type(4)));
 
-#define RR_CNT_STRIDE 64          // uints between arrival counters (256 B: atomics execute at the memory side)
+#define RR_FLAGS 128              // flag words per (batch tile, half): 4 waves x 32 column tiles, 512 contiguous bytes
+#ifndef RR_POLL_LEAD
+#define RR_POLL_LEAD 1           // the flags are requested this many k steps before they are looked at
+#endif
+#ifndef RR_NPRE
+#define RR_NPRE 2                // operand k steps requested ahead, at the end of the other half's sequence (the rest: own sequence)
+#endif
+#ifndef RR_S_E1
+#define RR_S_E1 3                // k step at which a half's publication is taken to have drained (tools/rr_stamps.py)
+#endif
+
 #define RR_HX_LD 20               // floats per row of the h exchange image (16-byte aligned rows)
 
 __device__ __forceinline__ unsigned rr_cvt_pk(float a, float b) {       // RNE, a in the low half
@@ -146,41 +156,80 @@ struct RRParams {
     const float *c0;           // [B][H] or NULL (zeros)
     float *cT, *hT;            // [B][H] or NULL
     float *out;                // [B][T][H] or [B][H]
-    unsigned *cnt;             // [NBT][2 halves] x RR_CNT_STRIDE, zeroed before the launch
+    unsigned *flags;           // [NBT][2 halves][RR_FLAGS], zeroed before the launch
     unsigned *fault;
     unsigned long long spin_ticks;
     int B, T, H, in, NBT, NCT, b_base, return_sequences;
 #ifdef NNTK_REC_STAMPS
-    unsigned long long *stamp; // [T][2 halves][8] s_memtime of workgroup 0, wave 0 (diagnostics build only)
+    unsigned long long *stamp; // [T][2 halves][16] s_memtime of workgroup 0, wave 0 (diagnostics build only)
 #endif
 };
+// timing ablations only (WRONG results; tools/rr_ablate.sh builds one library per mask): -DNNTK_RR_DBG=<mask>,
+// 1 no operand loads, 2 no finish, 4 no arrive / poll, 8 no x, 16 no MFMAs, 32 no partial-sum writes.  Compile-time on
+// purpose: a run-time mask changed the register allocation of the whole kernel (2x slower with the mask at 0).
+#ifdef NNTK_RR_DBG
+#define RR_DBG(bit) ((NNTK_RR_DBG) & (bit))
+#else
+#define RR_DBG(bit) 0
+#endif
 #ifdef NNTK_REC_STAMPS
 #define RR_STAMP(half, t, i) do { if (p.stamp && blockIdx.x == 0 && w == 0 && lane == 0) \
-        p.stamp[((size_t)(t) * 2 + (half)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+        p.stamp[((size_t)(t) * 2 + (half)) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define RR_STAMP(half, t, i) do {} while (0)
 #endif
 
 // raw barrier: LDS traffic ordered, vector-memory operations (the operand prefetch!) left in flight
 #define RR_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#ifndef RR_NO_PIN
+#define RR_PIN_A(v) asm volatile("" : "+a"(v))      // accumulator-file registers: MFMA operands only, never copied about
+#else
+#define RR_PIN_A(v) do {} while (0)
+#endif
+#define RR_OOB 0x7ffffff0          // out-of-range vector offset: a buffer load returns 0, a buffer store is dropped
 
-__device__ __forceinline__ void rr_lds_wait_ge(const unsigned *wd, unsigned target) {
-    while (__hip_atomic_load(wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
-    asm volatile("" ::: "memory");
-}
-
+// The kernel is a software pipeline of HALF-STEPS.  Half-step s multiplies half Y = s & 1 at timestep t = s >> 1 (its
+// operand fetched during half-step s - 1) and, sliced between the k steps of that MFMA sequence, FINISHES half X = 1 - Y,
+// whose partial sums half-step s - 1 left in LDS:
+//   k step S_RED   barrier; partial sums of X read and added (fixed order); gates; h written to the exchange image
+//          S_PUB   barrier; 16 lanes per wave assemble 8 consecutive hidden units of a row, split them into the three bf16
+//                  images and publish them write-through
+//          S_XSPL  x_t of X's next step split into its three images; x_{t+1} of Y requested (a whole half-step ahead)
+//          S_E1    the publication has had S_E1 - S_PUB k steps to drain: vmcnt(0), then every wave raises ITS OWN flag
+//          S_E2-1  every wave requests the 128 flags (4 waves x 32 column tiles) of X's next operand: two loads
+//          S_E2    check them (spin only if one is missing), store the f32 layer output of X, request the 24 operand fragments
+// so that the vector ALU, LDS and memory work of one half runs in the shadow of the other half's MFMAs (an MFMA holds the
+// issue port 8 of its 32 cycles).  Every vector-memory operation is a branch-free buffer operation (lanes that must not
+// load / store get an out-of-range offset), so the steady-state half-step is straight-line code apart from the poll.
+//
+// Signalling is by FLAG WORDS, not by an arrival counter: wave w of column tile ct stores (t + 1) write-through into
+// flags[batch tile][half][w * 32 + ct] once its own publishing stores have drained, and a consumer wave reads all 128
+// words (512 contiguous bytes) with two wave-wide sc1 loads.  Against the agent-scope counter of rec_persistent_kernel
+// this removes the serialisation of 32 read-modify-writes at the memory side (~12 ns each), the cross-wave gather in front of
+// the add, and makes the arrival a plain store.  Valid by the guide's sc1 hand-off table: every flag covers exactly
+// the stores of the wave that raises it, after that wave's vmcnt(0).
 // KH / KX: k steps (of 16) per wavefront for the h / x part: H <= 64 KH, in <= 64 KX (zero padded).
-// E1 / E2: k-step index inside a half's MFMA sequence (KX + KH steps) at which the OTHER half's arrival / poll + loads go.
-template <int KH, int KX, int E1, int E2>
+template <int KH, int KX>
 __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
     constexpr int NKS = 4 * KH;                       // k steps of the hand-off buffer (>= H / 16)
     constexpr int NST = KX + KH;                      // k steps one wavefront multiplies per half
+    constexpr int S_RED = 0, S_PUB = 1;
+    constexpr int S_XSPL = KX > 2 ? KX : 2;
+    constexpr int S_E1 = NST >= 8 ? RR_S_E1 : 3;
+    constexpr int S_E2 = NST - 1;
+    // Operand schedule: the fragments of h k step i are requested NPRE k steps ... see issue_h below: i < NPRE at S_E2 of the
+    // OTHER half's sequence (after the poll), i >= NPRE at k step i - NPRE of the half's own sequence (needed at KX + i).
+    constexpr int NPRE = RR_NPRE < KH ? RR_NPRE : KH;
+    // vector-memory operations a wave issues between a publication (S_PUB) and its arrival (S_E1): the own-sequence operand
+    // requests of k steps S_PUB .. S_E1 - 1 and the x request at S_XSPL -- what the arrival's counted wait leaves in flight
+    constexpr int own_lo = S_PUB + NPRE < KH ? S_PUB + NPRE : KH, own_hi = S_E1 + NPRE < KH ? S_E1 + NPRE : KH;
+    constexpr int N_AFTER_PUB = 3 * (own_hi - own_lo) + 2 * KX;
+    static_assert(NST >= 5 && S_E1 < S_E2 && S_E1 > S_PUB && S_XSPL >= KX && S_XSPL < S_E1 && S_XSPL > S_PUB && KH - NPRE <= S_E2, "slice schedule");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     rr_v4u *ULs = reinterpret_cast<rr_v4u *>(smem);                       // [4][KH][2] blocks
     rr_v4u *WXs = ULs + 4 * KH * 2 * 64;                                  // [4][KX][2][3] blocks
     rr_v4u *red = WXs + 4 * KX * 6 * 64;                                  // [dst 4][src 4][2] blocks: split-K exchange
     float *hx = reinterpret_cast<float *>(red + 32 * 64);                 // [32][RR_HX_LD] h exchange
-    unsigned *syncw = reinterpret_cast<unsigned *>(hx + 32 * RR_HX_LD);   // [0..1] drained waves, [2..3] poll passed (per half)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -190,7 +239,8 @@ __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
     const int ct = blockIdx.x / p.NBT;
     const int bt_abs = p.b_base / 64 + bt;
     const int b0 = p.b_base + bt * 64;
-    const int H = p.H;
+    const int H = p.H, T = p.T;
+    const int rows_valid = p.B - b0 < 64 ? p.B - b0 : 64;
 
     // ---- resident operands ----
     const rr_v4u *img = p.img + (size_t)ct * rr_blocks_per_ct(KH, KX) * 64;
@@ -200,14 +250,15 @@ __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < 2; ++m) {
                 uh[i][mt][m] = __builtin_bit_cast(rr_bf16x8, img[((((size_t)w * KH + i) * 2 + mt) * 2 + m) * 64 + lane]);
+                RR_PIN_A(uh[i][mt][m]);
+            }
     {
         const rr_v4u *src = img + (size_t)4 * KH * 4 * 64;                // UL then WX, contiguous, same order as in LDS
         constexpr int n16 = (4 * KH * 2 + 4 * KX * 6) * 64;
         for (int e = tid; e < n16; e += 256) ULs[e] = src[e];
     }
-    if (tid < 4) syncw[tid] = 0u;
     // this lane finishes hidden units jf, jf + 1 (all four gates) of batch row n of each half
     const int jl = 8 * kh + 4 * (w >> 1) + 2 * (w & 1);
     const int jf = 16 * ct + jl;
@@ -225,166 +276,102 @@ __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
             const int row = b0 + half * 32 + n;
             cst[half][e] = (p.c0 && row < p.B && jf + e < H) ? p.c0[(size_t)row * H + jf + e] : 0.0f;
         }
-    // publishing lanes: wave w takes rows 8 w .. 8 w + 7 of a half (16 lanes: 8 rows x 2 k halves)
-    const bool pub_lane = (n >> 3) == w;
+    // ---- buffer descriptors and per-lane offsets (everything that must be clipped rides in the range-checked vector offset) ----
     const int hb_bytes = (int)p.hb_parity_bytes;
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void *)p.hb, 0, hb_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.hb + p.hb_parity_bytes), 0, hb_bytes, 0x00020000);
     const int lane16 = lane * 16;
+    // x: the tile's rows [b0, b0 + rows_valid) of [B][T][in]; rows past the batch are out of range (zeros)
+    const long x_row_bytes = (long)p.T * p.in * 4;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + (size_t)b0 * p.T * p.in), 0,
+                                                                          (int)(rows_valid * x_row_bytes), 0x00020000);
+    int xvo[KX][2];
+#pragma unroll
+    for (int ix = 0; ix < KX; ++ix)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int k = (w * KX + ix) * 16 + 8 * kh + 4 * q;
+            xvo[ix][q] = k < p.in ? (int)(n * x_row_bytes) + k * 4 : RR_OOB;
+        }
+    // publishing lanes: wave w takes rows 8 w .. 8 w + 7 of a half (16 lanes: 8 rows x 2 k halves)
+    const bool pub_lane = (n >> 3) == w;
+    const long o_row_bytes = (long)(p.return_sequences ? p.T : 1) * H * 4;
+    const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(p.out + (size_t)b0 * (p.return_sequences ? p.T : 1) * H), 0, (int)(rows_valid * o_row_bytes), 0x00020000);
+    // one offset each for both halves (the half rides in the scalar offset): lanes that do not publish are out of range;
+    // output rows past the batch fall outside the descriptor; hand-off rows past the batch are written too (padding rows
+    // compute on zero inputs: finite, read only by themselves)
+    const int pub_vo = pub_lane ? lane16 : RR_OOB;
+    const int out_vo = pub_lane ? (int)(n * o_row_bytes) + (16 * ct + 8 * kh) * 4 : RR_OOB;
+    const int out_half = (int)(32 * o_row_bytes);
     RR_BARRIER();
 
-    rr_v4u hf[2][KH][3];           // the h operand of each half: issued at E2 of the other half's sequence
-    rr_v4u xr[2][KX][2];           // raw x_t (f32) of each half, split right before use
-    float hkeep[2][8];             // the publishing lanes' last h row piece (final state / last output)
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using Tt = std::true_type;
+    using Ff = std::false_type;
+    rr_v4u hf[2][KH][3];           // the h operand of each half
+    rr_v4u xr[KX][2];              // raw x_t (f32) of the half that multiplies next
+    rr_bf16x8 xf[KX][3];           // ... and its three bf16 images
 
-    auto issue_h = [&](int half, int t) __attribute__((always_inline)) {
+    // The operand's 3 KH fragment loads are SPREAD over the MFMA sequences instead of issued in one burst: a 1 KB wave-wide load
+    // occupies the CU's address path for ~16 cycles and the four wavefronts (in lockstep) share that path, so a burst of 24
+    // stalls the issuing wave -- and its MFMAs -- for ~1.5 k cycles.  Only the first NPRE k steps go out ahead (after the poll,
+    // at the end of the other half's sequence); k step i >= NPRE is requested at k step i - NPRE of the half's own sequence,
+    // KX + NPRE k steps before the MFMAs that consume it.
+    auto issue_h = [&](auto half_tag, int t, int j0, int j1) __attribute__((always_inline)) {      // fragments [j0, j1): constants once unrolled
+        constexpr int half = decltype(half_tag)::value;
         const int so = ((bt_abs * 2 + half) * NKS + w * KH) * 3 * 1024;
 #pragma unroll
-        for (int i = 0; i < KH; ++i)
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                if (t & 1) hf[half][i][m] = __builtin_amdgcn_raw_buffer_load_b128(rs1, lane16, so + (i * 3 + m) * 1024, 16 /* sc1 */);
-                else       hf[half][i][m] = __builtin_amdgcn_raw_buffer_load_b128(rs0, lane16, so + (i * 3 + m) * 1024, 16 /* sc1 */);
-            }
+        for (int blk = 0; blk < 3 * KH; ++blk) {
+            if (blk < j0 || blk >= j1) continue;
+            // four 1 KB blocks per scalar offset: the rest of the address rides in the instruction's immediate
+            const int i = blk / 3, m = blk % 3;
+            if (t & 1) hf[half][i][m] = __builtin_amdgcn_raw_buffer_load_b128(rs1, lane16 + (blk & 3) * 1024, so + (blk >> 2) * 4096, 16 /* sc1 */);
+            else       hf[half][i][m] = __builtin_amdgcn_raw_buffer_load_b128(rs0, lane16 + (blk & 3) * 1024, so + (blk >> 2) * 4096, 16 /* sc1 */);
+        }
     };
     auto issue_x = [&](int half, int t) __attribute__((always_inline)) {
-        const int row = b0 + half * 32 + n;
-        const float *xp = p.x + ((size_t)row * p.T + t) * p.in + (w * KX) * 16 + 8 * kh;
+        const int so = (int)((half * 32) * x_row_bytes) + t * p.in * 4;
 #pragma unroll
         for (int ix = 0; ix < KX; ++ix)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                rr_v4u v = (rr_v4u){0u, 0u, 0u, 0u};
-                if (row < p.B && (w * KX + ix) * 16 + 8 * kh + 4 * q < p.in) v = *reinterpret_cast<const rr_v4u *>(xp + ix * 16 + 4 * q);
-                xr[half][ix][q] = v;
-            }
+            for (int q = 0; q < 2; ++q) xr[ix][q] = __builtin_amdgcn_raw_buffer_load_b128(rsx, xvo[ix][q], so, 0);
     };
-    // the OTHER half's arrival: its publishing stores (end of the previous half-step) have had a third of this MFMA
-    // sequence to drain; every wave waits for its own, counts in on an LDS word, the last one signals
-    auto arrive = [&](int half, unsigned seq /* arrivals of this half so far */) __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) {
-            const unsigned old = __hip_atomic_fetch_add(&syncw[half], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (old == 4u * seq + 3u)
-                __hip_atomic_fetch_add(p.cnt + ((size_t)bt * 2 + half) * RR_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    };
-    // wait until every column tile of this batch tile has published h_{t-1} of `half`: one lane polls, the others follow
-    auto poll = [&](int half, int t) __attribute__((always_inline)) {
-        if (w == 0) {
-            if (lane == 0) {
-                unsigned *cnt = p.cnt + ((size_t)bt * 2 + half) * RR_CNT_STRIDE;
-                const unsigned target = (unsigned)p.NCT * (unsigned)t;
-                const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-                bool expired = p.spin_ticks == 0;                    // 0 = fault injection (tests)
-                while (!expired && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                    __builtin_amdgcn_s_sleep(1);
-                    expired = __builtin_amdgcn_s_memrealtime() - t_start > p.spin_ticks;
-                }
-                if (expired) {
-                    __hip_atomic_fetch_or(p.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_fetch_or(cnt, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __hip_atomic_store(&syncw[2 + half], (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        } else {
-            rr_lds_wait_ge(&syncw[2 + half], (unsigned)t);
-        }
-    };
-
-    // one half-step: multiply `half` at step t; inside the sequence serve the other half: `arr_seq` >= 0 -> arrive for its
-    // last publication; `nt` >= 0 -> poll for and fetch its operand of step nt
-    auto half_step = [&](auto half_tag, int t, int arr_seq, int nt) __attribute__((always_inline)) {
-        constexpr int half = decltype(half_tag)::value;
-        constexpr int other = 1 - half;
-        RR_STAMP(half, t, 0);
-        // ---- x_t of this half: split into the three bf16 images (fetched at E2 of the previous half-step) ----
-        rr_bf16x8 xf[KX][3];
+    auto split_x = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int ix = 0; ix < KX; ++ix) {
             float v[8];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                v[4 * q] = __uint_as_float(xr[half][ix][q].x); v[4 * q + 1] = __uint_as_float(xr[half][ix][q].y);
-                v[4 * q + 2] = __uint_as_float(xr[half][ix][q].z); v[4 * q + 3] = __uint_as_float(xr[half][ix][q].w);
+                v[4 * q] = __uint_as_float(xr[ix][q].x); v[4 * q + 1] = __uint_as_float(xr[ix][q].y);
+                v[4 * q + 2] = __uint_as_float(xr[ix][q].z); v[4 * q + 3] = __uint_as_float(xr[ix][q].w);
             }
             rr_v4u a, b, c;
             rr_split8(v, a, b, c);
             xf[ix][0] = __builtin_bit_cast(rr_bf16x8, a); xf[ix][1] = __builtin_bit_cast(rr_bf16x8, b); xf[ix][2] = __builtin_bit_cast(rr_bf16x8, c);
         }
-        f32x16 acc[2];
+    };
+    // ---- the finish of a half, in slices ----
+    float z[4][2];
+    auto fin_reduce = [&]() __attribute__((always_inline)) {
+        RR_BARRIER();                                   // every wave's partial sums are in `red`
+        rr_v4u s0[4], s1[4];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
-        // six products per (k step, tile), smallest terms first: (A image, B image) = (hi,lo) (lo,hi) (mid,mid) (hi,mid) (mid,hi) (hi,hi)
-        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
-#pragma unroll
-        for (int s = 0; s < NST; ++s) {
-            if (s == E1 && arr_seq >= 0) arrive(other, (unsigned)arr_seq);
-            if (s == E2 && nt >= 0) {
-                if (nt > 0) poll(other, nt);
-                issue_h(other, nt);
-                issue_x(other, nt);
-            }
-            if (s < KX) {                         // x part: W^T fragments from LDS
-                rr_bf16x8 a[2][3];
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int m = 0; m < 3; ++m)
-                        a[mt][m] = __builtin_bit_cast(rr_bf16x8, WXs[((((w * KX + s) * 2 + mt) * 3) + m) * 64 + lane]);
-#pragma unroll
-                for (int pr = 0; pr < 6; ++pr)
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][PA[pr]], xf[s][PB[pr]], acc[mt], 0, 0, 0);
-            } else {                              // h part: hi / mid from registers, lo from LDS
-                constexpr int dummy = 0; (void)dummy;
-                const int i = s - KX;
-                rr_bf16x8 ulo[2];
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) ulo[mt] = __builtin_bit_cast(rr_bf16x8, ULs[((w * KH + i) * 2 + mt) * 64 + lane]);
-                rr_bf16x8 b[3];
-#pragma unroll
-                for (int m = 0; m < 3; ++m) b[m] = __builtin_bit_cast(rr_bf16x8, hf[half][i][m]);
-#pragma unroll
-                for (int pr = 0; pr < 6; ++pr)
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        const rr_bf16x8 av = PA[pr] == 2 ? ulo[mt] : uh[i][mt][PA[pr]];
-                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b[PB[pr]], acc[mt], 0, 0, 0);
-                    }
-            }
+        for (int src = 0; src < 4; ++src) {
+            s0[src] = red[((w * 4 + src) * 2 + 0) * 64 + lane];
+            s1[src] = red[((w * 4 + src) * 2 + 1) * 64 + lane];
         }
-        RR_STAMP(half, t, 1);
-        // ---- split-K exchange: wave `dst` finishes registers 4 g + 2 (dst & 1) + {0, 1} of tile dst >> 1 ----
-#pragma unroll
-        for (int dst = 0; dst < 4; ++dst) {
-            const int mt = dst >> 1, o = 2 * (dst & 1);
-            const rr_v4u q0 = {__float_as_uint(acc[mt][o]), __float_as_uint(acc[mt][o + 1]), __float_as_uint(acc[mt][4 + o]), __float_as_uint(acc[mt][5 + o])};
-            const rr_v4u q1 = {__float_as_uint(acc[mt][8 + o]), __float_as_uint(acc[mt][9 + o]), __float_as_uint(acc[mt][12 + o]), __float_as_uint(acc[mt][13 + o])};
-            red[((dst * 4 + w) * 2 + 0) * 64 + lane] = q0;
-            red[((dst * 4 + w) * 2 + 1) * 64 + lane] = q1;
-        }
-        RR_BARRIER();
-        float z[4][2];
-        {
-            rr_v4u s0[4], s1[4];
-#pragma unroll
-            for (int src = 0; src < 4; ++src) {
-                s0[src] = red[((w * 4 + src) * 2 + 0) * 64 + lane];
-                s1[src] = red[((w * 4 + src) * 2 + 1) * 64 + lane];
-            }
-            auto sum4 = [&](unsigned a, unsigned b, unsigned c, unsigned d) {     // fixed order: ((w0 + w1) + w2) + w3
-                return ((__uint_as_float(a) + __uint_as_float(b)) + __uint_as_float(c)) + __uint_as_float(d);
-            };
-            z[0][0] = sum4(s0[0].x, s0[1].x, s0[2].x, s0[3].x); z[0][1] = sum4(s0[0].y, s0[1].y, s0[2].y, s0[3].y);
-            z[1][0] = sum4(s0[0].z, s0[1].z, s0[2].z, s0[3].z); z[1][1] = sum4(s0[0].w, s0[1].w, s0[2].w, s0[3].w);
-            z[2][0] = sum4(s1[0].x, s1[1].x, s1[2].x, s1[3].x); z[2][1] = sum4(s1[0].y, s1[1].y, s1[2].y, s1[3].y);
-            z[3][0] = sum4(s1[0].z, s1[1].z, s1[2].z, s1[3].z); z[3][1] = sum4(s1[0].w, s1[1].w, s1[2].w, s1[3].w);
-        }
-        // ---- gates (lstm.c:201-238): Z = xW + b_i + hU (+ b_h); blocks i | f | g | o ----
+        auto sum4 = [&](unsigned a, unsigned b, unsigned c, unsigned d) {     // fixed order: ((w0 + w1) + w2) + w3
+            return ((__uint_as_float(a) + __uint_as_float(b)) + __uint_as_float(c)) + __uint_as_float(d);
+        };
+        z[0][0] = sum4(s0[0].x, s0[1].x, s0[2].x, s0[3].x); z[0][1] = sum4(s0[0].y, s0[1].y, s0[2].y, s0[3].y);
+        z[1][0] = sum4(s0[0].z, s0[1].z, s0[2].z, s0[3].z); z[1][1] = sum4(s0[0].w, s0[1].w, s0[2].w, s0[3].w);
+        z[2][0] = sum4(s1[0].x, s1[1].x, s1[2].x, s1[3].x); z[2][1] = sum4(s1[0].y, s1[1].y, s1[2].y, s1[3].y);
+        z[3][0] = sum4(s1[0].z, s1[1].z, s1[2].z, s1[3].z); z[3][1] = sum4(s1[0].w, s1[1].w, s1[2].w, s1[3].w);
+    };
+    auto fin_gates = [&](auto half_tag) __attribute__((always_inline)) {      // lstm.c:201-238: Z = xW + b_i + hU (+ b_h); blocks i | f | g | o
+        constexpr int half = decltype(half_tag)::value;
         float hn[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -397,77 +384,223 @@ __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
             hn[e] = og * nntk_fast_tanh(cn);
         }
         *reinterpret_cast<float2 *>(hx + n * RR_HX_LD + jl) = make_float2(hn[0], hn[1]);
-        RR_BARRIER();
-        RR_STAMP(half, t, 2);
-        // ---- publish: 16 lanes per wave assemble 8 consecutive hidden units of one row, split them, store write-through ----
-        if (pub_lane) {
-            const float4 h_lo = *reinterpret_cast<const float4 *>(hx + n * RR_HX_LD + 8 * kh);
-            const float4 h_hi = *reinterpret_cast<const float4 *>(hx + n * RR_HX_LD + 8 * kh + 4);
-            const float v[8] = {h_lo.x, h_lo.y, h_lo.z, h_lo.w, h_hi.x, h_hi.y, h_hi.z, h_hi.w};
-            const int row = b0 + half * 32 + n;
-            if (row < p.B) {
-                rr_v4u a, b, c;
-                rr_split8(v, a, b, c);
-                const int so = (((bt_abs * 2 + half) * NKS + ct) * 3) * 1024;
-                if ((t + 1) & 1) {
-                    __builtin_amdgcn_raw_buffer_store_b128(a, rs1, lane16, so, 16 /* sc1 */);
-                    __builtin_amdgcn_raw_buffer_store_b128(b, rs1, lane16, so + 1024, 16);
-                    __builtin_amdgcn_raw_buffer_store_b128(c, rs1, lane16, so + 2048, 16);
-                } else {
-                    __builtin_amdgcn_raw_buffer_store_b128(a, rs0, lane16, so, 16);
-                    __builtin_amdgcn_raw_buffer_store_b128(b, rs0, lane16, so + 1024, 16);
-                    __builtin_amdgcn_raw_buffer_store_b128(c, rs0, lane16, so + 2048, 16);
-                }
-                if (p.return_sequences) {
-                    float *o = p.out + ((size_t)row * p.T + t) * H + 16 * ct + 8 * kh;
-                    *reinterpret_cast<float4 *>(o) = h_lo;
-                    *reinterpret_cast<float4 *>(o + 4) = h_hi;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) hkeep[half][q] = v[q];
-        }
-        RR_STAMP(half, t, 3);
     };
-
-    using H0 = std::integral_constant<int, 0>;
-    using H1 = std::integral_constant<int, 1>;
-    // prologue: operands of step 0 (h_0 sits in parity 0: no poll)
-    issue_h(0, 0); issue_x(0, 0);
-    for (int t = 0; t < p.T; ++t) {
-        // half A multiplies step t; half B: arrival of its step t-1 publication, then poll + fetch for step t
-        half_step(H0{}, t, t > 0 ? t - 1 : -1, t);
-        // half B multiplies step t; half A: arrival of the step-t publication just made, then poll + fetch for step t+1
-        half_step(H1{}, t, t, t + 1 < p.T ? t + 1 : -1);
-    }
-    // the very last publication of half B is never consumed; its stores only need to complete before the kernel ends
-    // ---- final state / last output ----
-    if (pub_lane) {
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int row = b0 + half * 32 + n;
-            if (row < p.B) {
-                const float4 a = make_float4(hkeep[half][0], hkeep[half][1], hkeep[half][2], hkeep[half][3]);
-                const float4 b = make_float4(hkeep[half][4], hkeep[half][5], hkeep[half][6], hkeep[half][7]);
+    rr_v4u pubv[2];                // the published row piece in f32: the layer output leaves later, off the drain path
+    auto store_out = [&](int half, int t) __attribute__((always_inline)) {
+        if (p.return_sequences) {
+            __builtin_amdgcn_raw_buffer_store_b128(pubv[0], rso, out_vo, half * out_half + t * H * 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(pubv[1], rso, out_vo + 16, half * out_half + t * H * 4, 0);
+        }
+    };
+    auto fin_publish = [&](auto half_tag, auto last_tag, int t) __attribute__((always_inline)) {
+        constexpr int half = decltype(half_tag)::value;
+        constexpr bool LAST = decltype(last_tag)::value;     // the half's last step: final state / last output leave from here
+        RR_BARRIER();                                   // the half's h row pieces are in `hx`
+        const float4 h_lo = *reinterpret_cast<const float4 *>(hx + n * RR_HX_LD + 8 * kh);
+        const float4 h_hi = *reinterpret_cast<const float4 *>(hx + n * RR_HX_LD + 8 * kh + 4);
+        const float v[8] = {h_lo.x, h_lo.y, h_lo.z, h_lo.w, h_hi.x, h_hi.y, h_hi.z, h_hi.w};
+        rr_v4u a, b, c;
+        rr_split8(v, a, b, c);
+        const int so = (((bt_abs * 2 + half) * NKS + ct) * 3) * 1024;
+        if ((t + 1) & 1) {
+            __builtin_amdgcn_raw_buffer_store_b128(a, rs1, pub_vo, so, 16 /* sc1 */);
+            __builtin_amdgcn_raw_buffer_store_b128(b, rs1, pub_vo + 1024, so, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(c, rs1, pub_vo + 2048, so, 16);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b128(a, rs0, pub_vo, so, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(b, rs0, pub_vo + 1024, so, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(c, rs0, pub_vo + 2048, so, 16);
+        }
+        pubv[0] = (rr_v4u){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+        pubv[1] = (rr_v4u){__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])};
+        if (LAST) {
+            int b0e = b0;
+            asm volatile("" : "+s"(b0e));                 // opaque: keeps these addresses from being computed (and spilled) ahead of the loop
+            const int row = b0e + half * 32 + n;
+            if (pub_lane && row < p.B) {
                 if (!p.return_sequences) {
                     float *o = p.out + (size_t)row * H + 16 * ct + 8 * kh;
-                    *reinterpret_cast<float4 *>(o) = a; *reinterpret_cast<float4 *>(o + 4) = b;
+                    *reinterpret_cast<float4 *>(o) = h_lo; *reinterpret_cast<float4 *>(o + 4) = h_hi;
                 }
                 if (p.hT) {
                     float *o = p.hT + (size_t)row * H + 16 * ct + 8 * kh;
-                    *reinterpret_cast<float4 *>(o) = a; *reinterpret_cast<float4 *>(o + 4) = b;
+                    *reinterpret_cast<float4 *>(o) = h_lo; *reinterpret_cast<float4 *>(o + 4) = h_hi;
                 }
             }
         }
-    }
-    if (p.cT) {
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int row = b0 + half * 32 + n;
-            if (row < p.B && jf + 1 < H + 1) {
-                if (jf < H) p.cT[(size_t)row * H + jf] = cst[half][0];
-                if (jf + 1 < H) p.cT[(size_t)row * H + jf + 1] = cst[half][1];
+    };
+    unsigned *const flags0 = p.flags + (size_t)bt * 2 * RR_FLAGS, *const flags1 = flags0 + RR_FLAGS;
+    // arrival: this wave's publishing stores have drained -> raise this wave's flag (write-through store of t + 1)
+    // (counted wait: the x request and the second operand batch, issued after the publication, stay in flight)
+    auto arrive = [&](int half, int t) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N_AFTER_PUB) : "memory");
+        if (lane == 0)
+            __hip_atomic_store((half ? flags1 : flags0) + w * 32 + ct, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // every wave polls for itself: two sc1 loads cover all 128 flags; requested a k step before they are looked at
+    unsigned pv0 = 0, pv1 = 0;
+    const bool flag_live = (lane & 31) < p.NCT;        // flags of column tiles that do not exist stay 0
+    auto poll_a = [&](int half) __attribute__((always_inline)) {
+        const unsigned *f = (half ? flags1 : flags0) + lane;
+        asm volatile("global_load_dword %0, %2, off sc1\n\tglobal_load_dword %1, %2, off offset:256 sc1"
+                     : "=&v"(pv0), "=&v"(pv1) : "v"(f) : "memory");
+    };
+    auto poll_b = [&](int half, int t) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv0), "+v"(pv1) :: "memory");
+        const unsigned target = (unsigned)t;
+        bool ok = !flag_live || (pv0 >= target && pv1 >= target);
+        // spin_ticks == 0 is fault injection (tests): behave as if the very first poll had found nothing and run out of budget
+        if (__builtin_amdgcn_ballot_w64(!ok) != 0 || p.spin_ticks == 0) {  // something has not arrived yet: spin (bounded)
+            const unsigned *f = (half ? flags1 : flags0) + lane;
+            const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+            bool expired = p.spin_ticks == 0;
+            while (!expired) {
+                const unsigned a = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned b = __hip_atomic_load(f + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = !flag_live || (a >= target && b >= target);
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+                // a peer that gave up has raised the fault word: every other spin ends at once
+                if (__hip_atomic_load(p.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { expired = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+                expired = __builtin_amdgcn_s_memrealtime() - t_start > p.spin_ticks;
             }
+            if (expired && lane == 0) __hip_atomic_fetch_or(p.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+
+    // one half-step: multiply half Y at step t; FIN: finish half X = 1 - Y (its step tX) on the way; NEXT: fetch X's operand of
+    // step tX + 1 (POLL: it was published inside this launch)
+    auto half_step = [&](auto y_tag, auto fin_tag, auto next_tag, auto poll_tag, auto last_tag, int t, int tX) __attribute__((always_inline)) {
+        constexpr int Y = decltype(y_tag)::value;
+        using XT = std::integral_constant<int, 1 - Y>;
+        constexpr int X = 1 - Y;
+        constexpr bool FIN = decltype(fin_tag)::value, NEXT = decltype(next_tag)::value, POLL = decltype(poll_tag)::value;
+        f32x16 acc[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+        // six products per (k step, tile), smallest terms first: (A image, B image) = (hi,lo) (lo,hi) (mid,mid) (hi,mid) (mid,hi) (hi,hi)
+        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+        for (int s = 0; s < NST; ++s) {
+            RR_STAMP(Y, t, s);                            // diagnostics build: start of every k step
+            // ---- this k step's MFMA operands from LDS, requested before the slice's own LDS traffic ----
+            rr_bf16x8 wa[2][3], ulo[2];
+            if (s < KX) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int m = 0; m < 3; ++m)
+                        wa[mt][m] = __builtin_bit_cast(rr_bf16x8, WXs[((((w * KX + s) * 2 + mt) * 3) + m) * 64 + lane]);
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) ulo[mt] = __builtin_bit_cast(rr_bf16x8, ULs[((w * KH + (s - KX)) * 2 + mt) * 64 + lane]);
+            }
+            // ---- slices of the other half's finish and of its next fetch ----
+            if (s == S_RED && FIN && !RR_DBG(2)) { fin_reduce(); fin_gates(XT{}); }
+            if (s == S_PUB && FIN && !RR_DBG(2)) { fin_publish(XT{}, last_tag, tX); }
+            if (s == S_E1 && FIN && !RR_DBG(4)) { arrive(X, tX); }
+            if (s == S_E2 - RR_POLL_LEAD && NEXT && POLL && !RR_DBG(4)) poll_a(X);
+            if (s == S_E2) {
+                if (NEXT && POLL && !RR_DBG(4)) poll_b(X, tX + 1);
+                if (FIN && !RR_DBG(2)) store_out(X, tX);
+            }
+            if (s == S_E2 && NEXT && !RR_DBG(1)) issue_h(XT{}, tX + 1, 0, 3 * NPRE);          // head of X's next operand
+            if (s + NPRE < KH && !RR_DBG(1)) issue_h(y_tag, t, 3 * (s + NPRE), 3 * (s + NPRE + 1));       // THIS half's operand, k step s + NPRE (published long ago)
+            // ---- multiply ----
+            if (RR_DBG(16)) {
+            } else if (s < KX) {
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[mt][PA[pr]], xf[s][PB[pr]], acc[mt], 0, 0, 0);
+            } else {
+                const int i = s - KX;
+                rr_bf16x8 b[3];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) b[m] = __builtin_bit_cast(rr_bf16x8, hf[Y][i][m]);
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const rr_bf16x8 av = PA[pr] == 2 ? ulo[mt] : uh[i][mt][PA[pr]];
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b[PB[pr]], acc[mt], 0, 0, 0);
+                    }
+            }
+            // x_t of the half that multiplies next: split (this half's own x part has been multiplied), then request this
+            // half's x_{t+1} -- a whole half-step ahead of its use
+            if (s == S_XSPL) {
+                if (NEXT && !RR_DBG(8)) split_x();
+                if (!RR_DBG(8)) issue_x(Y, t + 1);          // unconditional (t + 1 == T reads a row's neighbour or zeros, never used): the arrival's counted wait relies on it
+            }
+#ifndef RR_NO_INTERLEAVE
+            // spread this k step's vector-memory instructions between its MFMAs (2 MFMAs, then at most 1 memory operation,
+            // six times): the four wavefronts run in lockstep and share one address path, so back-to-back requests queue up
+            // behind each other and stall the issuing wave together with its MFMAs
+#ifdef RR_VALU_IL
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {                // ... and the slice's vector-ALU work in the MFMAs' shadow, RR_VALU_IL per MFMA
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, RR_VALU_IL, 0);
+                if (j & 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            }
+#else
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            }
+#endif
+#endif
+            __builtin_amdgcn_sched_barrier(0);            // a slice stays with its k step
+        }
+        RR_STAMP(Y, t, NST);
+        // ---- split-K exchange: wave `dst` finishes registers 4 g + 2 (dst & 1) + {0, 1} of tile dst >> 1 (read in the NEXT half-step) ----
+        if (!RR_DBG(32))
+#pragma unroll
+        for (int dst = 0; dst < 4; ++dst) {
+#ifdef RR_RED_SKIP_OWN
+            if (dst == w) continue;                       // uniform branch: a wave keeps its own part in registers ... (see fin_reduce)
+#endif
+            const int mt = dst >> 1, o = 2 * (dst & 1);
+            const rr_v4u q0 = {__float_as_uint(acc[mt][o]), __float_as_uint(acc[mt][o + 1]), __float_as_uint(acc[mt][4 + o]), __float_as_uint(acc[mt][5 + o])};
+            const rr_v4u q1 = {__float_as_uint(acc[mt][8 + o]), __float_as_uint(acc[mt][9 + o]), __float_as_uint(acc[mt][12 + o]), __float_as_uint(acc[mt][13 + o])};
+            red[((dst * 4 + w) * 2 + 0) * 64 + lane] = q0;
+            red[((dst * 4 + w) * 2 + 1) * 64 + lane] = q1;
+        }
+    };
+
+    // prologue: operands of half A, step 0 (h_0 sits in parity 0: no poll); x_0 of half B
+    issue_x(0, 0);
+    issue_h(I0{}, 0, 0, 3 * NPRE);
+    split_x();
+    issue_x(1, 0);
+    half_step(I0{}, Ff{}, Tt{}, Ff{}, Ff{}, 0, -1);                       // A(0); fetch B(0)
+    if (T > 1) {
+        half_step(I1{}, Tt{}, Tt{}, Tt{}, Ff{}, 0, 0);                    // B(0); finish A(0); fetch A(1)
+        for (int t = 1; t < T - 1; ++t) {
+            half_step(I0{}, Tt{}, Tt{}, Tt{}, Ff{}, t, t - 1);            // A(t); finish B(t-1); fetch B(t)
+            half_step(I1{}, Tt{}, Tt{}, Tt{}, Ff{}, t, t);                // B(t); finish A(t); fetch A(t+1)
+        }
+        half_step(I0{}, Tt{}, Tt{}, Tt{}, Ff{}, T - 1, T - 2);            // A(T-1); finish B(T-2); fetch B(T-1)
+    }
+    half_step(I1{}, Tt{}, Ff{}, Ff{}, Tt{}, T - 1, T - 1);                // B(T-1); finish A(T-1): its last step
+    // drain: finish B(T-1)
+    fin_reduce();
+    fin_gates(I1{});
+    fin_publish(I1{}, Tt{}, T - 1);
+    store_out(1, T - 1);
+    // ---- final cell state ----
+    int b0e = b0;
+    asm volatile("" : "+s"(b0e));
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int row = b0e + half * 32 + n;
+        if (p.cT && row < p.B) {
+            if (jf < H) p.cT[(size_t)row * H + jf] = cst[half][0];
+            if (jf + 1 < H) p.cT[(size_t)row * H + jf + 1] = cst[half][1];
         }
     }
 }
@@ -476,13 +609,11 @@ __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
 static bool rr_shape(int H, int in, int *KH, int *KX) {
     if (H < 64 || H > 512 || (H % 16) != 0 || in < 8 || (in % 8) != 0) return false;
     *KH = H <= 256 ? 4 : 8;
-    *KX = in <= 64 ? 1 : in <= 128 ? 2 : in <= 256 ? 4 : 0;
-    if (*KX == 0) return false;
-    if (*KH == 8 && *KX == 4) return false;             // 64 + 96 + 32 KB: past the CU's LDS
-    return true;
+    *KX = in <= 64 ? 1 : in <= 128 ? 2 : 0;              // in <= 256 (KX = 4) would need 96 KB of LDS for W^T: 32 + 96 + 32 KB > 160 KB
+    return *KX != 0;
 }
 static size_t rr_lds_bytes(int KH, int KX) {
-    return (size_t)(4 * KH * 2 + 4 * KX * 6 + 32) * 1024 + 32 * RR_HX_LD * 4 + 64;
+    return (size_t)(4 * KH * 2 + 4 * KX * 6 + 32) * 1024 + 32 * RR_HX_LD * 4;
 }
 static size_t rr_parity_bytes(int B, int KH) { return (size_t)((B + 63) / 64) * 2 * (4 * KH) * 3 * 1024; }
 
@@ -494,7 +625,7 @@ extern "C" size_t nntk_shim_lstm_rr_image_floats(int H, int in) {
 extern "C" size_t nntk_shim_lstm_rr_work_floats(int B, int H) {
     const int KH = H <= 256 ? 4 : 8;
     const size_t nbt = (size_t)(B + 63) / 64;
-    return 2 * rr_parity_bytes(B, KH) / 4 + (2 * nbt < 256 ? 256 : 2 * nbt) * RR_CNT_STRIDE;
+    return 2 * rr_parity_bytes(B, KH) / 4 + 2 * nbt * RR_FLAGS;
 }
 // d_ut / d_wp: the per-gate U^T and packed W^T the other kernels use (host: core_upload); d_img: nntk_shim_lstm_rr_image_floats
 extern "C" int nntk_shim_lstm_rr_pack(const float *d_ut, const float *d_wp, float *d_img, int H, int in) {
@@ -524,13 +655,13 @@ extern "C" int nntk_shim_lstm_rr(const float *d_x, const float *d_img, const flo
     if (!rr_shape(H, in, &KH, &KX)) return 1;
     if ((((size_t)d_x) & 15) != 0 || (in % 4) != 0) return 1;
     const int NCT = H / 16;
+    // the x and out rows of one 64-row batch tile are addressed with 32-bit buffer offsets
+    if ((double)64 * T * in * 4 >= 2.0e9 || (double)64 * T * H * 4 >= 2.0e9) return 1;
     void (*kern)(RRParams) = nullptr;
-    // E1 / E2: a third / three quarters into the KX + KH steps of a half (see the kernel header)
-    if (KH == 8 && KX == 2) kern = lstm_rr_kernel<8, 2, 3, 7>;
-    else if (KH == 8 && KX == 1) kern = lstm_rr_kernel<8, 1, 3, 6>;
-    else if (KH == 4 && KX == 4) kern = lstm_rr_kernel<4, 4, 2, 5>;
-    else if (KH == 4 && KX == 2) kern = lstm_rr_kernel<4, 2, 2, 4>;
-    else if (KH == 4 && KX == 1) kern = lstm_rr_kernel<4, 1, 1, 3>;
+    if (KH == 8 && KX == 2) kern = lstm_rr_kernel<8, 2>;
+    else if (KH == 8 && KX == 1) kern = lstm_rr_kernel<8, 1>;
+    else if (KH == 4 && KX == 2) kern = lstm_rr_kernel<4, 2>;
+    else if (KH == 4 && KX == 1) kern = lstm_rr_kernel<4, 1>;
     if (!kern) return 1;
     const size_t lds = rr_lds_bytes(KH, KX);
     if (lds > 160 * 1024) return 1;
@@ -543,9 +674,9 @@ extern "C" int nntk_shim_lstm_rr(const float *d_x, const float *d_img, const flo
     const size_t parity = rr_parity_bytes(B, KH);
     if (parity >= 0x7ffffff0ULL) return 1;
     const int nbt_total = (B + 63) / 64;
-    unsigned *cnt = reinterpret_cast<unsigned *>(d_work + 2 * parity / 4);
-    // both parities cleared (rows >= B and k steps >= H / 16 must stay zero), h_0 split into parity 0, counters zeroed
-    if (nntk_shim_memset(d_work, 0, 2 * parity + (size_t)nbt_total * 2 * RR_CNT_STRIDE * sizeof(unsigned))) return -1;
+    unsigned *flags = reinterpret_cast<unsigned *>(d_work + 2 * parity / 4);
+    // both parities cleared (k steps >= H / 16 must stay zero), h_0 split into parity 0, flags zeroed
+    if (nntk_shim_memset(d_work, 0, 2 * parity + (size_t)nbt_total * 2 * RR_FLAGS * sizeof(unsigned))) return -1;
     if (d_h0) {
         long g = ((long)nbt_total * 2 * NCT * 64 + 255) / 256;
         if (g > 2048) g = 2048;
@@ -562,8 +693,8 @@ extern "C" int nntk_shim_lstm_rr(const float *d_x, const float *d_img, const flo
     q.stamp = nullptr;
     const char *stamp_path = getenv("NNTK_REC_STAMP_FILE");
     if (stamp_path) {
-        if (hipMalloc((void **)&q.stamp, (size_t)T * 16 * 8) != hipSuccess) return nntk_fail_msg("stamp alloc");
-        (void)hipMemset(q.stamp, 0, (size_t)T * 16 * 8);
+        if (hipMalloc((void **)&q.stamp, (size_t)T * 32 * 8) != hipSuccess) return nntk_fail_msg("stamp alloc");
+        (void)hipMemset(q.stamp, 0, (size_t)T * 32 * 8);
     }
 #endif
     const int span = nntk_prof_span_begin(NNTK_SPAN_REC);
@@ -571,7 +702,7 @@ extern "C" int nntk_shim_lstm_rr(const float *d_x, const float *d_img, const flo
     for (int bt0 = 0; bt0 < nbt_total; bt0 += tiles_per_launch) {
         const int nbt = nbt_total - bt0 < tiles_per_launch ? nbt_total - bt0 : tiles_per_launch;
         q.NBT = nbt; q.b_base = bt0 * 64;
-        q.cnt = cnt + (size_t)bt0 * 2 * RR_CNT_STRIDE;
+        q.flags = flags + (size_t)bt0 * 2 * RR_FLAGS;
         hipLaunchKernelGGL(kern, dim3((unsigned)(nbt * NCT)), dim3(256), lds, nntk_stream(), q);
     }
     const int copy_rc = nntk_fault_enqueue_copy();
@@ -581,10 +712,10 @@ extern "C" int nntk_shim_lstm_rr(const float *d_x, const float *d_img, const flo
 #ifdef NNTK_REC_STAMPS
     if (q.stamp) {
         (void)hipStreamSynchronize(nntk_stream());
-        unsigned long long *hs = (unsigned long long *)malloc((size_t)T * 16 * 8);
-        (void)hipMemcpy(hs, q.stamp, (size_t)T * 16 * 8, hipMemcpyDeviceToHost);
+        unsigned long long *hs = (unsigned long long *)malloc((size_t)T * 32 * 8);
+        (void)hipMemcpy(hs, q.stamp, (size_t)T * 32 * 8, hipMemcpyDeviceToHost);
         FILE *f = fopen(stamp_path, "wb");
-        if (f) { fwrite(hs, 8, (size_t)T * 16, f); fclose(f); }
+        if (f) { fwrite(hs, 8, (size_t)T * 32, f); fclose(f); }
         free(hs); (void)hipFree(q.stamp);
     }
 #endif

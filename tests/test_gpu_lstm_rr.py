@@ -39,7 +39,7 @@ def _took_rr(lstm, xd):
     (64, 128, 512, 20, True, True),       # the stack's LSTM shape, one batch tile, KH = 8 / KX = 2
     (70, 64, 256, 33, True, False),       # ragged second tile, Keras one-bias form, KH = 4 / KX = 1
     (130, 40, 128, 9, False, True),       # last state only; in and H padded (40 -> 64, 128 -> 256 k steps)
-    (33, 256, 192, 12, True, True),       # KH = 4 / KX = 4; one row in the second half-tile
+    (33, 128, 192, 12, True, True),       # KH = 4 / KX = 2; one row in the second half-tile
     (96, 128, 320, 14, True, True),       # H between the compiled depths: 20 column tiles, padded k steps
     (40, 8, 64, 25, True, True),          # smallest shapes the kernel takes
     (200, 72, 512, 7, True, True),        # KH = 8 / KX = 2 with in = 72 (padded)

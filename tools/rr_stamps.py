@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Diagnostics build only (tools/build_variant.sh <lib> -DNNTK_REC_STAMPS; NNTK_LIB=<lib>): run the stack's LSTM on
+lstm_rr_kernel once and print where workgroup 0 / wave 0 spends a half-step (s_memtime cycles).
+usage: NNTK_LIB=gpurun_out/libs/libstamps.so python tools/rr_stamps.py [B] [T]"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch, bench
+    from nntoolkitcore_amd import capi, layers as NL
+    torch.cuda.set_device(0); capi.load(); NL.use_torch_stream()
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    T = int(sys.argv[2]) if len(sys.argv) > 2 else 996
+    w = bench.make_weights("stack", 3)
+    lstm = NL.LSTM(128, 512, True, T, v2=True)
+    lstm.set_weights(w["lstm_W"], w["lstm_U"], w["lstm_bi"], w["lstm_bh"])
+    x = torch.randn(B, T, 128, device="cuda"); h = torch.empty(B, T, 512, device="cuda")
+    for _ in range(3):
+        lstm.apply_device(x, out=h)
+    torch.cuda.synchronize()
+    path = os.path.join(ROOT, "gpurun_out", "rr_stamps.bin")
+    os.environ["NNTK_REC_STAMP_FILE"] = path
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); lstm.apply_device(x, out=h); e1.record(); torch.cuda.synchronize()
+    del os.environ["NNTK_REC_STAMP_FILE"]
+    s = np.fromfile(path, dtype=np.uint64).astype(np.int64).reshape(T, 2, 16)
+    lo, hi = T // 10, T - T // 10
+    nst = 10
+    print("launch %.3f ms incl. stamping = %.2f us/step" % (e0.elapsed_time(e1), e0.elapsed_time(e1) * 1e3 / T))
+    for half in range(2):
+        d = s[lo:hi, half]
+        nxt = s[lo:hi, 1 - half] if half == 0 else s[lo + 1:hi + 1, 0]
+        dur = [(d[:, i + 1] - d[:, i]) for i in range(nst)]
+        print("half %d: half-step %.0f cyc; k steps (mean): %s | end->next start %.0f" % (
+            half, (nxt[:, 0] - d[:, 0]).mean(), " ".join("%.0f" % x.mean() for x in dur), (nxt[:, 0] - d[:, nst]).mean()))
+        print("          k steps (p90):  %s" % " ".join("%.0f" % np.percentile(x, 90) for x in dur))
+    per = (s[hi, 0, 0] - s[lo, 0, 0]) / (hi - lo)
+    print("step period %.0f cycles" % per)
+    lstm.destroy()
+
+
+if __name__ == "__main__":
+    main()
