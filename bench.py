@@ -306,6 +306,26 @@ def roofline_for(wl, phase_ms, prof):
     if ms is None:
         return None
     tpl = prof["rec_timesteps_per_launch"]
+    last = prof.get("rec_kernel", "")
+    if last.startswith("lstm_rr_kernel"):
+        # register-resident split-bf16 LSTM: ONE launch does all T steps of [h | x_t] x [U ; W] (the input projection is
+        # fused: no separate GEMM, no [T, B, 4H] tensor), six bf16 MFMA products per f32 product -> the MFMA ceiling in
+        # ALGORITHMIC flops is the dense bf16 peak / 6
+        n_in = 128
+        flops = 2.0 * B * (H + n_in) * G * H * tpl
+        ach = flops / (ms * 1e-3) / 1e12
+        peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
+        traffic, traffic_source = pmc_traffic("lstm_rr_kernel", B)
+        # 6 products x 2 tiles x (H + in) / 16 k steps per half, two halves: MFMA instructions per wave and timestep
+        mfma_cycles = 6 * 2 * ((H + n_in) // 16) // 4 * 2 * 32
+        return {"kernel": last, "bound": "mfma", "achieved": ach, "peak": peak,
+                "peak_note": "dense bf16 MFMA peak / 6 products per f32 product (split-bf16 x 3 contraction)",
+                "unit": "TFLOP/s", "frac": ach / peak, "frac_of_exact_f32_mfma_peak": ach / F32_MFMA_PEAK_TFLOPS,
+                "traffic": traffic, "traffic_source": traffic_source, "ms_per_launch": ms, "algorithmic_flops": flops,
+                "algorithmic_flops_note": "recurrent h x U AND the fused input projection x_t x W, all T steps of one launch",
+                "timesteps_per_launch": tpl, "us_per_timestep": ms * 1e3 / tpl,
+                "mfma_pipe_cycles_per_timestep": mfma_cycles,
+                "launches_per_step": prof.get("rec_launches_per_step")}
     persistent = tpl > 1
     kern = ("rec_persistent_kernel" if persistent else "rec_step_kernel") + ("<4,LSTM>" if G == 4 else "<3,GRU>")
     flops = 2.0 * B * H * G * H * tpl          # algorithmic flops of ONE launch (tpl timesteps of h[B,H] x U[H,G*H])
@@ -533,6 +553,7 @@ def main():
         prof["rec_launch_ms"] = ms.value / cnt.value                 # average duration of one kernel launch
         prof["rec_timesteps_per_launch"] = units.value / cnt.value   # 1 = per-step kernels, T = persistent
         prof["rec_launches_per_step"] = cnt.value / max(1, a.steps + a.warmup)
+        prof["rec_kernel"] = (L.nntk_hip_last_recurrent_kernel() or b"").decode()
 
     total_frames = world * B * wl.frames_per_utt * a.steps
     value = total_frames / dt
@@ -549,7 +570,10 @@ def main():
             "parallelism": "utterance shards, dp%d, no data-path collective" % world,
             "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
             "ranks_seen": ranks_seen,
-            "gemm": gemm_mode() + " for conv / TDD" + ("; exact-f32 for the recurrent input projection and recurrences" if a.workload in ("stack", "gru") else ""),
+            "gemm": gemm_mode() + " for conv / TDD" + (
+                ("; LSTM: " + prof["rec_kernel"] + " (split-bf16x3 recurrence with the input projection fused into the step)")
+                if prof.get("rec_kernel", "").startswith("lstm_rr") else
+                ("; exact-f32 for the recurrent input projection and recurrences" if a.workload in ("stack", "gru") else "")),
             "gemm_accuracy": ("f32 results: error vs a float64 contraction <= the exact-f32 MFMA chain's on every BASELINE shape "
                               "(profiles/r02_split_error.log, tools/split_error.py); NNTK_GEMM_SPLIT_BF16=0 selects the exact chain")
                              if gemm_mode() != "exact-f32" else "exact-f32 MFMA chain"},

@@ -367,6 +367,8 @@ const char *nntk_version(void);
  * (nntk_hip_synchronize() before moving it to another stream).
  *
  * Tuning / diagnostics knobs by name; environment variables NNTK_<NAME> give the initial values (read once).
+ *   "rec_rr"         LSTM batches: 0 = never the register-resident split-bf16 kernel (recurrent_rr.hip; x W fused into the
+ *                    step, f32-accuracy contraction, not the exact-f32 chain), 1 = also below 32 sequences, auto = from 32
  *   "rec_persistent" 0 = per-timestep recurrent kernels only     "rec_pingpong" 0/1 = ping-pong halves off/on
  *   "rec_spin_us"    budget of the persistent kernel's spins     "gemm_tm_batch" 0/1
  *   "weights_check"  host-pointer calls look for in-place edits of the weight block before they launch:
@@ -382,6 +384,10 @@ int         nntk_hip_get_option(const char *name, int *value);
  * or poll it without blocking here (0 healthy, 1 a completed recurrent launch of this thread has faulted).  After a
  * fault the process keeps to the per-timestep kernels. */
 int         nntk_hip_device_status(void);
+/* Name of the recurrent kernel the calling thread launched last ("" before the first): "lstm_rr_kernel<8,2>" (register-
+ * resident split-bf16 LSTM with the fused input projection), "rec_persistent_kernel<4,LSTM>", "gru2_persistent_kernel<8>",
+ * "rec_step_kernel<3,GRU>", ...  Diagnostics: which of the paths described under "rec_rr" / "rec_persistent" a call took. */
+const char *nntk_hip_last_recurrent_kernel(void);
 /* Optional HIP-event spans around the recurrent kernel launches (name "rec_step"): enable,
  * run, then read the summed milliseconds, the number of kernel launches and the timesteps they
  * covered (a persistent launch covers all T of a sequence).  Reading clears the spans. */

@@ -274,6 +274,7 @@ SIGNATURES = {
     "nntk_hip_set_option": (C.c_int, [C.c_char_p, C.c_char_p]),
     "nntk_hip_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "nntk_hip_device_status": (C.c_int, []),
+    "nntk_hip_last_recurrent_kernel": (C.c_char_p, []),
     "nntk_hip_profile_enable": (None, [C.c_int]),
     "nntk_hip_profile_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "nntk_device_alloc": (vp, [C.c_size_t]),

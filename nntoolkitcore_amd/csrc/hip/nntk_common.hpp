@@ -41,6 +41,7 @@ int nntk_persistent_disabled();                   // set after a fault: take the
 void nntk_persistent_launch_begin();              // orders persistent launches across the process's streams (holds a mutex)
 void nntk_persistent_launch_end();
 int nntk_cu_count();                              // cached per device
+void nntk_set_last_rec_kernel(const char *name);  // static string; read back with nntk_hip_last_recurrent_kernel()
 int nntk_set_max_dynamic_lds(const void *kernel, size_t bytes);   // hipFuncSetAttribute once per (kernel, device)
 int nntk_resident_blocks(const void *kernel, int threads, size_t lds, int max_per_cu);   // occupancy x CUs (0: does not fit)
 

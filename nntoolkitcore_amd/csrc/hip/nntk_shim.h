@@ -44,6 +44,7 @@ int nntk_shim_get_option(const char *name, int *value);
 /* sticky fault word of the persistent recurrent kernel (see runtime.hip) */
 int nntk_shim_take_fault(void);            /* after a stream sync: 1 = a launch faulted (cleared, per-step kernels from now on) */
 int nntk_shim_persistent_disabled(void);
+const char *nntk_shim_last_rec_kernel(void);   /* name of the recurrent kernel this thread launched last ("" before the first) */
 int nntk_shim_device_status(void);         /* non-blocking: 1 = a completed recurrent launch has faulted */
 
 /* HIP-event spans around the recurrent step launches (off by default) */

@@ -1008,6 +1008,7 @@ extern "C" int nntk_shim_gru2(const float *d_xw1, const float *d_ut1, const floa
     if (copy_rc) return -1;
     nntk_prof_span_end(span, (nbt_total + tiles_per_launch - 1) / tiles_per_launch, T + 1);
     NNTK_LAUNCH_CHECK("gru2_persistent_kernel");
+    nntk_set_last_rec_kernel(nch_p == 4 ? "gru2_persistent_kernel<4>" : "gru2_persistent_kernel<8>");
     return 0;
 }
 
@@ -1351,6 +1352,7 @@ static int run_recurrent(const float *d_xw, const float *d_ut, const float *d_bh
             }
 #endif
             NNTK_LAUNCH_CHECK("rec_persistent_kernel");
+            nntk_set_last_rec_kernel(G == 1 ? "rec_persistent_kernel<1,RNN>" : IS_LSTM ? "rec_persistent_kernel<4,LSTM>" : "rec_persistent_kernel<3,GRU>");
             if (IS_LSTM && d_cT) { if (nntk_shim_copy_d2d(d_cT, cbuf, BH * 4)) return -1; }
             return 0;
             }
@@ -1381,6 +1383,7 @@ static int run_recurrent(const float *d_xw, const float *d_ut, const float *d_bh
     }
     nntk_prof_span_end(span, T, T);
     NNTK_LAUNCH_CHECK("rec_step_kernel");
+    nntk_set_last_rec_kernel(G == 1 ? "rec_step_kernel<1,RNN>" : IS_LSTM ? "rec_step_kernel<4,LSTM>" : "rec_step_kernel<3,GRU>");
     if (d_hT) { if (nntk_shim_copy_d2d(d_hT, hbuf[T & 1], BH * 4)) return -1; }
     if (IS_LSTM && d_cT) { if (nntk_shim_copy_d2d(d_cT, cbuf, BH * 4)) return -1; }
     return 0;

@@ -720,5 +720,6 @@ extern "C" int nntk_shim_lstm_rr(const float *d_x, const float *d_img, const flo
     }
 #endif
     NNTK_LAUNCH_CHECK("lstm_rr_kernel");
+    nntk_set_last_rec_kernel(KH == 8 ? (KX == 2 ? "lstm_rr_kernel<8,2>" : "lstm_rr_kernel<8,1>") : (KX == 2 ? "lstm_rr_kernel<4,2>" : "lstm_rr_kernel<4,1>"));
     return 0;
 }

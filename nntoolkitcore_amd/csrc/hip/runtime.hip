@@ -220,6 +220,10 @@ int nntk_resident_blocks(const void *kernel, int threads, size_t lds, int max_pe
     return per_cu * nntk_cu_count();
 }
 
+// name of the recurrent kernel the calling thread launched last (bench.py labels its roofline line with it)
+static thread_local const char *t_last_rec_kernel = "";
+void nntk_set_last_rec_kernel(const char *name) { t_last_rec_kernel = name; }
+
 extern "C" {
 
 int nntk_shim_set_option(const char *name, const char *value) {
@@ -281,6 +285,7 @@ int nntk_shim_set_device(int device) {
     NNTK_HIP_TRY(hipSetDevice(device));
     return 0;
 }
+const char *nntk_shim_last_rec_kernel(void) { return t_last_rec_kernel; }
 int nntk_shim_get_device(void) {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return -1; }

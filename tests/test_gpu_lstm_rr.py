@@ -188,3 +188,41 @@ def test_full_size_lstm_rr_stack_shard(gpu):
     print("lstm_rr B=512 T=996: max abs err vs oracle %.2e" % e)
     assert e < 3e-6
     lstm.destroy()
+
+
+def test_lstm_rr_fault_is_reported_and_heals(gpu):
+    """The register-resident kernel needs all its workgroups resident, like the other persistent kernels: a poll that runs
+    out of budget (forced with rec_spin_us = 0) raises the sticky fault word.  Device-pointer callers see -1 at the next
+    synchronize; the host-pointer call repeats itself on the per-timestep kernels and returns correct results."""
+    import torch
+    L = capi.load()
+    r = rng(91)
+    B, I, H, T = 70, 64, 128, 12
+    x = u(r, B, T, I)
+    W, U, bi, bh = lstm_weights(r, I, H)
+    ref = O.lstm(x, W, U, bi, bh, v2=True)
+    lstm = NL.LSTM(I, H, True, T, v2=True)
+    lstm.set_weights(W, U, bi, bh)
+    xd = torch.from_numpy(x).cuda()
+    good = lstm.apply_device(xd).cpu().numpy()
+    assert L.nntk_hip_last_recurrent_kernel().decode().startswith("lstm_rr_kernel")
+    np.testing.assert_allclose(good, ref, rtol=1e-5, atol=1e-5)
+    capi.set_option("rec_spin_us", 0)
+    lstm.apply_device(xd)
+    torch.cuda.synchronize()
+    assert L.nntk_hip_device_status() == 1
+    assert L.nntk_hip_synchronize() == -1 and "timed out" in capi.last_error()
+    # the process has switched to the per-timestep kernels
+    after = lstm.apply_device(xd).cpu().numpy()
+    assert L.nntk_hip_synchronize() == 0
+    assert L.nntk_hip_last_recurrent_kernel().decode().startswith("rec_step_kernel")
+    np.testing.assert_allclose(after, ref, rtol=1e-5, atol=1e-5)
+    # host-pointer call with the persistent kernels re-armed and the budget still zero: heals itself
+    capi.set_option("rec_persistent", 1)
+    healed = lstm.apply(x)
+    assert capi.last_error() == ""
+    np.testing.assert_allclose(healed, ref, rtol=1e-5, atol=1e-5)
+    capi.set_option("rec_spin_us", "auto"); capi.set_option("rec_persistent", "auto")
+    assert L.nntk_hip_synchronize() == 0
+    assert np.array_equal(lstm.apply_device(xd).cpu().numpy(), good)          # back on the register-resident kernel, same bits
+    lstm.destroy()
