@@ -43,7 +43,7 @@ typedef __bf16 rr_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float rr_f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned rr_v4u __attribute__((ext_vector_type(4)));
 
-#define RR_FLAGS 128              // flag words per (batch tile, half): 4 waves x 32 column tiles, 512 contiguous bytes
+#define RR_FLAGS 64               // flag words per (batch tile, half): one per column tile (<= 32), padded to one wave-wide load
 #ifndef RR_POLL_LEAD
 #define RR_POLL_LEAD 1           // the flags are requested this many k steps before they are looked at
 #endif
@@ -164,14 +164,7 @@ struct RRParams {
     unsigned long long *stamp; // [T][2 halves][16] s_memtime of workgroup 0, wave 0 (diagnostics build only)
 #endif
 };
-// timing ablations only (WRONG results; tools/rr_ablate.sh builds one library per mask): -DNNTK_RR_DBG=<mask>,
-// 1 no operand loads, 2 no finish, 4 no arrive / poll, 8 no x, 16 no MFMAs, 32 no partial-sum writes.  Compile-time on
-// purpose: a run-time mask changed the register allocation of the whole kernel (2x slower with the mask at 0).
-#ifdef NNTK_RR_DBG
-#define RR_DBG(bit) ((NNTK_RR_DBG) & (bit))
-#else
-#define RR_DBG(bit) 0
-#endif
+
 #ifdef NNTK_REC_STAMPS
 #define RR_STAMP(half, t, i) do { if (p.stamp && blockIdx.x == 0 && w == 0 && lane == 0) \
         p.stamp[((size_t)(t) * 2 + (half)) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -179,8 +172,18 @@ struct RRParams {
 #define RR_STAMP(half, t, i) do {} while (0)
 #endif
 
+// timing ablations only (WRONG results; tools/rr_ablate.sh builds one library per mask): -DNNTK_RR_DBG=<mask>,
+// 1 no operand loads, 2 no finish, 4 no arrive / poll, 8 no x, 16 no MFMAs, 32 no partial-sum writes,
+// 64 no gate arithmetic, 128 no publication (split + stores), 256 no partial-sum reads, 512 no workgroup barriers, 1024 no output stores.  Compile-time on
+// purpose: a run-time mask changed the register allocation of the whole kernel (2x slower with the mask at 0).
+#ifdef NNTK_RR_DBG
+#define RR_DBG(bit) ((NNTK_RR_DBG) & (bit))
+#else
+#define RR_DBG(bit) 0
+#endif
+
 // raw barrier: LDS traffic ordered, vector-memory operations (the operand prefetch!) left in flight
-#define RR_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define RR_BARRIER() do { if (!RR_DBG(512)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
 #ifndef RR_NO_PIN
 #define RR_PIN_A(v) asm volatile("" : "+a"(v))      // accumulator-file registers: MFMA operands only, never copied about
 #else
@@ -202,12 +205,17 @@ struct RRParams {
 // issue port 8 of its 32 cycles).  Every vector-memory operation is a branch-free buffer operation (lanes that must not
 // load / store get an out-of-range offset), so the steady-state half-step is straight-line code apart from the poll.
 //
-// Signalling is by FLAG WORDS, not by an arrival counter: wave w of column tile ct stores (t + 1) write-through into
-// flags[batch tile][half][w * 32 + ct] once its own publishing stores have drained, and a consumer wave reads all 128
-// words (512 contiguous bytes) with two wave-wide sc1 loads.  Against the agent-scope counter of rec_persistent_kernel
-// this removes the serialisation of 32 read-modify-writes at the memory side (~12 ns each), the cross-wave gather in front of
-// the add, and makes the arrival a plain store.  Valid by the guide's sc1 hand-off table: every flag covers exactly
-// the stores of the wave that raises it, after that wave's vmcnt(0).
+// ONE wavefront publishes a half (wave 2 * half: all 64 lanes = 32 rows x 2 k halves, three full 1 KB write-through stores)
+// and another one (wave 2 * half + 1) stores the f32 layer output: with the rows spread over the four wavefronts every one of
+// them issued five quarter-filled store instructions per half-step, and a store occupies the shared address path as long
+// whatever it carries (measured: publication + output stores cost 1.06 us of a 7.0 us step that way).
+//
+// Signalling is by FLAG WORDS, not by an arrival counter: the publishing wave of column tile ct stores (t + 1) write-through
+// into flags[batch tile][half][ct] once its publishing stores have drained, and every consumer wave reads the batch tile's
+// flags with one wave-wide sc1 load.  Against the agent-scope counter of rec_persistent_kernel this removes the
+// serialisation of 32 read-modify-writes at the memory side (~12 ns each) and the cross-wave gather in front of the add,
+// and makes the arrival a plain store.  Valid by the guide's sc1 hand-off table: the flag covers exactly the stores of the
+// wave that raises it, after that wave's vmcnt wait.
 // KH / KX: k steps (of 16) per wavefront for the h / x part: H <= 64 KH, in <= 64 KX (zero padded).
 template <int KH, int KX>
 __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
@@ -293,16 +301,13 @@ __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
             const int k = (w * KX + ix) * 16 + 8 * kh + 4 * q;
             xvo[ix][q] = k < p.in ? (int)(n * x_row_bytes) + k * 4 : RR_OOB;
         }
-    // publishing lanes: wave w takes rows 8 w .. 8 w + 7 of a half (16 lanes: 8 rows x 2 k halves)
-    const bool pub_lane = (n >> 3) == w;
+    // publication: lane (n, kh) of the publishing wave owns hidden units 8 kh .. 8 kh + 7 of row n -- one B fragment of the
+    // consumers; output rows past the batch fall outside the descriptor; hand-off rows past the batch are written too
+    // (padding rows compute on zero inputs: finite, read only by themselves)
     const long o_row_bytes = (long)(p.return_sequences ? p.T : 1) * H * 4;
     const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(p.out + (size_t)b0 * (p.return_sequences ? p.T : 1) * H), 0, (int)(rows_valid * o_row_bytes), 0x00020000);
-    // one offset each for both halves (the half rides in the scalar offset): lanes that do not publish are out of range;
-    // output rows past the batch fall outside the descriptor; hand-off rows past the batch are written too (padding rows
-    // compute on zero inputs: finite, read only by themselves)
-    const int pub_vo = pub_lane ? lane16 : RR_OOB;
-    const int out_vo = pub_lane ? (int)(n * o_row_bytes) + (16 * ct + 8 * kh) * 4 : RR_OOB;
+    const int out_vo = (int)(n * o_row_bytes) + (16 * ct + 8 * kh) * 4;
     const int out_half = (int)(32 * o_row_bytes);
     RR_BARRIER();
 
@@ -359,6 +364,7 @@ __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
         rr_v4u s0[4], s1[4];
 #pragma unroll
         for (int src = 0; src < 4; ++src) {
+            if (RR_DBG(256)) { s0[src] = (rr_v4u){0x3c000000u + lane, 0x3c100000u, 0x3c200000u, 0x3c300000u}; s1[src] = s0[src]; continue; }
             s0[src] = red[((w * 4 + src) * 2 + 0) * 64 + lane];
             s1[src] = red[((w * 4 + src) * 2 + 1) * 64 + lane];
         }
@@ -375,6 +381,7 @@ __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
         float hn[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
+            if (RR_DBG(64)) { hn[e] = z[0][e] + z[1][e] + z[2][e] + z[3][e] + cst[half][e]; continue; }
             const float ig = nntk_fast_sigmoid(z[0][e] + bsum[0][e]);
             const float fg = nntk_fast_sigmoid(z[1][e] + bsum[1][e]);
             const float gg = nntk_fast_tanh(z[2][e] + bsum[2][e]);
@@ -385,70 +392,72 @@ __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
         }
         *reinterpret_cast<float2 *>(hx + n * RR_HX_LD + jl) = make_float2(hn[0], hn[1]);
     };
-    rr_v4u pubv[2];                // the published row piece in f32: the layer output leaves later, off the drain path
-    auto store_out = [&](int half, int t) __attribute__((always_inline)) {
-        if (p.return_sequences) {
-            __builtin_amdgcn_raw_buffer_store_b128(pubv[0], rso, out_vo, half * out_half + t * H * 4, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(pubv[1], rso, out_vo + 16, half * out_half + t * H * 4, 0);
-        }
-    };
     auto fin_publish = [&](auto half_tag, auto last_tag, int t) __attribute__((always_inline)) {
         constexpr int half = decltype(half_tag)::value;
         constexpr bool LAST = decltype(last_tag)::value;     // the half's last step: final state / last output leave from here
         RR_BARRIER();                                   // the half's h row pieces are in `hx`
-        const float4 h_lo = *reinterpret_cast<const float4 *>(hx + n * RR_HX_LD + 8 * kh);
-        const float4 h_hi = *reinterpret_cast<const float4 *>(hx + n * RR_HX_LD + 8 * kh + 4);
-        const float v[8] = {h_lo.x, h_lo.y, h_lo.z, h_lo.w, h_hi.x, h_hi.y, h_hi.z, h_hi.w};
-        rr_v4u a, b, c;
-        rr_split8(v, a, b, c);
-        const int so = (((bt_abs * 2 + half) * NKS + ct) * 3) * 1024;
-        if ((t + 1) & 1) {
-            __builtin_amdgcn_raw_buffer_store_b128(a, rs1, pub_vo, so, 16 /* sc1 */);
-            __builtin_amdgcn_raw_buffer_store_b128(b, rs1, pub_vo + 1024, so, 16);
-            __builtin_amdgcn_raw_buffer_store_b128(c, rs1, pub_vo + 2048, so, 16);
-        } else {
-            __builtin_amdgcn_raw_buffer_store_b128(a, rs0, pub_vo, so, 16);
-            __builtin_amdgcn_raw_buffer_store_b128(b, rs0, pub_vo + 1024, so, 16);
-            __builtin_amdgcn_raw_buffer_store_b128(c, rs0, pub_vo + 2048, so, 16);
-        }
-        pubv[0] = (rr_v4u){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-        pubv[1] = (rr_v4u){__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])};
-        if (LAST) {
-            int b0e = b0;
-            asm volatile("" : "+s"(b0e));                 // opaque: keeps these addresses from being computed (and spilled) ahead of the loop
-            const int row = b0e + half * 32 + n;
-            if (pub_lane && row < p.B) {
-                if (!p.return_sequences) {
-                    float *o = p.out + (size_t)row * H + 16 * ct + 8 * kh;
-                    *reinterpret_cast<float4 *>(o) = h_lo; *reinterpret_cast<float4 *>(o + 4) = h_hi;
-                }
-                if (p.hT) {
-                    float *o = p.hT + (size_t)row * H + 16 * ct + 8 * kh;
-                    *reinterpret_cast<float4 *>(o) = h_lo; *reinterpret_cast<float4 *>(o + 4) = h_hi;
+        if (w == 2 * half) {                            // the publishing wave: split, three full write-through stores
+            const float4 h_lo = *reinterpret_cast<const float4 *>(hx + n * RR_HX_LD + 8 * kh);
+            const float4 h_hi = *reinterpret_cast<const float4 *>(hx + n * RR_HX_LD + 8 * kh + 4);
+            const float v[8] = {h_lo.x, h_lo.y, h_lo.z, h_lo.w, h_hi.x, h_hi.y, h_hi.z, h_hi.w};
+            rr_v4u a, b, c;
+            if (!RR_DBG(128)) rr_split8(v, a, b, c);
+            const int so = (((bt_abs * 2 + half) * NKS + ct) * 3) * 1024;
+            if (RR_DBG(128)) {
+            } else if ((t + 1) & 1) {
+                __builtin_amdgcn_raw_buffer_store_b128(a, rs1, lane16, so, 16 /* sc1 */);
+                __builtin_amdgcn_raw_buffer_store_b128(b, rs1, lane16 + 1024, so, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(c, rs1, lane16 + 2048, so, 16);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(a, rs0, lane16, so, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(b, rs0, lane16 + 1024, so, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(c, rs0, lane16 + 2048, so, 16);
+            }
+        } else if (w == 2 * half + 1) {                 // the output wave: the same row pieces in f32
+            const rr_v4u o0 = *reinterpret_cast<const rr_v4u *>(hx + n * RR_HX_LD + 8 * kh);
+            const rr_v4u o1 = *reinterpret_cast<const rr_v4u *>(hx + n * RR_HX_LD + 8 * kh + 4);
+            if (p.return_sequences && !RR_DBG(1024)) {
+                __builtin_amdgcn_raw_buffer_store_b128(o0, rso, out_vo, half * out_half + t * H * 4, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o1, rso, out_vo + 16, half * out_half + t * H * 4, 0);
+            }
+            if (LAST) {
+                int b0e = b0;
+                asm volatile("" : "+s"(b0e));             // opaque: keeps these addresses from being computed (and spilled) ahead of the loop
+                const int row = b0e + half * 32 + n;
+                if (row < p.B) {
+                    if (!p.return_sequences) {
+                        float *o = p.out + (size_t)row * H + 16 * ct + 8 * kh;
+                        *reinterpret_cast<rr_v4u *>(o) = o0; *reinterpret_cast<rr_v4u *>(o + 4) = o1;
+                    }
+                    if (p.hT) {
+                        float *o = p.hT + (size_t)row * H + 16 * ct + 8 * kh;
+                        *reinterpret_cast<rr_v4u *>(o) = o0; *reinterpret_cast<rr_v4u *>(o + 4) = o1;
+                    }
                 }
             }
         }
     };
     unsigned *const flags0 = p.flags + (size_t)bt * 2 * RR_FLAGS, *const flags1 = flags0 + RR_FLAGS;
-    // arrival: this wave's publishing stores have drained -> raise this wave's flag (write-through store of t + 1)
-    // (counted wait: the x request and the second operand batch, issued after the publication, stay in flight)
+    // arrival (publishing wave only): its publishing stores have drained -> raise the column tile's flag (write-through store
+    // of t + 1).  Counted wait: the x request and the own-sequence operand requests issued after the publication stay in flight.
     auto arrive = [&](int half, int t) __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N_AFTER_PUB) : "memory");
-        if (lane == 0)
-            __hip_atomic_store((half ? flags1 : flags0) + w * 32 + ct, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w == 2 * half) {
+            asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N_AFTER_PUB) : "memory");
+            if (lane == 0)
+                __hip_atomic_store((half ? flags1 : flags0) + ct, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     };
-    // every wave polls for itself: two sc1 loads cover all 128 flags; requested a k step before they are looked at
-    unsigned pv0 = 0, pv1 = 0;
-    const bool flag_live = (lane & 31) < p.NCT;        // flags of column tiles that do not exist stay 0
+    // every wave polls for itself: one sc1 load covers the batch tile's flags; requested RR_POLL_LEAD k steps before it is looked at
+    unsigned pv0 = 0;
+    const bool flag_live = lane < p.NCT;               // lanes past the last column tile read padding words (always 0)
     auto poll_a = [&](int half) __attribute__((always_inline)) {
         const unsigned *f = (half ? flags1 : flags0) + lane;
-        asm volatile("global_load_dword %0, %2, off sc1\n\tglobal_load_dword %1, %2, off offset:256 sc1"
-                     : "=&v"(pv0), "=&v"(pv1) : "v"(f) : "memory");
+        asm volatile("global_load_dword %0, %1, off sc1" : "=v"(pv0) : "v"(f) : "memory");
     };
     auto poll_b = [&](int half, int t) __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv0), "+v"(pv1) :: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv0) :: "memory");
         const unsigned target = (unsigned)t;
-        bool ok = !flag_live || (pv0 >= target && pv1 >= target);
+        bool ok = !flag_live || pv0 >= target;
         // spin_ticks == 0 is fault injection (tests): behave as if the very first poll had found nothing and run out of budget
         if (__builtin_amdgcn_ballot_w64(!ok) != 0 || p.spin_ticks == 0) {  // something has not arrived yet: spin (bounded)
             const unsigned *f = (half ? flags1 : flags0) + lane;
@@ -456,8 +465,7 @@ __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
             bool expired = p.spin_ticks == 0;
             while (!expired) {
                 const unsigned a = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned b = __hip_atomic_load(f + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = !flag_live || (a >= target && b >= target);
+                ok = !flag_live || a >= target;
                 if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
                 // a peer that gave up has raised the fault word: every other spin ends at once
                 if (__hip_atomic_load(p.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { expired = true; break; }
@@ -504,7 +512,6 @@ __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
             if (s == S_E2 - RR_POLL_LEAD && NEXT && POLL && !RR_DBG(4)) poll_a(X);
             if (s == S_E2) {
                 if (NEXT && POLL && !RR_DBG(4)) poll_b(X, tX + 1);
-                if (FIN && !RR_DBG(2)) store_out(X, tX);
             }
             if (s == S_E2 && NEXT && !RR_DBG(1)) issue_h(XT{}, tX + 1, 0, 3 * NPRE);          // head of X's next operand
             if (s + NPRE < KH && !RR_DBG(1)) issue_h(y_tag, t, 3 * (s + NPRE), 3 * (s + NPRE + 1));       // THIS half's operand, k step s + NPRE (published long ago)
@@ -591,7 +598,6 @@ __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
     fin_reduce();
     fin_gates(I1{});
     fin_publish(I1{}, Tt{}, T - 1);
-    store_out(1, T - 1);
     // ---- final cell state ----
     int b0e = b0;
     asm volatile("" : "+s"(b0e));
