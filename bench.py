@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--workload", default="stack", choices=["stack", "spectrogram", "conv", "gru"])
     ap.add_argument("--batch-per-gpu", type=int, default=0, help="utterances per GPU (0 = the BASELINE shape)")
     ap.add_argument("--frames", type=int, default=1000)
+    ap.add_argument("--conv-stride", type=int, default=1, help="stride of the conv workload's Conv1d (2 = the sub-sampling front end; not a BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--dry-run", action="store_true",
@@ -171,7 +172,7 @@ class Workload:
         if name in ("stack", "conv"):
             cin = 257 if name == "stack" else 40
             T = self.spec.out_shape[0] if name == "stack" else frames
-            self.conv = NL.Conv1d(cin, 128, 5, 1, T)
+            self.conv = NL.Conv1d(cin, 128, 5, int(os.environ.get("NNTK_BENCH_CONV_STRIDE", "1")) if name == "conv" else 1, T)
             Tc = self.conv.out_shape[0]
             self.bn = NL.BatchNorm(128, 1e-3, Tc)
             self.relu = NL.Activation("relu", Tc * 128, 1.0)
@@ -433,6 +434,8 @@ def dry_run(a, world, rank):
 
 def main():
     a = parse()
+    if a.conv_stride != 1:
+        os.environ["NNTK_BENCH_CONV_STRIDE"] = str(a.conv_stride)       # reaches Workload in this process and in self-launched ranks
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(a))          # parent: nothing below runs here, the GPU is never touched
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -564,7 +567,8 @@ def main():
         "config": {"workload": {
             "stack": "BASELINE configs[4]: Spectrogram(400/160/512)->Conv1d(257->128,k=5)+BN+ReLU->LSTM(512,v2)->TDD(1000)",
             "spectrogram": "BASELINE configs[1]: Spectrogram(400/160/512) on batch x 16000",
-            "conv": "BASELINE configs[2]: Conv1d(40->128,k=5)+BN+ReLU on batch x frames x 40",
+            "conv": ("BASELINE configs[2]: Conv1d(40->128,k=5)+BN+ReLU on batch x frames x 40" if a.conv_stride == 1 else
+                     "Conv1d(40->128,k=5,stride=%d)+BN+ReLU on batch x frames x 40 (NOT a BASELINE config: the sub-sampling variant of configs[2])" % a.conv_stride),
             "gru": "BASELINE configs[3]: 2-layer GRU(128->256->256) on batch x frames x 128"}[a.workload],
             "utterances_per_gpu": B, "frames_per_utterance": wl.frames_per_utt, "global_batch": B * world,
             "parallelism": "utterance shards, dp%d, no data-path collective" % world,

@@ -14,7 +14,7 @@ OBJ = os.path.join(PKG, "lib", "obj")
 LIB = os.path.join(PKG, "lib", "libnntoolkitcore_hip.so")
 
 HOST_SRC = ["runtime.c", "activation.c", "conv_1d.c", "recurrent.c", "dense.c", "spectrogram.c", "mel.c", "train.c"]
-HIP_SRC = ["runtime.hip", "conv1d.hip", "recurrent.hip", "recurrent_rr.hip", "spectrogram.hip", "dist.hip", "conv1d_grad.hip", "train.hip"]
+HIP_SRC = ["runtime.hip", "conv1d.hip", "conv1d_s2.hip", "recurrent.hip", "recurrent_rr.hip", "spectrogram.hip", "dist.hip", "conv1d_grad.hip", "train.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
@@ -26,6 +26,7 @@ def source_hash():
     h = hashlib.sha256()
     files = [os.path.join(CSRC, "host", f) for f in HOST_SRC] + [os.path.join(CSRC, "hip", f) for f in HIP_SRC]
     files += [os.path.join(CSRC, "hip", "nntk_shim.h"), os.path.join(CSRC, "hip", "nntk_common.hpp"),
+              os.path.join(CSRC, "hip", "conv1d_kernels.hpp"),
               os.path.join(CSRC, "host", "nntk_internal.h"), os.path.join(ROOT, "include", "nntoolkitcore_hip.h")]
     for f in sorted(files):
         h.update(os.path.basename(f).encode())
@@ -54,27 +55,32 @@ def build(force=False, verbose=False):
     headers = [os.path.join(ROOT, "include", "nntoolkitcore_hip.h"),
                os.path.join(CSRC, "hip", "nntk_shim.h"),
                os.path.join(CSRC, "hip", "nntk_common.hpp"),
+               os.path.join(CSRC, "hip", "conv1d_kernels.hpp"),
                os.path.join(CSRC, "host", "nntk_internal.h")]
-    objs = []
+    objs, jobs = [], []
     for f in HOST_SRC:
         src = os.path.join(CSRC, "host", f)
         obj = os.path.join(OBJ, f + ".o")
         objs.append(obj)
         if force or _newer([src] + headers, obj):
-            out = _run(["gcc", "-O2", "-fPIC", "-std=gnu11", "-Wall", "-Wextra", "-Wno-unused-parameter",
-                        "-fvisibility=default", "-I" + os.path.join(ROOT, "include"), "-c", src, "-o", obj])
-            if verbose and out:
-                print(out)
+            jobs.append(["gcc", "-O2", "-fPIC", "-std=gnu11", "-Wall", "-Wextra", "-Wno-unused-parameter",
+                         "-fvisibility=default", "-I" + os.path.join(ROOT, "include"), "-c", src, "-o", obj])
     for f in HIP_SRC:
         src = os.path.join(CSRC, "hip", f)
         obj = os.path.join(OBJ, f + ".o")
         objs.append(obj)
         if force or _newer([src] + headers, obj):
-            out = _run([HIPCC, "-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-Wall",
-                        "-Wno-unused-function"] + os.environ.get("NNTK_EXTRA_HIPFLAGS", "").split() +
-                       ["-c", src, "-o", obj])
-            if verbose and out:
-                print(out)
+            jobs.append([HIPCC, "-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-Wall",
+                         "-Wno-unused-function"] + os.environ.get("NNTK_EXTRA_HIPFLAGS", "").split() +
+                        ["-c", src, "-o", obj])
+    if jobs:
+        # the translation units are independent: compile them side by side (the two conv1d units take minutes each)
+        from concurrent.futures import ThreadPoolExecutor
+        workers = max(1, min(len(jobs), int(os.environ.get("NNTK_BUILD_JOBS", "0")) or (os.cpu_count() or 4)))
+        with ThreadPoolExecutor(workers) as pool:
+            for out in pool.map(_run, jobs):
+                if verbose and out:
+                    print(out)
     if force or _newer(objs, LIB):
         _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB

@@ -29,6 +29,7 @@ struct NntkOptions {
     int conv_a4 = 1;             // 16-byte window loads also for channel counts that are not multiples of 4 (0: 4-byte loads there)
     int conv_store = -1;         // GEMM epilogue: -1 auto, 0 row form (4-byte stores), 1 quad form (16-byte stores); bit-identical
     int gemm_split_bf16 = -1;    // 3-way split-bf16 contraction: -1 auto (conv / dense / TDD / mel, not the recurrent xW), 0 never, 1 all
+    int gemm_wide = -1;          // 128 x 256 tile for wide dense GEMMs on the split path (0 off)
     int conv_dbg = 0;            // diagnostics build only
     int weights_check = -1;      // host-pointer Apply: 1 (default) whole-block compare with the shadow each call, sampled only on
                                  // the streaming recurrent call; 2 whole block everywhere; 0 trust *SyncWeights

@@ -251,3 +251,54 @@ def test_persistent_lstm_while_rccl_broadcasts_on_another_stream(gpu):
         lstm.destroy()
     finally:
         assert L.nntk_dist_finalize() == 0
+
+
+# ------------------------------------------------------------ stride-2 Conv1d on the MFMA kernels ---
+# Reference: layers/conv_1d.c:128-140 (`input_row_offset = x * stride`).  Until round 3 every stride > 1 ran the
+# one-thread-per-output VALU kernel; stride 2 (window of (128 - 1) * 2 + k rows per tile) now has its own MFMA instantiations.
+
+@pytest.mark.parametrize("cin,cout,k,T,B", [
+    (16, 48, 3, 99, 1),           # BN = 64 tile, ragged
+    (40, 128, 5, 1000, 3),        # config 3 with stride 2: BN = 128 tile, 4 row tiles
+    (257, 128, 5, 300, 2),        # odd channel count (ragged last chunk, 16-byte loads on 1028-byte rows)
+    (24, 32, 9, 700, 2),          # BN = 32 tile, long kernel
+    (33, 100, 4, 257, 1),         # Cout not a multiple of 32, Cin not a multiple of 4 (4-byte window loads)
+])
+def test_conv1d_stride2_mfma_matches_oracle_split_and_exact(gpu, cin, cout, k, T, B):
+    r = rng(cin * 7 + cout)
+    x, W, b = u(r, B, T, cin), u(r, cout, cin, k, sc=(cin * k) ** -0.5), u(r, cout, sc=0.2)
+    conv = NL.Conv1d(cin, cout, k, 2, T)
+    conv.set_weights(W, b)
+    ref = np.stack([O.conv1d(xi, W, b, 2) for xi in x])
+    got = conv.apply(x)
+    capi.set_option("gemm_split_bf16", 0)
+    exact = conv.apply(x)
+    capi.set_option("gemm_split_bf16", "auto")
+    assert got.shape == ref.shape == (B, (T - (k - 2)) // 2, cout)
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(exact, ref, rtol=1e-5, atol=1e-5)
+    conv.destroy()
+
+
+def test_conv1d_stride2_fused_bn_relu_full_size(gpu):
+    """Conv1d(40 -> 128, k = 5, stride 2) + BatchNorm + ReLU on 1024 x 1000 x 40 (config 3's sub-sampling variant):
+    sampled utterances against the oracle."""
+    import torch
+    r = rng(3032)
+    B, T, cin, cout, k = 1024, 1000, 40, 128, 5
+    x = torch.randn(B, T, cin, device="cuda", generator=torch.Generator(device="cuda").manual_seed(9))
+    W, b = u(r, cout, cin, k, sc=(cin * k) ** -0.5), u(r, cout, sc=0.1)
+    g, be, mu, var = 1 + u(r, cout, sc=0.5), u(r, cout, sc=0.5), u(r, cout, sc=0.1), 1 + u(r, cout, sc=0.5)
+    conv = NL.Conv1d(cin, cout, k, 2, T)
+    conv.set_weights(W, b)
+    Tc = conv.out_shape[0]
+    assert Tc == 498
+    bn, relu = NL.BatchNorm(cout, 1e-3, Tc), NL.Activation("relu", Tc * cout, 1.0)
+    bn.set_weights(g, be, mu, var)
+    y = conv.apply_device(x, bn=bn, act=relu)
+    for i in (0, 511, 1023):
+        ref = O.activation(O.ACT_RELU, O.batch_norm(O.conv1d(x[i].cpu().numpy(), W, b, 2), g, be, mu, var, 1e-3))
+        np.testing.assert_allclose(y[i].cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    # timing against the VALU kernel it replaces is in profiles/r03_conv_stride2.log (bench.py --workload conv --conv-stride 2)
+    for o in (conv, bn, relu):
+        o.destroy()

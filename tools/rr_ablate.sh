@@ -8,7 +8,7 @@ T=$(mktemp -d)
 for f in runtime activation conv_1d recurrent dense spectrogram mel train; do
   gcc -O2 -fPIC -std=gnu11 -I$R/include -c $R/nntoolkitcore_amd/csrc/host/$f.c -o $T/$f.c.o &
 done
-for f in runtime conv1d recurrent spectrogram dist conv1d_grad train; do
+for f in runtime conv1d conv1d_s2 recurrent spectrogram dist conv1d_grad train; do
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wno-unused-function -c $R/nntoolkitcore_amd/csrc/hip/$f.hip -o $T/$f.hip.o &
 done
 for m in "$@"; do
