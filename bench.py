@@ -253,7 +253,7 @@ def pmc_traffic(kernel_prefix, B):
     import glob
     from nntoolkitcore_amd._build import source_hash
     want = source_hash()
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
         try:
             d = json.load(open(path))
         except (OSError, ValueError):
@@ -280,8 +280,10 @@ def roofline_for(wl, phase_ms, prof):
         bytes_ = B * (wl.x.shape[1] * 4 + nts * nfreq * 4)
         ms = phase_ms["spectrogram"]
         ach = bytes_ / (ms * 1e-3) / 1e9
+        traffic, traffic_source = pmc_traffic("spectrogram512_kernel", B)
         return {"kernel": "spectrogram512_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": None, "ms_per_launch": ms, "algorithmic_bytes": bytes_}
+                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "ms_per_launch": ms,
+                "algorithmic_bytes": bytes_}
     if wl.name == "conv":
         Tc = wl.conv.out_shape[0]
         cin = wl.conv.cfg.input_feature_channels
@@ -290,17 +292,18 @@ def roofline_for(wl, phase_ms, prof):
         ms = phase_ms["conv_bn_relu"]
         ach = flops / (ms * 1e-3) / 1e12
         hbm_frac = bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        traffic, traffic_source = pmc_traffic("conv1d_mfma_kernel" if gemm_mode() == "exact-f32" else "conv1d_mfma_bf16x3_kernel", B)
         if gemm_mode() == "exact-f32":
             return {"kernel": "conv1d_mfma_kernel<2,2,2,2>", "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None, "ms_per_launch": ms,
+                    "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source, "ms_per_launch": ms,
                     "algorithmic_flops": flops, "algorithmic_bytes": bytes_, "hbm_frac": hbm_frac}
         # split-bf16x3: six bf16 MFMA products per f32 product, so the MFMA ceiling in ALGORITHMIC flops is the dense
         # bf16 peak / 6 (still above the HBM ceiling's time here: 125 us vs 86 us at config 3)
         peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
         return {"kernel": "conv1d_mfma_bf16x3_kernel<2,2,2,2>", "bound": "mfma", "achieved": ach, "peak": peak,
                 "peak_note": "dense bf16 MFMA peak / 6 products per f32 product", "unit": "TFLOP/s", "frac": ach / peak,
-                "traffic": None, "ms_per_launch": ms, "algorithmic_flops": flops, "algorithmic_bytes": bytes_,
-                "hbm_frac": hbm_frac, "frac_of_exact_f32_mfma_peak": ach / F32_MFMA_PEAK_TFLOPS}
+                "traffic": traffic, "traffic_source": traffic_source, "ms_per_launch": ms, "algorithmic_flops": flops,
+                "algorithmic_bytes": bytes_, "hbm_frac": hbm_frac, "frac_of_exact_f32_mfma_peak": ach / F32_MFMA_PEAK_TFLOPS}
     # recurrent step kernel: one launch = one timestep of hU = h[B,H] x U[H,G*H] + fused gates
     H, G = (512, 4) if wl.name == "stack" else (256, 3)
     ms = prof.get("rec_launch_ms", None)
@@ -336,8 +339,7 @@ def roofline_for(wl, phase_ms, prof):
         tpl = tpl - 1
         flops = 3.0 * 2.0 * B * H * G * H * tpl
     ach = flops / (ms * 1e-3) / 1e12
-    traffic, traffic_source = (pmc_traffic("rec_persistent_kernel<4" if G == 4 else "rec_persistent_kernel<3", B)
-                               if (persistent and wl.name == "stack") else (None, "not profiled for this workload"))
+    traffic, traffic_source = (pmc_traffic(kern.split("<")[0], B) if persistent else (None, "per-timestep kernels: not profiled"))
     return {"kernel": kern, "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
             "ms_per_launch": ms, "algorithmic_flops": flops,
@@ -394,7 +396,7 @@ def cpu_baseline(workload, weights, frames, seed):
         # core/loop.h:23 -- so the 1-thread figure above stays the faithful one; this is its embarrassingly
         # parallel upper bound on this host).  ctypes releases the GIL inside the oracle's C calls.
         from concurrent.futures import ThreadPoolExecutor
-        n_thr = max(1, min(16, os.cpu_count() or 1))
+        n_thr = max(1, min(512, os.cpu_count() or 1))          # N = nproc; VERDICT r02: no cap at 16
         xs = (0.1 * r.standard_normal((n_thr, 240 + 160 * fr))).astype(np.float32)
 
         def one(i):

@@ -23,8 +23,19 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_write.log 2>&1; echo write $?
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_sq.log 2>&1; echo sq $?
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq_gru -- python3 $R/bench.py --workload gru --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_sq_gru.log 2>&1; echo sq_gru $?
+for wb in gru:1024 conv:1024 spectrogram:256; do
+  w=${wb%%:*}
+  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_$w -- python3 $R/bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_fetch_$w.log 2>&1; echo fetch_$w $?
+  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_$w -- python3 $R/bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_write_$w.log 2>&1; echo write_$w $?
+done
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_elementwise -- python3 $R/tools/elementwise_bench.py > $O/elementwise.log 2>&1; cat $O/elementwise.log | grep -v amdgpu.ids
+for f in $(ls $O/prof_elementwise/*/*kernel_stats.csv 2>/dev/null); do cut -c1-150 $f | head -7; done
 cd $R
-python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json 512 > /dev/null && echo traffic ok
+python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json 512 stack > /dev/null && echo traffic ok
+for wb in gru:1024 conv:1024 spectrogram:256; do
+  w=${wb%%:*}; b=${wb##*:}
+  python3 tools/pmc_summary.py $O/pmc_fetch_$w $O/pmc_write_$w $O/pmc_traffic_$w.json $b $w > /dev/null && echo traffic_$w ok
+done
 python3 tools/pmc_sq_summary.py $O/pmc_sq $O/pmc_sq.json > /dev/null && echo sq ok
 python3 tools/pmc_sq_summary.py $O/pmc_sq_gru $O/pmc_sq_gru.json > /dev/null && echo sq_gru ok
 ls $O
