@@ -528,15 +528,23 @@ def main():
     else:
         for i in range(a.steps):
             events.append(wl.step(timed=True))
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0          # this rank's own time for its K steps, before it waits for the others
     barrier()
     dt = time.perf_counter() - t0
     check_device_status("after the timed steps")
     crcs = [weights_crc]
+    rank_ms = [dt_own / a.steps * 1e3]
     if dist is not None:
         on_gpu = dist.get_backend() == "nccl"
         t = torch.tensor([dt], device="cuda" if on_gpu else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # per-rank step time: skew between the GPUs of a node is visible in the record
+        o = torch.tensor([dt_own / a.steps * 1e3], device="cuda" if on_gpu else "cpu", dtype=torch.float64)
+        os_ = [torch.zeros_like(o) for _ in range(world)]
+        dist.all_gather(os_, o)
+        rank_ms = [float(x.item()) for x in os_]
         # the broadcast really delivered rank 0's weights everywhere
         c = torch.tensor([weights_crc], device="cuda" if on_gpu else "cpu", dtype=torch.int64)
         cs = [torch.zeros_like(c) for _ in range(world)]
@@ -584,6 +592,7 @@ def main():
                               "(profiles/r02_split_error.log, tools/split_error.py); NNTK_GEMM_SPLIT_BF16=0 selects the exact chain")
                              if gemm_mode() != "exact-f32" else "exact-f32 MFMA chain"},
         "phase_ms": {k: round(v, 4) for k, v in phase_ms.items()},
+        "rank_ms_per_step": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4), "per_rank": [round(v, 4) for v in rank_ms]},
     }
     if rank == 0:
         out["roofline"] = roofline_for(wl, phase_ms, prof)

@@ -180,6 +180,10 @@ int nntk_shim_lstm(const float *d_xw, const float *d_ut, const float *d_bh,
 size_t nntk_shim_lstm_rr_image_floats(int H, int in);           /* 0: shape not taken */
 size_t nntk_shim_lstm_rr_work_floats(int B, int H);
 int nntk_shim_lstm_rr_pack(const float *d_ut, const float *d_wp, float *d_img, int H, int in);
+int nntk_shim_lstm_rr_pack_raw(const float *d_U /*[H][4H]*/, const float *d_W /*[in][4H]*/, float *d_img, int H, int in);
+/* training forward on the same kernel (zero initial state): h [B][T][H] and the BPTT caches c [B][T][H], zifgo [B][T][8H] */
+int nntk_shim_lstm_rr_train_forward(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,
+                                    float *d_h, float *d_c, float *d_zifgo, float *d_work, int B, int T, int in, int H);
 int nntk_shim_lstm_rr(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,
                       const float *d_h0, const float *d_c0, float *d_out, float *d_hT, float *d_cT,
                       float *d_work, int B, int T, int in, int H, int return_sequences);

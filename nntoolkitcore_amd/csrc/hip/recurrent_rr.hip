@@ -89,7 +89,10 @@ __device__ __forceinline__ void rr_split8(const float (&v)[8], rr_v4u &hi, rr_v4
 //   WX [w][ix < KX][mt][m = hi, mid, lo]  -> LDS
 __host__ __device__ inline int rr_blocks_per_ct(int KH, int KX) { return 4 * KH * 2 * 2 + 4 * KH * 2 + 4 * KX * 2 * 3; }
 
-// ut [4][Hj_p][Hk_p] f32 (U^T per gate), wp [4H padded][Kin_p] f32 (W^T, K-contiguous) -> images
+// ut [4][Hj_p][Hk_p] f32 (U^T per gate), wp [4H padded][Kin_p] f32 (W^T, K-contiguous) -> images.
+// RAW: the sources are the caller's own layout instead, U [H][4H] and W [in][4H] (recurrent_private.c:29-36): the training
+// forward re-packs every mini-batch (the weights change with every optimiser step) straight from the uploaded block.
+template <bool RAW>
 __global__ __launch_bounds__(256) void rr_pack_kernel(const float *__restrict__ ut, const float *__restrict__ wp,
                                                       rr_v4u *__restrict__ img, int H, int in, int Hj_p, int Hk_p, int Kin_p,
                                                       int KH, int KX, int NCT) {
@@ -115,8 +118,13 @@ __global__ __launch_bounds__(256) void rr_pack_kernel(const float *__restrict__ 
             const int k = 16 * ks + 8 * (l >> 5) + q;
             float val = 0.0f;
             if (j < H) {
-                if (part == 2) { if (k < in) val = wp[((size_t)g * H + j) * Kin_p + k]; }
-                else if (k < H) val = ut[((size_t)g * Hj_p + j) * Hk_p + k];
+                if (RAW) {
+                    if (part == 2) { if (k < in) val = wp[(size_t)k * 4 * H + (size_t)g * H + j]; }
+                    else if (k < H) val = ut[(size_t)k * 4 * H + (size_t)g * H + j];
+                } else {
+                    if (part == 2) { if (k < in) val = wp[((size_t)g * H + j) * Kin_p + k]; }
+                    else if (k < H) val = ut[((size_t)g * Hj_p + j) * Hk_p + k];
+                }
             }
             v[q] = val;
         }
@@ -157,6 +165,8 @@ struct RRParams {
     float *cT, *hT;            // [B][H] or NULL
     float *out;                // [B][T][H] or [B][H]
     unsigned *flags;           // [NBT][2 halves][RR_FLAGS], zeroed before the launch
+    float *c_cache;            // training forward (TRAIN): cell state of every step [B][T][H] ...
+    float *z_cache;            // ... and pre-activations | activations [B][T][8H] (lstm.c:426-475 keeps them for BPTT)
     unsigned *fault;
     unsigned long long spin_ticks;
     int B, T, H, in, NBT, NCT, b_base, return_sequences;
@@ -217,7 +227,9 @@ struct RRParams {
 // and makes the arrival a plain store.  Valid by the guide's sc1 hand-off table: the flag covers exactly the stores of the
 // wave that raises it, after that wave's vmcnt wait.
 // KH / KX: k steps (of 16) per wavefront for the h / x part: H <= 64 KH, in <= 64 KX (zero padded).
-template <int KH, int KX>
+// TRAIN: the training forward pass (LSTMApplyTrainingBatch, lstm.c:426-475): additionally keeps c_t and the gates' pre-activations
+// and activations of every step for back-propagation through time.
+template <int KH, int KX, bool TRAIN = false>
 __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
     constexpr int NKS = 4 * KH;                       // k steps of the hand-off buffer (>= H / 16)
     constexpr int NST = KX + KH;                      // k steps one wavefront multiplies per half
@@ -376,21 +388,36 @@ __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
         z[2][0] = sum4(s1[0].x, s1[1].x, s1[2].x, s1[3].x); z[2][1] = sum4(s1[0].y, s1[1].y, s1[2].y, s1[3].y);
         z[3][0] = sum4(s1[0].z, s1[1].z, s1[2].z, s1[3].z); z[3][1] = sum4(s1[0].w, s1[1].w, s1[2].w, s1[3].w);
     };
-    auto fin_gates = [&](auto half_tag) __attribute__((always_inline)) {      // lstm.c:201-238: Z = xW + b_i + hU (+ b_h); blocks i | f | g | o
+    auto fin_gates = [&](auto half_tag, int t) __attribute__((always_inline)) {      // lstm.c:201-238: Z = xW + b_i + hU (+ b_h); blocks i | f | g | o
         constexpr int half = decltype(half_tag)::value;
-        float hn[2];
+        float hn[2], zc[4][2], ac[4][2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             if (RR_DBG(64)) { hn[e] = z[0][e] + z[1][e] + z[2][e] + z[3][e] + cst[half][e]; continue; }
-            const float ig = nntk_fast_sigmoid(z[0][e] + bsum[0][e]);
-            const float fg = nntk_fast_sigmoid(z[1][e] + bsum[1][e]);
-            const float gg = nntk_fast_tanh(z[2][e] + bsum[2][e]);
-            const float og = nntk_fast_sigmoid(z[3][e] + bsum[3][e]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) zc[g][e] = z[g][e] + bsum[g][e];
+            const float ig = nntk_fast_sigmoid(zc[0][e]);
+            const float fg = nntk_fast_sigmoid(zc[1][e]);
+            const float gg = nntk_fast_tanh(zc[2][e]);
+            const float og = nntk_fast_sigmoid(zc[3][e]);
             const float cn = fmaf(fg, cst[half][e], ig * gg);
             cst[half][e] = cn;
             hn[e] = og * nntk_fast_tanh(cn);
+            ac[0][e] = ig; ac[1][e] = fg; ac[2][e] = gg; ac[3][e] = og;
         }
         *reinterpret_cast<float2 *>(hx + n * RR_HX_LD + jl) = make_float2(hn[0], hn[1]);
+        if (TRAIN) {
+            const int row = b0 + half * 32 + n;
+            if (row < p.B && jf + 1 < H + 1) {                 // H % 2 == 0 here (H % 16 == 0): both cells or none
+                float *zrow = p.z_cache + ((size_t)row * T + t) * 8 * H + jf;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    *reinterpret_cast<float2 *>(zrow + g * H) = make_float2(zc[g][0], zc[g][1]);
+                    *reinterpret_cast<float2 *>(zrow + (4 + g) * H) = make_float2(ac[g][0], ac[g][1]);
+                }
+                *reinterpret_cast<float2 *>(p.c_cache + ((size_t)row * T + t) * H + jf) = make_float2(cst[half][0], cst[half][1]);
+            }
+        }
     };
     auto fin_publish = [&](auto half_tag, auto last_tag, int t) __attribute__((always_inline)) {
         constexpr int half = decltype(half_tag)::value;
@@ -506,7 +533,7 @@ __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
                 for (int mt = 0; mt < 2; ++mt) ulo[mt] = __builtin_bit_cast(rr_bf16x8, ULs[((w * KH + (s - KX)) * 2 + mt) * 64 + lane]);
             }
             // ---- slices of the other half's finish and of its next fetch ----
-            if (s == S_RED && FIN && !RR_DBG(2)) { fin_reduce(); fin_gates(XT{}); }
+            if (s == S_RED && FIN && !RR_DBG(2)) { fin_reduce(); fin_gates(XT{}, tX); }
             if (s == S_PUB && FIN && !RR_DBG(2)) { fin_publish(XT{}, last_tag, tX); }
             if (s == S_E1 && FIN && !RR_DBG(4)) { arrive(X, tX); }
             if (s == S_E2 - RR_POLL_LEAD && NEXT && POLL && !RR_DBG(4)) poll_a(X);
@@ -596,7 +623,7 @@ __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
     half_step(I1{}, Tt{}, Ff{}, Ff{}, Tt{}, T - 1, T - 1);                // B(T-1); finish A(T-1): its last step
     // drain: finish B(T-1)
     fin_reduce();
-    fin_gates(I1{});
+    fin_gates(I1{}, T - 1);
     fin_publish(I1{}, Tt{}, T - 1);
     // ---- final cell state ----
     int b0e = b0;
@@ -644,16 +671,44 @@ extern "C" int nntk_shim_lstm_rr_pack(const float *d_ut, const float *d_wp, floa
     const long total = (long)NCT * rr_blocks_per_ct(KH, KX) * 64;
     long g = (total + 255) / 256;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(rr_pack_kernel, dim3((unsigned)g), dim3(256), 0, nntk_stream(), d_ut, d_wp, (rr_v4u *)d_img, H, in,
+    hipLaunchKernelGGL(rr_pack_kernel<false>, dim3((unsigned)g), dim3(256), 0, nntk_stream(), d_ut, d_wp, (rr_v4u *)d_img, H, in,
                        Hj_p, Hk_p, Kin_p, KH, KX, NCT);
+    NNTK_LAUNCH_CHECK("rr_pack_kernel");
+    return 0;
+}
+// the same images from the caller-layout weights U [H][4H], W [in][4H] already on the device (training forward)
+extern "C" int nntk_shim_lstm_rr_pack_raw(const float *d_U, const float *d_W, float *d_img, int H, int in) {
+    int KH, KX;
+    if (!rr_shape(H, in, &KH, &KX)) return nntk_fail_msg("lstm_rr_pack_raw: shape not taken by the register-resident kernel");
+    const int NCT = (H + 15) / 16;
+    const long total = (long)NCT * rr_blocks_per_ct(KH, KX) * 64;
+    long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(rr_pack_kernel<true>, dim3((unsigned)g), dim3(256), 0, nntk_stream(), d_U, d_W, (rr_v4u *)d_img, H, in,
+                       0, 0, 0, KH, KX, NCT);
     NNTK_LAUNCH_CHECK("rr_pack_kernel");
     return 0;
 }
 
 // 0 = launched; 1 = shape / configuration not taken (the caller runs projection GEMM + rec_persistent_kernel); -1 = error
+static int lstm_rr_launch(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,
+                          const float *d_h0, const float *d_c0, float *d_out, float *d_hT, float *d_cT,
+                          float *d_work, int B, int T, int in, int H, int return_sequences, float *d_c_cache, float *d_z_cache);
+
 extern "C" int nntk_shim_lstm_rr(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,
                                  const float *d_h0, const float *d_c0, float *d_out, float *d_hT, float *d_cT,
                                  float *d_work, int B, int T, int in, int H, int return_sequences) {
+    return lstm_rr_launch(d_x, d_img, d_bi, d_bh, d_h0, d_c0, d_out, d_hT, d_cT, d_work, B, T, in, H, return_sequences, nullptr, nullptr);
+}
+// training forward: zero initial state, h of every step to d_h [B][T][H], caches d_c [B][T][H] and d_zifgo [B][T][8H]
+extern "C" int nntk_shim_lstm_rr_train_forward(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,
+                                               float *d_h, float *d_c, float *d_zifgo, float *d_work, int B, int T, int in, int H) {
+    return lstm_rr_launch(d_x, d_img, d_bi, d_bh, nullptr, nullptr, d_h, nullptr, nullptr, d_work, B, T, in, H, 1, d_c, d_zifgo);
+}
+
+static int lstm_rr_launch(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,
+                          const float *d_h0, const float *d_c0, float *d_out, float *d_hT, float *d_cT,
+                          float *d_work, int B, int T, int in, int H, int return_sequences, float *d_c_cache, float *d_z_cache) {
     if (B <= 0 || T <= 0) return 0;
     const NntkOptions &opt = nntk_options();
     if (opt.rec_rr == 0 || opt.rec_persistent == 0 || nntk_persistent_disabled()) return 1;
@@ -664,10 +719,11 @@ extern "C" int nntk_shim_lstm_rr(const float *d_x, const float *d_img, const flo
     // the x and out rows of one 64-row batch tile are addressed with 32-bit buffer offsets
     if ((double)64 * T * in * 4 >= 2.0e9 || (double)64 * T * H * 4 >= 2.0e9) return 1;
     void (*kern)(RRParams) = nullptr;
-    if (KH == 8 && KX == 2) kern = lstm_rr_kernel<8, 2>;
-    else if (KH == 8 && KX == 1) kern = lstm_rr_kernel<8, 1>;
-    else if (KH == 4 && KX == 2) kern = lstm_rr_kernel<4, 2>;
-    else if (KH == 4 && KX == 1) kern = lstm_rr_kernel<4, 1>;
+    const bool train = d_c_cache != nullptr;
+    if (KH == 8 && KX == 2) kern = train ? lstm_rr_kernel<8, 2, true> : lstm_rr_kernel<8, 2>;
+    else if (KH == 8 && KX == 1) kern = train ? lstm_rr_kernel<8, 1, true> : lstm_rr_kernel<8, 1>;
+    else if (KH == 4 && KX == 2) kern = train ? lstm_rr_kernel<4, 2, true> : lstm_rr_kernel<4, 2>;
+    else if (KH == 4 && KX == 1) kern = train ? lstm_rr_kernel<4, 1, true> : lstm_rr_kernel<4, 1>;
     if (!kern) return 1;
     const size_t lds = rr_lds_bytes(KH, KX);
     if (lds > 160 * 1024) return 1;
@@ -692,6 +748,7 @@ extern "C" int nntk_shim_lstm_rr(const float *d_x, const float *d_img, const flo
     q.x = d_x; q.img = (const rr_v4u *)d_img; q.bi = d_bi; q.bh = d_bh;
     q.hb = (char *)d_work; q.hb_parity_bytes = parity;
     q.c0 = d_c0; q.cT = d_cT; q.hT = d_hT; q.out = d_out;
+    q.c_cache = d_c_cache; q.z_cache = d_z_cache;
     q.fault = fault;
     q.spin_ticks = (unsigned long long)(opt.rec_spin_us > 0 ? opt.rec_spin_us : 0) * 100ull;
     q.B = B; q.T = T; q.H = H; q.in = in; q.NCT = NCT; q.return_sequences = return_sequences;

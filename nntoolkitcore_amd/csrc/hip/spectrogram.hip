@@ -135,6 +135,7 @@ __device__ __forceinline__ void fft8(f2 v[8], const f2 S) {
 #define WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
                              __builtin_amdgcn_wave_barrier();                        \
                              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#define SPEC_DMA_DEFAULT false     // measured choice
 #define SPEC_LDS_FLOATS 1184      // per wave: exchange 1 uses 1024 floats, exchange 2 uses 8 * 144 = 1152; multiple of 16 B
 
 __device__ __forceinline__ float finish_bin(const SpecParams &p, float re, float im, int k) {
@@ -181,9 +182,15 @@ __device__ __forceinline__ float finish_bin(const SpecParams &p, float re, float
 // of nonzero weights (2 .. ~40 bins), so a lane takes one (frame, filter) pair and sums its run in ascending bin order
 // -- the order of the reference's dense product with the exact zeros left out.  The kernel then writes n_mels values
 // per frame instead of 257 (6.4x less write traffic for n_mels = 40) and the [B, nts, 257] tensor never exists.
-template <int MODE, bool NORM, bool NZ7, int NLD, bool MEL = false>
+// DMA = the sample image is filled by LDS-DMA (buffer_load ... lds): the pair's step + window samples go global -> LDS without
+// passing through registers (no 12-register staging set per prefetched pair, no ds_write_b128 -- at 13 LDS-issue cycles the
+// most expensive LDS instruction of the kernel).  Two image slots per wave (the pair being picked from, the pair in flight);
+// the wave waits for its DMA with a counted vmcnt (an LDS-DMA is ordered for a ds_read only by the issuing wave's vmcnt).
+#define SPEC_IMG_FLOATS 576       // one sample image: step + window <= 576 floats (2304 bytes)
+template <int MODE, bool NORM, bool NZ7, int NLD, bool MEL = false, bool DMA = false>
 __global__ __launch_bounds__(256) void spectrogram512_kernel(SpecParams p) {
     __shared__ __attribute__((aligned(16))) float lds_z[4][SPEC_LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds_img[DMA ? 4 : 1][DMA ? 2 * SPEC_IMG_FLOATS : 4];
     __shared__ int mel_tab_s[MEL ? 3 * 257 : 1];      // MEL: the run table and the runs, shared by the workgroup
     __shared__ float mel_w_s[MEL ? 2 * 257 + 8 : 1];
     const int lane = threadIdx.x & 63;
@@ -269,7 +276,16 @@ __global__ __launch_bounds__(256) void spectrogram512_kernel(SpecParams p) {
         // (two register sets, loop unrolled by two).
         int pr = blockIdx.x * 4 + wave;
         if (pr >= ppu) continue;
-        v4u32x ld0[NLD], ld1[NLD];
+        v4u32x ld0[DMA ? 1 : NLD], ld1[DMA ? 1 : NLD];
+        // LDS-DMA: slot `slot` of this wave's two sample images <- the pair's samples (lanes past the image are masked off:
+        // a DMA writes base + 16 * lane whatever the source offset says)
+#define SPEC_DMA(slot, pair) do {                                                                       \
+            const int soa_ = 2 * ((pair) < ppu ? (pair) : pr) * p.step * 4;                              \
+            float *img_ = lds_img[wave] + (slot) * SPEC_IMG_FLOATS;                                      \
+            _Pragma("unroll") for (int i = 0; i < NLD; ++i)                                              \
+                if (lane * 16 + 1024 * i < need_bytes)                                                   \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void *)(img_ + 256 * i), 16, lane * 16 + 1024 * i + soa_, 0, 0, 0); \
+            } while (0)
 
         // a pair beyond the wave's last one re-reads the last valid one (cache hit, result unused): no branches around loads
 #define SPEC_ISSUE(ld, pair) do {                                                                       \
@@ -279,22 +295,36 @@ __global__ __launch_bounds__(256) void spectrogram512_kernel(SpecParams p) {
                 ld[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, ld_off[i] + soa_, 0, 0);              \
             } } while (0)
 
-        auto transform = [&](v4u32x (&ld)[NLD]) __attribute__((always_inline)) {
+        auto transform = [&](v4u32x (&ld)[DMA ? 1 : NLD], int slot) __attribute__((always_inline)) {
             const int fa = 2 * pr;
             const bool has_b = fa + 1 < p.nts;        // wave-uniform
             f2 v[8];
+            unsigned xa[NR], xb[NR];
+            if (DMA) {
+                // this pair's image has landed once at most the NEXT pair's NLD requests and the previous pair's 3 output
+                // stores (younger, in issue order) are outstanding
+                asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NLD + 3) : "memory");
+                const float *img = lds_img[wave] + slot * SPEC_IMG_FLOATS;
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    xa[r] = __float_as_uint(img[sA + 64 * r]);
+                    xb[r] = __float_as_uint(img[sB + 64 * r]);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the picks are in registers: the slot is free
+                SPEC_DMA(slot, pr + 2 * stride);      // ... for the pair after next
+            } else {
             // ---- samples: registers -> LDS image -> the 2 x NR picks of pass 1 ----
 #pragma unroll
             for (int i = 0; i < NLD; ++i) *reinterpret_cast<v4u32x *>(z + lane * 4 + 256 * i) = ld[i];
             SPEC_ISSUE(ld, pr + 2 * stride);          // this register set is free again: fetch the pair after next
             WAVE_LDS_SYNC();
-            unsigned xa[NR], xb[NR];
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 xa[r] = __float_as_uint(z[sA + 64 * r]);
                 xb[r] = __float_as_uint(z[sB + 64 * r]);
             }
             WAVE_LDS_SYNC();
+            }
             // ---- pass 1 (Ns = 1): windowed samples, no twiddles ----
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
@@ -413,20 +443,32 @@ __global__ __launch_bounds__(256) void spectrogram512_kernel(SpecParams p) {
 #pragma unroll
                 for (int r = 0; r < 5; ++r)
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m[r].x), rout, r == 4 ? vo4 : vo, soa + 256 * r, 0);
+                if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // not the 3 stores the counted wait assumes: drain
             }
         };
 
-        SPEC_ISSUE(ld0, pr);
-        SPEC_ISSUE(ld1, pr + stride);
+        if (DMA) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // nothing of the previous utterance is in flight: the counts below start clean
+            SPEC_DMA(0, pr);
+            SPEC_DMA(1, pr + stride);
+            // the steady-state wait allows NLD + 3 younger operations; before the first stores exist that is 3 too many for the
+            // first pair: wait for it outright
+            asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NLD) : "memory");
+        } else {
+            SPEC_ISSUE(ld0, pr);
+            SPEC_ISSUE(ld1, pr + stride);
+        }
         for (;;) {
-            transform(ld0);
+            transform(ld0, 0);
             pr += stride;
             if (pr >= ppu) break;
-            transform(ld1);
+            transform(ld1, 1);
             pr += stride;
             if (pr >= ppu) break;
         }
+        if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two requests past the wave's last pair must land before the slots are reused
 #undef SPEC_ISSUE
+#undef SPEC_DMA
     }
 }
 
@@ -595,7 +637,10 @@ static int spectrogram_launch(const float *d_in, const float *d_window, const fl
         const bool norm = fft_norm != 1.0f;
         const bool nz7 = window_size > 384 && window_size <= 448;
         const bool ld3 = (step + window_size) * 4 <= 3072;          // 16-byte loads per lane for one pair's samples: 3 or 4
+        // LDS-DMA sample images: the BASELINE geometry (3 requests per pair, image <= 576 floats), no fused mel; option spec_variant = 0 / 1 forces
+        const bool dma = ld3 && !mel && (step + window_size) <= SPEC_IMG_FLOATS && (nntk_options().spec_variant < 0 ? SPEC_DMA_DEFAULT : nntk_options().spec_variant == 1);
 #define SPEC_KERN2(M, N, Z) (mel ? (ld3 ? spectrogram512_kernel<M, N, Z, 3, true> : spectrogram512_kernel<M, N, Z, 4, true>) \
+                                 : dma ? spectrogram512_kernel<M, N, Z, 3, false, true> \
                                  : (ld3 ? spectrogram512_kernel<M, N, Z, 3> : spectrogram512_kernel<M, N, Z, 4>))
 #define SPEC_KERN(M, N) (nz7 ? SPEC_KERN2(M, N, true) : SPEC_KERN2(M, N, false))
         auto kern = mode == 0 ? (norm ? SPEC_KERN(0, true) : SPEC_KERN(0, false))

@@ -514,6 +514,54 @@ __global__ __launch_bounds__(256) void rows_times_colmat_kernel(const float *__r
         out[row * I + i] = s;
     }
 }
+// The same product on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32) for the per-timestep BPTT step d_h_prev = dgates U^T once
+// the shapes are tile-sized (rows % 16 == 0, I % 16 == 0, K % 128 == 0: LSTM-512 / GRU-256 at mini-batch 64).  The VALU form
+// above re-reads the whole U^T for every batch row (64 x 4 MB out of L2 per step at LSTM-512: 55 us of a 64-us step); here a
+// workgroup owns one 16 x 16 output tile, its 8 wavefronts split K (deterministic: chunk sums added in order through LDS), and
+// U^T is read once per 16 rows.  An f32 MFMA is a k-ordered fmaf chain, so the result differs from the VALU form only in
+// summation order (fused multiply-adds, other chunk boundaries): same tolerance, not the same bits.
+// A operand: lane (m, q) reads d[row0 + m][kb + 4 q .. + 3] (one 16-byte load per 16-deep block) and feeds component c to
+// MFMA c, which therefore multiplies k = kb + 4 q + c (q = 0..3); B operand: MT[(kb + 4 q + c) * I + i0 + n].
+__global__ __launch_bounds__(512) void rows_times_colmat_mfma_kernel(const float *__restrict__ d, const float *__restrict__ MT,
+                                                                     float *__restrict__ out, int I, int K) {
+    __shared__ float part[8][4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int m = lane & 15, q = lane >> 4;
+    const int i0 = blockIdx.x * 16;
+    const long row0 = (long)blockIdx.y * 16;
+    const int per = K / 8, k0 = wv * per;
+    const float *dp = d + (row0 + m) * K + k0 + 4 * q;
+    const float *mp = MT + (size_t)(k0 + 4 * q) * I + i0 + m;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int kb = 0; kb < per; kb += 16) {
+        const float4 a = *reinterpret_cast<const float4 *>(dp + kb);
+        const float b0 = mp[(size_t)(kb + 0) * I], b1 = mp[(size_t)(kb + 1) * I], b2 = mp[(size_t)(kb + 2) * I], b3 = mp[(size_t)(kb + 3) * I];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b3, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[wv][r][lane] = acc[r];
+    __syncthreads();
+    if (wv == 0) {
+        // D layout: lane (n = lane & 15, q) holds rows 4 q + r of the tile, column n
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float sum = part[0][r][lane];
+#pragma unroll
+            for (int c = 1; c < 8; ++c) sum += part[c][r][lane];
+            out[(row0 + 4 * q + r) * I + i0 + m] = sum;
+        }
+    }
+}
+static void launch_rows_times_colmat(const float *d, const float *MT, float *out, long rows, int I, int K) {
+    if (rows % 16 == 0 && I % 16 == 0 && K % 128 == 0 && rows / 16 <= 65535)
+        hipLaunchKernelGGL(rows_times_colmat_mfma_kernel, dim3((unsigned)(I / 16), (unsigned)(rows / 16)), dim3(512), 0, nntk_stream(), d, MT, out, I, K);
+    else
+        hipLaunchKernelGGL(rows_times_colmat_kernel, dim3((unsigned)((I + 31) / 32), (unsigned)rows), dim3(256), 0, nntk_stream(), d, MT, out, rows, I, K);
+}
 // C[i][k] += sum_rows A[row][i] * Bm[row][k] and c[k] += sum_rows Bm[row][k]: row slices summed in order inside a slice,
 // slices added in order onto C (the reference adds each (b, t) term onto the gradient block one by one, gru.c:508)
 #define OUTER_SLICES 32
@@ -545,12 +593,26 @@ __global__ __launch_bounds__(256) void outer_reduce_kernel(const float *__restri
     }
 }
 
+// the bias row alone (I == 0: column sums of Bm): outer_partial_kernel would run it on OUTER_SLICES workgroups walking all of K
+// (1.25 ms for LSTM-512's [12800, 2048] dgates); here K is spread over the grid too.  Same slices, same order, same bits.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ Bm, float *__restrict__ partial, long rows, int K) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    const long r0 = rows * blockIdx.y / gridDim.y, r1 = rows * (blockIdx.y + 1) / gridDim.y;
+    float acc = 0.0f;
+    for (long r = r0; r < r1; ++r) acc = add_rn(acc, Bm[r * K + k]);
+    partial[(size_t)blockIdx.y * K + k] = acc;
+}
+
 extern "C" size_t nntk_shim_outer_scratch_floats(int I, int K) { return (size_t)OUTER_SLICES * (I + 1) * K; }
 extern "C" int nntk_shim_outer_accumulate(const float *d_A, const float *d_B, float *d_C, float *d_c, float *d_scratch,
                                           long rows, int I, int K, int a_shift_T) {
     if (rows <= 0 || I < 0 || K <= 0) return 0;             // I == 0: only the column sums c
-    hipLaunchKernelGGL(outer_partial_kernel, dim3((unsigned)(I + 1), OUTER_SLICES), dim3(K >= 256 ? 256 : ((K + 63) / 64) * 64), 0,
-                       nntk_stream(), d_A, d_B, d_scratch, rows, I, K, a_shift_T);
+    if (I == 0)
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)((K + 255) / 256), OUTER_SLICES), dim3(256), 0, nntk_stream(), d_B, d_scratch, rows, K);
+    else
+        hipLaunchKernelGGL(outer_partial_kernel, dim3((unsigned)(I + 1), OUTER_SLICES), dim3(K >= 256 ? 256 : ((K + 63) / 64) * 64), 0,
+                           nntk_stream(), d_A, d_B, d_scratch, rows, I, K, a_shift_T);
     NNTK_LAUNCH_CHECK("outer_partial_kernel");
     hipLaunchKernelGGL(outer_reduce_kernel, dim3(grid_for((long)(I + 1) * K, 256)), dim3(256), 0, nntk_stream(), d_scratch, d_C, d_c,
                        I, K, OUTER_SLICES);
@@ -597,8 +659,7 @@ extern "C" int nntk_shim_gru_train_backward(const float *d_dout, const float *d_
         p.t = t;
         hipLaunchKernelGGL(gru_train_bwd_step_kernel, dim3((B * H + 255) / 256), dim3(256), 0, nntk_stream(), p);
         if (t > 0)
-            hipLaunchKernelGGL(rows_times_colmat_kernel, dim3((unsigned)((H + 31) / 32), (unsigned)B), dim3(256), 0, nntk_stream(),
-                               (const float *)step, d_UT, dhp2, (long)B, H, 3 * H);
+            launch_rows_times_colmat(step, d_UT, dhp2, (long)B, H, 3 * H);
     }
     NNTK_LAUNCH_CHECK("gru_train_bwd_step_kernel");
     return 0;
@@ -705,8 +766,7 @@ extern "C" int nntk_shim_lstm_train_backward(const float *d_dout, const float *d
         p.t = t;
         hipLaunchKernelGGL(lstm_train_bwd_step_kernel, dim3((B * H + 255) / 256), dim3(256), 0, nntk_stream(), p);
         if (t > 0)
-            hipLaunchKernelGGL(rows_times_colmat_kernel, dim3((unsigned)((H + 31) / 32), (unsigned)B), dim3(256), 0, nntk_stream(),
-                               (const float *)step, d_UT, dh, (long)B, H, 4 * H);
+            launch_rows_times_colmat(step, d_UT, dh, (long)B, H, 4 * H);
     }
     NNTK_LAUNCH_CHECK("lstm_train_bwd_step_kernel");
     return 0;
@@ -771,8 +831,7 @@ extern "C" int nntk_shim_rnn_train_backward(const float *d_dout, const float *d_
         hipLaunchKernelGGL(rnn_train_bwd_step_kernel, dim3((B * H + 255) / 256), dim3(256), 0, nntk_stream(), d_dout, d_h, d_gate,
                            (const float *)dh, d_dG, step, B, T, H, t, return_sequences, act);
         if (t > 0)
-            hipLaunchKernelGGL(rows_times_colmat_kernel, dim3((unsigned)((H + 31) / 32), (unsigned)B), dim3(256), 0, nntk_stream(),
-                               (const float *)step, d_UT, dh, (long)B, H, H);
+            launch_rows_times_colmat(step, d_UT, dh, (long)B, H, H);
     }
     NNTK_LAUNCH_CHECK("rnn_train_bwd_step_kernel");
     return 0;

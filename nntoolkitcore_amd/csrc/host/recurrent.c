@@ -44,6 +44,7 @@ typedef struct {
     int wt_valid;
     float *d_rr;                /* LSTM: weight images of the register-resident split-bf16 kernel (recurrent_rr.hip), made on first use */
     int rr_valid;
+    float *d_rr_train;          /* ... and the training forward's own copy, re-packed every mini-batch from the raw block */
     /* persistent single-sequence state [H], double-buffered: a stateful call reads state[cur] and writes
      * state[cur ^ 1]; cur flips only once the call is known to be good, so a call that has to be repeated
      * (persistent-kernel fault, see core_apply_host) still finds its initial state intact */
@@ -86,7 +87,7 @@ static int core_init(rec_core *c, int G, RecurrentConfig base) {
 static void core_free(rec_core *c) {
     nntk_shim_synchronize();
     nntk_shim_free(c->d_wp); nntk_shim_free(c->d_bi); nntk_shim_free(c->d_ut); nntk_shim_free(c->d_bh); nntk_shim_free(c->d_wt);
-    nntk_shim_free(c->d_rr);
+    nntk_shim_free(c->d_rr); nntk_shim_free(c->d_rr_train);
     nntk_shim_free(c->d_h[0]);
     nntk_shim_host_free(c->pin_in); nntk_shim_host_free(c->pin_out); nntk_shim_host_free((void *)c->flag);
     nntk_shim_free(c->d_done);
@@ -730,7 +731,22 @@ int LSTMApplyTrainingBatch(LSTM filter, const float *input, float *output) {
     if (nntk_shim_upload(d_x, input, (size_t)B * T * in * sizeof(float))) return -1;
     if (nntk_shim_upload(d_raw, c->wb.host, nw * sizeof(float))) return -1;          /* W | U | b_i | b_h, caller layout */
     const float *dW = d_raw, *dU = dW + (size_t)in * 4 * H, *dbi = dU + (size_t)H * 4 * H, *dbh = dbi + 4 * (size_t)H;
-    if (nntk_shim_lstm_train_forward(d_x, dW, dU, dbi, dbh, d_h, d_c, d_z, B, T, in, H, filter->config.v2 ? 1 : 0, acts, sc)) return -1;
+    /* standard activations, mini-batches of >= 32 sequences: the register-resident inference kernel with the caches written
+     * from its gate phase (recurrent_rr.hip, TRAIN): ONE launch instead of T; its weight images are packed on the device from
+     * the block just uploaded (the weights change with every optimiser step).  Otherwise: one launch per timestep. */
+    int ran = 0, rr_on = -1;
+    (void)nntk_shim_get_option("rec_rr", &rr_on);
+    size_t img = nntk_shim_lstm_rr_image_floats(H, in);
+    if (rr_on != 0 && img && lstm_std_acts(acts) && (B >= NNTK_RR_MIN_BATCH || rr_on == 1)) {
+        if (!c->d_rr_train && !(c->d_rr_train = (float *)nntk_shim_malloc(img * sizeof(float)))) return -1;
+        float *d_wk = nntk_devbuf_reserve(&c->d_work_rr, nntk_shim_lstm_rr_work_floats(B, H));
+        if (!d_wk) return -1;
+        if (nntk_shim_lstm_rr_pack_raw(dU, dW, c->d_rr_train, H, in)) return -1;
+        int rc = nntk_shim_lstm_rr_train_forward(d_x, c->d_rr_train, dbi, filter->config.v2 ? dbh : NULL, d_h, d_c, d_z, d_wk, B, T, in, H);
+        if (rc < 0) return -1;
+        ran = rc == 0;
+    }
+    if (!ran && nntk_shim_lstm_train_forward(d_x, dW, dU, dbi, dbh, d_h, d_c, d_z, B, T, in, H, filter->config.v2 ? 1 : 0, acts, sc)) return -1;
     t->have_batch = 1;
     if (c->return_sequences) return nntk_shim_download(output, d_h, (size_t)B * T * H * sizeof(float));
     /* the last step of every sequence (gru.c:286-291, lstm.c:466-471, rnn.c:283-288): one strided copy */

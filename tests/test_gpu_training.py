@@ -325,6 +325,12 @@ def test_gru_training_forward_and_bptt(gpu, B, T, n_in, H, seq, acts):
     (8, 50, 40, 64, True, False, None),
     (2, 9, 6, 8, True, True, ("sigmoid", "tanh", "relu", "sigmoid", "sigmoid")),
     (16, 100, 128, 256, True, True, None),
+    # mini-batches of >= 32 sequences: the forward pass runs on the register-resident kernel (lstm_rr_kernel<.., TRAIN>),
+    # which writes the BPTT caches from its gate phase
+    (32, 20, 64, 128, True, True, None),
+    (40, 15, 40, 64, False, False, None),
+    (64, 60, 128, 512, True, True, None),
+    (70, 9, 72, 192, True, True, None),
 ])
 def test_lstm_training_forward_and_bptt(gpu, B, T, n_in, H, seq, v2, acts):
     """LSTMCreateForTraining / ApplyTrainingBatch / GradientCreate / CalculateGradient (lstm.c:294-556) against the oracle
