@@ -120,6 +120,11 @@ BatchNormGradient *BatchNormGradientCreate(BatchNormConfig config, BatchNormTrai
 void BatchNormGradientDestroy(BatchNormGradient *grad);
 int  BatchNormApplyTrainingBatch(BatchNorm filter, const float *input, float *output);   /* -1 on an inference-mode handle */
 void BatchNormCalculateGradient(BatchNorm filter, BatchNormGradient *gradient, float *d_out);
+/* additive device-pointer forms of the two calls above (the host forms move the whole mini-batch over PCIe twice per call):
+ * d_input must stay valid and unchanged until the matching gradient call; d_dbeta / d_dgamma [feature_channels] and d_dx are
+ * overwritten like the host form's gradient block.  0 ok, -1 error. */
+int  BatchNormApplyTrainingBatchDevice(BatchNorm filter, const float *d_input, float *d_output);
+int  BatchNormCalculateGradientDevice(BatchNorm filter, float *d_dbeta, float *d_dgamma, float *d_dx, const float *d_dout);
 
 /* ---- nntoolkitcore/layers/recurrent.h:17-56 ---------------------------- */
 typedef struct { int w; int u; int b_i; int b_h; int sum; } RecurrentWeightsSize;
@@ -263,6 +268,10 @@ DenseGradient *DenseGradientCreate(DenseConfig config, DenseTrainingConfig train
 DenseGradient *DenseGradientCreateFromFilter(Dense dense);                      /* NULL on an inference-mode handle */
 void DenseGradientDestroy(DenseGradient *gradient);
 void DenseCalculateGradient(Dense filter, DenseGradient *gradient, float *d_out /*[mini_batch, out]*/);
+/* additive device-pointer forms: d_input [mini_batch, in] must stay valid until the gradient call (it is the cached x);
+ * d_grad_Wb = device [in * out + out] floats (d_W | d_b), ACCUMULATED onto like the host form; d_dX overwritten. */
+int  DenseApplyTrainingBatchDevice(Dense filter, const float *d_input, float *d_output);
+int  DenseCalculateGradientDevice(Dense filter, float *d_grad_Wb, float *d_dX, const float *d_dout);
 
 /* ---- nntoolkitcore/layers/time_distributed_dense.h:19-45 --------------- */
 typedef struct { DenseConfig dense; int ts; } TimeDistributedDenseConfig;
@@ -279,6 +288,8 @@ TimeDistributedDense TimeDistributedDenseCreateForTraining(TimeDistributedDenseC
 DenseGradient *TimeDistributedDenseGradientCreate(TimeDistributedDense filter);
 int  TimeDistributedDenseApplyTrainingBatch(TimeDistributedDense filter, const float *input, float *output);
 void TimeDistributedDenseCalculateGradient(TimeDistributedDense filter, DenseGradient *gradient, float *d_out);
+int  TimeDistributedDenseApplyTrainingBatchDevice(TimeDistributedDense filter, const float *d_input, float *d_output);
+int  TimeDistributedDenseCalculateGradientDevice(TimeDistributedDense filter, float *d_grad_Wb, float *d_dX, const float *d_dout);
 void TimeDistributedDenseDestroy(TimeDistributedDense filter);
 
 /* ---- nntoolkitcore/signal/dft.h:15-47 ---------------------------------- */

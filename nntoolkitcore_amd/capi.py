@@ -218,6 +218,12 @@ SIGNATURES = {
     # training, second slice
     "DenseCreateForTraining": (vp, [DenseConfig, ConvTrainingConfig]),
     "DenseApplyTrainingBatch": (C.c_int, [vp, fp, fp]),
+    "DenseApplyTrainingBatchDevice": (C.c_int, [vp, vp, vp]),
+    "DenseCalculateGradientDevice": (C.c_int, [vp, vp, vp, vp]),
+    "TimeDistributedDenseApplyTrainingBatchDevice": (C.c_int, [vp, vp, vp]),
+    "TimeDistributedDenseCalculateGradientDevice": (C.c_int, [vp, vp, vp, vp]),
+    "BatchNormApplyTrainingBatchDevice": (C.c_int, [vp, vp, vp]),
+    "BatchNormCalculateGradientDevice": (C.c_int, [vp, vp, vp, vp, vp]),
     "DenseGradientCreate": (C.POINTER(DefaultGradient), [DenseConfig, ConvTrainingConfig]),
     "DenseGradientCreateFromFilter": (C.POINTER(DefaultGradient), [vp]),
     "DenseGradientDestroy": (None, [C.POINTER(DefaultGradient)]),

@@ -264,6 +264,7 @@ struct BatchNormFilterStruct {
     int training, mini_batch, have_batch;
     float momentum;
     nntk_devbuf d_x, d_dout, d_stats, d_partial, d_res;
+    const float *d_x_cur;       /* input of the last training forward: d_x.p (host form) or the caller's device buffer */
 };
 
 /* batch_norm.c:65-71 */
@@ -381,26 +382,18 @@ void BatchNormGradientDestroy(BatchNormGradient *grad) {
     free(grad);
 }
 
-int BatchNormApplyTrainingBatch(BatchNorm filter, const float *input, float *output) {
-    nntk_shim_clear_error();
-    if (!filter) NNTK_FAIL("BatchNormApplyTrainingBatch: NULL handle");
-    if (!filter->training) NNTK_FAIL("BatchNormApplyTrainingBatch: the handle was created for inference");   /* batch_norm.c:192-194 */
+/* forward on device buffers; the batch statistics stay on the device, the moving statistics are updated on the caller-visible
+ * weight block (batch_norm.c:247-257) in the reference's operation order */
+static int bn_train_forward_device(BatchNorm filter, const float *d_x, float *d_o) {
     const int F = filter->config.feature_channels;
     const long N = (long)filter->config.count * filter->mini_batch;
-    if (N <= 0 || F <= 0) return 0;
     const float *blk = nntk_batch_norm_device_block(filter, 1);
     if (!blk) return -1;
     int rps, slices = nntk_shim_bn_train_slices(N, &rps);
-    float *d_x = nntk_devbuf_reserve(&filter->d_x, (size_t)N * F);
-    float *d_o = nntk_devbuf_reserve(&filter->d_res, (size_t)N * F);
     float *d_stats = nntk_devbuf_reserve(&filter->d_stats, (size_t)8 * F);
     float *d_part = nntk_devbuf_reserve(&filter->d_partial, (size_t)slices * 3 * F);
-    if (!d_x || !d_o || !d_stats || !d_part) return -1;
-    if (nntk_shim_upload(d_x, input, (size_t)N * F * sizeof(float))) return -1;
+    if (!d_stats || !d_part) return -1;
     if (nntk_shim_bn_train_forward(d_x, blk, filter->config.epsilon, d_stats, d_part, d_o, N, F)) return -1;
-    if (nntk_shim_download(output, d_o, (size_t)N * F * sizeof(float))) return -1;
-    /* moving statistics (batch_norm.c:247-257), on the caller-visible weight block, in the reference's operation order;
-     * the next inference apply sees the edit and re-uploads */
     float *ms = (float *)malloc((size_t)2 * F * sizeof(float));
     if (!ms) NNTK_FAIL("out of host memory");
     if (nntk_shim_download(ms, d_stats, (size_t)2 * F * sizeof(float))) { free(ms); return -1; }
@@ -415,8 +408,33 @@ int BatchNormApplyTrainingBatch(BatchNorm filter, const float *input, float *out
         filter->weights->moving_variance[f] = b + mm;
     }
     free(ms);
+    filter->d_x_cur = d_x;
     filter->have_batch = 1;
     return 0;
+}
+
+int BatchNormApplyTrainingBatch(BatchNorm filter, const float *input, float *output) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("BatchNormApplyTrainingBatch: NULL handle");
+    if (!filter->training) NNTK_FAIL("BatchNormApplyTrainingBatch: the handle was created for inference");   /* batch_norm.c:192-194 */
+    const int F = filter->config.feature_channels;
+    const long N = (long)filter->config.count * filter->mini_batch;
+    if (N <= 0 || F <= 0) return 0;
+    float *d_x = nntk_devbuf_reserve(&filter->d_x, (size_t)N * F);
+    float *d_o = nntk_devbuf_reserve(&filter->d_res, (size_t)N * F);
+    if (!d_x || !d_o) return -1;
+    if (nntk_shim_upload(d_x, input, (size_t)N * F * sizeof(float))) return -1;
+    if (bn_train_forward_device(filter, d_x, d_o)) return -1;
+    return nntk_shim_download(output, d_o, (size_t)N * F * sizeof(float));
+}
+/* Device-pointer form (additive): d_input / d_output are device buffers of count * mini_batch rows; d_input must stay valid and
+ * unchanged until the matching BatchNormCalculateGradientDevice (x_mu and x_norm are recomputed from it). */
+int BatchNormApplyTrainingBatchDevice(BatchNorm filter, const float *d_input, float *d_output) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("BatchNormApplyTrainingBatchDevice: NULL handle");
+    if (!filter->training) NNTK_FAIL("BatchNormApplyTrainingBatchDevice: the handle was created for inference");
+    if ((long)filter->config.count * filter->mini_batch <= 0 || filter->config.feature_channels <= 0) return 0;
+    return bn_train_forward_device(filter, d_input, d_output);
 }
 
 /* d_beta, d_gamma, d_x are all OVERWRITTEN (op_vec_sum stores, batch_norm.c:286, :297, :384).  void in the reference;
@@ -433,10 +451,24 @@ void BatchNormCalculateGradient(BatchNorm filter, BatchNormGradient *gradient, f
     float *d_dx = nntk_devbuf_reserve(&filter->d_res, (size_t)N * F);
     if (!d_dout || !d_dx) return;
     if (nntk_shim_upload(d_dout, d_out, (size_t)N * F * sizeof(float))) return;
-    if (nntk_shim_bn_train_backward(filter->d_x.p, d_dout, blk, filter->d_stats.p, filter->d_partial.p, d_dx, N, F)) return;
+    if (nntk_shim_bn_train_backward(filter->d_x_cur, d_dout, blk, filter->d_stats.p, filter->d_partial.p, d_dx, N, F)) return;
     if (nntk_shim_download(gradient->d_beta, filter->d_stats.p + (size_t)4 * F, (size_t)F * sizeof(float))) return;
     if (nntk_shim_download(gradient->d_gamma, filter->d_stats.p + (size_t)5 * F, (size_t)F * sizeof(float))) return;
     nntk_shim_download(gradient->d_x, d_dx, (size_t)N * F * sizeof(float));
+}
+/* Device-pointer form (additive): d_dbeta, d_dgamma [feature_channels] and d_dx [rows, feature_channels] are device buffers,
+ * all overwritten; d_dout device [rows, feature_channels].  0 ok, -1 error. */
+int BatchNormCalculateGradientDevice(BatchNorm filter, float *d_dbeta, float *d_dgamma, float *d_dx, const float *d_dout) {
+    nntk_shim_clear_error();
+    if (!filter || !d_dbeta || !d_dgamma || !d_dx || !d_dout) NNTK_FAIL("BatchNormCalculateGradientDevice: NULL argument");
+    if (!filter->training || !filter->have_batch) NNTK_FAIL("BatchNormCalculateGradientDevice: run BatchNormApplyTrainingBatch[Device] on a training handle first");
+    const int F = filter->config.feature_channels;
+    const long N = (long)filter->config.count * filter->mini_batch;
+    const float *blk = nntk_batch_norm_device_block(filter, 1);
+    if (!blk) return -1;
+    if (nntk_shim_bn_train_backward(filter->d_x_cur, d_dout, blk, filter->d_stats.p, filter->d_partial.p, d_dx, N, F)) return -1;
+    if (nntk_shim_copy_d2d(d_dbeta, filter->d_stats.p + (size_t)4 * F, (size_t)F * sizeof(float))) return -1;
+    return nntk_shim_copy_d2d(d_dgamma, filter->d_stats.p + (size_t)5 * F, (size_t)F * sizeof(float));
 }
 
 /* batch_norm.c:166-189: `count` rows of `feature_channels`; -1 for a training-mode handle (:167-169) */

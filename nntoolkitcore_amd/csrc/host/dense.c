@@ -19,6 +19,7 @@ struct DenseStruct {
     /* training (dense.c:18-48): x | z | a kept from DenseApplyTrainingBatch for DenseCalculateGradient */
     int training, mini_batch;
     nntk_devbuf d_x, d_z, d_a, d_dz, d_dout, d_grad, d_wraw, d_dx;
+    const float *d_x_cur;       /* the mini-batch input of the last training forward: d_x.p (host form) or the caller's device buffer */
 };
 
 /* dense.c:67-73 */
@@ -176,20 +177,12 @@ static int dense_act_matches(Dense f) {
     return n == f->config.output_size;
 }
 
-int DenseApplyTrainingBatch(Dense filter, const float *input, float *output) {
-    nntk_shim_clear_error();
-    if (!filter) NNTK_FAIL("DenseApplyTrainingBatch: NULL handle");
-    if (!filter->training) NNTK_FAIL("DenseApplyTrainingBatch: the handle was created for inference");      /* dense.c:145-147 */
-    if (!dense_act_matches(filter))
-        NNTK_FAIL("DenseApplyTrainingBatch: the activation must be built-in and sized to the dense output_size");
+/* the forward pass on device buffers: x kept (by pointer when the caller's buffer is a device buffer), z and a cached */
+static int dense_train_forward_device(Dense filter, const float *d_x, float *d_out_or_null) {
     const int B = filter->mini_batch, in = filter->config.input_size, out = filter->config.output_size;
-    if (B <= 0) return 0;
-    if (dense_ensure(filter, 1)) return -1;
-    float *d_x = nntk_devbuf_reserve(&filter->d_x, (size_t)B * in);
     float *d_z = nntk_devbuf_reserve(&filter->d_z, (size_t)B * out);
     float *d_a = nntk_devbuf_reserve(&filter->d_a, (size_t)B * out);
-    if (!d_x || !d_z || !d_a) return -1;
-    if (nntk_shim_upload(d_x, input, (size_t)B * in * sizeof(float))) return -1;
+    if (!d_z || !d_a) return -1;
     /* z = x W + b for the whole mini-batch (one GEMM), then a = activation(z) as its own pass: z is needed later */
     if (nntk_shim_conv1d(d_x, filter->d_wp, filter->d_bias, NULL, 0.f, NNTK_ACT_IDENTITY, 1.f, d_z, 1, B, in, out, 1, 1, B, 0))
         return -1;
@@ -199,7 +192,62 @@ int DenseApplyTrainingBatch(Dense filter, const float *input, float *output) {
     } else if (nntk_shim_copy_d2d(d_a, d_z, (size_t)B * out * sizeof(float))) {
         return -1;
     }
-    return nntk_shim_download(output, d_a, (size_t)B * out * sizeof(float));
+    filter->d_x_cur = d_x;
+    if (d_out_or_null && nntk_shim_copy_d2d(d_out_or_null, d_a, (size_t)B * out * sizeof(float))) return -1;
+    return 0;
+}
+static int dense_train_check(Dense filter, const char *who) {
+    if (!filter) { nntk_set_error("Dense training call: NULL handle"); return -1; }
+    if (!filter->training) { nntk_set_error(who); return -1; }      /* dense.c:145-147 */
+    if (!dense_act_matches(filter)) { nntk_set_error("Dense training: the activation must be built-in and sized to the dense output_size"); return -1; }
+    return 0;
+}
+
+int DenseApplyTrainingBatch(Dense filter, const float *input, float *output) {
+    nntk_shim_clear_error();
+    if (dense_train_check(filter, "DenseApplyTrainingBatch: the handle was created for inference")) return -1;
+    const int B = filter->mini_batch, in = filter->config.input_size, out = filter->config.output_size;
+    if (B <= 0) return 0;
+    if (dense_ensure(filter, 1)) return -1;
+    float *d_x = nntk_devbuf_reserve(&filter->d_x, (size_t)B * in);
+    if (!d_x) return -1;
+    if (nntk_shim_upload(d_x, input, (size_t)B * in * sizeof(float))) return -1;
+    if (dense_train_forward_device(filter, d_x, NULL)) return -1;
+    return nntk_shim_download(output, filter->d_a.p, (size_t)B * out * sizeof(float));
+}
+/* Device-pointer form (additive): d_input [mini_batch, in] and d_output [mini_batch, out] are device buffers; d_input must
+ * stay valid and unchanged until the matching DenseCalculateGradientDevice (it is the cached x).  Weight edits are picked up
+ * like in the host form (whole-block compare). */
+int DenseApplyTrainingBatchDevice(Dense filter, const float *d_input, float *d_output) {
+    nntk_shim_clear_error();
+    if (dense_train_check(filter, "DenseApplyTrainingBatchDevice: the handle was created for inference")) return -1;
+    if (filter->mini_batch <= 0) return 0;
+    if (dense_ensure(filter, 1)) return -1;
+    return dense_train_forward_device(filter, d_input, d_output);
+}
+
+/* gradient on device buffers: d_grad = d_W | d_b (accumulated onto), d_dx overwritten */
+static int dense_gradient_device(Dense filter, const float *d_dout, float *d_grad, float *d_dx) {
+    const int B = filter->mini_batch, in = filter->config.input_size, out = filter->config.output_size;
+    const size_t w = (size_t)in * out;
+    float *d_dz = nntk_devbuf_reserve(&filter->d_dz, (size_t)B * out);
+    float *d_wraw = nntk_devbuf_reserve(&filter->d_wraw, w);
+    if (!d_dz || !d_wraw) return -1;
+    if (nntk_shim_upload(d_wraw, filter->weights->W, w * sizeof(float))) return -1;             /* caller layout [in, out] */
+    ActivationFunction act = filter->config.activation;
+    const float *dz = d_dout;
+    if (act) {      /* dz = d_out * activation'(z)  (per sample in the reference; the kernels are elementwise / per vector) */
+        int vpc = act->kind == NNTK_ACT_SOFTMAX ? act->input_size : 1;
+        if (nntk_shim_activation_grad(act->kind, act->vector_size, vpc, filter->d_z.p, filter->d_a.p, d_dout, d_dz, (long)B * out)) return -1;
+        dz = d_dz;
+    }
+    if ((double)B * in * out < (double)(1 << 27)) {       /* small: the reference's mini-batch order exactly */
+        if (nntk_shim_dense_grad(filter->d_x_cur, d_wraw, dz, d_grad, d_grad + w, d_dx, B, in, out)) return -1;
+    } else {                                              /* large: the MFMA GEMM (train.c) */
+        if (nntk_train_outer_accumulate(filter->d_x_cur, dz, d_grad, d_grad + w, B, in, out, 0)) return -1;
+        if (nntk_train_rows_times_rowmat(dz, d_wraw, d_dx, B, in, out)) return -1;
+    }
+    return 0;
 }
 
 /* d_W and d_b are accumulated onto the caller's block in mini-batch order (default_gradient_sum, weights_private.c:43-48),
@@ -207,33 +255,26 @@ int DenseApplyTrainingBatch(Dense filter, const float *input, float *output) {
 void DenseCalculateGradient(Dense filter, DenseGradient *gradient, float *d_out) {
     nntk_shim_clear_error();
     if (!filter || !gradient || !d_out) { nntk_set_error("DenseCalculateGradient: NULL argument"); return; }
-    if (!filter->training || !filter->d_x.p) { nntk_set_error("DenseCalculateGradient: run DenseApplyTrainingBatch on a training handle first"); return; }
+    if (!filter->training || !filter->d_x_cur) { nntk_set_error("DenseCalculateGradient: run DenseApplyTrainingBatch on a training handle first"); return; }
     const int B = filter->mini_batch, in = filter->config.input_size, out = filter->config.output_size;
     const size_t w = (size_t)in * out;
     float *d_dout = nntk_devbuf_reserve(&filter->d_dout, (size_t)B * out);
-    float *d_dz = nntk_devbuf_reserve(&filter->d_dz, (size_t)B * out);
     float *d_grad = nntk_devbuf_reserve(&filter->d_grad, w + out);
-    float *d_wraw = nntk_devbuf_reserve(&filter->d_wraw, w);
     float *d_dx = nntk_devbuf_reserve(&filter->d_dx, (size_t)B * in);
-    if (!d_dout || !d_dz || !d_grad || !d_wraw || !d_dx) return;
+    if (!d_dout || !d_grad || !d_dx) return;
     if (nntk_shim_upload(d_dout, d_out, (size_t)B * out * sizeof(float))) return;
-    if (nntk_shim_upload(d_wraw, filter->weights->W, w * sizeof(float))) return;             /* caller layout [in, out] */
     if (nntk_shim_upload(d_grad, gradient->d_W, (w + out) * sizeof(float))) return;          /* d_W | d_b are contiguous */
-    ActivationFunction act = filter->config.activation;
-    const float *dz = d_dout;
-    if (act) {      /* dz = d_out * activation'(z)  (per sample in the reference; the kernels are elementwise / per vector) */
-        int vpc = act->kind == NNTK_ACT_SOFTMAX ? act->input_size : 1;
-        if (nntk_shim_activation_grad(act->kind, act->vector_size, vpc, filter->d_z.p, filter->d_a.p, d_dout, d_dz, (long)B * out)) return;
-        dz = d_dz;
-    }
-    if ((double)B * in * out < (double)(1 << 27)) {       /* small: the reference's mini-batch order exactly */
-        if (nntk_shim_dense_grad(filter->d_x.p, d_wraw, dz, d_grad, d_grad + w, d_dx, B, in, out)) return;
-    } else {                                              /* large: the MFMA GEMM (train.c) */
-        if (nntk_train_outer_accumulate(filter->d_x.p, dz, d_grad, d_grad + w, B, in, out, 0)) return;
-        if (nntk_train_rows_times_rowmat(dz, d_wraw, d_dx, B, in, out)) return;
-    }
+    if (dense_gradient_device(filter, d_dout, d_grad, d_dx)) return;
     if (nntk_shim_download(gradient->d_W, d_grad, (w + out) * sizeof(float))) return;
     nntk_shim_download(gradient->d_X, d_dx, (size_t)B * in * sizeof(float));
+}
+/* Device-pointer form (additive): d_grad_Wb = device [in * out + out] floats (d_W | d_b), ACCUMULATED onto like the host form;
+ * d_dX = device [mini_batch, in], overwritten; d_dout = device [mini_batch, out].  0 ok, -1 error. */
+int DenseCalculateGradientDevice(Dense filter, float *d_grad_Wb, float *d_dX, const float *d_dout) {
+    nntk_shim_clear_error();
+    if (!filter || !d_grad_Wb || !d_dX || !d_dout) NNTK_FAIL("DenseCalculateGradientDevice: NULL argument");
+    if (!filter->training || !filter->d_x_cur) NNTK_FAIL("DenseCalculateGradientDevice: run DenseApplyTrainingBatch[Device] on a training handle first");
+    return dense_gradient_device(filter, d_dout, d_grad_Wb, d_dX);
 }
 
 /* ========================= TimeDistributedDense =========================== */
@@ -283,6 +324,14 @@ int TimeDistributedDenseApplyTrainingBatch(TimeDistributedDense filter, const fl
 void TimeDistributedDenseCalculateGradient(TimeDistributedDense filter, DenseGradient *gradient, float *d_out) {
     if (!filter) { nntk_shim_clear_error(); nntk_set_error("TimeDistributedDenseCalculateGradient: NULL handle"); return; }
     DenseCalculateGradient(filter->dense, gradient, d_out);
+}
+int TimeDistributedDenseApplyTrainingBatchDevice(TimeDistributedDense filter, const float *d_input, float *d_output) {
+    if (!filter) { nntk_shim_clear_error(); NNTK_FAIL("TimeDistributedDenseApplyTrainingBatchDevice: NULL handle"); }
+    return DenseApplyTrainingBatchDevice(filter->dense, d_input, d_output);
+}
+int TimeDistributedDenseCalculateGradientDevice(TimeDistributedDense filter, float *d_grad_Wb, float *d_dX, const float *d_dout) {
+    if (!filter) { nntk_shim_clear_error(); NNTK_FAIL("TimeDistributedDenseCalculateGradientDevice: NULL handle"); }
+    return DenseCalculateGradientDevice(filter->dense, d_grad_Wb, d_dX, d_dout);
 }
 DenseWeights *TimeDistributedDenseGetWeights(TimeDistributedDense filter) { return DenseGetWeights(filter->dense); }
 void TimeDistributedDenseDestroy(TimeDistributedDense filter) {

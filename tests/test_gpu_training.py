@@ -496,3 +496,69 @@ def test_bidirectional_gradient_helpers(gpu):
     out = np.empty_like(fx)
     L.bd_accumulate_d_x(P(fx), P(bx), P(out), cfg, B)
     np.testing.assert_array_equal(out, fx + bx[:, ::-1])
+
+
+# ---- device-pointer forms of the Dense / TimeDistributedDense / BatchNorm training calls (additive) ----
+
+def test_dense_and_batchnorm_training_device_forms_equal_the_host_forms(gpu):
+    """The device-pointer calls run the same kernels on the caller's HBM buffers: results are bit-identical to the
+    host-pointer forms (which upload, call the same core and download)."""
+    import torch
+    L = capi.load()
+    r = rng(77)
+    dp = lambda t: C.c_void_p(t.data_ptr())
+    # Dense with a sigmoid
+    B, n_in, n_out = 96, 40, 24
+    x, W, b, dout = u(r, B, n_in), u(r, n_in, n_out, sc=0.3), u(r, n_out, sc=0.1), u(r, B, n_out)
+    ah = L.ActivationFunctionCreateSigmoid(n_out)
+    cfg = L.DenseConfigCreate(n_in, n_out, ah)
+    h = L.DenseCreateForTraining(cfg, capi.ConvTrainingConfig(B))
+    w = L.DenseGetWeights(h).contents
+    C.memmove(w.W, W.ctypes.data, W.nbytes); C.memmove(w.b, b.ctypes.data, b.nbytes)
+    y = np.empty((B, n_out), np.float32)
+    assert L.DenseApplyTrainingBatch(h, P(x), P(y)) == 0
+    g = L.DenseGradientCreateFromFilter(h)
+    L.DenseCalculateGradient(h, g, P(dout))
+    gW = np.ctypeslib.as_array(g.contents.d_W, shape=(n_in * n_out + n_out,)).copy()
+    gX = np.ctypeslib.as_array(g.contents.d_X, shape=(B, n_in)).copy()
+    xd, dd = torch.from_numpy(x).cuda(), torch.from_numpy(dout).cuda()
+    yd, gWd, gXd = torch.empty(B, n_out, device="cuda"), torch.zeros(n_in * n_out + n_out, device="cuda"), torch.empty(B, n_in, device="cuda")
+    assert L.DenseApplyTrainingBatchDevice(h, dp(xd), dp(yd)) == 0, capi.last_error()
+    assert L.DenseCalculateGradientDevice(h, dp(gWd), dp(gXd), dp(dd)) == 0, capi.last_error()
+    torch.cuda.synchronize()
+    assert np.array_equal(yd.cpu().numpy(), y) and np.array_equal(gWd.cpu().numpy(), gW) and np.array_equal(gXd.cpu().numpy(), gX)
+    z_o, a_o = O.dense_forward_training(x, W, b, act=O.ACT_SIGMOID)
+    np.testing.assert_allclose(y, a_o, rtol=1e-5, atol=1e-5)
+    # accumulation onto the device gradient block: a second call adds the same amount
+    assert L.DenseCalculateGradientDevice(h, dp(gWd), dp(gXd), dp(dd)) == 0
+    np.testing.assert_allclose(gWd.cpu().numpy(), 2 * gW, rtol=1e-6, atol=1e-6)
+    L.DenseGradientDestroy(g); L.DenseDestroy(h); L.ActivationFunctionDestroy(ah)
+    # BatchNorm
+    count, mb, F = 50, 8, 64
+    N = count * mb
+    x, dout = u(r, N, F), u(r, N, F)
+    bcfg = L.BatchNormConfigCreate(F, 1e-3, count)
+    btc = L.BatchNormTrainingConfigCreate(0.9, mb)
+    hb = L.BatchNormCreateForTraining(bcfg, btc)
+    wb = L.BatchNormGetWeights(hb).contents
+    gam, bet = (1 + u(r, F, sc=0.3)), u(r, F, sc=0.3)
+    C.memmove(wb.gamma, gam.ctypes.data, gam.nbytes); C.memmove(wb.beta, bet.ctypes.data, bet.nbytes)
+    y = np.empty((N, F), np.float32)
+    assert L.BatchNormApplyTrainingBatch(hb, P(x), P(y)) == 0
+    gb = L.BatchNormGradientCreate(bcfg, btc)
+    L.BatchNormCalculateGradient(hb, gb, P(dout))
+    ref = [np.ctypeslib.as_array(getattr(gb.contents, k), shape=s).copy() for k, s in (("d_beta", (F,)), ("d_gamma", (F,)), ("d_x", (N, F)))]
+    mm = np.ctypeslib.as_array(wb.moving_mean, shape=(F,)).copy()
+    # same handle, device forms (the moving statistics advance once more: compared against a second host call below)
+    xd, dd = torch.from_numpy(x).cuda(), torch.from_numpy(dout).cuda()
+    yd = torch.empty(N, F, device="cuda")
+    dbe, dga, dxx = torch.empty(F, device="cuda"), torch.empty(F, device="cuda"), torch.empty(N, F, device="cuda")
+    assert L.BatchNormApplyTrainingBatchDevice(hb, dp(xd), dp(yd)) == 0, capi.last_error()
+    assert L.BatchNormCalculateGradientDevice(hb, dp(dbe), dp(dga), dp(dxx), dp(dd)) == 0, capi.last_error()
+    torch.cuda.synchronize()
+    assert np.array_equal(yd.cpu().numpy(), y)
+    for got, want in zip((dbe, dga, dxx), ref):
+        assert np.array_equal(got.cpu().numpy(), want)
+    mm2 = np.ctypeslib.as_array(wb.moving_mean, shape=(F,))
+    assert not np.array_equal(mm2, mm)                       # the device call updated the caller-visible moving statistics
+    L.BatchNormGradientDestroy(gb); L.BatchNormDestroy(hb)

@@ -78,7 +78,30 @@ def main():
     g = L.DenseGradientCreateFromFilter(h)
     timed("Dense(512->1000) rows=%d" % B, lambda: L.DenseApplyTrainingBatch(h, P(x), P(y)), lambda: L.DenseCalculateGradient(h, g, P(d)),
           "%.1f GFLOP fwd" % (2e-9 * B * n_in * n_out))
+    # the same mini-batch through the device-pointer forms (tensors stay in HBM: no PCIe in the timed region)
+    import torch
+    torch.cuda.set_device(0)
+    dp = lambda t: C.c_void_p(t.data_ptr())
+    xd, dd = torch.from_numpy(x).cuda(), torch.from_numpy(d).cuda()
+    yd = torch.empty(B, n_out, device="cuda"); gWd = torch.zeros(n_in * n_out + n_out, device="cuda"); gXd = torch.empty(B, n_in, device="cuda")
+    sync = capi.load().nntk_hip_synchronize
+    timed("Dense(512->1000) rows=%d, device pointers" % B,
+          lambda: (L.DenseApplyTrainingBatchDevice(h, dp(xd), dp(yd)), sync()),
+          lambda: (L.DenseCalculateGradientDevice(h, dp(gWd), dp(gXd), dp(dd)), sync()), "same")
     L.DenseGradientDestroy(g); L.DenseDestroy(h)
+    F, count, Bm = 128, 996, 64
+    bcfg = L.BatchNormConfigCreate(F, 1e-3, count)
+    btc = L.BatchNormTrainingConfigCreate(0.9, Bm)
+    hb = L.BatchNormCreateForTraining(bcfg, btc)
+    wb = L.BatchNormGetWeights(hb).contents
+    gam = np.ones(F, np.float32); C.memmove(wb.gamma, gam.ctypes.data, gam.nbytes)
+    N = Bm * count
+    xd, dd, yd = torch.randn(N, F, device="cuda"), torch.randn(N, F, device="cuda"), torch.empty(N, F, device="cuda")
+    dbe, dga, dxx = torch.empty(F, device="cuda"), torch.empty(F, device="cuda"), torch.empty(N, F, device="cuda")
+    timed("BatchNorm(128) N=%d rows, device pointers" % N,
+          lambda: (L.BatchNormApplyTrainingBatchDevice(hb, dp(xd), dp(yd)), sync()),
+          lambda: (L.BatchNormCalculateGradientDevice(hb, dp(dbe), dp(dga), dp(dxx), dp(dd)), sync()), "33 MB tensor")
+    L.BatchNormDestroy(hb)
 
 
 if __name__ == "__main__":
