@@ -691,7 +691,10 @@ struct Gru2Params {
     const float *ut1, *bh1;          // layer 1: U1^T [3][Hj_p][Hk_p], b_h1 [3H]
     const float *wt2, *bi2;          // layer 2: W2^T in the same layout, b_i2 [3H]
     const float *ut2, *bh2;          // layer 2: U2^T, b_h2
-    float *hbuf1, *hbuf2;            // [2][hb_floats] tiled hand-off buffers of the two layers (zeroed before the launch)
+    float *hbuf1, *hbuf2;            // tiled hand-off buffers (zeroed before the launch): layer 1 THREE slots [3][hb_floats], layer 2 two.
+                                     // h1_k lives in slot (k + 1) % 3: layer 2 reads h1_{i-1} one phase AFTER layer 1 did, so with two slots
+                                     // a workgroup that has already run ahead into layer 1 of iteration i + 1 (all it waits for is every
+                                     // peer's h1_i) could publish h1_{i+1} over the h1_{i-1} a slower peer's layer-2 loads are still reading
     size_t hb_floats;
     float *out;                      // [B, T, H] layer-2 outputs (or [B, H] when !return_sequences)
     float *out1;                     // [B, T, H] layer-1 outputs, or NULL (not needed by the stack itself)
@@ -759,8 +762,8 @@ __global__ __launch_bounds__(512, 2) void gru2_persistent_kernel(Gru2Params p) {
     constexpr int KB = KP / 16;
     const int slab_abs = (b0 >> 4) + slab;
     const int hb_bytes = (int)(p.hb_floats * 4);
-    const __amdgpu_buffer_rsrc_t r1a = __builtin_amdgcn_make_buffer_rsrc((void *)p.hbuf1, 0, hb_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r1b = __builtin_amdgcn_make_buffer_rsrc((void *)(p.hbuf1 + p.hb_floats), 0, hb_bytes, 0x00020000);
+    // ONE descriptor over layer 1's three slots; the slot rides in the (scalar) offset
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void *)p.hbuf1, 0, 3 * hb_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t r2a = __builtin_amdgcn_make_buffer_rsrc((void *)p.hbuf2, 0, hb_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t r2b = __builtin_amdgcn_make_buffer_rsrc((void *)(p.hbuf2 + p.hb_floats), 0, hb_bytes, 0x00020000);
     const int h_lane_off = lane * 16;
@@ -797,11 +800,11 @@ __global__ __launch_bounds__(512, 2) void gru2_persistent_kernel(Gru2Params p) {
         if (do1) {
             if (i > 0) wait_for(cnt1, (unsigned)p.NCT * (unsigned)i);      // h1_{i-1} is published
             v4u32 h1own[NCH];
+            const int slot1 = (i % 3) * hb_bytes;                           // h1_{i-1}
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
-                const int so = h_slab_off + (2 * ch + grp) * 1024;
-                h1own[ch] = (i & 1) ? __builtin_amdgcn_raw_buffer_load_b128(r1b, h_lane_off, so, 16)
-                                    : __builtin_amdgcn_raw_buffer_load_b128(r1a, h_lane_off, so, 16);
+                const int so = slot1 + h_slab_off + (2 * ch + grp) * 1024;
+                h1own[ch] = __builtin_amdgcn_raw_buffer_load_b128(r1, h_lane_off, so, 16);
             }
             // xW for this step: one 16-byte load per gate (the quad of hidden units this lane and its partner share)
             float xw1[2][G];
@@ -857,7 +860,7 @@ __global__ __launch_bounds__(512, 2) void gru2_persistent_kernel(Gru2Params p) {
                 h1n[e] = fmaf(-z + 1.0f, ht, z * prev1[e]);
                 prev1[e] = h1n[e];
             }
-            float *hdst = p.hbuf1 + (size_t)((i + 1) & 1) * p.hb_floats + h_pub_off;
+            float *hdst = p.hbuf1 + (size_t)((i + 1) % 3) * p.hb_floats + h_pub_off;       // h1_i -> slot (i + 1) % 3
             if (ok1) {
                 const unsigned long long pk = ((unsigned long long)__float_as_uint(h1n[1]) << 32) | __float_as_uint(h1n[0]);
                 __hip_atomic_store(reinterpret_cast<unsigned long long *>(hdst), pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -884,8 +887,7 @@ __global__ __launch_bounds__(512, 2) void gru2_persistent_kernel(Gru2Params p) {
 #pragma unroll
             for (int pc = 0; pc < 2 * NCH; ++pc) {
                 const int so = h_slab_off + pc * 1024;
-                if (grp == 0) hfull[pc] = (i & 1) ? __builtin_amdgcn_raw_buffer_load_b128(r1b, h_lane_off, so, 16)
-                                                  : __builtin_amdgcn_raw_buffer_load_b128(r1a, h_lane_off, so, 16);
+                if (grp == 0) hfull[pc] = __builtin_amdgcn_raw_buffer_load_b128(r1, h_lane_off, (i % 3) * hb_bytes + so, 16);      // h1_{i-1}
                 else          hfull[pc] = ((i - 1) & 1) ? __builtin_amdgcn_raw_buffer_load_b128(r2b, h_lane_off, so, 16)
                                                         : __builtin_amdgcn_raw_buffer_load_b128(r2a, h_lane_off, so, 16);
             }
@@ -953,9 +955,9 @@ __global__ __launch_bounds__(512, 2) void gru2_persistent_kernel(Gru2Params p) {
     }
 }
 
-// Both layers' work areas: [hbuf1 ping | pong][hbuf2 ping | pong][counters]
+// Both layers' work areas: [hbuf1 x 3 slots][hbuf2 ping | pong][counters]
 extern "C" size_t nntk_shim_gru2_work_floats(int B, int H) {
-    return 4 * rec_hb_floats_fwd(B, H) + rec_cnt_words_fwd(B);
+    return 5 * rec_hb_floats_fwd(B, H) + rec_cnt_words_fwd(B);
 }
 
 // 0 = launched; 1 = this shape / configuration is not taken by the fused kernel (caller runs the two layers one after
@@ -978,7 +980,7 @@ extern "C" int nntk_shim_gru2(const float *d_xw1, const float *d_ut1, const floa
     if (!fault) return 1;
     const size_t hbmax = rec_hb_floats_fwd(B, H);
     const size_t hb_floats = (size_t)((B + 63) & ~63) * (size_t)KP;
-    if (hb_floats * 4 >= 0x3ffffff0ULL) return 1;
+    if (hb_floats * 4 * 3 >= 0x7ffffff0ULL) return 1;       // one descriptor spans layer 1's three slots
     auto kern = nch_p == 4 ? gru2_persistent_kernel<4> : gru2_persistent_kernel<8>;
     if (nntk_set_max_dynamic_lds((const void *)kern, lds)) return -1;
     // every workgroup of a launch must be resident: the grid comes from the runtime's occupancy answer for THIS kernel
@@ -986,12 +988,12 @@ extern "C" int nntk_shim_gru2(const float *d_xw1, const float *d_ut1, const floa
     const int resident = nntk_resident_blocks((const void *)kern, 512, lds, 1);
     const int tiles_per_launch = NCT > 0 ? resident / NCT : 0;
     if (tiles_per_launch < 1) return 1;
-    unsigned *cnt = reinterpret_cast<unsigned *>(d_work + 4 * hbmax);
+    unsigned *cnt = reinterpret_cast<unsigned *>(d_work + 5 * hbmax);
     const int nbt_total = (B + REC_BM - 1) / REC_BM;
-    if (nntk_shim_memset(d_work, 0, 4 * hbmax * 4 + (size_t)nbt_total * 2 * RECP_CNT_STRIDE * sizeof(unsigned))) return -1;
+    if (nntk_shim_memset(d_work, 0, 5 * hbmax * 4 + (size_t)nbt_total * 2 * RECP_CNT_STRIDE * sizeof(unsigned))) return -1;
     Gru2Params q;
     q.xw1 = d_xw1; q.ut1 = d_ut1; q.bh1 = d_bh1; q.wt2 = d_wt2; q.bi2 = d_bi2; q.ut2 = d_ut2; q.bh2 = d_bh2;
-    q.hbuf1 = d_work; q.hbuf2 = d_work + 2 * hbmax; q.hb_floats = hb_floats;
+    q.hbuf1 = d_work; q.hbuf2 = d_work + 3 * hbmax; q.hb_floats = hb_floats;      // layer 1's slots are hb_floats (<= hbmax) apart
     q.out = d_out; q.out1 = d_out1; q.fault = fault;
     q.spin_ticks = (unsigned long long)(opt.rec_spin_us > 0 ? opt.rec_spin_us : 0) * 100ull;
     q.B = B; q.T = T; q.H = H; q.Hj_p = Hj_p; q.Hk_p = Hk_p; q.NCT = NCT; q.return_sequences = return_sequences;
