@@ -471,9 +471,12 @@ __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
     unsigned *const flags0 = p.flags + (size_t)bt * 2 * RR_FLAGS, *const flags1 = flags0 + RR_FLAGS;
     // arrival (publishing wave only): its publishing stores have drained -> raise the column tile's flag (write-through store
     // of t + 1).  Counted wait: the x request and the own-sequence operand requests issued after the publication stay in flight.
-    auto arrive = [&](int half, int t) __attribute__((always_inline)) {
+    // XLIVE: the half-step carries the x request (the last half-step of each half does not: nothing would consume it, the
+    // compiler would drop the loads and the count would be 2 KX too lenient -- tools/check_rr_waits.py checks every
+    // instantiation's counts against the ISA)
+    auto arrive = [&](int half, int t, auto xlive_tag) __attribute__((always_inline)) {
         if (w == 2 * half) {
-            asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N_AFTER_PUB) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N_AFTER_PUB - (decltype(xlive_tag)::value ? 0 : 2 * KX)) : "memory");
             if (lane == 0)
                 __hip_atomic_store((half ? flags1 : flags0) + ct, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -509,7 +512,8 @@ __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
 
     // one half-step: multiply half Y at step t; FIN: finish half X = 1 - Y (its step tX) on the way; NEXT: fetch X's operand of
     // step tX + 1 (POLL: it was published inside this launch)
-    auto half_step = [&](auto y_tag, auto fin_tag, auto next_tag, auto poll_tag, auto last_tag, int t, int tX) __attribute__((always_inline)) {
+    auto half_step = [&](auto y_tag, auto fin_tag, auto next_tag, auto poll_tag, auto last_tag, auto xlive_tag, int t, int tX) __attribute__((always_inline)) {
+        constexpr bool XLIVE = decltype(xlive_tag)::value;      // x_{t+1} of this half exists and a later half-step consumes it
         constexpr int Y = decltype(y_tag)::value;
         using XT = std::integral_constant<int, 1 - Y>;
         constexpr int X = 1 - Y;
@@ -539,7 +543,7 @@ __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
             // ---- slices of the other half's finish and of its next fetch ----
             if (s == S_RED && FIN && !RR_DBG(2)) { fin_reduce(); fin_gates(XT{}, tX); }
             if (s == S_PUB && FIN && !RR_DBG(2)) { fin_publish(XT{}, last_tag, tX); }
-            if (s == S_E1 && FIN && !RR_DBG(4)) { arrive(X, tX); }
+            if (s == S_E1 && FIN && !RR_DBG(4)) { arrive(X, tX, xlive_tag); }
             if (s == S_E2 - RR_POLL_LEAD && NEXT && POLL && !RR_DBG(4)) poll_a(X);
             if (s == S_E2) {
                 if (NEXT && POLL && !RR_DBG(4)) poll_b(X, tX + 1);
@@ -571,7 +575,7 @@ __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
             // half's x_{t+1} -- a whole half-step ahead of its use
             if (s == S_XSPL) {
                 if (NEXT && !RR_DBG(8)) split_x();
-                if (!RR_DBG(8)) issue_x(Y, t + 1);          // unconditional (t + 1 == T reads a row's neighbour or zeros, never used): the arrival's counted wait relies on it
+                if (XLIVE && !RR_DBG(8)) issue_x(Y, t + 1);  // the arrival's counted wait counts these requests
             }
 #ifndef RR_NO_INTERLEAVE
             // spread this k step's vector-memory instructions between its MFMAs (2 MFMAs, then at most 1 memory operation,
@@ -615,16 +619,18 @@ __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
     issue_h(I0{}, 0, 0, 3 * NPRE);
     split_x();
     issue_x(1, 0);
-    half_step(I0{}, Ff{}, Tt{}, Ff{}, Ff{}, 0, -1);                       // A(0); fetch B(0)
     if (T > 1) {
-        half_step(I1{}, Tt{}, Tt{}, Tt{}, Ff{}, 0, 0);                    // B(0); finish A(0); fetch A(1)
+        half_step(I0{}, Ff{}, Tt{}, Ff{}, Ff{}, Tt{}, 0, -1);                   // A(0); fetch B(0)
+        half_step(I1{}, Tt{}, Tt{}, Tt{}, Ff{}, Tt{}, 0, 0);                    // B(0); finish A(0); fetch A(1)
         for (int t = 1; t < T - 1; ++t) {
-            half_step(I0{}, Tt{}, Tt{}, Tt{}, Ff{}, t, t - 1);            // A(t); finish B(t-1); fetch B(t)
-            half_step(I1{}, Tt{}, Tt{}, Tt{}, Ff{}, t, t);                // B(t); finish A(t); fetch A(t+1)
+            half_step(I0{}, Tt{}, Tt{}, Tt{}, Ff{}, Tt{}, t, t - 1);            // A(t); finish B(t-1); fetch B(t)
+            half_step(I1{}, Tt{}, Tt{}, Tt{}, Ff{}, Tt{}, t, t);                // B(t); finish A(t); fetch A(t+1)
         }
-        half_step(I0{}, Tt{}, Tt{}, Tt{}, Ff{}, T - 1, T - 2);            // A(T-1); finish B(T-2); fetch B(T-1)
+        half_step(I0{}, Tt{}, Tt{}, Tt{}, Ff{}, Ff{}, T - 1, T - 2);            // A(T-1); finish B(T-2); fetch B(T-1)
+    } else {
+        half_step(I0{}, Ff{}, Tt{}, Ff{}, Ff{}, Ff{}, 0, -1);                   // T == 1: A(0); fetch B(0)
     }
-    half_step(I1{}, Tt{}, Ff{}, Ff{}, Tt{}, T - 1, T - 1);                // B(T-1); finish A(T-1): its last step
+    half_step(I1{}, Tt{}, Ff{}, Ff{}, Tt{}, Ff{}, T - 1, T - 1);                // B(T-1); finish A(T-1): its last step
     // drain: finish B(T-1)
     fin_reduce();
     fin_gates(I1{}, T - 1);

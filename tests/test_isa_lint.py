@@ -26,3 +26,12 @@ def test_no_kernel_has_the_wide_store_sgpr_soffset_hazard():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_store_hazard.py")], capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_lstm_rr_counted_waits_match_the_isa():
+    """recurrent_rr.hip raises a half's flag after a COUNTED vmcnt wait (the operand prefetch stays in flight): the count must
+    equal the vector-memory instructions the compiler really emitted between the publication and the wait, in every
+    instantiation and every peeled copy of the half-step (dead x loads in the last half-steps once made it 2 KX too lenient)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_rr_waits.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 mismatches" in r.stdout
