@@ -398,6 +398,37 @@ __global__ __launch_bounds__(256) void bn_kernel_vec4(const float4 *in, const fl
     }
 }
 
+// The same arithmetic with everything per-channel hoisted out of the element loop: when the grid stride is a multiple of the
+// row (256 % (C / 4) == 0) a thread stays on ONE channel quad, so gamma / beta / mean and sd = sqrtf(var + eps), 1 / sd are
+// computed once per thread, and the division is a reciprocal multiply refined by one FMA step -- the correctly rounded
+// quotient (the fused conv epilogue's form, conv1d_kernels.hpp) without the 11-instruction IEEE sequence.  bn_kernel_vec4 spent
+// its time there (IEEE sqrt + divide + four parameter loads per ELEMENT): 0.50 ms = 2.1 TB/s on config 3's [1024 x 996, 128]
+// tensor against 0.19 ms for the activations (profiles/r03_elementwise.log).  Same bits as bn_kernel_vec4.
+__global__ __launch_bounds__(256) void bn_kernel_vec4_rows(const float4 *in, const float *__restrict__ bn,
+                                                           float eps, float4 *out, long n4, int C) {
+    const long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const int c = (int)((i0 * 4) % C);
+    float ga[4], be[4], mu[4], sd[4], rsd[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ga[j] = bn[c + j]; be[j] = bn[C + c + j]; mu[j] = bn[2 * C + c + j];
+        sd[j] = sqrtf(bn[3 * C + c + j] + eps);
+        rsd[j] = 1.0f / sd[j];
+    }
+    for (long i = i0; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 x = in[i];
+        float v[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = v[j] - mu[j];
+            float q = d * rsd[j];
+            q = __builtin_fmaf(__builtin_fmaf(-q, sd[j], d), rsd[j], q);       // = d / sd, correctly rounded
+            v[j] = q * ga[j] + be[j];                                            // two roundings (contract off)
+        }
+        out[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 __global__ __launch_bounds__(256) void bn_kernel(const float *in, const float *__restrict__ bn, float eps,
                                                  float *out, long n, int C) {
     const float *gamma = bn, *beta = bn + C, *mean = bn + 2 * C, *var = bn + 3 * C;
@@ -450,6 +481,25 @@ __global__ __launch_bounds__(256) void softmax_kernel(const float *in, float *ou
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
         for (int i = lane; i < vsize; i += 64) y[i] = y[i] / sum;
+    }
+}
+
+// Short vectors (vsize = 4 * LPV, LPV a power of two <= 64, 16-byte aligned): LPV lanes hold one vector as one float4 each,
+// 64 / LPV vectors per wavefront, the exponentials stay in registers -- one 16-byte load and one 16-byte store per lane where
+// the generic kernel writes the exponentials, reads them back and writes again with 4- or 8-byte accesses (0.34 ms against
+// 0.19 ms for a plain activation on [1024 x 996] vectors of 128).  Same operations: expf, sum (shuffle tree), true divide.
+template <int LPV>
+__global__ __launch_bounds__(256) void softmax_short_kernel(const float4 *in, float4 *out, long vectors) {
+    const long g = (blockIdx.x * (long)blockDim.x + threadIdx.x) / LPV;        // vector index of this lane group
+    const int l = threadIdx.x % LPV;
+    const long ngroups = ((long)gridDim.x * blockDim.x) / LPV;
+    for (long v = g; v < vectors; v += ngroups) {
+        const float4 x = in[v * LPV + l];
+        float4 e = make_float4(expf(x.x), expf(x.y), expf(x.z), expf(x.w));
+        float sum = (e.x + e.y) + (e.z + e.w);
+#pragma unroll
+        for (int off = LPV / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        out[v * LPV + l] = make_float4(e.x / sum, e.y / sum, e.z / sum, e.w / sum);
     }
 }
 
@@ -536,7 +586,10 @@ int nntk_shim_batch_norm(const float *d_in, const float *d_bn, float eps, float 
     if (rows <= 0 || C <= 0) return 0;
     long n = rows * C;
     bool vec = (C % 4 == 0) && (((size_t)d_in | (size_t)d_out) % 16 == 0);
-    if (vec) {
+    if (vec && 256 % (C / 4) == 0) {          // a thread keeps its channel quad: per-channel work hoisted
+        hipLaunchKernelGGL(bn_kernel_vec4_rows, dim3(grid_for(n / 4, 256)), dim3(256), 0, nntk_stream(),
+                           (const float4 *)d_in, d_bn, eps, (float4 *)d_out, n / 4, C);
+    } else if (vec) {
         hipLaunchKernelGGL(bn_kernel_vec4, dim3(grid_for(n / 4, 256)), dim3(256), 0, nntk_stream(),
                            (const float4 *)d_in, d_bn, eps, (float4 *)d_out, n / 4, C);
     } else {
@@ -595,6 +648,16 @@ int nntk_shim_activation(int kind, float relu_a, int softmax_vector_size, const 
     if (kind == NNTK_ACT_SOFTMAX) {
         if (softmax_vector_size <= 0) return nntk_fail_msg("softmax: vector_size must be > 0");
         long vectors = n_elems / softmax_vector_size;
+        const int lpv = softmax_vector_size / 4;
+        if (softmax_vector_size % 4 == 0 && lpv >= 1 && lpv <= 64 && (lpv & (lpv - 1)) == 0 && (((size_t)d_in | (size_t)d_out) % 16) == 0) {
+            const unsigned grid = (unsigned)grid_for(vectors * lpv, 256);
+#define NNTK_SM(L) hipLaunchKernelGGL(softmax_short_kernel<L>, dim3(grid), dim3(256), 0, nntk_stream(), (const float4 *)d_in, (float4 *)d_out, vectors)
+            switch (lpv) { case 1: NNTK_SM(1); break; case 2: NNTK_SM(2); break; case 4: NNTK_SM(4); break; case 8: NNTK_SM(8); break;
+                           case 16: NNTK_SM(16); break; case 32: NNTK_SM(32); break; default: NNTK_SM(64); break; }
+#undef NNTK_SM
+            NNTK_LAUNCH_CHECK("softmax_short_kernel");
+            return 0;
+        }
         hipLaunchKernelGGL(softmax_kernel, dim3(grid_for(vectors * 64, 256)), dim3(256), 0, nntk_stream(),
                            d_in, d_out, vectors, softmax_vector_size);
         NNTK_LAUNCH_CHECK("softmax_kernel");

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The standalone elementwise kernels at BASELINE config 3's size ([1024 x 996, 128] f32): BatchNorm (runtime.hip
-bn_kernel_vec4; batch_norm.c:140-163), ReLU and sigmoid (act_kernel; activation_default.c:28-33, :123-129), softmax over
-128-vectors (softmax_kernel; activation_default.c:149-167).  In the stack they are fused into the conv / GEMM epilogues; this
+bn_kernel_vec4_rows; batch_norm.c:140-163), ReLU and sigmoid (act_kernel; activation_default.c:28-33, :123-129), softmax over
+128-vectors (softmax_short_kernel; activation_default.c:149-167).  In the stack they are fused into the conv / GEMM epilogues; this
 is the memory-bound path north_star asks a GB/s figure for.  Prints achieved GB/s from HIP events (algorithmic bytes = one
 read + one write of the tensor); run it under `rocprofv3 --kernel-trace --stats` for the per-kernel durations
 (tools/final_profile.sh does, profiles/r03_elementwise_kernel_stats.csv)."""
@@ -25,10 +25,10 @@ def main():
     bn.set_weights(*(r.uniform(0.5, 1.5, Cc).astype(np.float32) for _ in range(4)))
     relu, sig = NL.Activation("relu", rows * Cc, 1.0), NL.Activation("sigmoid", rows * Cc)
     sm = NL.Activation("softmax", rows, 1.0, Cc)
-    cases = [("BatchNormApplyDevice  (bn_kernel_vec4)", lambda: bn.apply_device(x, out=y)),
+    cases = [("BatchNormApplyDevice  (bn_kernel_vec4_rows)", lambda: bn.apply_device(x, out=y)),
              ("ReLU                  (act_kernel)", lambda: relu.apply_device(x, out=y)),
              ("sigmoid               (act_kernel)", lambda: sig.apply_device(x, out=y)),
-             ("softmax over 128      (softmax_kernel)", lambda: sm.apply_device(x, out=y))]
+             ("softmax over 128      (softmax_short_kernel<32>)", lambda: sm.apply_device(x, out=y))]
     for name, fn in cases:
         for _ in range(3):
             fn()
