@@ -23,7 +23,8 @@ struct NntkOptions {
     int rec_fused2 = -1;         // fused two-layer GRU kernel (0 off)
     int rec_rr = -1;             // register-resident split-bf16 LSTM kernel with the fused input projection (0 off, 1 also for small batches)
     int spec_ppw = 0;            // frame pairs per wavefront in K1 (0 = auto)
-    int spec_variant = -1;       // K1 kernel variant (A/B runs)
+    int spec_variant = -1;       // 1: log-mel as two kernels (K1, then the GEMM) instead of the fused output stage (A/B, tests)
+    int spec_dma = -1;           // K1 sample images by LDS-DMA (1) or through registers (0); auto = registers (measured faster)
     int bn_fast = 0;             // reciprocal-multiply BatchNorm (not the reference's divide)
     int gemm_tm_batch = -1;      // tile time-major GEMM outputs over the batch
     int conv_a4 = 1;             // 16-byte window loads also for channel counts that are not multiples of 4 (0: 4-byte loads there)

@@ -46,6 +46,7 @@ static const OptDesc g_opt_table[] = {
     {"rec_rr", "NNTK_REC_RR", &NntkOptions::rec_rr},
     {"spec_ppw", "NNTK_SPEC_PPW", &NntkOptions::spec_ppw},
     {"spec_variant", "NNTK_SPEC_VARIANT", &NntkOptions::spec_variant},
+    {"spec_dma", "NNTK_SPEC_DMA", &NntkOptions::spec_dma},
     {"bn_fast", "NNTK_BN_FAST", &NntkOptions::bn_fast},
     {"gemm_tm_batch", "NNTK_GEMM_TM_BATCH", &NntkOptions::gemm_tm_batch},
     {"gemm_split_bf16", "NNTK_GEMM_SPLIT_BF16", &NntkOptions::gemm_split_bf16},

@@ -637,8 +637,8 @@ static int spectrogram_launch(const float *d_in, const float *d_window, const fl
         const bool norm = fft_norm != 1.0f;
         const bool nz7 = window_size > 384 && window_size <= 448;
         const bool ld3 = (step + window_size) * 4 <= 3072;          // 16-byte loads per lane for one pair's samples: 3 or 4
-        // LDS-DMA sample images: the BASELINE geometry (3 requests per pair, image <= 576 floats), no fused mel; option spec_variant = 0 / 1 forces
-        const bool dma = ld3 && !mel && (step + window_size) <= SPEC_IMG_FLOATS && (nntk_options().spec_variant < 0 ? SPEC_DMA_DEFAULT : nntk_options().spec_variant == 1);
+        // LDS-DMA sample images: the BASELINE geometry (3 requests per pair, image <= 576 floats), no fused mel; option spec_dma = 0 / 1 forces
+        const bool dma = ld3 && !mel && (step + window_size) <= SPEC_IMG_FLOATS && (nntk_options().spec_dma < 0 ? SPEC_DMA_DEFAULT : nntk_options().spec_dma == 1);
 #define SPEC_KERN2(M, N, Z) (mel ? (ld3 ? spectrogram512_kernel<M, N, Z, 3, true> : spectrogram512_kernel<M, N, Z, 4, true>) \
                                  : dma ? spectrogram512_kernel<M, N, Z, 3, false, true> \
                                  : (ld3 ? spectrogram512_kernel<M, N, Z, 3> : spectrogram512_kernel<M, N, Z, 4>))
