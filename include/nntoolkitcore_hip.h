@@ -378,6 +378,12 @@ const char *nntk_version(void);
  * (nntk_hip_synchronize() before moving it to another stream).
  *
  * Tuning / diagnostics knobs by name; environment variables NNTK_<NAME> give the initial values (read once).
+ *   "gemm_split_bf16" contraction of Conv1d / Dense / TimeDistributedDense / mel: auto = split-bf16 x 3 (every f32 operand as
+ *                    three bf16 terms, six bf16 MFMA products accumulated in f32: f32 accuracy, not the k-ordered f32 chain),
+ *                    0 = the exact-f32 chain everywhere, 1 = split also for the recurrent input projection.  EDGE VALUES under
+ *                    auto: a non-finite input, or one above 3.39e38, gives NaN (where the chain gives +-inf) in exactly the outputs
+ *                    whose window holds it; inputs below 1.18e-38 count as zero; a WEIGHT block holding such a value is detected
+ *                    at upload and runs on the exact kernel.  INTEGRATION.md section 6 has the table, tests/test_gpu_edges.py pins it.
  *   "rec_rr"         LSTM batches: 0 = never the register-resident split-bf16 kernel (recurrent_rr.hip; x W fused into the
  *                    step, f32-accuracy contraction, not the exact-f32 chain), 1 = also below 32 sequences, auto = from 32
  *   "rec_persistent" 0 = per-timestep recurrent kernels only     "rec_pingpong" 0/1 = ping-pong halves off/on
