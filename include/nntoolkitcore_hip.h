@@ -386,6 +386,7 @@ const char *nntk_version(void);
  *                    at upload and runs on the exact kernel.  INTEGRATION.md section 6 has the table, tests/test_gpu_edges.py pins it.
  *   "rec_rr"         LSTM batches: 0 = never the register-resident split-bf16 kernel (recurrent_rr.hip; x W fused into the
  *                    step, f32-accuracy contraction, not the exact-f32 chain), 1 = also below 32 sequences, auto = from 32
+ *   "train_bptt"     0 = GRU / LSTM gradients walk time with two launches per step instead of the persistent BPTT kernel
  *   "rec_persistent" 0 = per-timestep recurrent kernels only     "rec_pingpong" 0/1 = ping-pong halves off/on
  *   "rec_spin_us"    budget of the persistent kernel's spins     "gemm_tm_batch" 0/1
  *   "weights_check"  host-pointer calls look for in-place edits of the weight block before they launch:

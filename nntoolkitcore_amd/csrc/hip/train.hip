@@ -595,27 +595,103 @@ __global__ __launch_bounds__(256) void outer_reduce_kernel(const float *__restri
 
 // the bias row alone (I == 0: column sums of Bm): outer_partial_kernel would run it on OUTER_SLICES workgroups walking all of K
 // (1.25 ms for LSTM-512's [12800, 2048] dgates); here K is spread over the grid too.  Same slices, same order, same bits.
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ Bm, float *__restrict__ partial, long rows, int K) {
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ Bm, float *__restrict__ partial, long rows, int K,
+                                                             size_t slice_stride) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= K) return;
     const long r0 = rows * blockIdx.y / gridDim.y, r1 = rows * (blockIdx.y + 1) / gridDim.y;
     float acc = 0.0f;
     for (long r = r0; r < r1; ++r) acc = add_rn(acc, Bm[r * K + k]);
-    partial[(size_t)blockIdx.y * K + k] = acc;
+    partial[(size_t)blockIdx.y * slice_stride + k] = acc;
+}
+
+// The weight-gradient product C[i][k] += sum_rows A[row][i] Bm[row][k] on the exact-f32 MFMA (v_mfma_f32_32x32x2_f32) once it is
+// large: d_W / d_U of a recurrent layer ([128 | 512] x 2048 over 12800 rows) and Dense's d_W ([512] x 1000 over 63744 rows).
+// The output is small and the contraction (the ROWS) is long, so an output-tiled GEMM has 8-32 workgroups walking thousands of
+// k-steps each (1.1 ms per product at LSTM-512, 5.5 ms at Dense-1000).  Here the rows are cut into `slices` (grid z) and every
+// (128 x 128 tile, slice) is one workgroup: hundreds of workgroups, each a k-ordered fmaf chain over its slice; the slices are
+// then added in order by outer_reduce_kernel (same structure as the VALU form above, 32x32x2 blocks instead of single dots).
+// No operand is transposed or staged: for this MFMA shape lane l supplies A[k = l / 32][m = l % 32] and B[k = l / 32][n = l % 32],
+// i.e. 32 consecutive floats of one source row -- both operands load straight from their row-major tensors, coalesced.
+//   wave (wi, wk) of a workgroup owns the 64 x 64 sub-tile at (i0 + 64 wi, k0 + 64 wk): 2 x 2 MFMAs per pair of rows
+//   a_shift_T > 0: A is h [B][T][I] and row (b, t) uses h_{t-1} (zero at t = 0), as in outer_partial_kernel
+#define OUTER_TILE 128
+__global__ __launch_bounds__(256) void outer_mfma_kernel(const float *__restrict__ A, const float *__restrict__ Bm, float *__restrict__ partial,
+                                                         long rows, int I, int K, int a_shift_T) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = lane & 31, kk = lane >> 5;
+    const int i0 = blockIdx.y * OUTER_TILE + (wv >> 1) * 64, k0 = blockIdx.x * OUTER_TILE + (wv & 1) * 64;
+    if (i0 >= I || k0 >= K) return;                          // no barrier below: a wave outside the matrix just leaves
+    const long r0 = rows * blockIdx.z / gridDim.z, r1 = rows * (blockIdx.z + 1) / gridDim.z;
+    const bool iv0 = i0 + c < I, iv1 = i0 + 32 + c < I, kv0 = k0 + c < K, kv1 = k0 + 32 + c < K;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[x][y][v] = 0.f;
+    long tt = a_shift_T > 0 ? (r0 + kk) % a_shift_T : 1;    // t of this lane's row (only "is it 0" matters)
+    const float *ap = A + (r0 + kk - (a_shift_T > 0 ? 1 : 0)) * (long)I + i0 + c;
+    const float *bp = Bm + (r0 + kk) * (long)K + k0 + c;
+    // four row pairs per trip (a constant inner trip count: a loop holding MFMAs is only unrolled without a remainder loop);
+    // pairs past the slice's end load zeros
+    for (long rb = r0 + kk; rb < r1 + kk; rb += 8) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool rv = rb + 2 * u < r1, av = rv && tt != 0;
+            const float a0 = av && iv0 ? ap[0] : 0.f, a1 = av && iv1 ? ap[32] : 0.f;
+            const float b0 = rv && kv0 ? bp[0] : 0.f, b1 = rv && kv1 ? bp[32] : 0.f;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            ap += 2 * (long)I; bp += 2 * (long)K;
+            if (a_shift_T > 0) { tt += 2; if (tt >= a_shift_T) tt -= a_shift_T; if (tt >= a_shift_T) tt -= a_shift_T; }     // T = 1 needs both
+        }
+    }
+    // D layout: lane (n = c, kk) holds rows 8 (v / 4) + 4 kk + v % 4 of each 32 x 32 block, column n
+    float *dst = partial + (size_t)blockIdx.z * (I + 1) * K;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int k = k0 + 32 * y + c;
+            if (k >= K) continue;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int i = i0 + 32 * x + 8 * (v >> 2) + 4 * kk + (v & 3);
+                if (i < I) dst[(size_t)i * K + k] = acc[x][y][v];
+            }
+        }
 }
 
 extern "C" size_t nntk_shim_outer_scratch_floats(int I, int K) { return (size_t)OUTER_SLICES * (I + 1) * K; }
 extern "C" int nntk_shim_outer_accumulate(const float *d_A, const float *d_B, float *d_C, float *d_c, float *d_scratch,
                                           long rows, int I, int K, int a_shift_T) {
     if (rows <= 0 || I < 0 || K <= 0) return 0;             // I == 0: only the column sums c
-    if (I == 0)
-        hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)((K + 255) / 256), OUTER_SLICES), dim3(256), 0, nntk_stream(), d_B, d_scratch, rows, K);
+    int slices = OUTER_SLICES;
+    if (I >= 32 && K >= 32 && (double)rows * I * K >= (double)(1 << 27)) {
+        // sliced MFMA form: enough (tile, slice) workgroups for three waves per SIMD, at least 64 rows per slice
+        const int ti = (I + OUTER_TILE - 1) / OUTER_TILE, tk = (K + OUTER_TILE - 1) / OUTER_TILE;
+        slices = (768 + ti * tk - 1) / (ti * tk);
+        if (slices > OUTER_SLICES) slices = OUTER_SLICES;
+        if ((long)slices > rows / 64) slices = (int)(rows / 64);
+        if (slices < 1) slices = 1;
+        hipLaunchKernelGGL(outer_mfma_kernel, dim3((unsigned)tk, (unsigned)ti, (unsigned)slices), dim3(256), 0, nntk_stream(),
+                           d_A, d_B, d_scratch, rows, I, K, a_shift_T);
+        NNTK_LAUNCH_CHECK("outer_mfma_kernel");
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)((K + 255) / 256), (unsigned)slices), dim3(256), 0, nntk_stream(),
+                           d_B, d_scratch + (size_t)I * K, rows, K, (size_t)(I + 1) * K);
+    } else if (I == 0)
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)((K + 255) / 256), OUTER_SLICES), dim3(256), 0, nntk_stream(), d_B, d_scratch, rows, K,
+                           (size_t)K);
     else
         hipLaunchKernelGGL(outer_partial_kernel, dim3((unsigned)(I + 1), OUTER_SLICES), dim3(K >= 256 ? 256 : ((K + 63) / 64) * 64), 0,
                            nntk_stream(), d_A, d_B, d_scratch, rows, I, K, a_shift_T);
     NNTK_LAUNCH_CHECK("outer_partial_kernel");
     hipLaunchKernelGGL(outer_reduce_kernel, dim3(grid_for((long)(I + 1) * K, 256)), dim3(256), 0, nntk_stream(), d_scratch, d_C, d_c,
-                       I, K, OUTER_SLICES);
+                       I, K, slices);
     NNTK_LAUNCH_CHECK("outer_reduce_kernel");
     return 0;
 }
@@ -625,6 +701,174 @@ extern "C" int nntk_shim_rows_times_rowmat(const float *d_d, const float *d_M, f
     NNTK_LAUNCH_CHECK("rows_times_rowmat_kernel");
     return 0;
 }
+// ---- persistent BPTT (GRU and LSTM) ------------------------------------------------------------------------------------
+// The per-timestep loops above cost two launches per step (elementwise cell backward, then d_h_prev = dgates U^T): 17 us per
+// step at LSTM-512 / mini-batch 64, most of it launch boundaries and re-reading U^T (4 MB) from L2 every step.  This kernel
+// runs the whole loop in one launch.
+//   workgroup (ct, bt): hidden units [16 ct, 16 ct + 16) of batch rows [16 bt, 16 bt + 16) -- one (b, j) per thread for the
+//     elementwise part, whose carries (d_c / d_h_prev_1) therefore live in a register for the whole loop;
+//   the product: the same 16 x 16 tile of d_h_prev = dgates_t [16 x K] U^T [K x 16] on v_mfma_f32_16x16x4_f32, K = 3H | 4H
+//     split over the 4 waves; each wave's slice of U^T ([K / 4] x 16) is loaded ONCE into registers (H / 4 <= 128 VGPRs);
+//   exchange: dgates_t itself ([B][T][K], an output of the call anyway) -- every workgroup writes its 16 x (3 | 4 x 16) piece with
+//     write-through stores, the 16 batch rows' H / 16 workgroups meet on one counter per batch tile, then each reads the
+//     full 16 x K rows back (sc1 loads).  Rows of different t never share an address, so there is no reuse hazard.
+// Hand-off: Guideline 16 R1 (sc1 stores, vmcnt(0) in every storing wave, workgroup barrier, one agent-scope add; one polling
+// lane, sc1 loads after a barrier); the spin is bounded and raises the runtime's fault word (runtime.hip).
+// Same arithmetic as the per-step kernels: the elementwise part is their code, the product their chunked k-ordered MFMA chain
+// (4 chunks of K / 4 here instead of 8 of K / 8: a few roundings apart, inside the gradient tests' tolerance).
+typedef unsigned bp_v4u __attribute__((ext_vector_type(4)));
+struct BpttParams {
+    const float *dout;           // [B][T][H] or [B][H]
+    const float *UT;             // [K][H]
+    const float *c, *zifgo;      // LSTM caches
+    const float *h, *Zg, *hU;    // GRU caches
+    float *dG;                   // LSTM dgates [B][T][4H] / GRU d_hU [B][T][3H]: output and exchange
+    float *dxW;                  // GRU only [B][T][3H]
+    unsigned *count;             // [ceil(B / 16)], zeroed by the host
+    unsigned *fault;
+    unsigned long long spin_ticks;
+    int B, T, H, return_sequences;
+    int act[5];
+    float sc_out;
+};
+template <int CELL>              // 0: GRU, 1: LSTM
+__global__ __launch_bounds__(256) void bptt_persistent_kernel(BpttParams p) {
+    constexpr int NG = CELL ? 4 : 3;
+    __shared__ float part[4][4][64];
+    __shared__ int s_stop;
+    const int H = p.H, K = NG * H, NCT = H / 16, T = p.T;
+    const int ct = blockIdx.x % NCT, bt = blockIdx.x / NCT;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const int i0 = ct * 16;
+    const int kw = K / 4, k0 = wv * kw, nb = kw / 16;            // this wave's K range, in blocks of 16
+    float ut[32][4];
+#pragma unroll
+    for (int kbi = 0; kbi < 32; ++kbi)
+        if (kbi < nb) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ut[kbi][c] = p.UT[(size_t)(k0 + kbi * 16 + 4 * q + c) * H + i0 + n];
+        }
+    const int bl = tid >> 4, jl = tid & 15;
+    const int b = bt * 16 + bl, j = i0 + jl;
+    const bool live = b < p.B;
+    const int am = bt * 16 + n;                                  // the batch row this lane feeds to the MFMA
+    const bool a_live = am < p.B;
+    const size_t tile_bytes = (size_t)(p.B - bt * 16 < 16 ? p.B - bt * 16 : 16) * T * K * 4;
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)(p.dG + (size_t)bt * 16 * T * K), 0, (unsigned)tile_bytes, 0x00020000);
+    if (tid == 0) s_stop = 0;
+    float carry = 0.0f;          // LSTM: d_c carry; GRU: d_h_prev_1
+    float dh2 = 0.0f;            // this thread's element of the product
+    for (int t = T - 1; t >= 0; --t) {
+        const bool last = t == T - 1;
+        if (live) {
+            const size_t row = (size_t)b * T + t;
+            float dout = 0.0f;
+            if (p.return_sequences) dout = p.dout[row * H + j];
+            else if (last) dout = p.dout[(size_t)b * H + j];
+            const int vo = ((bl * T + t) * K + j) * 4;
+            if (CELL) {
+                const float dh = add_rn(last ? 0.0f : dh2, dout);
+                const float *zg = p.zifgo + row * 8 * H;
+                const float it = zg[4 * H + j], ft = zg[5 * H + j], gt = zg[6 * H + j], ot = zg[7 * H + j];
+                const float cv = p.c[row * H + j];
+                const float tc = nntk_gate_act(p.act[4], cv, p.sc_out);
+                const float d_o = gate_grad(p.act[3], zg[3 * H + j], ot, mul_rn(dh, tc));
+                float dc = gate_grad(p.act[4], cv, nntk_gate_act(p.act[4], cv, 1.0f), mul_rn(dh, ot));
+                if (!last) dc = add_rn(dc, carry);
+                const float d_i = gate_grad(p.act[0], zg[j], it, mul_rn(dc, gt));
+                const float d_f = t == 0 ? 0.0f : gate_grad(p.act[1], zg[H + j], ft, mul_rn(p.c[(row - 1) * H + j], dc));
+                const float d_g = gate_grad(p.act[2], zg[2 * H + j], gt, mul_rn(dc, it));
+                carry = mul_rn(dc, ft);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d_i), rg, vo, 0, 16 /* sc1 */);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d_f), rg, vo + H * 4, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d_g), rg, vo + 2 * H * 4, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d_o), rg, vo + 3 * H * 4, 0, 16);
+            } else {
+                const float dh = add_rn(last ? 0.0f : add_rn(carry, dh2), dout);
+                const float *Zg = p.Zg + row * 6 * H;
+                const float z = Zg[3 * H + j], r = Zg[4 * H + j], ht = Zg[5 * H + j];
+                carry = mul_rn(z, dh);
+                const float dht = add_rn(mul_rn(-z, dh), dh);
+                const float dz = mul_rn(t > 0 ? sub_rn(p.h[(row - 1) * H + j], ht) : -ht, dh);
+                const float dZh = gate_grad(p.act[1], Zg[2 * H + j], ht, dht);
+                const float dr = mul_rn(p.hU[row * H + j], dZh);
+                const float dZz = gate_grad(p.act[0], Zg[j], z, dz);
+                const float dZr = gate_grad(p.act[2], Zg[H + j], r, dr);
+                const float dhUh = mul_rn(r, dZh);
+                float *dxW = p.dxW + row * 3 * H;
+                dxW[j] = dZz; dxW[H + j] = dZr; dxW[2 * H + j] = dZh;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dZz), rg, vo, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dZr), rg, vo + H * 4, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dhUh), rg, vo + 2 * H * 4, 0, 16);
+            }
+        }
+        if (t == 0) break;
+        __builtin_amdgcn_s_waitcnt(0x0f70);                     // vmcnt(0): this wave's stores have been written through
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(p.count + bt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = (unsigned)NCT * (unsigned)(T - t);
+            const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+            bool expired = p.spin_ticks == 0;                    // 0: fault injection (tests)
+            while (!expired && __hip_atomic_load(p.count + bt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if (__hip_atomic_load(p.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) expired = true;
+                else expired = __builtin_amdgcn_s_memrealtime() - t_start > p.spin_ticks;
+            }
+            if (expired) {
+                __hip_atomic_fetch_or(p.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_stop = 1;
+            }
+        }
+        __syncthreads();
+        if (s_stop) return;                                      // uniform: every wave of the workgroup leaves
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int ao = a_live ? ((n * T + t) * K + k0 + 4 * q) * 4 : 0x7ffffff0;      // out of range: the load returns 0
+#pragma unroll
+        for (int kbi = 0; kbi < 32; ++kbi)
+            if (kbi < nb) {
+                const bp_v4u a = __builtin_amdgcn_raw_buffer_load_b128(rg, ao + kbi * 64, 0, 16 /* sc1 */);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), ut[kbi][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), ut[kbi][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), ut[kbi][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), ut[kbi][3], acc, 0, 0, 0);
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wv][r][lane] = acc[r];
+        __syncthreads();
+        // D layout: lane (n, q) holds rows 4 q + r, column n  ->  element (row bl, column jl)
+        const int sl = (bl >> 2) * 16 + jl, sr = bl & 3;
+        dh2 = add_rn(add_rn(add_rn(part[0][sr][sl], part[1][sr][sl]), part[2][sr][sl]), part[3][sr][sl]);
+        // part is rewritten only after the next step's two barriers
+    }
+}
+// 0: ran; 1: shape not taken (the caller falls back to the per-step loop); -1: error
+template <int CELL>
+static int bptt_persistent(BpttParams &p, float *d_count_words) {
+    const int NG = CELL ? 4 : 3;
+    const int B = p.B, T = p.T, H = p.H, K = NG * H;
+    const NntkOptions &opt = nntk_options();
+    if (opt.train_bptt == 0 || nntk_persistent_disabled()) return 1;         // after a fault the process keeps to per-step launches
+    if (H % 16 != 0 || K % 64 != 0 || K > 2048 || B < 1 || T < 2) return 1;
+    if ((double)16 * T * K * 4 >= 2.0e9) return 1;               // 32-bit buffer offsets inside a batch tile
+    const int nbt = (B + 15) / 16, grid = nbt * (H / 16);
+    void (*kern)(BpttParams) = bptt_persistent_kernel<CELL>;
+    if (nntk_resident_blocks((const void *)kern, 256, 0, 8) < grid) return 1;      // every workgroup must be resident
+    p.fault = nntk_fault_word();
+    if (!p.fault) return 1;
+    p.spin_ticks = (unsigned long long)(opt.rec_spin_us > 0 ? opt.rec_spin_us : 0) * 100ull;
+    p.count = reinterpret_cast<unsigned *>(d_count_words);
+    if (nntk_shim_memset(d_count_words, 0, (size_t)nbt * sizeof(unsigned))) return -1;
+    nntk_persistent_launch_begin();
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, nntk_stream(), p);
+    const int copy_rc = nntk_fault_enqueue_copy();
+    nntk_persistent_launch_end();
+    if (copy_rc) return -1;
+    NNTK_LAUNCH_CHECK("bptt_persistent_kernel");
+    return 0;
+}
+
 // forward over all timesteps; caches: d_h [B][T][H], d_Zg [B][T][6H], d_hU [B][T][H]
 extern "C" int nntk_shim_gru_train_forward(const float *d_x, const float *d_W, const float *d_U, const float *d_bi, const float *d_bh,
                                            float *d_h, float *d_Zg, float *d_hU, int B, int T, int in, int H,
@@ -649,9 +893,17 @@ extern "C" int nntk_shim_gru_train_backward(const float *d_dout, const float *d_
                                             int return_sequences, const int *acts) {
     if (B <= 0 || T <= 0) return 0;
     if (B > 65535) return nntk_fail_msg("recurrent training: mini-batch above 65535 (one grid row per batch entry)");
+    float *dhp1 = d_work, *dhp2 = d_work + (size_t)B * H, *step = d_work + (size_t)2 * B * H;
+    {
+        BpttParams q{};
+        q.dout = d_dout; q.UT = d_UT; q.h = d_h; q.Zg = d_Zg; q.hU = d_hU; q.dG = d_dhU; q.dxW = d_dxW;
+        q.B = B; q.T = T; q.H = H; q.return_sequences = return_sequences;
+        q.act[0] = acts[0]; q.act[1] = acts[1]; q.act[2] = acts[2];
+        const int rc = bptt_persistent<0>(q, step);
+        if (rc <= 0) return rc;
+    }
     GruBwdParams p{};
     p.dout = d_dout; p.h = d_h; p.Zg = d_Zg; p.hU = d_hU; p.dxW = d_dxW; p.dhU = d_dhU;
-    float *dhp1 = d_work, *dhp2 = d_work + (size_t)B * H, *step = d_work + (size_t)2 * B * H;
     p.dhp1 = dhp1; p.dhp2 = dhp2; p.dhp1_out = dhp1; p.dhU_step = step;
     p.B = B; p.T = T; p.H = H; p.return_sequences = return_sequences;
     p.act_z = acts[0]; p.act_h = acts[1]; p.act_r = acts[2];
@@ -756,8 +1008,17 @@ extern "C" int nntk_shim_lstm_train_backward(const float *d_dout, const float *d
                                              const int *acts, const float *scales) {
     if (B <= 0 || T <= 0) return 0;
     if (B > 65535) return nntk_fail_msg("recurrent training: mini-batch above 65535 (one grid row per batch entry)");
-    LstmBwdParams p{};
     float *dh = d_work, *dc = d_work + (size_t)B * H, *step = d_work + (size_t)2 * B * H;
+    {
+        BpttParams q{};
+        q.dout = d_dout; q.UT = d_UT; q.c = d_c; q.zifgo = d_zifgo; q.dG = d_dG;
+        q.B = B; q.T = T; q.H = H; q.return_sequences = return_sequences;
+        for (int g = 0; g < 5; ++g) q.act[g] = acts[g];
+        q.sc_out = scales[4];
+        const int rc = bptt_persistent<1>(q, step);
+        if (rc <= 0) return rc;
+    }
+    LstmBwdParams p{};
     p.dout = d_dout; p.c = d_c; p.zifgo = d_zifgo; p.dh_carry = dh; p.dc_carry = dc; p.dG = d_dG; p.dG_step = step;
     p.B = B; p.T = T; p.H = H; p.return_sequences = return_sequences;
     for (int g = 0; g < 5; ++g) p.act[g] = acts[g];

@@ -25,24 +25,10 @@
 /* C [I][K] += A [rows][I]^T B [rows][K];  c [K] += column sums of B.  a_shift_T > 0: A is h [B][T][I], row (b,t) uses h_{t-1} */
 int nntk_train_outer_accumulate(const float *d_A, const float *d_B, float *d_C, float *d_c, long rows, int I, int K, int a_shift_T) {
     if (rows <= 0 || K <= 0) return 0;
-    /* the product is only [I][K]: it needs enough 128 x 128 output tiles to occupy the chip, else the 32-slice VALU dots
-     * ((I + 1) * 32 workgroups) spread better */
-    const int tiles = ((I + 127) / 128) * ((K + 127) / 128);
-    const int mfma = (double)rows * I * K >= NNTK_TRAIN_MFMA_MACS && I >= 16 && K >= 32 && rows >= 16 && tiles >= 6;
-    if (!mfma) {
-        float *scr = nntk_devbuf_reserve(&t_scr, nntk_shim_outer_scratch_floats(I, K));
-        if (!scr) return -1;
-        return nntk_shim_outer_accumulate(d_A, d_B, d_C, d_c, scr, rows, I, K, a_shift_T);
-    }
-    /* C = A^T B as a GEMM with K = rows: both operands transposed so that rows are contiguous */
-    float *at = nntk_devbuf_reserve(&t_at, (size_t)I * rows), *bt = nntk_devbuf_reserve(&t_bt, (size_t)K * rows);
-    float *pack = nntk_devbuf_reserve(&t_pack, nntk_shim_gemm_nt_scratch_floats(K, (int)rows));
-    float *tmp = nntk_devbuf_reserve(&t_tmp, (size_t)I * K);
-    float *scr = nntk_devbuf_reserve(&t_scr, nntk_shim_outer_scratch_floats(0, K));
-    if (!at || !bt || !pack || !tmp || !scr) return -1;
-    if (nntk_shim_transpose(d_A, at, rows, I, a_shift_T) || nntk_shim_transpose(d_B, bt, rows, K, 0)) return -1;
-    if (nntk_shim_gemm_nt(at, bt, d_C, pack, tmp, I, K, (int)rows, 1)) return -1;
-    return nntk_shim_outer_accumulate(NULL, d_B, d_C, d_c, scr, rows, 0, K, 0);          /* the bias row only */
+    /* large products take the row-sliced MFMA form inside the call (train.hip outer_mfma_kernel), small ones the VALU dots */
+    float *scr = nntk_devbuf_reserve(&t_scr, nntk_shim_outer_scratch_floats(I, K));
+    if (!scr) return -1;
+    return nntk_shim_outer_accumulate(d_A, d_B, d_C, d_c, scr, rows, I, K, a_shift_T);
 }
 /* out [rows][I] = d [rows][K] M [I][K]^T */
 int nntk_train_rows_times_rowmat(const float *d_d, const float *d_M, float *d_out, long rows, int I, int K) {

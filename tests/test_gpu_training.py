@@ -70,7 +70,8 @@ def test_relu_gradient_is_the_reference_clamp_not_a_step(gpu):
 
 @pytest.mark.parametrize("B,n_in,n_out,act,v", [(5, 12, 7, None, 0), (16, 64, 32, "sigmoid", 0), (8, 33, 10, "softmax", 10),
                                                 (32, 512, 1000, "tanh", 0), (3, 20, 24, "relu", 0), (64, 256, 40, "softmax", 40),
-                                                (2048, 256, 320, "sigmoid", 0)])       # last: large enough for the MFMA forms
+                                                (2048, 256, 320, "sigmoid", 0), (2603, 72, 1000, "tanh", 0)])
+# the last two are large enough for the MFMA forms; (2603, 72, 1000): ragged tiles and an odd row count in outer_mfma_kernel
 def test_dense_training_forward_and_gradient(gpu, B, n_in, n_out, act, v):
     import torch
     L = capi.load()
@@ -114,7 +115,8 @@ def test_dense_training_forward_and_gradient(gpu, B, n_in, n_out, act, v):
             assert err <= tol * sc, (part, nm, err)
     # a second call accumulates d_W / d_b onto the block and rewrites d_X
     L.DenseCalculateGradient(h, g, P(dout))
-    np.testing.assert_allclose(np.ctypeslib.as_array(g.contents.d_W, shape=(n_in, n_out)), 2 * gW, rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(np.ctypeslib.as_array(g.contents.d_W, shape=(n_in, n_out)), 2 * gW, rtol=2e-6,
+                               atol=1e-6 * max(1.0, float(np.abs(gW).max())))
     np.testing.assert_array_equal(np.ctypeslib.as_array(g.contents.d_X, shape=(B, n_in)), gX)
     # mode checks like the reference
     hi = L.DenseCreateForInference(cfg)
@@ -392,6 +394,83 @@ def test_lstm_training_forward_and_bptt(gpu, B, T, n_in, H, seq, v2, acts):
     assert L.LSTMApplyTrainingBatch(hi, P(x), P(y)) == -1                    # lstm.c:419-421
     L.LSTMDestroy(hi); L.RecurrentGradientDestroy(g); L.LSTMDestroy(h)
     for a in ah: L.ActivationFunctionDestroy(a)
+
+
+def _recurrent_gradient(kind, B, T, n_in, H, seq, seed, inject_fault=False):
+    """one training forward + gradient call of a GRU / LSTM with default activations: (d_W, d_U, d_b_i, d_b_h, d_X), error text"""
+    L = capi.load()
+    r = rng(seed)
+    ng = 4 if kind == "lstm" else 3
+    x = u(r, B, T, n_in)
+    W, U = u(r, n_in, ng * H, sc=n_in ** -0.5), u(r, H, ng * H, sc=H ** -0.5)
+    bi, bh = u(r, ng * H, sc=0.1), u(r, ng * H, sc=0.1)
+    tc = capi.ConvTrainingConfig(B)
+    if kind == "lstm":
+        ah = [make_act(L, a, H) for a in ("sigmoid", "sigmoid", "tanh", "sigmoid", "tanh")]
+        cfg = L.LSTMConfigCreate(n_in, H, seq, T, True, L.LSTMActivationsCreate(*ah))
+        h = L.LSTMCreateForTraining(cfg, tc); w = L.LSTMGetWeights(h).contents
+        apply_, grad_new, grad, destroy = L.LSTMApplyTrainingBatch, L.LSTMGradientCreate, L.LSTMCalculateGradient, L.LSTMDestroy
+    else:
+        ah = [make_act(L, a, H) for a in ("sigmoid", "tanh", "sigmoid")]
+        cfg = L.GRUConfigCreate(n_in, H, seq, T, L.GRUActivationsCreate(*ah))
+        h = L.GRUCreateForTraining(cfg, tc); w = L.GRUGetWeights(h).contents
+        apply_, grad_new, grad, destroy = L.GRUApplyTrainingBatch, L.GRUGradientCreate, L.GRUCalculateGradient, L.GRUDestroy
+    for dst, src in ((w.W, W), (w.U, U), (w.b_i, bi), (w.b_h, bh)):
+        C.memmove(dst, src.ctypes.data, src.nbytes)
+    n_out = (B, T, H) if seq else (B, H)
+    y = np.empty(n_out, np.float32)
+    assert apply_(h, P(x), P(y)) == 0, capi.last_error()
+    dout = u(r, *n_out)
+    g = grad_new(cfg, tc)
+    if inject_fault: capi.set_option("rec_spin_us", 0)                        # the gradient call only: every poll gives up at once
+    grad(h, g, P(dout))
+    err = capi.last_error()
+    if inject_fault: capi.set_option("rec_spin_us", "auto")
+    gc = g.contents
+    got = [np.ctypeslib.as_array(p_, shape=s_).copy() for p_, s_ in ((gc.d_W, W.shape), (gc.d_U, U.shape), (gc.d_b_i, bi.shape),
+                                                                     (gc.d_b_h, bh.shape), (gc.d_X, x.shape))]
+    L.RecurrentGradientDestroy(g); destroy(h)
+    for a in ah: L.ActivationFunctionDestroy(a)
+    return got, err
+
+
+@pytest.mark.parametrize("kind,B,T,n_in,H,seq", [("lstm", 64, 40, 128, 512, True), ("lstm", 37, 12, 40, 64, False),
+                                                 ("gru", 64, 40, 128, 256, True), ("gru", 20, 9, 16, 64, False)])
+def test_persistent_bptt_equals_the_per_step_loop(gpu, kind, B, T, n_in, H, seq):
+    """train.hip bptt_persistent_kernel (the whole backward-through-time loop in one launch, carries in registers, d_gates
+    exchanged through HBM) against the two-launches-per-step loop it replaces (option train_bptt = 0): the same elementwise
+    code and a product that differs only in how K is chunked, so the two agree to a few roundings."""
+    L = capi.load()
+    a, e1 = _recurrent_gradient(kind, B, T, n_in, H, seq, 4242)
+    capi.set_option("train_bptt", 0)
+    b_, e2 = _recurrent_gradient(kind, B, T, n_in, H, seq, 4242)
+    capi.set_option("train_bptt", "auto")
+    assert e1 == "" and e2 == ""
+    for nm, p_, q_ in zip(("dW", "dU", "dbi", "dbh", "dX"), a, b_):
+        sc = max(1.0, float(np.abs(q_).max()))
+        err = float(np.abs(p_ - q_).max())
+        print("persistent vs per-step BPTT %s %s: %.2e (scale %.1f)" % (kind, nm, err, sc))
+        assert err <= 2e-5 * sc, (nm, err)
+
+
+def test_persistent_bptt_fault_is_reported(gpu):
+    """A spin that runs out of budget (rec_spin_us = 0 injects it) must not hand back a gradient silently: the call leaves an
+    error, the process moves to the per-step loop, and re-arming (rec_persistent = 1) brings the kernel back."""
+    L = capi.load()
+    good, e0 = _recurrent_gradient("lstm", 32, 10, 64, 128, True, 99)
+    assert e0 == ""
+    _, e1 = _recurrent_gradient("lstm", 32, 10, 64, 128, True, 99, inject_fault=True)
+    assert "timed out" in e1
+    after, e2 = _recurrent_gradient("lstm", 32, 10, 64, 128, True, 99)      # per-step loop now
+    assert e2 == ""
+    capi.set_option("rec_persistent", 1)                                     # re-arm
+    again, e3 = _recurrent_gradient("lstm", 32, 10, 64, 128, True, 99)
+    capi.set_option("rec_persistent", "auto")
+    assert e3 == "" and L.nntk_hip_synchronize() == 0
+    for p_, q_, s_ in zip(good, after, again):
+        sc = max(1.0, float(np.abs(p_).max()))
+        assert float(np.abs(p_ - q_).max()) <= 2e-5 * sc
+        np.testing.assert_array_equal(p_, s_)
 
 
 @pytest.mark.parametrize("B,T,n_in,H,seq,v2,act", [(3, 7, 5, 4, True, True, "tanh"), (4, 20, 16, 32, False, False, "tanh"),
