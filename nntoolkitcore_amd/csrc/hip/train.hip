@@ -611,6 +611,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__rest
 // k-steps each (1.1 ms per product at LSTM-512, 5.5 ms at Dense-1000).  Here the rows are cut into `slices` (grid z) and every
 // (128 x 128 tile, slice) is one workgroup: hundreds of workgroups, each a k-ordered fmaf chain over its slice; the slices are
 // then added in order by outer_reduce_kernel (same structure as the VALU form above, 32x32x2 blocks instead of single dots).
+// The waves of i-tile 0 also keep the column sums of Bm (the bias gradient, row I of every slice) from the B values they load.
 // No operand is transposed or staged: for this MFMA shape lane l supplies A[k = l / 32][m = l % 32] and B[k = l / 32][n = l % 32],
 // i.e. 32 consecutive floats of one source row -- both operands load straight from their row-major tensors, coalesced.
 //   wave (wi, wk) of a workgroup owns the 64 x 64 sub-tile at (i0 + 64 wi, k0 + 64 wk): 2 x 2 MFMAs per pair of rows
@@ -631,6 +632,7 @@ __global__ __launch_bounds__(256) void outer_mfma_kernel(const float *__restrict
         for (int y = 0; y < 2; ++y)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[x][y][v] = 0.f;
+    float bs0 = 0.f, bs1 = 0.f;
     long tt = a_shift_T > 0 ? (r0 + kk) % a_shift_T : 1;    // t of this lane's row (only "is it 0" matters)
     const float *ap = A + (r0 + kk - (a_shift_T > 0 ? 1 : 0)) * (long)I + i0 + c;
     const float *bp = Bm + (r0 + kk) * (long)K + k0 + c;
@@ -642,6 +644,7 @@ __global__ __launch_bounds__(256) void outer_mfma_kernel(const float *__restrict
             const bool rv = rb + 2 * u < r1, av = rv && tt != 0;
             const float a0 = av && iv0 ? ap[0] : 0.f, a1 = av && iv1 ? ap[32] : 0.f;
             const float b0 = rv && kv0 ? bp[0] : 0.f, b1 = rv && kv1 ? bp[32] : 0.f;
+            bs0 += b0; bs1 += b1;                                // column sums of Bm (the bias gradient), kept by the i-tile-0 waves
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
@@ -652,6 +655,13 @@ __global__ __launch_bounds__(256) void outer_mfma_kernel(const float *__restrict
     }
     // D layout: lane (n = c, kk) holds rows 8 (v / 4) + 4 kk + v % 4 of each 32 x 32 block, column n
     float *dst = partial + (size_t)blockIdx.z * (I + 1) * K;
+    if (blockIdx.y == 0 && (wv >> 1) == 0) {                 // row I of the slice: even rows + odd rows of the slice
+        bs0 += __shfl_xor(bs0, 32, 64); bs1 += __shfl_xor(bs1, 32, 64);
+        if (kk == 0) {
+            if (kv0) dst[(size_t)I * K + k0 + c] = bs0;
+            if (kv1) dst[(size_t)I * K + k0 + 32 + c] = bs1;
+        }
+    }
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -681,8 +691,6 @@ extern "C" int nntk_shim_outer_accumulate(const float *d_A, const float *d_B, fl
         hipLaunchKernelGGL(outer_mfma_kernel, dim3((unsigned)tk, (unsigned)ti, (unsigned)slices), dim3(256), 0, nntk_stream(),
                            d_A, d_B, d_scratch, rows, I, K, a_shift_T);
         NNTK_LAUNCH_CHECK("outer_mfma_kernel");
-        hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)((K + 255) / 256), (unsigned)slices), dim3(256), 0, nntk_stream(),
-                           d_B, d_scratch + (size_t)I * K, rows, K, (size_t)(I + 1) * K);
     } else if (I == 0)
         hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)((K + 255) / 256), OUTER_SLICES), dim3(256), 0, nntk_stream(), d_B, d_scratch, rows, K,
                            (size_t)K);
@@ -710,10 +718,10 @@ extern "C" int nntk_shim_rows_times_rowmat(const float *d_d, const float *d_M, f
 //   the product: the same 16 x 16 tile of d_h_prev = dgates_t [16 x K] U^T [K x 16] on v_mfma_f32_16x16x4_f32, K = 3H | 4H
 //     split over the 4 waves; each wave's slice of U^T ([K / 4] x 16) is loaded ONCE into registers (H / 4 <= 128 VGPRs);
 //   exchange: dgates_t itself ([B][T][K], an output of the call anyway) -- every workgroup writes its 16 x (3 | 4 x 16) piece with
-//     write-through stores, the 16 batch rows' H / 16 workgroups meet on one counter per batch tile, then each reads the
-//     full 16 x K rows back (sc1 loads).  Rows of different t never share an address, so there is no reuse hazard.
-// Hand-off: Guideline 16 R1 (sc1 stores, vmcnt(0) in every storing wave, workgroup barrier, one agent-scope add; one polling
-// lane, sc1 loads after a barrier); the spin is bounded and raises the runtime's fault word (runtime.hip).
+//     write-through stores and raises its own flag word, wave 0 of every workgroup polls the batch tile's H / 16 flags with one
+//     wave-wide load, then each workgroup reads the full 16 x K rows back (sc1 loads).  Rows of different t never share an address, so there is no reuse hazard.
+// Hand-off: Guideline 16 R1 (sc1 stores, vmcnt(0) in every storing wave, workgroup barrier, one agent-scope flag store; one
+// polling wave, sc1 loads after a barrier); the spin is bounded and raises the runtime's fault word (runtime.hip).
 // Same arithmetic as the per-step kernels: the elementwise part is their code, the product their chunked k-ordered MFMA chain
 // (4 chunks of K / 4 here instead of 8 of K / 8: a few roundings apart, inside the gradient tests' tolerance).
 typedef unsigned bp_v4u __attribute__((ext_vector_type(4)));
@@ -724,14 +732,20 @@ struct BpttParams {
     const float *h, *Zg, *hU;    // GRU caches
     float *dG;                   // LSTM dgates [B][T][4H] / GRU d_hU [B][T][3H]: output and exchange
     float *dxW;                  // GRU only [B][T][3H]
-    unsigned *count;             // [ceil(B / 16)], zeroed by the host
+    unsigned *count;             // [ceil(B / 16)][32] arrival flags (steps handed off per column tile), zeroed by the host
     unsigned *fault;
     unsigned long long spin_ticks;
     int B, T, H, return_sequences;
     int act[5];
     float sc_out;
 };
-template <int CELL>              // 0: GRU, 1: LSTM
+// timing ablations (tools/bptt_ablate.sh): compile-time mask, 0 in the product.  1 no poll, 2 no operand loads, 4 no MFMAs,
+// 8 no wait for the stores, 16 no stores, 32 no cache fetch
+#ifndef NNTK_BPTT_DBG
+#define NNTK_BPTT_DBG 0
+#endif
+#define BPTT_DBG(bit) ((NNTK_BPTT_DBG & (bit)) != 0)
+template <int CELL, int NB>      // CELL 0: GRU, 1: LSTM;  NB: 16-deep K blocks per wave, compile-time (>= K / 64; the excess multiplies zeros)
 __global__ __launch_bounds__(256) void bptt_persistent_kernel(BpttParams p) {
     constexpr int NG = CELL ? 4 : 3;
     __shared__ float part[4][4][64];
@@ -742,13 +756,11 @@ __global__ __launch_bounds__(256) void bptt_persistent_kernel(BpttParams p) {
     const int n = lane & 15, q = lane >> 4;
     const int i0 = ct * 16;
     const int kw = K / 4, k0 = wv * kw, nb = kw / 16;            // this wave's K range, in blocks of 16
-    float ut[32][4];
+    float ut[NB][4];
 #pragma unroll
-    for (int kbi = 0; kbi < 32; ++kbi)
-        if (kbi < nb) {
+    for (int kbi = 0; kbi < NB; ++kbi)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) ut[kbi][c] = p.UT[(size_t)(k0 + kbi * 16 + 4 * q + c) * H + i0 + n];
-        }
+        for (int c = 0; c < 4; ++c) ut[kbi][c] = kbi < nb ? p.UT[(size_t)(k0 + kbi * 16 + 4 * q + c) * H + i0 + n] : 0.0f;
     const int bl = tid >> 4, jl = tid & 15;
     const int b = bt * 16 + bl, j = i0 + jl;
     const bool live = b < p.B;
@@ -759,42 +771,64 @@ __global__ __launch_bounds__(256) void bptt_persistent_kernel(BpttParams p) {
     if (tid == 0) s_stop = 0;
     float carry = 0.0f;          // LSTM: d_c carry; GRU: d_h_prev_1
     float dh2 = 0.0f;            // this thread's element of the product
+    // forward caches of one step for this thread's (b, j): fetched one step ahead (the loads fly during the hand-off and the product)
+    struct Cached { float z[8]; float c, cprev, dout; };
+    auto fetch = [&](int t) {
+        Cached f{};
+        if (!live || t < 0 || (BPTT_DBG(32) && t < T - 1)) return f;
+        const size_t row = (size_t)b * T + t;
+        if (p.return_sequences) f.dout = p.dout[row * H + j];
+        else if (t == T - 1) f.dout = p.dout[(size_t)b * H + j];
+        if (CELL) {
+            const float *zg = p.zifgo + row * 8 * H;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) f.z[g] = zg[g * H + j];
+            f.c = p.c[row * H + j];
+            f.cprev = t > 0 ? p.c[(row - 1) * H + j] : 0.0f;
+        } else {
+            const float *Zg = p.Zg + row * 6 * H;
+#pragma unroll
+            for (int g = 0; g < 6; ++g) f.z[g] = Zg[g * H + j];
+            f.c = p.hU[row * H + j];
+            f.cprev = t > 0 ? p.h[(row - 1) * H + j] : 0.0f;
+        }
+        return f;
+    };
+    Cached cur = fetch(T - 1);
     for (int t = T - 1; t >= 0; --t) {
         const bool last = t == T - 1;
         if (live) {
             const size_t row = (size_t)b * T + t;
-            float dout = 0.0f;
-            if (p.return_sequences) dout = p.dout[row * H + j];
-            else if (last) dout = p.dout[(size_t)b * H + j];
+            const float dout = cur.dout;
             const int vo = ((bl * T + t) * K + j) * 4;
             if (CELL) {
                 const float dh = add_rn(last ? 0.0f : dh2, dout);
-                const float *zg = p.zifgo + row * 8 * H;
-                const float it = zg[4 * H + j], ft = zg[5 * H + j], gt = zg[6 * H + j], ot = zg[7 * H + j];
-                const float cv = p.c[row * H + j];
+                const float it = cur.z[4], ft = cur.z[5], gt = cur.z[6], ot = cur.z[7];
+                const float cv = cur.c;
                 const float tc = nntk_gate_act(p.act[4], cv, p.sc_out);
-                const float d_o = gate_grad(p.act[3], zg[3 * H + j], ot, mul_rn(dh, tc));
+                const float d_o = gate_grad(p.act[3], cur.z[3], ot, mul_rn(dh, tc));
                 float dc = gate_grad(p.act[4], cv, nntk_gate_act(p.act[4], cv, 1.0f), mul_rn(dh, ot));
                 if (!last) dc = add_rn(dc, carry);
-                const float d_i = gate_grad(p.act[0], zg[j], it, mul_rn(dc, gt));
-                const float d_f = t == 0 ? 0.0f : gate_grad(p.act[1], zg[H + j], ft, mul_rn(p.c[(row - 1) * H + j], dc));
-                const float d_g = gate_grad(p.act[2], zg[2 * H + j], gt, mul_rn(dc, it));
+                const float d_i = gate_grad(p.act[0], cur.z[0], it, mul_rn(dc, gt));
+                const float d_f = t == 0 ? 0.0f : gate_grad(p.act[1], cur.z[1], ft, mul_rn(cur.cprev, dc));
+                const float d_g = gate_grad(p.act[2], cur.z[2], gt, mul_rn(dc, it));
                 carry = mul_rn(dc, ft);
+                if (BPTT_DBG(16)) { if (d_i + d_f + d_g + d_o == 1.2345f) carry += 1.f; } else {
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d_i), rg, vo, 0, 16 /* sc1 */);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d_f), rg, vo + H * 4, 0, 16);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d_g), rg, vo + 2 * H * 4, 0, 16);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d_o), rg, vo + 3 * H * 4, 0, 16);
+                }
             } else {
                 const float dh = add_rn(last ? 0.0f : add_rn(carry, dh2), dout);
-                const float *Zg = p.Zg + row * 6 * H;
-                const float z = Zg[3 * H + j], r = Zg[4 * H + j], ht = Zg[5 * H + j];
+                const float z = cur.z[3], r = cur.z[4], ht = cur.z[5];
                 carry = mul_rn(z, dh);
                 const float dht = add_rn(mul_rn(-z, dh), dh);
-                const float dz = mul_rn(t > 0 ? sub_rn(p.h[(row - 1) * H + j], ht) : -ht, dh);
-                const float dZh = gate_grad(p.act[1], Zg[2 * H + j], ht, dht);
-                const float dr = mul_rn(p.hU[row * H + j], dZh);
-                const float dZz = gate_grad(p.act[0], Zg[j], z, dz);
-                const float dZr = gate_grad(p.act[2], Zg[H + j], r, dr);
+                const float dz = mul_rn(t > 0 ? sub_rn(cur.cprev, ht) : -ht, dh);
+                const float dZh = gate_grad(p.act[1], cur.z[2], ht, dht);
+                const float dr = mul_rn(cur.c, dZh);
+                const float dZz = gate_grad(p.act[0], cur.z[0], z, dz);
+                const float dZr = gate_grad(p.act[2], cur.z[1], r, dr);
                 const float dhUh = mul_rn(r, dZh);
                 float *dxW = p.dxW + row * 3 * H;
                 dxW[j] = dZz; dxW[H + j] = dZr; dxW[2 * H + j] = dZh;
@@ -804,19 +838,30 @@ __global__ __launch_bounds__(256) void bptt_persistent_kernel(BpttParams p) {
             }
         }
         if (t == 0) break;
-        __builtin_amdgcn_s_waitcnt(0x0f70);                     // vmcnt(0): this wave's stores have been written through
+        if (!BPTT_DBG(8)) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's stores have been written through
         __syncthreads();
-        if (tid == 0) {
-            __hip_atomic_fetch_add(p.count + bt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned target = (unsigned)NCT * (unsigned)(T - t);
+        cur = fetch(t - 1);                                      // in flight across the hand-off and the product
+        // arrival: one flag word per (batch tile, column tile) holding the number of steps handed off -- a plain write-through
+        // store, no read-modify-write on a shared counter (32 workgroups adding to one word queue up at L2); wave 0 polls all of
+        // the batch tile's flags with one wave-wide load
+        if (wv == 0) {
+            const unsigned tag = (unsigned)(T - t);
+            unsigned *flags = p.count + (size_t)bt * 32;
+            if (lane == 0) __hip_atomic_store(flags + ct, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
             bool expired = p.spin_ticks == 0;                    // 0: fault injection (tests)
-            while (!expired && __hip_atomic_load(p.count + bt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            unsigned spins = 0;
+            if (!BPTT_DBG(1))
+            while (!expired) {
+                const unsigned v = lane < NCT ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+                if (__builtin_amdgcn_ballot_w64(v < tag) == 0) break;
                 __builtin_amdgcn_s_sleep(1);
-                if (__hip_atomic_load(p.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) expired = true;
-                else expired = __builtin_amdgcn_s_memrealtime() - t_start > p.spin_ticks;
+                if ((++spins & 63u) == 0) {                      // a peer that gave up has raised the fault word: stop spinning too
+                    if (__hip_atomic_load(p.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) expired = true;
+                    else expired = __builtin_amdgcn_s_memrealtime() - t_start > p.spin_ticks;
+                }
             }
-            if (expired) {
+            if (expired && lane == 0) {
                 __hip_atomic_fetch_or(p.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s_stop = 1;
             }
@@ -825,15 +870,23 @@ __global__ __launch_bounds__(256) void bptt_persistent_kernel(BpttParams p) {
         if (s_stop) return;                                      // uniform: every wave of the workgroup leaves
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const int ao = a_live ? ((n * T + t) * K + k0 + 4 * q) * 4 : 0x7ffffff0;      // out of range: the load returns 0
+        // all of the wave's operand loads are requested before the first MFMA: one memory round trip per step, not one per
+        // batch of loads (the rows were written through moments ago, so every load goes out to memory)
+        bp_v4u a[NB];
 #pragma unroll
-        for (int kbi = 0; kbi < 32; ++kbi)
-            if (kbi < nb) {
-                const bp_v4u a = __builtin_amdgcn_raw_buffer_load_b128(rg, ao + kbi * 64, 0, 16 /* sc1 */);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), ut[kbi][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), ut[kbi][1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), ut[kbi][2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), ut[kbi][3], acc, 0, 0, 0);
-            }
+        for (int kbi = 0; kbi < NB; ++kbi) {
+            if (BPTT_DBG(2)) a[kbi] = (bp_v4u){(unsigned)kbi, 1u, 2u, (unsigned)t};
+            else a[kbi] = __builtin_amdgcn_raw_buffer_load_b128(rg, kbi < nb ? ao + kbi * 64 : 0x7ffffff0, 0, 16 /* sc1 */);
+        }
+        __builtin_amdgcn_sched_barrier(0);                      // keep the requests ahead of the MFMAs (the scheduler otherwise pairs them up)
+#pragma unroll
+        for (int kbi = 0; kbi < NB; ++kbi) {
+            if (BPTT_DBG(4)) { acc[0] += __uint_as_float(a[kbi].x + a[kbi].y + a[kbi].z + a[kbi].w); continue; }
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[kbi].x), ut[kbi][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[kbi].y), ut[kbi][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[kbi].z), ut[kbi][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[kbi].w), ut[kbi][3], acc, 0, 0, 0);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) part[wv][r][lane] = acc[r];
         __syncthreads();
@@ -850,16 +903,19 @@ static int bptt_persistent(BpttParams &p, float *d_count_words) {
     const int B = p.B, T = p.T, H = p.H, K = NG * H;
     const NntkOptions &opt = nntk_options();
     if (opt.train_bptt == 0 || nntk_persistent_disabled()) return 1;         // after a fault the process keeps to per-step launches
-    if (H % 16 != 0 || K % 64 != 0 || K > 2048 || B < 1 || T < 2) return 1;
+    if (H % 16 != 0 || H > 512 || K % 64 != 0 || K > 2048 || B < 1 || T < 2) return 1;      // H / 16 <= 32 flags per batch tile
     if ((double)16 * T * K * 4 >= 2.0e9) return 1;               // 32-bit buffer offsets inside a batch tile
     const int nbt = (B + 15) / 16, grid = nbt * (H / 16);
-    void (*kern)(BpttParams) = bptt_persistent_kernel<CELL>;
+    const int nb = K / 64;
+    void (*kern)(BpttParams) = nb <= 8 ? bptt_persistent_kernel<CELL, 8> : nb <= 12 ? bptt_persistent_kernel<CELL, 12> :
+                               nb <= 16 ? bptt_persistent_kernel<CELL, 16> : nb <= 24 ? bptt_persistent_kernel<CELL, 24> :
+                               bptt_persistent_kernel<CELL, 32>;
     if (nntk_resident_blocks((const void *)kern, 256, 0, 8) < grid) return 1;      // every workgroup must be resident
     p.fault = nntk_fault_word();
     if (!p.fault) return 1;
     p.spin_ticks = (unsigned long long)(opt.rec_spin_us > 0 ? opt.rec_spin_us : 0) * 100ull;
     p.count = reinterpret_cast<unsigned *>(d_count_words);
-    if (nntk_shim_memset(d_count_words, 0, (size_t)nbt * sizeof(unsigned))) return -1;
+    if (nntk_shim_memset(d_count_words, 0, (size_t)nbt * 32 * sizeof(unsigned))) return -1;      // B * NG * H floats available: >= nbt * 32
     nntk_persistent_launch_begin();
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, nntk_stream(), p);
     const int copy_rc = nntk_fault_enqueue_copy();
