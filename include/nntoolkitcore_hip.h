@@ -168,6 +168,11 @@ GRU  GRUCreateForTraining(GRUConfig config, GRUTrainingConfig training_config);
 GRUGradient *GRUGradientCreate(GRUConfig config, GRUTrainingConfig training_config);
 int  GRUApplyTrainingBatch(GRU filter, const float *input, float *output);      /* -1 on an inference-mode handle (gru.c:247) */
 void GRUCalculateGradient(GRU filter, GRUGradient *gradients, float *d_out);
+/* Additive device-pointer forms (tensors stay in HBM, asynchronous on the calling thread's stream): d_input [B][T][in] must
+ * stay valid until the gradient call; d_grad = W [in][3H] | U [H][3H] | b_i [3H] | b_h [3H] (the layout of the gradient block)
+ * is ADDED to, d_dX [B][T][in] is overwritten.  Same kernels as the host-pointer forms: bit-identical results. */
+int  GRUApplyTrainingBatchDevice(GRU filter, const float *d_input, float *d_output);
+int  GRUCalculateGradientDevice(GRU filter, float *d_grad, float *d_dX, const float *d_dout);
 GRU  GRUCreateForInference(GRUConfig config);
 int  GRUApplyInference(GRU filter, const float *input, float *output);  /* host, one sequence, STATEFUL */
 void GRUDestroy(GRU filter);
@@ -202,6 +207,9 @@ LSTM LSTMCreateForTraining(LSTMConfig config, LSTMTrainingConfig training_config
 LSTMGradient *LSTMGradientCreate(LSTMConfig config, LSTMTrainingConfig training_config);
 int  LSTMApplyTrainingBatch(LSTM filter, const float *input, float *output);     /* -1 on an inference-mode handle (lstm.c:419) */
 void LSTMCalculateGradient(LSTM filter, LSTMGradient *gradient, float *d_out);
+/* device-pointer forms, as for the GRU (gate width 4H) */
+int  LSTMApplyTrainingBatchDevice(LSTM filter, const float *d_input, float *d_output);
+int  LSTMCalculateGradientDevice(LSTM filter, float *d_grad, float *d_dX, const float *d_dout);
 LSTM LSTMCreateForInference(LSTMConfig config);
 int  LSTMApplyInference(LSTM filter, const float *input, float *output); /* host, one sequence, STATEFUL */
 void LSTMDestroy(LSTM filter);

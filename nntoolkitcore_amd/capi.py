@@ -183,6 +183,10 @@ SIGNATURES = {
     "LSTMGradientCreate": (C.POINTER(RecurrentGradient), [LSTMConfig, ConvTrainingConfig]),
     "LSTMApplyTrainingBatch": (C.c_int, [vp, fp, fp]),
     "LSTMCalculateGradient": (None, [vp, C.POINTER(RecurrentGradient), fp]),
+    "LSTMApplyTrainingBatchDevice": (C.c_int, [vp, vp, vp]),
+    "LSTMCalculateGradientDevice": (C.c_int, [vp, vp, vp, vp]),
+    "GRUApplyTrainingBatchDevice": (C.c_int, [vp, vp, vp]),
+    "GRUCalculateGradientDevice": (C.c_int, [vp, vp, vp, vp]),
     "GRUCreateForTraining": (vp, [GRUConfig, ConvTrainingConfig]),
     "GRUGradientCreate": (C.POINTER(RecurrentGradient), [GRUConfig, ConvTrainingConfig]),
     "RecurrentGradientDestroy": (None, [C.POINTER(RecurrentGradient)]),

@@ -61,6 +61,7 @@ int   nntk_shim_download(void *h_dst, const void *d_src, size_t bytes);   /* blo
 int   nntk_shim_download_nocheck(void *h_dst, const void *d_src, size_t bytes);    /* blocking; leaves a fault for nntk_shim_take_fault */
 int   nntk_shim_download_rows(void *h_dst, const void *d_src, size_t spitch, size_t width, size_t height);   /* strided rows, packed at the destination */
 int   nntk_shim_copy_d2d(void *d_dst, const void *d_src, size_t bytes);   /* async on stream */
+int   nntk_shim_copy_rows_d2d(void *d_dst, const void *d_src, size_t spitch, size_t width, size_t height);   /* strided rows -> packed, async */
 int   nntk_shim_memset(void *d_ptr, int value, size_t bytes);             /* async on stream */
 
 /* ---- K2/K3: implicit-GEMM conv1d / dense on f32 MFMA with fused epilogue ----

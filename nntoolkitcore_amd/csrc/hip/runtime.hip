@@ -345,6 +345,11 @@ int nntk_shim_download_rows(void *h_dst, const void *d_src, size_t spitch, size_
     NNTK_HIP_TRY(hipStreamSynchronize(t_stream));
     return post_sync();
 }
+int nntk_shim_copy_rows_d2d(void *d_dst, const void *d_src, size_t spitch, size_t width, size_t height) {
+    if (!width || !height) return 0;
+    NNTK_HIP_TRY(hipMemcpy2DAsync(d_dst, width, d_src, spitch, width, height, hipMemcpyDeviceToDevice, t_stream));
+    return 0;
+}
 int nntk_shim_upload_async(void *d_dst, const void *h_src, size_t bytes) {
     if (!bytes) return 0;
     NNTK_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, t_stream));

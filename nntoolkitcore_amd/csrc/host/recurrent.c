@@ -326,6 +326,7 @@ static int gate_kind(ActivationFunction a, int *kind, float *scale) {
 /* training state shared by the recurrent layers (gru.c:85-108): the mini-batch input and the forward caches on the device */
 typedef struct {
     int on, mini_batch, have_batch;
+    const float *d_x_cur;        /* the mini-batch input of the last forward: d_x below (host-pointer calls) or the caller's device tensor */
     nntk_devbuf d_x, d_h, d_Zg, d_hU, d_dxW, d_dhU, d_work, d_raw, d_grad, d_scr, d_dout, d_dX;
 } rec_train;
 static void train_free(rec_train *t) {
@@ -440,68 +441,109 @@ void RecurrentGradientDestroy(RecurrentGradient *gradient) {
     free(gradient);
 }
 
-int GRUApplyTrainingBatch(GRU filter, const float *input, float *output) {
-    nntk_shim_clear_error();
-    if (!filter) NNTK_FAIL("GRUApplyTrainingBatch: NULL handle");
-    if (!filter->train.on) NNTK_FAIL("GRUApplyTrainingBatch: the handle was created for inference");      /* gru.c:247-249 */
+/* forward over the mini-batch with the caches kept for the gradient; d_x is a device tensor that stays valid until the gradient call */
+static int gru_train_forward_dev(GRU filter, const float *d_x) {
     int acts[3];
     float sc[3];
     if (gru_acts(filter, acts, sc)) return -1;
     rec_core *c = &filter->core;
     rec_train *t = &filter->train;
     const int B = t->mini_batch, T = c->T, in = c->in, H = c->H;
-    if (B <= 0 || T <= 0) return 0;
     const size_t nw = (size_t)in * 3 * H + (size_t)H * 3 * H + 6 * (size_t)H;
-    float *d_x = nntk_devbuf_reserve(&t->d_x, (size_t)B * T * in);
     float *d_h = nntk_devbuf_reserve(&t->d_h, (size_t)B * T * H);
     float *d_Zg = nntk_devbuf_reserve(&t->d_Zg, (size_t)B * T * 6 * H);
     float *d_hU = nntk_devbuf_reserve(&t->d_hU, (size_t)B * T * H);
     float *d_raw = nntk_devbuf_reserve(&t->d_raw, nw);
-    if (!d_x || !d_h || !d_Zg || !d_hU || !d_raw) return -1;
-    if (nntk_shim_upload(d_x, input, (size_t)B * T * in * sizeof(float))) return -1;
+    if (!d_h || !d_Zg || !d_hU || !d_raw) return -1;
     if (nntk_shim_upload(d_raw, c->wb.host, nw * sizeof(float))) return -1;          /* W | U | b_i | b_h, caller layout */
     const float *dW = d_raw, *dU = dW + (size_t)in * 3 * H, *dbi = dU + (size_t)H * 3 * H, *dbh = dbi + 3 * (size_t)H;
     if (nntk_shim_gru_train_forward(d_x, dW, dU, dbi, dbh, d_h, d_Zg, d_hU, B, T, in, H, acts, sc)) return -1;
+    t->d_x_cur = d_x;
     t->have_batch = 1;
+    return 0;
+}
+int GRUApplyTrainingBatch(GRU filter, const float *input, float *output) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("GRUApplyTrainingBatch: NULL handle");
+    if (!filter->train.on) NNTK_FAIL("GRUApplyTrainingBatch: the handle was created for inference");      /* gru.c:247-249 */
+    rec_core *c = &filter->core;
+    rec_train *t = &filter->train;
+    const int B = t->mini_batch, T = c->T, in = c->in, H = c->H;
+    if (B <= 0 || T <= 0) return 0;
+    float *d_x = nntk_devbuf_reserve(&t->d_x, (size_t)B * T * in);
+    if (!d_x) return -1;
+    if (nntk_shim_upload(d_x, input, (size_t)B * T * in * sizeof(float))) return -1;
+    if (gru_train_forward_dev(filter, d_x)) return -1;
+    const float *d_h = t->d_h.p;
     if (c->return_sequences) return nntk_shim_download(output, d_h, (size_t)B * T * H * sizeof(float));
     /* the last step of every sequence (gru.c:286-291, lstm.c:466-471, rnn.c:283-288): one strided copy */
     return nntk_shim_download_rows(output, d_h + (size_t)(T - 1) * H, (size_t)T * H * sizeof(float), (size_t)H * sizeof(float), (size_t)B);
 }
+/* device-pointer form: d_input [B][T][in] must stay valid until GRUCalculateGradientDevice; d_output [B][T][H] or [B][H] */
+int GRUApplyTrainingBatchDevice(GRU filter, const float *d_input, float *d_output) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("GRUApplyTrainingBatchDevice: NULL handle");
+    if (!filter->train.on) NNTK_FAIL("GRUApplyTrainingBatchDevice: the handle was created for inference");
+    rec_core *c = &filter->core;
+    rec_train *t = &filter->train;
+    const int B = t->mini_batch, T = c->T, H = c->H;
+    if (B <= 0 || T <= 0) return 0;
+    if (gru_train_forward_dev(filter, d_input)) return -1;
+    if (!d_output) return 0;
+    if (c->return_sequences) return nntk_shim_copy_d2d(d_output, t->d_h.p, (size_t)B * T * H * sizeof(float));
+    return nntk_shim_copy_rows_d2d(d_output, t->d_h.p + (size_t)(T - 1) * H, (size_t)T * H * sizeof(float), (size_t)H * sizeof(float), (size_t)B);
+}
 
 /* d_W, d_U, d_b_i, d_b_h are ADDED onto the caller's block (recurrent_gradient_sum per (b, t), gru.c:508), d_X is
  * overwritten.  void in the reference; errors through nntk_last_error(). */
+static int gru_train_gradient_dev(GRU filter, const float *d_dout, float *d_grad, float *d_dX) {
+    rec_core *c = &filter->core;
+    rec_train *t = &filter->train;
+    int acts[3];
+    float sc[3];
+    if (gru_acts(filter, acts, sc)) return -1;
+    const int B = t->mini_batch, T = c->T, in = c->in, H = c->H;
+    const size_t w = (size_t)in * 3 * H, u = (size_t)H * 3 * H, b3 = 3 * (size_t)H, rows = (size_t)B * T;
+    float *d_dxW = nntk_devbuf_reserve(&t->d_dxW, rows * 3 * H);
+    float *d_dhU = nntk_devbuf_reserve(&t->d_dhU, rows * 3 * H);
+    float *d_work = nntk_devbuf_reserve(&t->d_work, (size_t)B * 5 * H);
+    float *d_UT = nntk_devbuf_reserve(&t->d_scr, u);
+    if (!d_dxW || !d_dhU || !d_work || !d_UT) return -1;
+    const float *dW = t->d_raw.p, *dU = dW + w;
+    if (nntk_shim_transpose(dU, d_UT, H, 3 * H, 0)) return -1;                  /* U^T [3H][H]: coalesced per-step product */
+    if (nntk_shim_gru_train_backward(d_dout, d_UT, t->d_h.p, t->d_Zg.p, t->d_hU.p, d_dxW, d_dhU, d_work, B, T, H,
+                                     c->return_sequences ? 1 : 0, acts)) return -1;
+    /* d_W += x^T d_xW, d_b_i += colsum d_xW;  d_U += h_prev^T d_hU, d_b_h += colsum d_hU;  d_X = d_xW W^T */
+    if (nntk_train_outer_accumulate(t->d_x_cur, d_dxW, d_grad, d_grad + w + u, (long)rows, in, 3 * H, 0)) return -1;
+    if (nntk_train_outer_accumulate(t->d_h.p, d_dhU, d_grad + w, d_grad + w + u + b3, (long)rows, H, 3 * H, T)) return -1;
+    return nntk_train_rows_times_rowmat(d_dxW, dW, d_dX, (long)rows, in, 3 * H);
+}
 void GRUCalculateGradient(GRU filter, GRUGradient *gradient, float *d_out) {
     nntk_shim_clear_error();
     if (!filter || !gradient || !d_out) { nntk_set_error("GRUCalculateGradient: NULL argument"); return; }
     rec_core *c = &filter->core;
     rec_train *t = &filter->train;
     if (!t->on || !t->have_batch) { nntk_set_error("GRUCalculateGradient: run GRUApplyTrainingBatch on a training handle first"); return; }
-    int acts[3];
-    float sc[3];
-    if (gru_acts(filter, acts, sc)) return;
     const int B = t->mini_batch, T = c->T, in = c->in, H = c->H;
     const size_t w = (size_t)in * 3 * H, u = (size_t)H * 3 * H, b3 = 3 * (size_t)H, rows = (size_t)B * T;
     const size_t n_do = c->return_sequences ? rows * H : (size_t)B * H;
     float *d_dout = nntk_devbuf_reserve(&t->d_dout, n_do);
-    float *d_dxW = nntk_devbuf_reserve(&t->d_dxW, rows * 3 * H);
-    float *d_dhU = nntk_devbuf_reserve(&t->d_dhU, rows * 3 * H);
-    float *d_work = nntk_devbuf_reserve(&t->d_work, (size_t)B * 5 * H);
     float *d_grad = nntk_devbuf_reserve(&t->d_grad, w + u + 2 * b3);
-    float *d_UT = nntk_devbuf_reserve(&t->d_scr, u);
     float *d_dX = nntk_devbuf_reserve(&t->d_dX, rows * in);
-    if (!d_dout || !d_dxW || !d_dhU || !d_work || !d_grad || !d_UT || !d_dX) return;
-    const float *dW = t->d_raw.p, *dU = dW + w;
+    if (!d_dout || !d_grad || !d_dX) return;
     if (nntk_shim_upload(d_dout, d_out, n_do * sizeof(float))) return;
     if (nntk_shim_upload(d_grad, gradient->d_W, (w + u + 2 * b3) * sizeof(float))) return;       /* the block is contiguous */
-    if (nntk_shim_transpose(dU, d_UT, H, 3 * H, 0)) return;                     /* U^T [3H][H]: coalesced per-step product */
-    if (nntk_shim_gru_train_backward(d_dout, d_UT, t->d_h.p, t->d_Zg.p, t->d_hU.p, d_dxW, d_dhU, d_work, B, T, H,
-                                     c->return_sequences ? 1 : 0, acts)) return;
-    /* d_W += x^T d_xW, d_b_i += colsum d_xW;  d_U += h_prev^T d_hU, d_b_h += colsum d_hU;  d_X = d_xW W^T */
-    if (nntk_train_outer_accumulate(t->d_x.p, d_dxW, d_grad, d_grad + w + u, (long)rows, in, 3 * H, 0)) return;
-    if (nntk_train_outer_accumulate(t->d_h.p, d_dhU, d_grad + w, d_grad + w + u + b3, (long)rows, H, 3 * H, T)) return;
-    if (nntk_train_rows_times_rowmat(d_dxW, dW, d_dX, (long)rows, in, 3 * H)) return;
+    if (gru_train_gradient_dev(filter, d_dout, d_grad, d_dX)) return;
     if (nntk_shim_download(gradient->d_W, d_grad, (w + u + 2 * b3) * sizeof(float))) return;
     nntk_shim_download(gradient->d_X, d_dX, rows * in * sizeof(float));
+}
+/* device-pointer form: d_grad = W [in][3H] | U [H][3H] | b_i [3H] | b_h [3H] (the gradient block's layout) is ADDED to, d_dX
+ * [B][T][in] overwritten; d_dout [B][T][H] or [B][H].  Asynchronous on the calling thread's stream. */
+int GRUCalculateGradientDevice(GRU filter, float *d_grad, float *d_dX, const float *d_dout) {
+    nntk_shim_clear_error();
+    if (!filter || !d_grad || !d_dX || !d_dout) NNTK_FAIL("GRUCalculateGradientDevice: NULL argument");
+    if (!filter->train.on || !filter->train.have_batch) NNTK_FAIL("GRUCalculateGradientDevice: run GRUApplyTrainingBatch[Device] on a training handle first");
+    return gru_train_gradient_dev(filter, d_dout, d_grad, d_dX);
 }
 
 int GRUApplyInference(GRU filter, const float *input, float *output) {
@@ -710,25 +752,19 @@ LSTMGradient *LSTMGradientCreate(LSTMConfig config, LSTMTrainingConfig training_
     return g;
 }
 
-int LSTMApplyTrainingBatch(LSTM filter, const float *input, float *output) {
-    nntk_shim_clear_error();
-    if (!filter) NNTK_FAIL("LSTMApplyTrainingBatch: NULL handle");
-    if (!filter->train.on) NNTK_FAIL("LSTMApplyTrainingBatch: the handle was created for inference");    /* lstm.c:419-421 */
+static int lstm_train_forward_dev(LSTM filter, const float *d_x) {
     int acts[5];
     float sc[5];
     if (lstm_acts(filter, acts, sc)) return -1;
     rec_core *c = &filter->core;
     rec_train *t = &filter->train;
     const int B = t->mini_batch, T = c->T, in = c->in, H = c->H;
-    if (B <= 0 || T <= 0) return 0;
     const size_t nw = (size_t)in * 4 * H + (size_t)H * 4 * H + 8 * (size_t)H;
-    float *d_x = nntk_devbuf_reserve(&t->d_x, (size_t)B * T * in);
     float *d_h = nntk_devbuf_reserve(&t->d_h, (size_t)B * T * H);
     float *d_z = nntk_devbuf_reserve(&t->d_Zg, (size_t)B * T * 8 * H);
     float *d_c = nntk_devbuf_reserve(&t->d_hU, (size_t)B * T * H);
     float *d_raw = nntk_devbuf_reserve(&t->d_raw, nw);
-    if (!d_x || !d_h || !d_z || !d_c || !d_raw) return -1;
-    if (nntk_shim_upload(d_x, input, (size_t)B * T * in * sizeof(float))) return -1;
+    if (!d_h || !d_z || !d_c || !d_raw) return -1;
     if (nntk_shim_upload(d_raw, c->wb.host, nw * sizeof(float))) return -1;          /* W | U | b_i | b_h, caller layout */
     const float *dW = d_raw, *dU = dW + (size_t)in * 4 * H, *dbi = dU + (size_t)H * 4 * H, *dbh = dbi + 4 * (size_t)H;
     /* standard activations, mini-batches of >= 32 sequences: the register-resident inference kernel with the caches written
@@ -747,42 +783,87 @@ int LSTMApplyTrainingBatch(LSTM filter, const float *input, float *output) {
         ran = rc == 0;
     }
     if (!ran && nntk_shim_lstm_train_forward(d_x, dW, dU, dbi, dbh, d_h, d_c, d_z, B, T, in, H, filter->config.v2 ? 1 : 0, acts, sc)) return -1;
+    t->d_x_cur = d_x;
     t->have_batch = 1;
+    return 0;
+}
+int LSTMApplyTrainingBatch(LSTM filter, const float *input, float *output) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("LSTMApplyTrainingBatch: NULL handle");
+    if (!filter->train.on) NNTK_FAIL("LSTMApplyTrainingBatch: the handle was created for inference");    /* lstm.c:419-421 */
+    rec_core *c = &filter->core;
+    rec_train *t = &filter->train;
+    const int B = t->mini_batch, T = c->T, in = c->in, H = c->H;
+    if (B <= 0 || T <= 0) return 0;
+    float *d_x = nntk_devbuf_reserve(&t->d_x, (size_t)B * T * in);
+    if (!d_x) return -1;
+    if (nntk_shim_upload(d_x, input, (size_t)B * T * in * sizeof(float))) return -1;
+    if (lstm_train_forward_dev(filter, d_x)) return -1;
+    const float *d_h = t->d_h.p;
     if (c->return_sequences) return nntk_shim_download(output, d_h, (size_t)B * T * H * sizeof(float));
     /* the last step of every sequence (gru.c:286-291, lstm.c:466-471, rnn.c:283-288): one strided copy */
     return nntk_shim_download_rows(output, d_h + (size_t)(T - 1) * H, (size_t)T * H * sizeof(float), (size_t)H * sizeof(float), (size_t)B);
 }
+/* device-pointer form: d_input [B][T][in] must stay valid until LSTMCalculateGradientDevice; d_output [B][T][H] or [B][H] */
+int LSTMApplyTrainingBatchDevice(LSTM filter, const float *d_input, float *d_output) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("LSTMApplyTrainingBatchDevice: NULL handle");
+    if (!filter->train.on) NNTK_FAIL("LSTMApplyTrainingBatchDevice: the handle was created for inference");
+    rec_core *c = &filter->core;
+    rec_train *t = &filter->train;
+    const int B = t->mini_batch, T = c->T, H = c->H;
+    if (B <= 0 || T <= 0) return 0;
+    if (lstm_train_forward_dev(filter, d_input)) return -1;
+    if (!d_output) return 0;
+    if (c->return_sequences) return nntk_shim_copy_d2d(d_output, t->d_h.p, (size_t)B * T * H * sizeof(float));
+    return nntk_shim_copy_rows_d2d(d_output, t->d_h.p + (size_t)(T - 1) * H, (size_t)T * H * sizeof(float), (size_t)H * sizeof(float), (size_t)B);
+}
 
+static int lstm_train_gradient_dev(LSTM filter, const float *d_dout, float *d_grad, float *d_dX) {
+    rec_core *c = &filter->core;
+    rec_train *t = &filter->train;
+    int acts[5];
+    float sc[5];
+    if (lstm_acts(filter, acts, sc)) return -1;
+    const int B = t->mini_batch, T = c->T, in = c->in, H = c->H;
+    const size_t w = (size_t)in * 4 * H, u = (size_t)H * 4 * H, b4 = 4 * (size_t)H, rows = (size_t)B * T;
+    float *d_dG = nntk_devbuf_reserve(&t->d_dxW, rows * 4 * H);
+    float *d_work = nntk_devbuf_reserve(&t->d_work, (size_t)B * 6 * H);
+    float *d_UT = nntk_devbuf_reserve(&t->d_scr, u);
+    if (!d_dG || !d_work || !d_UT) return -1;
+    const float *dW = t->d_raw.p, *dU = dW + w;
+    if (nntk_shim_transpose(dU, d_UT, H, 4 * H, 0)) return -1;
+    if (nntk_shim_lstm_train_backward(d_dout, d_UT, t->d_hU.p, t->d_Zg.p, d_dG, d_work, B, T, H, c->return_sequences ? 1 : 0, acts, sc)) return -1;
+    /* d_W += x^T dgates, d_U += h_prev^T dgates, d_b_i += colsum, d_b_h += colsum (lstm.c:412-415), d_X = dgates W^T */
+    if (nntk_train_outer_accumulate(t->d_x_cur, d_dG, d_grad, d_grad + w + u, (long)rows, in, 4 * H, 0)) return -1;
+    if (nntk_train_outer_accumulate(t->d_h.p, d_dG, d_grad + w, d_grad + w + u + b4, (long)rows, H, 4 * H, T)) return -1;
+    return nntk_train_rows_times_rowmat(d_dG, dW, d_dX, (long)rows, in, 4 * H);
+}
 void LSTMCalculateGradient(LSTM filter, LSTMGradient *gradient, float *d_out) {
     nntk_shim_clear_error();
     if (!filter || !gradient || !d_out) { nntk_set_error("LSTMCalculateGradient: NULL argument"); return; }
     rec_core *c = &filter->core;
     rec_train *t = &filter->train;
     if (!t->on || !t->have_batch) { nntk_set_error("LSTMCalculateGradient: run LSTMApplyTrainingBatch on a training handle first"); return; }
-    int acts[5];
-    float sc[5];
-    if (lstm_acts(filter, acts, sc)) return;
     const int B = t->mini_batch, T = c->T, in = c->in, H = c->H;
     const size_t w = (size_t)in * 4 * H, u = (size_t)H * 4 * H, b4 = 4 * (size_t)H, rows = (size_t)B * T;
     const size_t n_do = c->return_sequences ? rows * H : (size_t)B * H;
     float *d_dout = nntk_devbuf_reserve(&t->d_dout, n_do);
-    float *d_dG = nntk_devbuf_reserve(&t->d_dxW, rows * 4 * H);
-    float *d_work = nntk_devbuf_reserve(&t->d_work, (size_t)B * 6 * H);
     float *d_grad = nntk_devbuf_reserve(&t->d_grad, w + u + 2 * b4);
-    float *d_UT = nntk_devbuf_reserve(&t->d_scr, u);
     float *d_dX = nntk_devbuf_reserve(&t->d_dX, rows * in);
-    if (!d_dout || !d_dG || !d_work || !d_grad || !d_UT || !d_dX) return;
-    const float *dW = t->d_raw.p, *dU = dW + w;
+    if (!d_dout || !d_grad || !d_dX) return;
     if (nntk_shim_upload(d_dout, d_out, n_do * sizeof(float))) return;
     if (nntk_shim_upload(d_grad, gradient->d_W, (w + u + 2 * b4) * sizeof(float))) return;
-    if (nntk_shim_transpose(dU, d_UT, H, 4 * H, 0)) return;
-    if (nntk_shim_lstm_train_backward(d_dout, d_UT, t->d_hU.p, t->d_Zg.p, d_dG, d_work, B, T, H, c->return_sequences ? 1 : 0, acts, sc)) return;
-    /* d_W += x^T dgates, d_U += h_prev^T dgates, d_b_i += colsum, d_b_h += colsum (lstm.c:412-415), d_X = dgates W^T */
-    if (nntk_train_outer_accumulate(t->d_x.p, d_dG, d_grad, d_grad + w + u, (long)rows, in, 4 * H, 0)) return;
-    if (nntk_train_outer_accumulate(t->d_h.p, d_dG, d_grad + w, d_grad + w + u + b4, (long)rows, H, 4 * H, T)) return;
-    if (nntk_train_rows_times_rowmat(d_dG, dW, d_dX, (long)rows, in, 4 * H)) return;
+    if (lstm_train_gradient_dev(filter, d_dout, d_grad, d_dX)) return;
     if (nntk_shim_download(gradient->d_W, d_grad, (w + u + 2 * b4) * sizeof(float))) return;
     nntk_shim_download(gradient->d_X, d_dX, rows * in * sizeof(float));
+}
+/* device-pointer form: d_grad = W [in][4H] | U [H][4H] | b_i [4H] | b_h [4H] is ADDED to, d_dX [B][T][in] overwritten */
+int LSTMCalculateGradientDevice(LSTM filter, float *d_grad, float *d_dX, const float *d_dout) {
+    nntk_shim_clear_error();
+    if (!filter || !d_grad || !d_dX || !d_dout) NNTK_FAIL("LSTMCalculateGradientDevice: NULL argument");
+    if (!filter->train.on || !filter->train.have_batch) NNTK_FAIL("LSTMCalculateGradientDevice: run LSTMApplyTrainingBatch[Device] on a training handle first");
+    return lstm_train_gradient_dev(filter, d_dout, d_grad, d_dX);
 }
 
 int LSTMApplyInference(LSTM filter, const float *input, float *output) {

@@ -579,6 +579,47 @@ def test_bidirectional_gradient_helpers(gpu):
 
 # ---- device-pointer forms of the Dense / TimeDistributedDense / BatchNorm training calls (additive) ----
 
+@pytest.mark.parametrize("kind,B,T,n_in,H,seq", [("lstm", 32, 12, 64, 128, True), ("lstm", 5, 9, 12, 16, False),
+                                                 ("gru", 16, 20, 32, 64, True), ("gru", 3, 7, 5, 4, False)])
+def test_recurrent_training_device_forms_equal_the_host_forms(gpu, kind, B, T, n_in, H, seq):
+    """GRU / LSTM ApplyTrainingBatchDevice + CalculateGradientDevice run the same device cores on the caller's HBM tensors:
+    bit-identical to the host-pointer calls, and the gradient block is accumulated onto."""
+    import torch
+    L = capi.load()
+    r = rng(B * 7 + H)
+    ng = 4 if kind == "lstm" else 3
+    x = u(r, B, T, n_in)
+    Wall = u(r, n_in * ng * H + H * ng * H + 2 * ng * H, sc=0.2)
+    tc = capi.ConvTrainingConfig(B)
+    if kind == "lstm":
+        cfg = L.LSTMConfigCreate(n_in, H, seq, T, True, L.LSTMActivationsCreateDefault(H))
+        h = L.LSTMCreateForTraining(cfg, tc); w = L.LSTMGetWeights(h).contents; g = L.LSTMGradientCreate(cfg, tc)
+        fw, bw, fwd, bwd, de = L.LSTMApplyTrainingBatch, L.LSTMCalculateGradient, L.LSTMApplyTrainingBatchDevice, L.LSTMCalculateGradientDevice, L.LSTMDestroy
+    else:
+        cfg = L.GRUConfigCreate(n_in, H, seq, T, L.GRUActivationsCreateDefault(H))
+        h = L.GRUCreateForTraining(cfg, tc); w = L.GRUGetWeights(h).contents; g = L.GRUGradientCreate(cfg, tc)
+        fw, bw, fwd, bwd, de = L.GRUApplyTrainingBatch, L.GRUCalculateGradient, L.GRUApplyTrainingBatchDevice, L.GRUCalculateGradientDevice, L.GRUDestroy
+    C.memmove(w.W, Wall.ctypes.data, Wall.nbytes)                            # W | U | b_i | b_h are one block
+    n_out = (B, T, H) if seq else (B, H)
+    y, dout = np.empty(n_out, np.float32), u(r, *n_out)
+    assert fw(h, P(x), P(y)) == 0, capi.last_error()
+    bw(h, g, P(dout))
+    assert capi.last_error() == ""
+    gW = np.ctypeslib.as_array(g.contents.d_W, shape=(Wall.size,)).copy()
+    gX = np.ctypeslib.as_array(g.contents.d_X, shape=x.shape).copy()
+    dp = lambda t: C.c_void_p(t.data_ptr())
+    xd, dd = torch.from_numpy(x).cuda(), torch.from_numpy(dout).cuda()
+    yd, gd, gxd = torch.empty(*n_out, device="cuda"), torch.zeros(Wall.size, device="cuda"), torch.empty(*x.shape, device="cuda")
+    assert fwd(h, dp(xd), dp(yd)) == 0, capi.last_error()
+    assert bwd(h, dp(gd), dp(gxd), dp(dd)) == 0, capi.last_error()
+    assert L.nntk_hip_synchronize() == 0
+    assert np.array_equal(yd.cpu().numpy(), y) and np.array_equal(gd.cpu().numpy(), gW) and np.array_equal(gxd.cpu().numpy(), gX)
+    assert bwd(h, dp(gd), dp(gxd), dp(dd)) == 0 and L.nntk_hip_synchronize() == 0
+    np.testing.assert_allclose(gd.cpu().numpy(), 2 * gW, rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(gW).max())))
+    assert bwd(h, None, dp(gxd), dp(dd)) == -1                                # NULL argument
+    L.RecurrentGradientDestroy(g); de(h)
+
+
 def test_dense_and_batchnorm_training_device_forms_equal_the_host_forms(gpu):
     """The device-pointer calls run the same kernels on the caller's HBM buffers: results are bit-identical to the
     host-pointer forms (which upload, call the same core and download)."""

@@ -69,6 +69,14 @@ def main():
         x, y, d = u(B, T, n_in), np.empty((B, T, H), np.float32), u(B, T, H)
         timed("%s B=64 T=200" % name, lambda: fw(h, P(x), P(y)), lambda: bw(h, g, P(d)),
               "%.1f GFLOP fwd" % (2e-9 * B * T * G * H * (n_in + H)))
+        import torch
+        torch.cuda.set_device(0)
+        dp_ = lambda t: C.c_void_p(t.data_ptr())
+        xd, dd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(d).cuda(), torch.empty(B, T, H, device="cuda")
+        gd, gx = torch.zeros(W.size, device="cuda"), torch.empty(B, T, n_in, device="cuda")
+        fwd_, bwd_ = (L.GRUApplyTrainingBatchDevice, L.GRUCalculateGradientDevice) if G == 3 else (L.LSTMApplyTrainingBatchDevice, L.LSTMCalculateGradientDevice)
+        timed("%s B=64 T=200, device pointers" % name, lambda: (fwd_(h, dp_(xd), dp_(yd)), L.nntk_hip_synchronize()),
+              lambda: (bwd_(h, dp_(gd), dp_(gx), dp_(dd)), L.nntk_hip_synchronize()), "same")
         L.RecurrentGradientDestroy(g); de(h)
     # dense head
     B, n_in, n_out = 64 * 996, 512, 1000
