@@ -260,9 +260,10 @@ def pmc_traffic(kernel_prefix, B):
             continue
         if d.get("source_hash") != want or d.get("utterances_per_gpu") != B:
             continue
-        for name, v in d.get("kernels", {}).items():
-            if name.startswith(kernel_prefix):
-                return v.get("hbm_bytes_per_launch"), "%s (source_hash %s)" % (os.path.relpath(path, ROOT), want)
+        hits = [v.get("hbm_bytes_per_launch") for name, v in d.get("kernels", {}).items() if name.startswith(kernel_prefix)]
+        hits = [h for h in hits if h is not None]
+        if hits:      # several instantiations of one kernel in a step (the two GRU layers): their average, like ms_per_launch
+            return sum(hits) / len(hits), "%s (source_hash %s)" % (os.path.relpath(path, ROOT), want)
     return None, "no profiles/*_pmc_traffic.json stamped with this library's source_hash %s at %d utterances/GPU" % (want, B)
 
 
@@ -330,6 +331,23 @@ def roofline_for(wl, phase_ms, prof):
                 "timesteps_per_launch": tpl, "us_per_timestep": ms * 1e3 / tpl,
                 "mfma_pipe_cycles_per_timestep": mfma_cycles,
                 "launches_per_step": prof.get("rec_launches_per_step")}
+    if last.startswith("gru_rr_kernel") and wl.name == "gru":
+        # the two stacked GRU-256 layers as two launches of the register-resident split-bf16 kernel (input projections fused):
+        # rec_launch_ms is the AVERAGE of the two, so are the algorithmic flops ([h | x_t] x [U ; W], three gates, T steps)
+        n_l = prof.get("rec_launches_per_step") or 2.0
+        flops_l1, flops_l2 = 2.0 * B * (H + 128) * G * H * tpl, 2.0 * B * (H + H) * G * H * tpl
+        flops = (flops_l1 + flops_l2) / 2
+        ach = flops / (ms * 1e-3) / 1e12
+        peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
+        traffic, traffic_source = pmc_traffic("gru_rr_kernel", B)
+        return {"kernel": "gru_rr_kernel<4,2> (layer 1) + gru_rr_kernel<4,4> (layer 2)", "bound": "mfma", "achieved": ach, "peak": peak,
+                "peak_note": "dense bf16 MFMA peak / 6 products per f32 product (split-bf16 x 3 contraction); one gate slot in four "
+                             "multiplies a zero weight block (the GRU's candidate gate keeps its x and h parts apart), not counted as flops",
+                "unit": "TFLOP/s", "frac": ach / peak, "frac_of_exact_f32_mfma_peak": ach / F32_MFMA_PEAK_TFLOPS,
+                "traffic": traffic, "traffic_source": traffic_source, "ms_per_launch": ms, "algorithmic_flops": flops,
+                "algorithmic_flops_note": "average of the two layer launches; recurrent h x U and the fused input projection x_t x W",
+                "timesteps_per_launch": tpl, "us_per_timestep": ms * 1e3 / tpl * n_l,
+                "us_per_timestep_note": "both layers", "launches_per_step": n_l}
     persistent = tpl > 1
     kern = ("rec_persistent_kernel" if persistent else "rec_step_kernel") + ("<4,LSTM>" if G == 4 else "<3,GRU>")
     flops = 2.0 * B * H * G * H * tpl          # algorithmic flops of ONE launch (tpl timesteps of h[B,H] x U[H,G*H])
@@ -590,6 +608,8 @@ def main():
             "gemm": gemm_mode() + " for conv / TDD" + (
                 ("; LSTM: " + prof["rec_kernel"] + " (split-bf16x3 recurrence with the input projection fused into the step)")
                 if prof.get("rec_kernel", "").startswith("lstm_rr") else
+                ("; GRU layers: gru_rr_kernel (split-bf16x3 recurrences with the input projections fused into the step)")
+                if prof.get("rec_kernel", "").startswith("gru_rr") else
                 ("; exact-f32 for the recurrent input projection and recurrences" if a.workload in ("stack", "gru") else "")),
             "gemm_accuracy": ("f32 results: error vs a float64 contraction <= the exact-f32 MFMA chain's on every BASELINE shape "
                               "(profiles/r02_split_error.log, tools/split_error.py); NNTK_GEMM_SPLIT_BF16=0 selects the exact chain")

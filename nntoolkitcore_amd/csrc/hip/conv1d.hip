@@ -208,9 +208,10 @@ extern "C" int nntk_shim_conv1d(const float *d_in, const float *d_wp, const floa
         p.out_mode = 0;                               // row (t, b) -> t * B + b: exactly the time-major layout
         p.tiles_per_seq = (p.Tout + CONV_BM - 1) / CONV_BM;
     }
-    // auto: every contraction except the recurrent input projection (out_mode 1) of a SMALL batch, whose exact k-ordered
-    // chain the streaming kernel reproduces bit for bit (recurrent.hip rec_stream_step_kernel; streaming is B < 64 only)
-    bool split = opt.gemm_split_bf16 == 1 || (opt.gemm_split_bf16 < 0 && (out_mode == 0 || B >= 64)) ||
+    // auto: every contraction except the recurrent input projection (out_mode 1), whose exact k-ordered chain the
+    // streaming kernel reproduces bit for bit (recurrent.hip rec_stream_step_kernel) -- and a batch-size threshold here would
+    // make a row's bits depend on the size of the batch it arrives in (the exact kernels' shards are bit-identical)
+    bool split = opt.gemm_split_bf16 == 1 || (opt.gemm_split_bf16 < 0 && out_mode == 0) ||
                        (opt.gemm_split_bf16 == 2 && out_mode == 0 && k > 1) ||        // 2 / 3: convolutions only / dense only (A/B)
                        (opt.gemm_split_bf16 == 3 && out_mode == 0 && k == 1);
     if (split && opt.gemm_split_bf16 < 0 && weights_exact_only(d_wp)) split = false;      // "auto" only: 1 / 2 / 3 force the split (A/B runs)

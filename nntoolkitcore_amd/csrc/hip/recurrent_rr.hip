@@ -229,13 +229,26 @@ struct RRParams {
 // KH / KX: k steps (of 16) per wavefront for the h / x part: H <= 64 KH, in <= 64 KX (zero padded).
 // TRAIN: the training forward pass (LSTMApplyTrainingBatch, lstm.c:426-475): additionally keeps c_t and the gates' pre-activations
 // and activations of every step for back-propagation through time.
-template <int KH, int KX, bool TRAIN = false>
-__global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
+// CELL 1: GRU (gru.c:129-187) on the same frame.  The GRU's three gates ride in the four gate slots as z | r | h.U_h | x.W_h: the
+// host packs U as [U_z | U_r | U_h | 0] and W as [W_z | W_r | 0 | W_h] (recurrent.c core_try_gru_rr), so slot 2 collects only the
+// recurrent part of the candidate and slot 3 only its input part -- the reset gate multiplies the former (reset-after form) -- and the
+// multiply phase is the LSTM's, instruction for instruction; only the gate arithmetic (fin_gates) differs.  The state register
+// that is the LSTM's c_t holds the GRU's own f32 h_t.
+// ULR (in > 128, H <= 256): U's low image lives in registers (32 VGPRs at KH = 4) instead of LDS, which makes room for the
+// 96 KB of W images a 256-wide input needs.
+template <int KH, int KX, bool TRAIN, int CELL>
+__device__ __forceinline__ void rr_body(const RRParams &p) {
+    constexpr bool ULR = KX > 2;
     constexpr int NKS = 4 * KH;                       // k steps of the hand-off buffer (>= H / 16)
     constexpr int NST = KX + KH;                      // k steps one wavefront multiplies per half
     constexpr int S_RED = 0, S_PUB = 1;
     constexpr int S_XSPL = KX > 2 ? KX : 2;
     constexpr int S_E1 = NST >= 8 ? RR_S_E1 : 3;
+    // X_LATE (KX = 4): the eight x requests of a half-step touch 32 rows each (2 x 16 bytes per row and request): they hold the
+    // address path for ~2 k cycles and take ~3 us to return, and the poll's vmcnt(0) at S_E2 waited for them (stamps: 6 k cycles
+    // in that k step).  They go out AFTER the poll instead, at the end of the half-step, and have the next half-step up to its
+    // S_XSPL to arrive.
+    constexpr bool X_LATE = KX > 2;
     constexpr int S_E2 = NST - 1;
     // Operand schedule: the fragments of h k step i are requested NPRE k steps ... see issue_h below: i < NPRE at S_E2 of the
     // OTHER half's sequence (after the poll), i >= NPRE at k step i - NPRE of the half's own sequence (needed at KX + i).
@@ -243,11 +256,13 @@ __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
     // vector-memory operations a wave issues between a publication (S_PUB) and its arrival (S_E1): the own-sequence operand
     // requests of k steps S_PUB .. S_E1 - 1 and the x request at S_XSPL -- what the arrival's counted wait leaves in flight
     constexpr int own_lo = S_PUB + NPRE < KH ? S_PUB + NPRE : KH, own_hi = S_E1 + NPRE < KH ? S_E1 + NPRE : KH;
-    constexpr int N_AFTER_PUB = 3 * (own_hi - own_lo) + 2 * KX;
-    static_assert(NST >= 5 && S_E1 < S_E2 && S_E1 > S_PUB && S_XSPL >= KX && S_XSPL < S_E1 && S_XSPL > S_PUB && KH - NPRE <= S_E2, "slice schedule");
+    constexpr int N_X_AFTER_PUB = X_LATE ? 0 : 2 * KX;
+    constexpr int N_AFTER_PUB = 3 * (own_hi - own_lo) + N_X_AFTER_PUB;
+    static_assert(NST >= 5 && S_E1 < S_E2 && S_E1 > S_PUB && S_XSPL >= KX && (X_LATE ? S_XSPL < S_E2 - RR_POLL_LEAD : S_XSPL < S_E1) &&
+                  S_XSPL > S_PUB && KH - NPRE <= S_E2, "slice schedule");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    rr_v4u *ULs = reinterpret_cast<rr_v4u *>(smem);                       // [4][KH][2] blocks
-    rr_v4u *WXs = ULs + 4 * KH * 2 * 64;                                  // [4][KX][2][3] blocks
+    rr_v4u *ULs = reinterpret_cast<rr_v4u *>(smem);                       // [4][KH][2] blocks (not with ULR)
+    rr_v4u *WXs = ULs + (ULR ? 0 : 4 * KH * 2 * 64);                      // [4][KX][2][3] blocks
     rr_v4u *red = WXs + 4 * KX * 6 * 64;                                  // [dst 4][src 4][2] blocks: split-K exchange
     float *hx = reinterpret_cast<float *>(red + 32 * 64);                 // [32][RR_HX_LD] h exchange
 
@@ -274,7 +289,17 @@ __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
                 uh[i][mt][m] = __builtin_bit_cast(rr_bf16x8, img[((((size_t)w * KH + i) * 2 + mt) * 2 + m) * 64 + lane]);
                 RR_PIN_A(uh[i][mt][m]);
             }
-    {
+    rr_bf16x8 ulr[ULR ? KH : 1][2];
+    if (ULR) {
+#pragma unroll
+        for (int i = 0; i < KH; ++i)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                ulr[i][mt] = __builtin_bit_cast(rr_bf16x8, img[(size_t)4 * KH * 4 * 64 + ((w * KH + i) * 2 + mt) * 64 + lane]);
+        const rr_v4u *src = img + (size_t)4 * KH * 4 * 64 + (size_t)4 * KH * 2 * 64;      // WX only
+        constexpr int n16 = 4 * KX * 6 * 64;
+        for (int e = tid; e < n16; e += 256) WXs[e] = src[e];
+    } else {
         const rr_v4u *src = img + (size_t)4 * KH * 4 * 64;                // UL then WX, contiguous, same order as in LDS
         constexpr int n16 = (4 * KH * 2 + 4 * KX * 6) * 64;
         for (int e = tid; e < n16; e += 256) ULs[e] = src[e];
@@ -396,6 +421,15 @@ __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
             if (RR_DBG(64)) { hn[e] = z[0][e] + z[1][e] + z[2][e] + z[3][e] + cst[half][e]; continue; }
 #pragma unroll
             for (int g = 0; g < 4; ++g) zc[g][e] = z[g][e] + bsum[g][e];
+            if (CELL == 1) {
+                // gru.c:144-186 (same expressions as rec_persistent_kernel's): slots z | r | h.U_h + b_h | x.W_h + b_i
+                const float zg = nntk_fast_sigmoid(zc[0][e]);
+                const float rg = nntk_fast_sigmoid(zc[1][e]);
+                const float ht = nntk_fast_tanh(fmaf(rg, zc[2][e], zc[3][e]));
+                hn[e] = fmaf(-zg + 1.0f, ht, zg * cst[half][e]);
+                cst[half][e] = hn[e];
+                continue;
+            }
             const float ig = nntk_fast_sigmoid(zc[0][e]);
             const float fg = nntk_fast_sigmoid(zc[1][e]);
             const float gg = nntk_fast_tanh(zc[2][e]);
@@ -476,7 +510,7 @@ __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
     // instantiation's counts against the ISA)
     auto arrive = [&](int half, int t, auto xlive_tag) __attribute__((always_inline)) {
         if (w == 2 * half) {
-            asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N_AFTER_PUB - (decltype(xlive_tag)::value ? 0 : 2 * KX)) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N_AFTER_PUB - (decltype(xlive_tag)::value ? 0 : N_X_AFTER_PUB)) : "memory");
             if (lane == 0)
                 __hip_atomic_store((half ? flags1 : flags0) + ct, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -536,6 +570,9 @@ __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
 #pragma unroll
                     for (int m = 0; m < 3; ++m)
                         wa[mt][m] = __builtin_bit_cast(rr_bf16x8, WXs[((((w * KX + s) * 2 + mt) * 3) + m) * 64 + lane]);
+            } else if (ULR) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) ulo[mt] = ulr[s - KX][mt];
             } else {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) ulo[mt] = __builtin_bit_cast(rr_bf16x8, ULs[((w * KH + (s - KX)) * 2 + mt) * 64 + lane]);
@@ -549,6 +586,7 @@ __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
                 if (NEXT && POLL && !RR_DBG(4)) poll_b(X, tX + 1);
             }
             if (s == S_E2 && NEXT && !RR_DBG(1)) issue_h(XT{}, tX + 1, 0, 3 * NPRE);          // head of X's next operand
+            if (s == S_E2 && X_LATE && XLIVE && !RR_DBG(8)) issue_x(Y, t + 1);                // (xr is free since this half-step's S_XSPL)
             if (s + NPRE < KH && !RR_DBG(1)) issue_h(y_tag, t, 3 * (s + NPRE), 3 * (s + NPRE + 1));       // THIS half's operand, k step s + NPRE (published long ago)
             // ---- multiply ----
             if (RR_DBG(16)) {
@@ -575,7 +613,7 @@ __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
             // half's x_{t+1} -- a whole half-step ahead of its use
             if (s == S_XSPL) {
                 if (NEXT && !RR_DBG(8)) split_x();
-                if (XLIVE && !RR_DBG(8)) issue_x(Y, t + 1);  // the arrival's counted wait counts these requests
+                if (!X_LATE && XLIVE && !RR_DBG(8)) issue_x(Y, t + 1);  // the arrival's counted wait counts these requests
             }
 #ifndef RR_NO_INTERLEAVE
             // spread this k step's vector-memory instructions between its MFMAs (2 MFMAs, then at most 1 memory operation,
@@ -647,16 +685,22 @@ __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) {
         }
     }
 }
+template <int KH, int KX, bool TRAIN = false>
+__global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) { rr_body<KH, KX, TRAIN, 0>(p); }
+template <int KH, int KX>
+__global__ __launch_bounds__(256) void gru_rr_kernel(RRParams p) { rr_body<KH, KX, false, 1>(p); }
 
 // ---- host side --------------------------------------------------------------------------------------------------
 static bool rr_shape(int H, int in, int *KH, int *KX) {
     if (H < 64 || H > 512 || (H % 16) != 0 || in < 8 || (in % 8) != 0) return false;
     *KH = H <= 256 ? 4 : 8;
-    *KX = in <= 64 ? 1 : in <= 128 ? 2 : 0;              // in <= 256 (KX = 4) would need 96 KB of LDS for W^T: 32 + 96 + 32 KB > 160 KB
+    // in <= 256 (KX = 4) needs 96 KB of LDS for the W images: it fits once U's low image moves to registers, which the register
+    // budget allows at KH = 4 (H <= 256) only
+    *KX = in <= 64 ? 1 : in <= 128 ? 2 : (in <= 256 && *KH == 4) ? 4 : 0;
     return *KX != 0;
 }
 static size_t rr_lds_bytes(int KH, int KX) {
-    return (size_t)(4 * KH * 2 + 4 * KX * 6 + 32) * 1024 + 32 * RR_HX_LD * 4;
+    return (size_t)((KX > 2 ? 0 : 4 * KH * 2) + 4 * KX * 6 + 32) * 1024 + 32 * RR_HX_LD * 4;
 }
 static size_t rr_parity_bytes(int B, int KH) { return (size_t)((B + 63) / 64) * 2 * (4 * KH) * 3 * 1024; }
 
@@ -703,22 +747,28 @@ extern "C" int nntk_shim_lstm_rr_pack_raw(const float *d_U, const float *d_W, fl
 // 0 = launched; 1 = shape / configuration not taken (the caller runs projection GEMM + rec_persistent_kernel); -1 = error
 static int lstm_rr_launch(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,
                           const float *d_h0, const float *d_c0, float *d_out, float *d_hT, float *d_cT,
-                          float *d_work, int B, int T, int in, int H, int return_sequences, float *d_c_cache, float *d_z_cache);
+                          float *d_work, int B, int T, int in, int H, int return_sequences, float *d_c_cache, float *d_z_cache, int cell);
 
 extern "C" int nntk_shim_lstm_rr(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,
                                  const float *d_h0, const float *d_c0, float *d_out, float *d_hT, float *d_cT,
                                  float *d_work, int B, int T, int in, int H, int return_sequences) {
-    return lstm_rr_launch(d_x, d_img, d_bi, d_bh, d_h0, d_c0, d_out, d_hT, d_cT, d_work, B, T, in, H, return_sequences, nullptr, nullptr);
+    return lstm_rr_launch(d_x, d_img, d_bi, d_bh, d_h0, d_c0, d_out, d_hT, d_cT, d_work, B, T, in, H, return_sequences, nullptr, nullptr, 0);
+}
+// GRU on the same kernel frame (gru_rr_kernel): d_img packed from the four-slot matrices [U_z | U_r | U_h | 0] / [W_z | W_r | 0 | W_h],
+// d_b4 [4H] = b_i,z + b_h,z | b_i,r + b_h,r | b_h,h | b_i,h.  The f32 state register starts from h_0 (which is also the published operand).
+extern "C" int nntk_shim_gru_rr(const float *d_x, const float *d_img, const float *d_b4, const float *d_h0, float *d_out, float *d_hT,
+                                float *d_work, int B, int T, int in, int H, int return_sequences) {
+    return lstm_rr_launch(d_x, d_img, d_b4, nullptr, d_h0, d_h0, d_out, d_hT, nullptr, d_work, B, T, in, H, return_sequences, nullptr, nullptr, 1);
 }
 // training forward: zero initial state, h of every step to d_h [B][T][H], caches d_c [B][T][H] and d_zifgo [B][T][8H]
 extern "C" int nntk_shim_lstm_rr_train_forward(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,
                                                float *d_h, float *d_c, float *d_zifgo, float *d_work, int B, int T, int in, int H) {
-    return lstm_rr_launch(d_x, d_img, d_bi, d_bh, nullptr, nullptr, d_h, nullptr, nullptr, d_work, B, T, in, H, 1, d_c, d_zifgo);
+    return lstm_rr_launch(d_x, d_img, d_bi, d_bh, nullptr, nullptr, d_h, nullptr, nullptr, d_work, B, T, in, H, 1, d_c, d_zifgo, 0);
 }
 
 static int lstm_rr_launch(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,
                           const float *d_h0, const float *d_c0, float *d_out, float *d_hT, float *d_cT,
-                          float *d_work, int B, int T, int in, int H, int return_sequences, float *d_c_cache, float *d_z_cache) {
+                          float *d_work, int B, int T, int in, int H, int return_sequences, float *d_c_cache, float *d_z_cache, int cell) {
     if (B <= 0 || T <= 0) return 0;
     const NntkOptions &opt = nntk_options();
     if (opt.rec_rr == 0 || opt.rec_persistent == 0 || nntk_persistent_disabled()) return 1;
@@ -730,8 +780,16 @@ static int lstm_rr_launch(const float *d_x, const float *d_img, const float *d_b
     if ((double)64 * T * in * 4 >= 2.0e9 || (double)64 * T * H * 4 >= 2.0e9) return 1;
     void (*kern)(RRParams) = nullptr;
     const bool train = d_c_cache != nullptr;
-    if (KH == 8 && KX == 2) kern = train ? lstm_rr_kernel<8, 2, true> : lstm_rr_kernel<8, 2>;
+    if (cell == 1) {
+        if (train) return 1;
+        if (KH == 8 && KX == 2) kern = gru_rr_kernel<8, 2>;
+        else if (KH == 8 && KX == 1) kern = gru_rr_kernel<8, 1>;
+        else if (KH == 4 && KX == 4) kern = gru_rr_kernel<4, 4>;
+        else if (KH == 4 && KX == 2) kern = gru_rr_kernel<4, 2>;
+        else if (KH == 4 && KX == 1) kern = gru_rr_kernel<4, 1>;
+    } else if (KH == 8 && KX == 2) kern = train ? lstm_rr_kernel<8, 2, true> : lstm_rr_kernel<8, 2>;
     else if (KH == 8 && KX == 1) kern = train ? lstm_rr_kernel<8, 1, true> : lstm_rr_kernel<8, 1>;
+    else if (KH == 4 && KX == 4) kern = train ? nullptr : lstm_rr_kernel<4, 4>;
     else if (KH == 4 && KX == 2) kern = train ? lstm_rr_kernel<4, 2, true> : lstm_rr_kernel<4, 2>;
     else if (KH == 4 && KX == 1) kern = train ? lstm_rr_kernel<4, 1, true> : lstm_rr_kernel<4, 1>;
     if (!kern) return 1;
@@ -793,6 +851,8 @@ static int lstm_rr_launch(const float *d_x, const float *d_img, const float *d_b
     }
 #endif
     NNTK_LAUNCH_CHECK("lstm_rr_kernel");
-    nntk_set_last_rec_kernel(KH == 8 ? (KX == 2 ? "lstm_rr_kernel<8,2>" : "lstm_rr_kernel<8,1>") : (KX == 2 ? "lstm_rr_kernel<4,2>" : "lstm_rr_kernel<4,1>"));
+    static const char *const names[2][2][3] = {{{"lstm_rr_kernel<4,1>", "lstm_rr_kernel<4,2>", "lstm_rr_kernel<4,4>"}, {"lstm_rr_kernel<8,1>", "lstm_rr_kernel<8,2>", ""}},
+                                               {{"gru_rr_kernel<4,1>", "gru_rr_kernel<4,2>", "gru_rr_kernel<4,4>"}, {"gru_rr_kernel<8,1>", "gru_rr_kernel<8,2>", ""}}};
+    nntk_set_last_rec_kernel(names[cell == 1][KH == 8][KX == 1 ? 0 : KX == 2 ? 1 : 2]);
     return 0;
 }

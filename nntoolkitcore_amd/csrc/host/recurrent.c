@@ -44,6 +44,7 @@ typedef struct {
     int wt_valid;
     float *d_rr;                /* LSTM: weight images of the register-resident split-bf16 kernel (recurrent_rr.hip), made on first use */
     int rr_valid;
+    float *d_b4;                /* GRU on those kernels: the four-slot bias vector (core_try_gru_rr) */
     float *d_rr_train;          /* ... and the training forward's own copy, re-packed every mini-batch from the raw block */
     /* persistent single-sequence state [H], double-buffered: a stateful call reads state[cur] and writes
      * state[cur ^ 1]; cur flips only once the call is known to be good, so a call that has to be repeated
@@ -87,7 +88,7 @@ static int core_init(rec_core *c, int G, RecurrentConfig base) {
 static void core_free(rec_core *c) {
     nntk_shim_synchronize();
     nntk_shim_free(c->d_wp); nntk_shim_free(c->d_bi); nntk_shim_free(c->d_ut); nntk_shim_free(c->d_bh); nntk_shim_free(c->d_wt);
-    nntk_shim_free(c->d_rr); nntk_shim_free(c->d_rr_train);
+    nntk_shim_free(c->d_rr); nntk_shim_free(c->d_rr_train); nntk_shim_free(c->d_b4);
     nntk_shim_free(c->d_h[0]);
     nntk_shim_host_free(c->pin_in); nntk_shim_host_free(c->pin_out); nntk_shim_host_free((void *)c->flag);
     nntk_shim_free(c->d_done);
@@ -189,6 +190,59 @@ static int core_try_lstm_rr(rec_core *c, int use_bh, const int *acts, const floa
                              B, c->T, c->in, c->H, c->return_sequences);
 }
 
+/* GRU on the register-resident split-bf16 kernels (recurrent_rr.hip gru_rr_kernel).  The three gates ride in four slots,
+ * z | r | h.U_h | x.W_h: the image is packed from [U_z | U_r | U_h | 0] and [W_z | W_r | 0 | W_h], the bias vector is
+ * b_i,z + b_h,z | b_i,r + b_h,r | b_h,h | b_i,h (gru.c:144-186: the reset gate multiplies h.U_h + b_h,h only).
+ * 0 = ran; 1 = not taken; -1 = error */
+static int gru_std_acts(const int *acts) {
+    return acts[0] == NNTK_ACT_SIGMOID && acts[1] == NNTK_ACT_TANH && acts[2] == NNTK_ACT_SIGMOID;      /* z, h, r */
+}
+static int core_try_gru_rr(rec_core *c, const int *acts, const float *d_in, float *d_out, int B, int stateful) {
+    int on = -1;
+    (void)nntk_shim_get_option("rec_rr", &on);
+    if (on == 0 || c->G != 3 || !gru_std_acts(acts)) return 1;
+    if (on != 1 && B < NNTK_RR_MIN_BATCH) return 1;
+    const int H = c->H, in = c->in;
+    size_t img = nntk_shim_lstm_rr_image_floats(H, in);
+    if (!img) return 1;
+    if (!c->rr_valid) {
+        const size_t nW = (size_t)in * 4 * H, nU = (size_t)H * 4 * H;
+        float *tmp = (float *)calloc(nW + nU + 4 * (size_t)H, sizeof(float));
+        if (!tmp) NNTK_FAIL("out of host memory while packing GRU weights");
+        const float *W = c->weights->W, *U = c->weights->U, *bi = c->weights->b_i, *bh = c->weights->b_h;
+        float *W4 = tmp, *U4 = tmp + nW, *b4 = U4 + nU;
+        for (int k = 0; k < in; ++k) {
+            memcpy(W4 + (size_t)k * 4 * H, W + (size_t)k * 3 * H, 2 * (size_t)H * sizeof(float));                 /* W_z | W_r */
+            memcpy(W4 + (size_t)k * 4 * H + 3 * (size_t)H, W + (size_t)k * 3 * H + 2 * (size_t)H, (size_t)H * sizeof(float));   /* slot 3: W_h */
+        }
+        for (int k = 0; k < H; ++k) memcpy(U4 + (size_t)k * 4 * H, U + (size_t)k * 3 * H, 3 * (size_t)H * sizeof(float));      /* U_z | U_r | U_h | 0 */
+        for (int j = 0; j < H; ++j) {
+            b4[j] = bi[j] + bh[j];
+            b4[H + j] = bi[H + j] + bh[H + j];
+            b4[2 * H + j] = bh[2 * H + j];
+            b4[3 * H + j] = bi[2 * H + j];
+        }
+        int rc = 0;
+        float *d_tmp = (float *)nntk_shim_malloc((nW + nU) * sizeof(float));
+        if (!d_tmp) rc = -1;
+        if (!rc && !c->d_rr && !(c->d_rr = (float *)nntk_shim_malloc(img * sizeof(float)))) rc = -1;
+        if (!rc && !c->d_b4 && !(c->d_b4 = (float *)nntk_shim_malloc(4 * (size_t)H * sizeof(float)))) rc = -1;
+        if (!rc) rc = nntk_shim_upload(d_tmp, tmp, (nW + nU) * sizeof(float));
+        if (!rc) rc = nntk_shim_upload(c->d_b4, b4, 4 * (size_t)H * sizeof(float));
+        if (!rc) rc = nntk_shim_lstm_rr_pack_raw(d_tmp + nW, d_tmp, c->d_rr, H, in);
+        if (!rc) rc = nntk_shim_synchronize();                  /* the pack kernel reads d_tmp */
+        nntk_shim_free(d_tmp);
+        free(tmp);
+        if (rc) return -1;
+        c->rr_valid = 1;
+    }
+    float *d_work = nntk_devbuf_reserve(&c->d_work_rr, nntk_shim_lstm_rr_work_floats(B, H));
+    if (!d_work) return -1;
+    const float *h0 = stateful ? c->d_h[c->cur] : NULL;
+    float *hT = stateful ? c->d_h[c->cur ^ 1] : NULL;
+    return nntk_shim_gru_rr(d_in, c->d_rr, c->d_b4, h0, d_out, hT, d_work, B, c->T, in, H, c->return_sequences);
+}
+
 /* stateful != 0: continue from / store into the handle's state (B must be 1) */
 static int core_apply_device(rec_core *c, int is_lstm, int use_bh, const int *acts, const float *scales,
                              const float *d_in, float *d_out, int B, int stateful) {
@@ -196,6 +250,10 @@ static int core_apply_device(rec_core *c, int is_lstm, int use_bh, const int *ac
     if (B <= 0 || T <= 0) return 0;
     if (is_lstm) {
         int rc = core_try_lstm_rr(c, use_bh, acts, d_in, d_out, B, stateful);
+        if (rc <= 0) return rc;
+    }
+    if (!is_lstm && G == 3) {
+        int rc = core_try_gru_rr(c, acts, d_in, d_out, B, stateful);
         if (rc <= 0) return rc;
     }
     float *d_xw = nntk_devbuf_reserve(&c->d_xw, (size_t)T * B * G * H);
@@ -604,7 +662,14 @@ int GRUStack2ApplyDevice(GRU l1, GRU l2, const float *d_input, float *d_output, 
     const int H = c1->H, T = c1->T, B = batch;
     int d1 = gru_default_acts(l1), d2 = gru_default_acts(l2);
     if (d1 < 0 || d2 < 0) return -1;
-    if (d1 && d2 && c2->H == H) {
+    /* both layers on the register-resident split-bf16 kernels (gru_rr_kernel, one launch per layer, projections fused) when their
+     * shapes allow it: measured faster than the fused exact-f32 kernel below (DESIGN K4b); rec_fused2 = 1 forces the fused kernel */
+    int rr_on = -1, fused_on = -1;
+    (void)nntk_shim_get_option("rec_rr", &rr_on);
+    (void)nntk_shim_get_option("rec_fused2", &fused_on);
+    const int rr_pair = rr_on != 0 && (B >= NNTK_RR_MIN_BATCH || rr_on == 1) && d1 && d2 &&
+                        nntk_shim_lstm_rr_image_floats(c1->H, c1->in) && nntk_shim_lstm_rr_image_floats(c2->H, c2->in);
+    if (d1 && d2 && c2->H == H && !(rr_pair && fused_on != 1)) {
         if (core_ensure_wt(c2)) return -1;
         float *d_xw = nntk_devbuf_reserve(&c1->d_xw, (size_t)T * B * 3 * H);
         float *d_work = nntk_devbuf_reserve(&c1->d_work, nntk_shim_gru2_work_floats(B, H) > nntk_shim_recurrent_work_floats(B, H)

@@ -94,7 +94,7 @@ def test_bench_gpus_2_runs_the_device_pipeline_on_two_ranks(gpu):
     out = lines[0]
     assert out["n_gpus"] == 2 and out["config"]["ranks_seen"] == [0, 1] and out["scaling"] == "weak"
     assert out["config"]["global_batch"] == 128 and out["value"] > 0
-    assert out["roofline"]["kernel"].startswith(("rec_", "lstm_rr_kernel"))
+    assert out["roofline"]["kernel"].startswith(("rec_", "lstm_rr_kernel", "gru_rr_kernel"))
     assert out["rank_ms_per_step"]["min"] > 0 and len(out["rank_ms_per_step"]["per_rank"]) == 2
     # the N=1 line keeps its shape
     r1 = _run([sys.executable, BENCH, "--batch-per-gpu", "64", "--frames", "40", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])

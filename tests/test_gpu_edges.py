@@ -318,6 +318,6 @@ def test_spectrogram_lds_dma_variant_matches_the_default_bit_for_bit(gpu):
         b = spec.apply_device(x).clone()
         capi.set_option("spec_dma", "auto")
         assert torch.equal(a, b)
-        ref = O.spectrogram(x.cpu().numpy(), O.window("ones", 400), 512, 240)
+        ref = O.spectrogram(x.cpu().numpy(), O.window("hann", 400), 512, 240)
         np.testing.assert_allclose(b.cpu().numpy(), ref, rtol=2e-5, atol=1e-6 * float(np.abs(ref).max()))
         spec.destroy()

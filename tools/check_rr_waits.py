@@ -17,7 +17,7 @@ def main():
                                "--cuda-device-only", "-S", SRC, "-o", out], stderr=subprocess.DEVNULL)
         txt = open(out).read()
     bad = total = 0
-    for kname in re.findall(r'^(_Z14lstm_rr_kernel\w+):', txt, re.M):
+    for kname in re.findall(r'^(_Z1[34](?:lstm|gru)_rr_kernel\w+):', txt, re.M):
         a = txt.index("\n" + kname + ":")
         s = txt[a:txt.index("s_endpgm", a)].split("\n")
         for i, l in enumerate(s):
@@ -38,7 +38,7 @@ def main():
                         bad += 1
                         print("%s: wait vmcnt(%s) at +%d but %d vector-memory instructions follow the publication" % (kname, m.group(1), j, younger))
                     break
-    print("lstm_rr_kernel: %d counted waits checked, %d mismatches" % (total, bad))
+    print("lstm_rr_kernel / gru_rr_kernel: %d counted waits checked, %d mismatches" % (total, bad))
     return 1 if bad or total == 0 else 0
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostics build only (tools/build_variant.sh <lib> -DNNTK_REC_STAMPS; NNTK_LIB=<lib>): run the stack's LSTM on
 lstm_rr_kernel once and print where workgroup 0 / wave 0 spends a half-step (s_memtime cycles).
-usage: NNTK_LIB=gpurun_out/libs/libstamps.so python tools/rr_stamps.py [B] [T]"""
+usage: NNTK_LIB=<lib built with -DNNTK_REC_STAMPS> python tools/rr_stamps.py [B] [T] [lstm|gru] [in] [H]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,10 +14,16 @@ def main():
     torch.cuda.set_device(0); capi.load(); NL.use_torch_stream()
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     T = int(sys.argv[2]) if len(sys.argv) > 2 else 996
-    w = bench.make_weights("stack", 3)
-    lstm = NL.LSTM(128, 512, True, T, v2=True)
-    lstm.set_weights(w["lstm_W"], w["lstm_U"], w["lstm_bi"], w["lstm_bh"])
-    x = torch.randn(B, T, 128, device="cuda"); h = torch.empty(B, T, 512, device="cuda")
+    kind = sys.argv[3] if len(sys.argv) > 3 else "lstm"
+    I = int(sys.argv[4]) if len(sys.argv) > 4 else 128
+    H = int(sys.argv[5]) if len(sys.argv) > 5 else 512
+    G = 4 if kind == "lstm" else 3
+    r = np.random.default_rng(3)
+    u = lambda *sh, sc=1.0: r.uniform(-sc, sc, sh).astype(np.float32)
+    lstm = NL.LSTM(I, H, True, T, v2=True) if kind == "lstm" else NL.GRU(I, H, True, T)
+    lstm.set_weights(u(I, G * H, sc=I ** -0.5), u(H, G * H, sc=H ** -0.5), u(G * H, sc=0.1), u(G * H, sc=0.1))
+    capi.set_option("rec_rr", 1)
+    x = torch.randn(B, T, I, device="cuda"); h = torch.empty(B, T, H, device="cuda")
     for _ in range(3):
         lstm.apply_device(x, out=h)
     torch.cuda.synchronize()
@@ -28,7 +34,8 @@ def main():
     del os.environ["NNTK_REC_STAMP_FILE"]
     s = np.fromfile(path, dtype=np.uint64).astype(np.int64).reshape(T, 2, 16)
     lo, hi = T // 10, T - T // 10
-    nst = 10
+    nst = (4 if H <= 256 else 8) + (1 if I <= 64 else 2 if I <= 128 else 4)
+    print("%s in=%d H=%d: %s, %d k steps per half" % (kind, I, H, capi.load().nntk_hip_last_recurrent_kernel().decode(), nst))
     print("launch %.3f ms incl. stamping = %.2f us/step" % (e0.elapsed_time(e1), e0.elapsed_time(e1) * 1e3 / T))
     for half in range(2):
         d = s[lo:hi, half]
