@@ -392,8 +392,11 @@ const char *nntk_version(void);
  *                    auto: a non-finite input, or one above 3.39e38, gives NaN (where the chain gives +-inf) in exactly the outputs
  *                    whose window holds it; inputs below 1.18e-38 count as zero; a WEIGHT block holding such a value is detected
  *                    at upload and runs on the exact kernel.  INTEGRATION.md section 6 has the table, tests/test_gpu_edges.py pins it.
- *   "rec_rr"         LSTM batches: 0 = never the register-resident split-bf16 kernel (recurrent_rr.hip; x W fused into the
- *                    step, f32-accuracy contraction, not the exact-f32 chain), 1 = also below 32 sequences, auto = from 32
+ *   "rec_rr"         GRU / LSTM batches: 0 = never the register-resident split-bf16 kernels (recurrent_rr.hip lstm_rr_kernel /
+ *                    gru_rr_kernel; x W fused into the step, f32-accuracy contraction, not the exact-f32 chain), 1 = also below 32
+ *                    sequences, auto = from 32.  Shapes: H 64..512 (multiple of 16), in <= 128, or in <= 256 when H <= 256; default
+ *                    gate activations.  GRUStack2Apply* runs two such launches when both layers qualify ("rec_fused2" = 1: the fused
+ *                    exact-f32 two-layer kernel instead)
  *   "train_bptt"     0 = GRU / LSTM gradients walk time with two launches per step instead of the persistent BPTT kernel
  *   "rec_persistent" 0 = per-timestep recurrent kernels only     "rec_pingpong" 0/1 = ping-pong halves off/on
  *   "rec_spin_us"    budget of the persistent kernel's spins     "gemm_tm_batch" 0/1

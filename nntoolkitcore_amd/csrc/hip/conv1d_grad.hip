@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void conv1d_db_partial_kernel(const float *dou
 
 // fixed-order sum of the slices; writes dW in the caller's [Cout][Cin][k] layout and db
 __global__ __launch_bounds__(256) void conv1d_grad_reduce_kernel(const float *pw, const float *pb, float *dW, float *db,
-                                                                 int Cin, int Cout, int k, int slices) {
+                                                                 int Cin, int Cout, int k, int slices, size_t pw_slice, size_t pb_slice) {
     const int ncol = k * Cin;
     const long total = (long)ncol * Cout;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total + Cout; e += (long)gridDim.x * blockDim.x) {
@@ -47,12 +47,12 @@ __global__ __launch_bounds__(256) void conv1d_grad_reduce_kernel(const float *pw
             const int col = (int)(e / Cout), o = (int)(e % Cout);
             const int kk = col / Cin, i = col % Cin;
             float s = 0.0f;
-            for (int sl = 0; sl < slices; ++sl) s += pw[((size_t)sl * ncol + col) * Cout + o];
+            for (int sl = 0; sl < slices; ++sl) s += pw[(size_t)sl * pw_slice + (size_t)col * Cout + o];
             dW[((size_t)o * Cin + i) * k + kk] = s;
         } else {
             const int o = (int)(e - total);
             float s = 0.0f;
-            for (int sl = 0; sl < slices; ++sl) s += pb[(size_t)sl * Cout + o];
+            for (int sl = 0; sl < slices; ++sl) s += pb[(size_t)sl * pb_slice + o];
             db[o] = s;
         }
     }
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void conv1d_dx_kernel(const float *dout, const
 // d_in [B,T,Cin] (the forward pass's input), d_W [Cout][Cin][k] (caller layout), d_dout [B,Tout,Cout]
 // -> d_dW [Cout][Cin][k], d_db [Cout], d_dX [B,T,Cin]; d_scratch >= nntk_shim_conv1d_grad_scratch_floats(...) floats
 extern "C" size_t nntk_shim_conv1d_grad_scratch_floats(int Cin, int Cout, int k) {
-    return (size_t)GRAD_SLICES * ((size_t)k * Cin + 1) * Cout;
+    return (size_t)GRAD_SLICES * ((size_t)k * Cin + 1) * Cout;       // also the MFMA form's [slices <= 32][k Cin + 1][Cout]
 }
 extern "C" int nntk_shim_conv1d_grad(const float *d_in, const float *d_W, const float *d_dout, float *d_dW, float *d_db,
                                      float *d_dX, float *d_scratch, int B, int T, int Cin, int Cout, int k, int stride, int Tout) {
@@ -92,12 +92,23 @@ extern "C" int nntk_shim_conv1d_grad(const float *d_in, const float *d_W, const 
     float *pw = d_scratch, *pb = d_scratch + (size_t)GRAD_SLICES * k * Cin * Cout;
     const long rows = (long)B * (Tout > 0 ? Tout : 0);
     const int bs = Cout >= 256 ? 256 : ((Cout + 63) / 64) * 64;
-    hipLaunchKernelGGL(conv1d_dw_partial_kernel, dim3((unsigned)(k * Cin), GRAD_SLICES), dim3(bs), 0, st, d_in, d_dout, pw,
-                       B, T, Cin, Cout, k, stride, Tout > 0 ? Tout : 0);
-    hipLaunchKernelGGL(conv1d_db_partial_kernel, dim3(GRAD_SLICES), dim3(bs), 0, st, d_dout, pb, rows, Cout);
     const long tot = (long)k * Cin * Cout + Cout;
-    hipLaunchKernelGGL(conv1d_grad_reduce_kernel, dim3((unsigned)((tot + 255) / 256 > 2048 ? 2048 : (tot + 255) / 256)), dim3(256), 0, st,
-                       pw, pb, d_dW, d_db, Cin, Cout, k, GRAD_SLICES);
+    const unsigned rg = (unsigned)((tot + 255) / 256 > 2048 ? 2048 : (tot + 255) / 256);
+    // large products: the row-sliced f32-MFMA form (train.hip outer_mfma_kernel) on the im2col VIEW of the input -- row (b, x) is the
+    // contiguous window in[b, x * stride .. + k - 1, :], so A = [rows][k Cin] needs no buffer; column sums of dout (d_b) come with it
+    const int ncol = k * Cin;
+    const int ms = rows > 0 ? nntk_outer_mfma_launch(d_in, d_dout, d_scratch, rows, ncol, Cout, 0, Tout, (long)T * Cin, (long)stride * Cin) : 0;
+    if (ms > 0) {
+        const size_t sl = (size_t)(ncol + 1) * Cout;
+        hipLaunchKernelGGL(conv1d_grad_reduce_kernel, dim3(rg), dim3(256), 0, st, d_scratch, d_scratch + (size_t)ncol * Cout, d_dW, d_db,
+                           Cin, Cout, k, ms, sl, sl);
+    } else {
+        hipLaunchKernelGGL(conv1d_dw_partial_kernel, dim3((unsigned)(k * Cin), GRAD_SLICES), dim3(bs), 0, st, d_in, d_dout, pw,
+                           B, T, Cin, Cout, k, stride, Tout > 0 ? Tout : 0);
+        hipLaunchKernelGGL(conv1d_db_partial_kernel, dim3(GRAD_SLICES), dim3(bs), 0, st, d_dout, pb, rows, Cout);
+        hipLaunchKernelGGL(conv1d_grad_reduce_kernel, dim3(rg), dim3(256), 0, st, pw, pb, d_dW, d_db, Cin, Cout, k, GRAD_SLICES,
+                           (size_t)ncol * Cout, (size_t)Cout);
+    }
     const long nx = (long)B * T * Cin;
     if (nx > 0 && d_dX)                       // d_dX == NULL: the caller computes d_X itself (MFMA form, train.hip)
         hipLaunchKernelGGL(conv1d_dx_kernel, dim3((unsigned)((nx + 255) / 256 > 8192 ? 8192 : (nx + 255) / 256)), dim3(256), 0, st,

@@ -46,6 +46,9 @@ void nntk_persistent_launch_end();
 int nntk_cu_count();                              // cached per device
 void nntk_set_last_rec_kernel(const char *name);  // static string; read back with nntk_hip_last_recurrent_kernel()
 int nntk_set_max_dynamic_lds(const void *kernel, size_t bytes);   // hipFuncSetAttribute once per (kernel, device)
+// train.hip: C^T-sliced weight-gradient product on the f32 MFMA (outer_mfma_kernel); 0 = shape not taken, else slices written
+int nntk_outer_mfma_launch(const float *d_A, const float *d_B, float *d_partial, long rows, int I, int K, int a_shift_T,
+                           long rps, long seq_pitch, long row_pitch);
 int nntk_resident_blocks(const void *kernel, int threads, size_t lds, int max_per_cu);   // occupancy x CUs (0: does not fit)
 
 #define NNTK_HIP_TRY(expr)                                             \

@@ -617,8 +617,11 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__rest
 //   wave (wi, wk) of a workgroup owns the 64 x 64 sub-tile at (i0 + 64 wi, k0 + 64 wk): 2 x 2 MFMAs per pair of rows
 //   a_shift_T > 0: A is h [B][T][I] and row (b, t) uses h_{t-1} (zero at t = 0), as in outer_partial_kernel
 #define OUTER_TILE 128
+//   rps / seq_pitch / row_pitch: A's row r starts at A + (r / rps) * seq_pitch + (r % rps) * row_pitch -- a plain matrix is rps = rows,
+//   row_pitch = I; a channels-last convolution's im2col matrix (row (b, x) = the CONTIGUOUS window in[b, x * stride .. + k - 1, :],
+//   I = k * Cin) is rps = Tout, seq_pitch = T * Cin, row_pitch = stride * Cin: Conv1d's d_W needs no im2col buffer either
 __global__ __launch_bounds__(256) void outer_mfma_kernel(const float *__restrict__ A, const float *__restrict__ Bm, float *__restrict__ partial,
-                                                         long rows, int I, int K, int a_shift_T) {
+                                                         long rows, int I, int K, int a_shift_T, long rps, long seq_pitch, long row_pitch) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int c = lane & 31, kk = lane >> 5;
     const int i0 = blockIdx.y * OUTER_TILE + (wv >> 1) * 64, k0 = blockIdx.x * OUTER_TILE + (wv & 1) * 64;
@@ -634,7 +637,10 @@ __global__ __launch_bounds__(256) void outer_mfma_kernel(const float *__restrict
             for (int v = 0; v < 16; ++v) acc[x][y][v] = 0.f;
     float bs0 = 0.f, bs1 = 0.f;
     long tt = a_shift_T > 0 ? (r0 + kk) % a_shift_T : 1;    // t of this lane's row (only "is it 0" matters)
-    const float *ap = A + (r0 + kk - (a_shift_T > 0 ? 1 : 0)) * (long)I + i0 + c;
+    const long ra = r0 + kk - (a_shift_T > 0 ? 1 : 0);      // (a_shift_T only with plain matrices: rps = rows, so ra = -1 stays in "sequence" 0)
+    long ax = ra >= 0 ? ra % rps : ra;                       // position inside the sequence; the row's address follows it
+    const float *ap = A + (ra >= 0 ? ra / rps : 0) * seq_pitch + ax * row_pitch + i0 + c;
+    const long seq_step = seq_pitch - rps * row_pitch;      // pointer correction when a row pair crosses into the next sequence
     const float *bp = Bm + (r0 + kk) * (long)K + k0 + c;
     // four row pairs per trip (a constant inner trip count: a loop holding MFMAs is only unrolled without a remainder loop);
     // pairs past the slice's end load zeros
@@ -649,7 +655,9 @@ __global__ __launch_bounds__(256) void outer_mfma_kernel(const float *__restrict
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            ap += 2 * (long)I; bp += 2 * (long)K;
+            ap += 2 * row_pitch; bp += 2 * (long)K;
+            ax += 2;
+            if (ax >= rps) { ax -= rps; ap += seq_step; if (ax >= rps) { ax -= rps; ap += seq_step; } }       // rps = 1 needs both
             if (a_shift_T > 0) { tt += 2; if (tt >= a_shift_T) tt -= a_shift_T; if (tt >= a_shift_T) tt -= a_shift_T; }     // T = 1 needs both
         }
     }
@@ -677,19 +685,27 @@ __global__ __launch_bounds__(256) void outer_mfma_kernel(const float *__restrict
 }
 
 extern "C" size_t nntk_shim_outer_scratch_floats(int I, int K) { return (size_t)OUTER_SLICES * (I + 1) * K; }
+// partial [slices][I + 1][K] (row I: column sums of Bm); returns the number of slices written, 0 when the shape is not taken
+int nntk_outer_mfma_launch(const float *d_A, const float *d_B, float *d_partial, long rows, int I, int K, int a_shift_T,
+                           long rps, long seq_pitch, long row_pitch) {
+    if (!(I >= 32 && K >= 32 && rps >= 1 && (double)rows * I * K >= (double)(1 << 27))) return 0;
+    // enough (tile, slice) workgroups for three waves per SIMD, at least 64 rows per slice
+    const int ti = (I + OUTER_TILE - 1) / OUTER_TILE, tk = (K + OUTER_TILE - 1) / OUTER_TILE;
+    int slices = (768 + ti * tk - 1) / (ti * tk);
+    if (slices > OUTER_SLICES) slices = OUTER_SLICES;
+    if ((long)slices > rows / 64) slices = (int)(rows / 64);
+    if (slices < 1) slices = 1;
+    hipLaunchKernelGGL(outer_mfma_kernel, dim3((unsigned)tk, (unsigned)ti, (unsigned)slices), dim3(256), 0, nntk_stream(),
+                       d_A, d_B, d_partial, rows, I, K, a_shift_T, rps, seq_pitch, row_pitch);
+    return slices;
+}
 extern "C" int nntk_shim_outer_accumulate(const float *d_A, const float *d_B, float *d_C, float *d_c, float *d_scratch,
                                           long rows, int I, int K, int a_shift_T) {
     if (rows <= 0 || I < 0 || K <= 0) return 0;             // I == 0: only the column sums c
     int slices = OUTER_SLICES;
-    if (I >= 32 && K >= 32 && (double)rows * I * K >= (double)(1 << 27)) {
-        // sliced MFMA form: enough (tile, slice) workgroups for three waves per SIMD, at least 64 rows per slice
-        const int ti = (I + OUTER_TILE - 1) / OUTER_TILE, tk = (K + OUTER_TILE - 1) / OUTER_TILE;
-        slices = (768 + ti * tk - 1) / (ti * tk);
-        if (slices > OUTER_SLICES) slices = OUTER_SLICES;
-        if ((long)slices > rows / 64) slices = (int)(rows / 64);
-        if (slices < 1) slices = 1;
-        hipLaunchKernelGGL(outer_mfma_kernel, dim3((unsigned)tk, (unsigned)ti, (unsigned)slices), dim3(256), 0, nntk_stream(),
-                           d_A, d_B, d_scratch, rows, I, K, a_shift_T);
+    const int ms = I > 0 ? nntk_outer_mfma_launch(d_A, d_B, d_scratch, rows, I, K, a_shift_T, rows, 0, I) : 0;
+    if (ms > 0) {
+        slices = ms;
         NNTK_LAUNCH_CHECK("outer_mfma_kernel");
     } else if (I == 0)
         hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)((K + 255) / 256), OUTER_SLICES), dim3(256), 0, nntk_stream(), d_B, d_scratch, rows, K,

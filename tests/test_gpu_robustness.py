@@ -380,7 +380,8 @@ def test_fused_gru_stack_falls_back_for_other_activations(gpu):
 # ---- training, first slice: Conv1dCalculateGradient ----
 
 @pytest.mark.parametrize("B,T,Cin,Cout,k,s", [(2, 23, 3, 4, 5, 2), (3, 40, 8, 16, 5, 1), (2, 17, 5, 3, 3, 3), (4, 300, 40, 128, 5, 1),
-                                             (12, 450, 40, 128, 5, 1), (24, 400, 33, 96, 3, 1)])      # the last two: d_X on the MFMA form
+                                             (12, 450, 40, 128, 5, 1), (24, 400, 33, 96, 3, 1),       # d_X on the MFMA form
+                                             (40, 300, 40, 128, 5, 2), (16, 500, 36, 72, 7, 1)])      # d_W on outer_mfma_kernel (stride 2; ragged tiles)
 def test_conv1d_training_forward_and_gradient(gpu, B, T, Cin, Cout, k, s):
     """Conv1dCreateForTraining / ApplyTrainingBatch / CreateGradient / CalculateGradient through the C boundary against
     the oracle (reference loop order) and torch autograd (float64).  d_W, d_b accumulate into the block, d_X is overwritten."""

@@ -1,11 +1,14 @@
 #!/bin/bash
 # Round-end measurement pass on the GPU box: benches, rocprofv3 kernel stats, PMC passes.
-# usage (from the repo root, inside gpurun): bash tools/final_profile.sh <outdir-under-gpurun_out>
+# usage (from the repo root, inside gpurun): bash tools/final_profile.sh <outdir-under-gpurun_out> [bench|prof]
+# (two gpurun calls: "bench" = the bench lines and logs, "prof" = rocprofv3 kernel stats and PMC passes; default both)
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/${1:-final}
 mkdir -p $O
 cd $R
+PART=${2:-all}
+if [ "$PART" != prof ]; then
 for w in stack gru conv spectrogram; do
   timeout -k 10 300 python bench.py --workload $w > $O/bench_$w.json 2> $O/bench_$w.err; tail -c 300 $O/bench_$w.json; echo
 done
@@ -14,7 +17,13 @@ NNTK_GEMM_SPLIT_BF16=0 timeout -k 10 300 python bench.py --no-cpu-baseline > $O/
 timeout -k 10 300 python tools/split_error.py 2>&1 | grep -v amdgpu.ids > $O/split_error.log; timeout -k 10 200 python tools/split_error.py --stress 2>&1 | grep -v amdgpu.ids >> $O/split_error.log; echo split_error $?
 timeout -k 10 300 python tools/conv_probe.py gemm_split_bf16=0,1 2>&1 | grep -v amdgpu.ids > $O/conv_probe_ab.log; cat $O/conv_probe_ab.log
 timeout -k 10 300 python tools/train_bench.py 2>&1 | grep -v amdgpu.ids > $O/train_bench.log; cat $O/train_bench.log
+timeout -k 10 300 python tools/rec_ab.py 1024 500 2>&1 | grep -v amdgpu.ids > $O/rec_ab.log; cat $O/rec_ab.log
+NNTK_REC_FUSED2=1 timeout -k 10 300 python bench.py --workload gru --no-cpu-baseline > $O/bench_gru_fused.json 2> /dev/null; tail -c 200 $O/bench_gru_fused.json; echo
+fi
+[ "$PART" = bench ] && { ls $O; exit 0; }
 cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_lstm_train -- python3 $R/tools/lstm_train_prof.py > $O/lstm_train_prof.log 2>&1; grep "^fwd" $O/lstm_train_prof.log
+for f in $(ls $O/prof_lstm_train/*/*kernel_stats.csv 2>/dev/null); do cut -c1-150 $f | head -8; done
 for w in stack gru conv spectrogram; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$w -- python3 $R/bench.py --workload $w --no-cpu-baseline --steps 5 > $O/prof_$w.log 2>&1
   for f in $(ls $O/prof_$w/*/*kernel_stats.csv 2>/dev/null); do cut -c1-150 $f | head -7; done
