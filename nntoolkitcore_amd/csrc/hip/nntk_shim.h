@@ -186,6 +186,8 @@ int nntk_shim_lstm_rr_pack_raw(const float *d_U /*[H][4H]*/, const float *d_W /*
 /* GRU on the same kernels (gru_rr_kernel): image from the four-slot matrices, d_b4 [4H]; see recurrent_rr.hip */
 int nntk_shim_gru_rr(const float *d_x, const float *d_img, const float *d_b4, const float *d_h0, float *d_out, float *d_hT,
                      float *d_work, int B, int T, int in, int H, int return_sequences);
+int nntk_shim_gru_rr_train_forward(const float *d_x, const float *d_img, const float *d_b4, float *d_h, float *d_hU, float *d_Zg,
+                                   float *d_work, int B, int T, int in, int H);
 int nntk_shim_lstm_rr_train_forward(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,
                                     float *d_h, float *d_c, float *d_zifgo, float *d_work, int B, int T, int in, int H);
 int nntk_shim_lstm_rr(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,

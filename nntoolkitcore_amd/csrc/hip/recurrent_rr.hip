@@ -428,6 +428,11 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
                 const float ht = nntk_fast_tanh(fmaf(rg, zc[2][e], zc[3][e]));
                 hn[e] = fmaf(-zg + 1.0f, ht, zg * cst[half][e]);
                 cst[half][e] = hn[e];
+                if (TRAIN) {      // the BPTT caches (train.hip gru_train_fwd_step_kernel's): Z_z | Z_r | Z_h | z | r | h~, and h.U_h + b_h
+                    zc[2][e] = fmaf(rg, zc[2][e], zc[3][e]);       // Z_h; zc[3] keeps h.U_h + b_h from here on
+                    zc[3][e] = z[2][e] + bsum[2][e];
+                    ac[0][e] = zg; ac[1][e] = rg; ac[2][e] = ht;
+                }
                 continue;
             }
             const float ig = nntk_fast_sigmoid(zc[0][e]);
@@ -440,7 +445,18 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
             ac[0][e] = ig; ac[1][e] = fg; ac[2][e] = gg; ac[3][e] = og;
         }
         *reinterpret_cast<float2 *>(hx + n * RR_HX_LD + jl) = make_float2(hn[0], hn[1]);
-        if (TRAIN) {
+        if (TRAIN && CELL == 1) {
+            const int row = b0 + half * 32 + n;
+            if (row < p.B && jf + 1 < H + 1) {
+                float *zrow = p.z_cache + ((size_t)row * T + t) * 6 * H + jf;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    *reinterpret_cast<float2 *>(zrow + g * H) = make_float2(zc[g][0], zc[g][1]);
+                    *reinterpret_cast<float2 *>(zrow + (3 + g) * H) = make_float2(ac[g][0], ac[g][1]);
+                }
+                *reinterpret_cast<float2 *>(p.c_cache + ((size_t)row * T + t) * H + jf) = make_float2(zc[3][0], zc[3][1]);
+            }
+        } else if (TRAIN) {
             const int row = b0 + half * 32 + n;
             if (row < p.B && jf + 1 < H + 1) {                 // H % 2 == 0 here (H % 16 == 0): both cells or none
                 float *zrow = p.z_cache + ((size_t)row * T + t) * 8 * H + jf;
@@ -687,8 +703,8 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
 }
 template <int KH, int KX, bool TRAIN = false>
 __global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) { rr_body<KH, KX, TRAIN, 0>(p); }
-template <int KH, int KX>
-__global__ __launch_bounds__(256) void gru_rr_kernel(RRParams p) { rr_body<KH, KX, false, 1>(p); }
+template <int KH, int KX, bool TRAIN = false>
+__global__ __launch_bounds__(256) void gru_rr_kernel(RRParams p) { rr_body<KH, KX, TRAIN, 1>(p); }
 
 // ---- host side --------------------------------------------------------------------------------------------------
 static bool rr_shape(int H, int in, int *KH, int *KX) {
@@ -760,6 +776,11 @@ extern "C" int nntk_shim_gru_rr(const float *d_x, const float *d_img, const floa
                                 float *d_work, int B, int T, int in, int H, int return_sequences) {
     return lstm_rr_launch(d_x, d_img, d_b4, nullptr, d_h0, d_h0, d_out, d_hT, nullptr, d_work, B, T, in, H, return_sequences, nullptr, nullptr, 1);
 }
+// GRU training forward: zero initial state, h of every step to d_h [B][T][H], caches d_hU [B][T][H] (h.U_h + b_h) and d_Zg [B][T][6H]
+extern "C" int nntk_shim_gru_rr_train_forward(const float *d_x, const float *d_img, const float *d_b4, float *d_h, float *d_hU, float *d_Zg,
+                                              float *d_work, int B, int T, int in, int H) {
+    return lstm_rr_launch(d_x, d_img, d_b4, nullptr, nullptr, nullptr, d_h, nullptr, nullptr, d_work, B, T, in, H, 1, d_hU, d_Zg, 1);
+}
 // training forward: zero initial state, h of every step to d_h [B][T][H], caches d_c [B][T][H] and d_zifgo [B][T][8H]
 extern "C" int nntk_shim_lstm_rr_train_forward(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,
                                                float *d_h, float *d_c, float *d_zifgo, float *d_work, int B, int T, int in, int H) {
@@ -781,12 +802,11 @@ static int lstm_rr_launch(const float *d_x, const float *d_img, const float *d_b
     void (*kern)(RRParams) = nullptr;
     const bool train = d_c_cache != nullptr;
     if (cell == 1) {
-        if (train) return 1;
-        if (KH == 8 && KX == 2) kern = gru_rr_kernel<8, 2>;
-        else if (KH == 8 && KX == 1) kern = gru_rr_kernel<8, 1>;
-        else if (KH == 4 && KX == 4) kern = gru_rr_kernel<4, 4>;
-        else if (KH == 4 && KX == 2) kern = gru_rr_kernel<4, 2>;
-        else if (KH == 4 && KX == 1) kern = gru_rr_kernel<4, 1>;
+        if (KH == 8 && KX == 2) kern = train ? gru_rr_kernel<8, 2, true> : gru_rr_kernel<8, 2>;
+        else if (KH == 8 && KX == 1) kern = train ? gru_rr_kernel<8, 1, true> : gru_rr_kernel<8, 1>;
+        else if (KH == 4 && KX == 4) kern = train ? gru_rr_kernel<4, 4, true> : gru_rr_kernel<4, 4>;
+        else if (KH == 4 && KX == 2) kern = train ? gru_rr_kernel<4, 2, true> : gru_rr_kernel<4, 2>;
+        else if (KH == 4 && KX == 1) kern = train ? gru_rr_kernel<4, 1, true> : gru_rr_kernel<4, 1>;
     } else if (KH == 8 && KX == 2) kern = train ? lstm_rr_kernel<8, 2, true> : lstm_rr_kernel<8, 2>;
     else if (KH == 8 && KX == 1) kern = train ? lstm_rr_kernel<8, 1, true> : lstm_rr_kernel<8, 1>;
     else if (KH == 4 && KX == 4) kern = train ? nullptr : lstm_rr_kernel<4, 4>;

@@ -44,7 +44,7 @@ typedef struct {
     int wt_valid;
     float *d_rr;                /* LSTM: weight images of the register-resident split-bf16 kernel (recurrent_rr.hip), made on first use */
     int rr_valid;
-    float *d_b4;                /* GRU on those kernels: the four-slot bias vector (core_try_gru_rr) */
+    float *d_b4, *d_b4_train;   /* GRU on those kernels: the four-slot bias vector (core_try_gru_rr; the training forward's copy) */
     float *d_rr_train;          /* ... and the training forward's own copy, re-packed every mini-batch from the raw block */
     /* persistent single-sequence state [H], double-buffered: a stateful call reads state[cur] and writes
      * state[cur ^ 1]; cur flips only once the call is known to be good, so a call that has to be repeated
@@ -58,7 +58,7 @@ typedef struct {
     unsigned *d_done;
     volatile unsigned *flag;
     unsigned seq;
-    nntk_devbuf d_in, d_out, d_xw, d_work, d_work_rr;
+    nntk_devbuf d_in, d_out, d_xw, d_work, d_work_rr, d_rr_stage;
 } rec_core;
 
 static int core_init(rec_core *c, int G, RecurrentConfig base) {
@@ -88,11 +88,11 @@ static int core_init(rec_core *c, int G, RecurrentConfig base) {
 static void core_free(rec_core *c) {
     nntk_shim_synchronize();
     nntk_shim_free(c->d_wp); nntk_shim_free(c->d_bi); nntk_shim_free(c->d_ut); nntk_shim_free(c->d_bh); nntk_shim_free(c->d_wt);
-    nntk_shim_free(c->d_rr); nntk_shim_free(c->d_rr_train); nntk_shim_free(c->d_b4);
+    nntk_shim_free(c->d_rr); nntk_shim_free(c->d_rr_train); nntk_shim_free(c->d_b4); nntk_shim_free(c->d_b4_train);
     nntk_shim_free(c->d_h[0]);
     nntk_shim_host_free(c->pin_in); nntk_shim_host_free(c->pin_out); nntk_shim_host_free((void *)c->flag);
     nntk_shim_free(c->d_done);
-    nntk_devbuf_free(&c->d_in); nntk_devbuf_free(&c->d_out); nntk_devbuf_free(&c->d_xw); nntk_devbuf_free(&c->d_work); nntk_devbuf_free(&c->d_work_rr);
+    nntk_devbuf_free(&c->d_in); nntk_devbuf_free(&c->d_out); nntk_devbuf_free(&c->d_xw); nntk_devbuf_free(&c->d_work); nntk_devbuf_free(&c->d_work_rr); nntk_devbuf_free(&c->d_rr_stage);
     nntk_wblock_free(&c->wb);
     free(c->weights);
 }
@@ -197,6 +197,35 @@ static int core_try_lstm_rr(rec_core *c, int use_bh, const int *acts, const floa
 static int gru_std_acts(const int *acts) {
     return acts[0] == NNTK_ACT_SIGMOID && acts[1] == NNTK_ACT_TANH && acts[2] == NNTK_ACT_SIGMOID;      /* z, h, r */
 }
+/* packs *d_img (allocated on first use, `img` floats) and *d_b4 from the caller-layout weights W [in][3H], U [H][3H], b_i, b_h */
+static int gru_rr_build_image(int in, int H, const float *W, const float *U, const float *bi, const float *bh,
+                              float **d_img, size_t img, float **d_b4, nntk_devbuf *stage) {
+    const size_t nW = (size_t)in * 4 * H, nU = (size_t)H * 4 * H;
+    float *tmp = (float *)calloc(nW + nU + 4 * (size_t)H, sizeof(float));
+    if (!tmp) NNTK_FAIL("out of host memory while packing GRU weights");
+    float *W4 = tmp, *U4 = tmp + nW, *b4 = U4 + nU;
+    for (int k = 0; k < in; ++k) {
+        memcpy(W4 + (size_t)k * 4 * H, W + (size_t)k * 3 * H, 2 * (size_t)H * sizeof(float));                 /* W_z | W_r */
+        memcpy(W4 + (size_t)k * 4 * H + 3 * (size_t)H, W + (size_t)k * 3 * H + 2 * (size_t)H, (size_t)H * sizeof(float));   /* slot 3: W_h */
+    }
+    for (int k = 0; k < H; ++k) memcpy(U4 + (size_t)k * 4 * H, U + (size_t)k * 3 * H, 3 * (size_t)H * sizeof(float));      /* U_z | U_r | U_h | 0 */
+    for (int j = 0; j < H; ++j) {
+        b4[j] = bi[j] + bh[j];
+        b4[H + j] = bi[H + j] + bh[H + j];
+        b4[2 * H + j] = bh[2 * H + j];
+        b4[3 * H + j] = bi[2 * H + j];
+    }
+    int rc = 0;
+    float *d_tmp = nntk_devbuf_reserve(stage, nW + nU);        /* kept with the handle: stream order protects it, no synchronisation */
+    if (!d_tmp) rc = -1;
+    if (!rc && !*d_img && !(*d_img = (float *)nntk_shim_malloc(img * sizeof(float)))) rc = -1;
+    if (!rc && !*d_b4 && !(*d_b4 = (float *)nntk_shim_malloc(4 * (size_t)H * sizeof(float)))) rc = -1;
+    if (!rc) rc = nntk_shim_upload(d_tmp, tmp, (nW + nU) * sizeof(float));
+    if (!rc) rc = nntk_shim_upload(*d_b4, b4, 4 * (size_t)H * sizeof(float));
+    if (!rc) rc = nntk_shim_lstm_rr_pack_raw(d_tmp + nW, d_tmp, *d_img, H, in);
+    free(tmp);                                              /* (nntk_shim_upload has copied it) */
+    return rc ? -1 : 0;
+}
 static int core_try_gru_rr(rec_core *c, const int *acts, const float *d_in, float *d_out, int B, int stateful) {
     int on = -1;
     (void)nntk_shim_get_option("rec_rr", &on);
@@ -206,34 +235,7 @@ static int core_try_gru_rr(rec_core *c, const int *acts, const float *d_in, floa
     size_t img = nntk_shim_lstm_rr_image_floats(H, in);
     if (!img) return 1;
     if (!c->rr_valid) {
-        const size_t nW = (size_t)in * 4 * H, nU = (size_t)H * 4 * H;
-        float *tmp = (float *)calloc(nW + nU + 4 * (size_t)H, sizeof(float));
-        if (!tmp) NNTK_FAIL("out of host memory while packing GRU weights");
-        const float *W = c->weights->W, *U = c->weights->U, *bi = c->weights->b_i, *bh = c->weights->b_h;
-        float *W4 = tmp, *U4 = tmp + nW, *b4 = U4 + nU;
-        for (int k = 0; k < in; ++k) {
-            memcpy(W4 + (size_t)k * 4 * H, W + (size_t)k * 3 * H, 2 * (size_t)H * sizeof(float));                 /* W_z | W_r */
-            memcpy(W4 + (size_t)k * 4 * H + 3 * (size_t)H, W + (size_t)k * 3 * H + 2 * (size_t)H, (size_t)H * sizeof(float));   /* slot 3: W_h */
-        }
-        for (int k = 0; k < H; ++k) memcpy(U4 + (size_t)k * 4 * H, U + (size_t)k * 3 * H, 3 * (size_t)H * sizeof(float));      /* U_z | U_r | U_h | 0 */
-        for (int j = 0; j < H; ++j) {
-            b4[j] = bi[j] + bh[j];
-            b4[H + j] = bi[H + j] + bh[H + j];
-            b4[2 * H + j] = bh[2 * H + j];
-            b4[3 * H + j] = bi[2 * H + j];
-        }
-        int rc = 0;
-        float *d_tmp = (float *)nntk_shim_malloc((nW + nU) * sizeof(float));
-        if (!d_tmp) rc = -1;
-        if (!rc && !c->d_rr && !(c->d_rr = (float *)nntk_shim_malloc(img * sizeof(float)))) rc = -1;
-        if (!rc && !c->d_b4 && !(c->d_b4 = (float *)nntk_shim_malloc(4 * (size_t)H * sizeof(float)))) rc = -1;
-        if (!rc) rc = nntk_shim_upload(d_tmp, tmp, (nW + nU) * sizeof(float));
-        if (!rc) rc = nntk_shim_upload(c->d_b4, b4, 4 * (size_t)H * sizeof(float));
-        if (!rc) rc = nntk_shim_lstm_rr_pack_raw(d_tmp + nW, d_tmp, c->d_rr, H, in);
-        if (!rc) rc = nntk_shim_synchronize();                  /* the pack kernel reads d_tmp */
-        nntk_shim_free(d_tmp);
-        free(tmp);
-        if (rc) return -1;
+        if (gru_rr_build_image(in, H, c->weights->W, c->weights->U, c->weights->b_i, c->weights->b_h, &c->d_rr, img, &c->d_b4, &c->d_rr_stage)) return -1;
         c->rr_valid = 1;
     }
     float *d_work = nntk_devbuf_reserve(&c->d_work_rr, nntk_shim_lstm_rr_work_floats(B, H));
@@ -515,7 +517,20 @@ static int gru_train_forward_dev(GRU filter, const float *d_x) {
     if (!d_h || !d_Zg || !d_hU || !d_raw) return -1;
     if (nntk_shim_upload(d_raw, c->wb.host, nw * sizeof(float))) return -1;          /* W | U | b_i | b_h, caller layout */
     const float *dW = d_raw, *dU = dW + (size_t)in * 3 * H, *dbi = dU + (size_t)H * 3 * H, *dbh = dbi + 3 * (size_t)H;
-    if (nntk_shim_gru_train_forward(d_x, dW, dU, dbi, dbh, d_h, d_Zg, d_hU, B, T, in, H, acts, sc)) return -1;
+    /* default activations, mini-batches of >= 32 sequences: ONE launch of the register-resident kernel with the caches written from
+     * its gate phase (recurrent_rr.hip gru_rr_kernel<.., TRAIN>); its image is re-packed from the current weights every call */
+    int ran = 0, rr_on = -1;
+    (void)nntk_shim_get_option("rec_rr", &rr_on);
+    size_t img = nntk_shim_lstm_rr_image_floats(H, in);
+    if (rr_on != 0 && img && gru_std_acts(acts) && (B >= NNTK_RR_MIN_BATCH || rr_on == 1)) {
+        float *d_wk = nntk_devbuf_reserve(&c->d_work_rr, nntk_shim_lstm_rr_work_floats(B, H));
+        if (!d_wk) return -1;
+        if (gru_rr_build_image(in, H, c->weights->W, c->weights->U, c->weights->b_i, c->weights->b_h, &c->d_rr_train, img, &c->d_b4_train, &c->d_rr_stage)) return -1;
+        int rc = nntk_shim_gru_rr_train_forward(d_x, c->d_rr_train, c->d_b4_train, d_h, d_hU, d_Zg, d_wk, B, T, in, H);
+        if (rc < 0) return -1;
+        ran = rc == 0;
+    }
+    if (!ran && nntk_shim_gru_train_forward(d_x, dW, dU, dbi, dbh, d_h, d_Zg, d_hU, B, T, in, H, acts, sc)) return -1;
     t->d_x_cur = d_x;
     t->have_batch = 1;
     return 0;

@@ -259,6 +259,13 @@ def test_batch_norm_training_forward_and_gradient(gpu, count, mb, F):
     (8, 50, 40, 64, True, ("sigmoid", "tanh", "sigmoid")),
     (2, 9, 6, 8, True, ("sigmoid", "relu", "tanh")),
     (16, 100, 128, 256, True, ("sigmoid", "tanh", "sigmoid")),
+    # mini-batches of >= 32 sequences: the forward pass runs on the register-resident kernel (gru_rr_kernel<.., TRAIN>), which writes
+    # the BPTT caches from its gate phase
+    (32, 20, 64, 128, True, ("sigmoid", "tanh", "sigmoid")),
+    (40, 15, 40, 64, False, ("sigmoid", "tanh", "sigmoid")),
+    (64, 40, 128, 256, True, ("sigmoid", "tanh", "sigmoid")),
+    (70, 9, 72, 192, True, ("sigmoid", "tanh", "sigmoid")),
+    (48, 12, 200, 128, True, ("sigmoid", "tanh", "sigmoid")),          # in > 128: the <4, 4> instantiation
 ])
 def test_gru_training_forward_and_bptt(gpu, B, T, n_in, H, seq, acts):
     """GRUCreateForTraining / ApplyTrainingBatch / GradientCreate / CalculateGradient (gru.c:232-512) through the C boundary
