@@ -45,6 +45,9 @@ def _both(layer, xd):
     (48, 128, 512, 12, True),        # KH = 8 / KX = 2
     (33, 200, 192, 11, True),        # in = 200 (padded to 256), H = 192 (12 column tiles)
     (96, 72, 320, 8, True),          # KH = 8 with padded k steps
+    (32, 128, 256, 1, True),         # T = 1: the peeled pipeline's shortest form
+    (32, 256, 128, 2, False),        # T = 2, KX = 4, last state only
+    (1100, 64, 64, 5, True),         # more batch tiles than one launch holds at this H (4 column tiles x 18 batch tiles fit; checks the tiling loop)
 ])
 def test_gru_rr_matches_oracle(gpu, B, I, H, T, seq):
     import torch

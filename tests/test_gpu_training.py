@@ -442,7 +442,10 @@ def _recurrent_gradient(kind, B, T, n_in, H, seq, seed, inject_fault=False):
 
 
 @pytest.mark.parametrize("kind,B,T,n_in,H,seq", [("lstm", 64, 40, 128, 512, True), ("lstm", 37, 12, 40, 64, False),
-                                                 ("gru", 64, 40, 128, 256, True), ("gru", 20, 9, 16, 64, False)])
+                                                 ("gru", 64, 40, 128, 256, True), ("gru", 20, 9, 16, 64, False),
+                                                 ("lstm", 256, 6, 64, 512, True),      # 512 workgroups: two per CU
+                                                 ("lstm", 300, 5, 64, 512, True),      # 608 workgroups: not co-resident -> per-step loop both ways
+                                                 ("gru", 33, 2, 24, 64, True)])        # T = 2: one hand-off
 def test_persistent_bptt_equals_the_per_step_loop(gpu, kind, B, T, n_in, H, seq):
     """train.hip bptt_persistent_kernel (the whole backward-through-time loop in one launch, carries in registers, d_gates
     exchanged through HBM) against the two-launches-per-step loop it replaces (option train_bptt = 0): the same elementwise
