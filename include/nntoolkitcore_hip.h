@@ -456,6 +456,11 @@ int  nntk_dist_rank(void);
 int  nntk_dist_world_size(void);
 int  nntk_dist_broadcast(float *host_block, size_t n_floats, int root);      /* any host block, in place, blocking */
 int  nntk_dist_barrier(void);
+/* Data-parallel TRAINING: in-place SUM of a gradient block over the ranks (RCCL all-reduce over xGMI).  nntk_dist_allreduce: a host
+ * block, staged, blocking.  nntk_dist_allreduce_device: a block in HBM (what <Layer>CalculateGradientDevice accumulates into),
+ * asynchronous on the calling thread's stream.  Both are no-ops without a communicator (one rank). */
+int  nntk_dist_allreduce(float *host_block, size_t n_floats);
+int  nntk_dist_allreduce_device(float *d_block, size_t n_floats);
 int  nntk_dist_finalize(void);
 void nntk_dist_shard_range(int n_utterances, int world_size, int rank, int *lo, int *hi);
 int Conv1dBroadcastWeights(Conv1d filter, int root);

@@ -297,6 +297,8 @@ SIGNATURES = {
     "nntk_dist_world_size": (C.c_int, []),
     "nntk_dist_broadcast": (C.c_int, [fp, C.c_size_t, C.c_int]),
     "nntk_dist_barrier": (C.c_int, []),
+    "nntk_dist_allreduce": (C.c_int, [fp, C.c_size_t]),
+    "nntk_dist_allreduce_device": (C.c_int, [vp, C.c_size_t]),
     "nntk_dist_finalize": (C.c_int, []),
     "nntk_dist_shard_range": (None, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "Conv1dBroadcastWeights": (C.c_int, [vp, C.c_int]),

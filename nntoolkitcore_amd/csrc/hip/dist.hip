@@ -102,6 +102,34 @@ int nntk_shim_dist_broadcast_host(float *block, size_t n, int root) {
     return 0;
 }
 
+// Data-parallel training ("where gradient all-reduce over xGMI would first appear"): in-place SUM of a gradient
+// block over the ranks.  Device form: asynchronous on the calling thread's stream -- a caller overlaps one layer's all-reduce
+// with the next layer's backward pass by issuing them from two threads / streams (nntk_hip_set_stream); the device-pointer
+// gradient calls (<Layer>CalculateGradientDevice) leave their blocks in HBM for exactly this.  Host form: staged and blocking.
+// Without a communicator both are no-ops (world size 1: the sum over one rank).
+int nntk_shim_dist_allreduce_device(float *d_block, size_t n) {
+    std::lock_guard<std::mutex> lk(g_mutex);
+    if (!g_comm || n == 0) return 0;
+    NNTK_RCCL_TRY(R.AllReduce(d_block, d_block, n, ncclFloat, ncclSum, g_comm, nntk_stream()));
+    return 0;
+}
+int nntk_shim_dist_allreduce_host(float *block, size_t n) {
+    std::lock_guard<std::mutex> lk(g_mutex);
+    if (!g_comm || n == 0) return 0;
+    if (g_stage_n < n) {
+        if (g_stage) (void)hipFree(g_stage);
+        g_stage = nullptr; g_stage_n = 0;
+        NNTK_HIP_TRY(hipMalloc((void **)&g_stage, n * sizeof(float)));
+        g_stage_n = n;
+    }
+    hipStream_t st = nntk_stream();
+    NNTK_HIP_TRY(hipMemcpyAsync(g_stage, block, n * sizeof(float), hipMemcpyHostToDevice, st));
+    NNTK_RCCL_TRY(R.AllReduce(g_stage, g_stage, n, ncclFloat, ncclSum, g_comm, st));
+    NNTK_HIP_TRY(hipMemcpyAsync(block, g_stage, n * sizeof(float), hipMemcpyDeviceToHost, st));
+    NNTK_HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
 int nntk_shim_dist_barrier(void) {
     std::lock_guard<std::mutex> lk(g_mutex);
     if (!g_comm) return 0;

@@ -217,6 +217,8 @@ int nntk_shim_dist_rank(void);
 int nntk_shim_dist_world(void);
 int nntk_shim_dist_broadcast_host(float *block, size_t n, int root);
 int nntk_shim_dist_barrier(void);
+int nntk_shim_dist_allreduce_device(float *d_block, size_t n);    /* in-place sum over the ranks, async on the stream */
+int nntk_shim_dist_allreduce_host(float *block, size_t n);          /* staged, blocking */
 int nntk_shim_dist_finalize(void);
 
 /* ---- K1: framed STFT magnitude / PSD ---------------------------------------

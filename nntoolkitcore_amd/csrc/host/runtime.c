@@ -32,6 +32,8 @@ int nntk_dist_rank(void) { return nntk_shim_dist_rank(); }
 int nntk_dist_world_size(void) { return nntk_shim_dist_world(); }
 int nntk_dist_broadcast(float *host_block, size_t n_floats, int root) { nntk_shim_clear_error(); return nntk_shim_dist_broadcast_host(host_block, n_floats, root); }
 int nntk_dist_barrier(void) { nntk_shim_clear_error(); return nntk_shim_dist_barrier(); }
+int nntk_dist_allreduce(float *host_block, size_t n_floats) { nntk_shim_clear_error(); return nntk_shim_dist_allreduce_host(host_block, n_floats); }
+int nntk_dist_allreduce_device(float *d_block, size_t n_floats) { nntk_shim_clear_error(); return nntk_shim_dist_allreduce_device(d_block, n_floats); }
 int nntk_dist_finalize(void) { nntk_shim_clear_error(); return nntk_shim_dist_finalize(); }
 /* contiguous, balanced utterance shard of `rank` (the first ranks take the remainder) */
 void nntk_dist_shard_range(int n_utterances, int world_size, int rank, int *lo, int *hi) {

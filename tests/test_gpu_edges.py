@@ -253,6 +253,53 @@ def test_persistent_lstm_while_rccl_broadcasts_on_another_stream(gpu):
         assert L.nntk_dist_finalize() == 0
 
 
+def test_gradient_allreduce_over_rccl_world_of_one(gpu):
+    """nntk_dist_allreduce[_device]: the data-parallel training collective (in-place SUM of a gradient block over the ranks).
+    One rank here (the box has one GPU): the RCCL call really runs -- in place, on the calling thread's stream -- and the sum
+    over one rank leaves the block as it was; without a communicator the calls are no-ops.  A Dense gradient accumulated by
+    DenseCalculateGradientDevice goes through it and then through the SGD step, all in HBM."""
+    import torch
+    L = capi.load()
+    dp = lambda t: C.c_void_p(t.data_ptr())
+    g = torch.arange(1 << 20, dtype=torch.float32, device="cuda") * 0.25
+    keep = g.clone()
+    assert L.nntk_dist_allreduce_device(dp(g), g.numel()) == 0           # no communicator: no-op
+    ident = (C.c_ubyte * 128)()
+    if L.nntk_dist_get_unique_id(C.cast(ident, C.c_char_p)) != 0:
+        pytest.skip("RCCL not loadable here: " + capi.last_error())
+    assert L.nntk_dist_init(C.cast(ident, C.c_char_p), 0, 1) == 0, capi.last_error()
+    try:
+        assert L.nntk_dist_allreduce_device(dp(g), g.numel()) == 0, capi.last_error()
+        assert L.nntk_hip_synchronize() == 0
+        assert torch.equal(g, keep)
+        h = np.linspace(-1, 1, 4097, dtype=np.float32)
+        h0 = h.copy()
+        assert L.nntk_dist_allreduce(h.ctypes.data_as(capi.fp), h.size) == 0, capi.last_error()
+        assert np.array_equal(h, h0)
+        # a training step with its tensors in HBM: forward, gradient (accumulated on the device), all-reduce, SGD
+        r = rng(8)
+        B, n_in, n_out = 64, 48, 32
+        x, W, b, dout = u(r, B, n_in), u(r, n_in, n_out, sc=0.3), u(r, n_out, sc=0.1), u(r, B, n_out)
+        cfg = L.DenseConfigCreate(n_in, n_out, None)
+        d = L.DenseCreateForTraining(cfg, capi.ConvTrainingConfig(B))
+        w = L.DenseGetWeights(d).contents
+        C.memmove(w.W, W.ctypes.data, W.nbytes); C.memmove(w.b, b.ctypes.data, b.nbytes)
+        xd, dd = torch.from_numpy(x).cuda(), torch.from_numpy(dout).cuda()
+        yd, gd, gx = torch.empty(B, n_out, device="cuda"), torch.zeros(n_in * n_out + n_out, device="cuda"), torch.empty(B, n_in, device="cuda")
+        wd = torch.from_numpy(np.concatenate([W.ravel(), b])).cuda()
+        assert L.DenseApplyTrainingBatchDevice(d, dp(xd), dp(yd)) == 0
+        assert L.DenseCalculateGradientDevice(d, dp(gd), dp(gx), dp(dd)) == 0
+        assert L.nntk_dist_allreduce_device(dp(gd), gd.numel()) == 0
+        assert L.nntk_sgd_optimize_device(capi.SGD(0.1), dp(gd), dp(wd), gd.numel()) == 0
+        assert L.nntk_hip_synchronize() == 0
+        oW, ob, _ = O.dense_gradient(x, W, x @ W + b, x @ W + b, dout, act=None, softmax_vector_size=0)
+        ref = np.concatenate([(W - np.float32(0.1) * oW).ravel(), b - np.float32(0.1) * ob])
+        np.testing.assert_allclose(wd.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+        L.DenseDestroy(d)
+    finally:
+        assert L.nntk_dist_finalize() == 0
+
+
 # ------------------------------------------------------------ stride-2 Conv1d on the MFMA kernels ---
 # Reference: layers/conv_1d.c:128-140 (`input_row_offset = x * stride`).  Until round 3 every stride > 1 ran the
 # one-thread-per-output VALU kernel; stride 2 (window of (128 - 1) * 2 + k rows per tile) now has its own MFMA instantiations.
