@@ -98,6 +98,10 @@ ConvGradient *Conv1dCreateGradient(Conv1dConfig config, ConvTrainingConfig train
 void ConvGradientDestroy(ConvGradient *gradient);
 int  Conv1dApplyTrainingBatch(Conv1d filter, const float *input /*[mini_batch,T,Cin]*/, float *output);   /* -1 on an inference handle */
 void Conv1dCalculateGradient(Conv1d filter, ConvGradient *gradient, const float *d_out /*[mini_batch,Tout,Cout]*/);
+/* Additive device-pointer forms (tensors stay in HBM, asynchronous on the calling thread's stream; same kernels, same bits):
+ * d_input must stay valid until the gradient call; d_grad_Wb = W [Cout][Cin][k] | b [Cout] is ADDED to, d_dX overwritten. */
+int  Conv1dApplyTrainingBatchDevice(Conv1d filter, const float *d_input /*[mini_batch,T,Cin]*/, float *d_output);
+int  Conv1dCalculateGradientDevice(Conv1d filter, float *d_grad_Wb, float *d_dX, const float *d_dout);
 
 /* ---- nntoolkitcore/layers/batch_norm.h:19-66 --------------------------- */
 typedef struct { float *gamma; float *beta; float *moving_mean; float *moving_variance; } BatchNormWeights;

@@ -141,6 +141,8 @@ SIGNATURES = {
     "ConvGradientDestroy": (None, [C.POINTER(DefaultGradient)]),
     "Conv1dApplyTrainingBatch": (C.c_int, [vp, fp, fp]),
     "Conv1dCalculateGradient": (None, [vp, C.POINTER(DefaultGradient), fp]),
+    "Conv1dApplyTrainingBatchDevice": (C.c_int, [vp, vp, vp]),
+    "Conv1dCalculateGradientDevice": (C.c_int, [vp, vp, vp, vp]),
     # batch_norm.h
     "BatchNormConfigCreate": (BatchNormConfig, [C.c_int, C.c_float, C.c_int]),
     "BatchNormCreateForInference": (vp, [BatchNormConfig]),

@@ -216,6 +216,7 @@ int nntk_shim_dist_init(const unsigned char *id128, int rank, int world);
 int nntk_shim_dist_rank(void);
 int nntk_shim_dist_world(void);
 int nntk_shim_dist_broadcast_host(float *block, size_t n, int root);
+int nntk_shim_add_into(float *d_dst, const float *d_src, long n);      /* dst += src, async */
 int nntk_shim_dist_barrier(void);
 int nntk_shim_dist_allreduce_device(float *d_block, size_t n);    /* in-place sum over the ranks, async on the stream */
 int nntk_shim_dist_allreduce_host(float *block, size_t n);          /* staged, blocking */

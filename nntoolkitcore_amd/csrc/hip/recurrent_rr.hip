@@ -809,7 +809,7 @@ static int lstm_rr_launch(const float *d_x, const float *d_img, const float *d_b
         else if (KH == 4 && KX == 1) kern = train ? gru_rr_kernel<4, 1, true> : gru_rr_kernel<4, 1>;
     } else if (KH == 8 && KX == 2) kern = train ? lstm_rr_kernel<8, 2, true> : lstm_rr_kernel<8, 2>;
     else if (KH == 8 && KX == 1) kern = train ? lstm_rr_kernel<8, 1, true> : lstm_rr_kernel<8, 1>;
-    else if (KH == 4 && KX == 4) kern = train ? nullptr : lstm_rr_kernel<4, 4>;
+    else if (KH == 4 && KX == 4) kern = train ? lstm_rr_kernel<4, 4, true> : lstm_rr_kernel<4, 4>;
     else if (KH == 4 && KX == 2) kern = train ? lstm_rr_kernel<4, 2, true> : lstm_rr_kernel<4, 2>;
     else if (KH == 4 && KX == 1) kern = train ? lstm_rr_kernel<4, 1, true> : lstm_rr_kernel<4, 1>;
     if (!kern) return 1;

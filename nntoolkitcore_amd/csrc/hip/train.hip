@@ -1210,6 +1210,12 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
 __global__ __launch_bounds__(256) void add_into_kernel(float *__restrict__ dst, const float *__restrict__ src, long n) {
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) dst[e] = add_rn(dst[e], src[e]);
 }
+extern "C" int nntk_shim_add_into(float *d_dst, const float *d_src, long n) {      // dst += src (gradient blocks accumulate)
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(add_into_kernel, dim3(grid_for(n, 256)), dim3(256), 0, nntk_stream(), d_dst, d_src, n);
+    NNTK_LAUNCH_CHECK("add_into_kernel");
+    return 0;
+}
 extern "C" int nntk_shim_transpose(const float *d_src, float *d_dst, long R, int Cc, int shift_T) {
     if (R <= 0 || Cc <= 0) return 0;
     hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((R + 31) / 32), (unsigned)((Cc + 31) / 32)), dim3(256), 0, nntk_stream(),

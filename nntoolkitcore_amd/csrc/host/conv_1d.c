@@ -20,6 +20,7 @@ struct Conv1dStruct {
      * gradient, and the gradient scratch */
     int training, mini_batch;
     nntk_devbuf d_cache, d_dout, d_grad, d_wraw, d_scratch, d_pad, d_wpk;
+    const float *d_x_cur;     /* the last training forward's input: d_cache (host-pointer call) or the caller's device tensor */
 };
 
 /* conv_1d.c:77-87 */
@@ -193,7 +194,20 @@ int Conv1dApplyTrainingBatch(Conv1d filter, const float *input, float *output) {
     if (!d_in || !d_out) return -1;
     if (nntk_shim_upload(d_in, input, n_in * sizeof(float))) return -1;
     if (conv_launch(filter, NULL, 0.f, NNTK_ACT_IDENTITY, 1.f, d_in, d_out, B)) return -1;
+    filter->d_x_cur = d_in;
     return nntk_shim_download(output, d_out, n_out * sizeof(float));
+}
+/* device-pointer form: d_input [B][T][Cin] must stay valid until Conv1dCalculateGradientDevice; d_output [B][Tout][Cout] */
+int Conv1dApplyTrainingBatchDevice(Conv1d filter, const float *d_input, float *d_output) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("Conv1dApplyTrainingBatchDevice: NULL handle");
+    if (!filter->training) NNTK_FAIL("Conv1dApplyTrainingBatchDevice: the handle was created for inference");
+    if (filter->mini_batch <= 0) return 0;
+    if (!d_input || !d_output) NNTK_FAIL("Conv1dApplyTrainingBatchDevice: NULL argument");
+    if (conv_ensure(filter, 1)) return -1;
+    if (conv_launch(filter, NULL, 0.f, NNTK_ACT_IDENTITY, 1.f, d_input, d_output, filter->mini_batch)) return -1;
+    filter->d_x_cur = d_input;
+    return 0;
 }
 
 /* conv_1d.c:157-161 with weights_private.c:29-36: ONE zeroed block d_W | d_b | d_X */
@@ -216,32 +230,40 @@ void ConvGradientDestroy(ConvGradient *gradient) {
 
 /* d_W and d_b are ADDED to the gradient block (as default_gradient_sum does, weights_private.c:50-55), d_X is overwritten
  * (conv_1d.c:242).  void in the reference; errors through nntk_last_error(). */
+/* d_dW_db [Cout][Cin][k] | [Cout] is OVERWRITTEN (the callers add it onto their blocks), d_dX [B][T][Cin] too */
+static int conv_gradient_dev(Conv1d filter, const float *d_dout, float *d_dW_db, float *d_dX) {
+    const Conv1dConfig *c = &filter->config;
+    const int B = filter->mini_batch, Cin = c->input_feature_channels, Cout = c->output_feature_channels, k = c->kernel_size;
+    const size_t w = (size_t)k * Cin * Cout;
+    float *d_wraw = nntk_devbuf_reserve(&filter->d_wraw, w);
+    float *d_scr = nntk_devbuf_reserve(&filter->d_scratch, nntk_shim_conv1d_grad_scratch_floats(Cin, Cout, k));
+    if (!d_wraw || !d_scr) return -1;
+    if (nntk_shim_upload(d_wraw, filter->weights->W, w * sizeof(float))) return -1;       /* caller layout [Cout][Cin][k] */
+    const long rows = (long)B * c->output_size;
+    if (c->stride == 1 && c->output_size > 0 && (double)rows * Cout * k * Cin >= (double)(1 << 27) && Cin >= 32 && Cout >= 16) {
+        /* large, stride 1: d_X on the MFMA forward kernel (train.hip); d_W, d_b on the row-sliced MFMA product or the sliced dots */
+        const int T = c->input_size, Tout = c->output_size;
+        float *d_pad = nntk_devbuf_reserve(&filter->d_pad, (size_t)B * (Tout + 2 * (k - 1)) * Cout);
+        float *d_wpk = nntk_devbuf_reserve(&filter->d_wpk, nntk_shim_conv_dx_pack_floats(Cin, Cout, k));
+        if (!d_pad || !d_wpk) return -1;
+        if (nntk_shim_conv1d_grad(filter->d_x_cur, d_wraw, d_dout, d_dW_db, d_dW_db + w, NULL, d_scr, B, T, Cin, Cout, k, 1, Tout)) return -1;
+        return nntk_shim_conv_dx_mfma(d_dout, d_wraw, d_dX, d_pad, d_wpk, B, T, Cin, Cout, k, Tout);
+    }
+    return nntk_shim_conv1d_grad(filter->d_x_cur, d_wraw, d_dout, d_dW_db, d_dW_db + w, d_dX, d_scr,
+                                 B, c->input_size, Cin, Cout, k, c->stride, c->output_size);
+}
 void Conv1dCalculateGradient(Conv1d filter, ConvGradient *gradient, const float *d_out) {
     nntk_shim_clear_error();
     if (!filter || !gradient) { nntk_set_error("Conv1dCalculateGradient: NULL argument"); return; }
-    if (!filter->training || !filter->d_cache.p) { nntk_set_error("Conv1dCalculateGradient: run Conv1dApplyTrainingBatch on a training handle first"); return; }
+    if (!filter->training || !filter->d_x_cur) { nntk_set_error("Conv1dCalculateGradient: run Conv1dApplyTrainingBatch on a training handle first"); return; }
     const Conv1dConfig *c = &filter->config;
     const int B = filter->mini_batch, Cin = c->input_feature_channels, Cout = c->output_feature_channels, k = c->kernel_size;
     const size_t w = (size_t)k * Cin * Cout, n_x = (size_t)B * c->input_size * Cin, n_do = (size_t)B * c->output_size * Cout;
     float *d_dout = nntk_devbuf_reserve(&filter->d_dout, n_do);
     float *d_grad = nntk_devbuf_reserve(&filter->d_grad, w + Cout + n_x);
-    float *d_wraw = nntk_devbuf_reserve(&filter->d_wraw, w);
-    float *d_scr = nntk_devbuf_reserve(&filter->d_scratch, nntk_shim_conv1d_grad_scratch_floats(Cin, Cout, k));
-    if (!d_dout || !d_grad || !d_wraw || !d_scr) return;
+    if (!d_dout || !d_grad) return;
     if (nntk_shim_upload(d_dout, d_out, n_do * sizeof(float))) return;
-    if (nntk_shim_upload(d_wraw, filter->weights->W, w * sizeof(float))) return;         /* caller layout [Cout][Cin][k] */
-    const long rows = (long)B * c->output_size;
-    if (c->stride == 1 && c->output_size > 0 && (double)rows * Cout * k * Cin >= (double)(1 << 27) && Cin >= 32 && Cout >= 16) {
-        /* large, stride 1: d_X on the MFMA forward kernel (train.hip); d_W, d_b on the sliced dots (few output tiles) */
-        const int T = c->input_size, Tout = c->output_size;
-        float *d_pad = nntk_devbuf_reserve(&filter->d_pad, (size_t)B * (Tout + 2 * (k - 1)) * Cout);
-        float *d_wpk = nntk_devbuf_reserve(&filter->d_wpk, nntk_shim_conv_dx_pack_floats(Cin, Cout, k));
-        if (!d_pad || !d_wpk) return;
-        if (nntk_shim_conv1d_grad(filter->d_cache.p, d_wraw, d_dout, d_grad, d_grad + w, NULL, d_scr,
-                                  B, T, Cin, Cout, k, 1, Tout)) return;
-        if (nntk_shim_conv_dx_mfma(d_dout, d_wraw, d_grad + w + Cout, d_pad, d_wpk, B, T, Cin, Cout, k, Tout)) return;
-    } else if (nntk_shim_conv1d_grad(filter->d_cache.p, d_wraw, d_dout, d_grad, d_grad + w, d_grad + w + Cout, d_scr,
-                                     B, c->input_size, Cin, Cout, k, c->stride, c->output_size)) return;
+    if (conv_gradient_dev(filter, d_dout, d_grad, d_grad + w + Cout)) return;
     float *tmp = (float *)malloc((w + Cout) * sizeof(float));
     if (!tmp) { nntk_set_error("out of host memory"); return; }
     if (nntk_shim_download(tmp, d_grad, (w + Cout) * sizeof(float)) == 0 &&
@@ -250,6 +272,18 @@ void Conv1dCalculateGradient(Conv1d filter, ConvGradient *gradient, const float 
         for (int i = 0; i < Cout; ++i) gradient->d_b[i] += tmp[w + i];
     }
     free(tmp);
+}
+/* device-pointer form: d_grad_Wb = W [Cout][Cin][k] | b [Cout] (the gradient block's layout) is ADDED to, d_dX [B][T][Cin] overwritten */
+int Conv1dCalculateGradientDevice(Conv1d filter, float *d_grad_Wb, float *d_dX, const float *d_dout) {
+    nntk_shim_clear_error();
+    if (!filter || !d_grad_Wb || !d_dX || !d_dout) NNTK_FAIL("Conv1dCalculateGradientDevice: NULL argument");
+    if (!filter->training || !filter->d_x_cur) NNTK_FAIL("Conv1dCalculateGradientDevice: run Conv1dApplyTrainingBatch[Device] on a training handle first");
+    const Conv1dConfig *c = &filter->config;
+    const size_t w = (size_t)c->kernel_size * c->input_feature_channels * c->output_feature_channels;
+    float *d_grad = nntk_devbuf_reserve(&filter->d_grad, w + c->output_feature_channels);
+    if (!d_grad) return -1;
+    if (conv_gradient_dev(filter, d_dout, d_grad, d_dX)) return -1;
+    return nntk_shim_add_into(d_grad_Wb, d_grad, (long)(w + c->output_feature_channels));
 }
 
 /* ============================== BatchNorm ================================= */

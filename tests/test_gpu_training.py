@@ -340,6 +340,7 @@ def test_gru_training_forward_and_bptt(gpu, B, T, n_in, H, seq, acts):
     (40, 15, 40, 64, False, False, None),
     (64, 60, 128, 512, True, True, None),
     (70, 9, 72, 192, True, True, None),
+    (48, 12, 200, 128, True, True, None),          # in > 128: the <4, 4, TRAIN> instantiation
 ])
 def test_lstm_training_forward_and_bptt(gpu, B, T, n_in, H, seq, v2, acts):
     """LSTMCreateForTraining / ApplyTrainingBatch / GradientCreate / CalculateGradient (lstm.c:294-556) against the oracle
@@ -628,6 +629,42 @@ def test_recurrent_training_device_forms_equal_the_host_forms(gpu, kind, B, T, n
     np.testing.assert_allclose(gd.cpu().numpy(), 2 * gW, rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(gW).max())))
     assert bwd(h, None, dp(gxd), dp(dd)) == -1                                # NULL argument
     L.RecurrentGradientDestroy(g); de(h)
+
+
+@pytest.mark.parametrize("B,T,Cin,Cout,k,s", [(4, 60, 8, 16, 5, 1), (12, 450, 40, 128, 5, 1), (6, 90, 12, 24, 3, 2)])
+def test_conv1d_training_device_forms_equal_the_host_forms(gpu, B, T, Cin, Cout, k, s):
+    """Conv1dApplyTrainingBatchDevice / Conv1dCalculateGradientDevice: the host forms' device core on the caller's HBM tensors
+    (small VALU shapes, the MFMA shapes, stride 2): bit-identical, and the gradient block accumulates."""
+    import torch
+    L = capi.load()
+    r = rng(B + T + Cout)
+    x = u(r, B, T, Cin)
+    W, b = u(r, Cout, Cin, k, sc=(Cin * k) ** -0.5), u(r, Cout, sc=0.1)
+    cfg = L.Conv1dConfigCreate(Cin, Cout, k, s, T)
+    tc = capi.ConvTrainingConfig(B)
+    h = L.Conv1dCreateForTraining(cfg, tc)
+    w = L.Conv1dGetWeights(h).contents
+    C.memmove(w.W, W.ctypes.data, W.nbytes); C.memmove(w.b, b.ctypes.data, b.nbytes)
+    Tout = cfg.output_size
+    y, dout = np.empty((B, Tout, Cout), np.float32), u(r, B, Tout, Cout)
+    assert L.Conv1dApplyTrainingBatch(h, P(x), P(y)) == 0, capi.last_error()
+    g = L.Conv1dCreateGradient(cfg, tc)
+    L.Conv1dCalculateGradient(h, g, P(dout))
+    assert capi.last_error() == ""
+    nW = Cout * Cin * k
+    gWb = np.ctypeslib.as_array(g.contents.d_W, shape=(nW + Cout,)).copy()
+    gX = np.ctypeslib.as_array(g.contents.d_X, shape=(B, T, Cin)).copy()
+    dp = lambda t: C.c_void_p(t.data_ptr())
+    xd, dd = torch.from_numpy(x).cuda(), torch.from_numpy(dout).cuda()
+    yd, gd, gxd = torch.empty(B, Tout, Cout, device="cuda"), torch.zeros(nW + Cout, device="cuda"), torch.empty(B, T, Cin, device="cuda")
+    assert L.Conv1dApplyTrainingBatchDevice(h, dp(xd), dp(yd)) == 0, capi.last_error()
+    assert L.Conv1dCalculateGradientDevice(h, dp(gd), dp(gxd), dp(dd)) == 0, capi.last_error()
+    assert L.nntk_hip_synchronize() == 0
+    assert np.array_equal(yd.cpu().numpy(), y) and np.array_equal(gd.cpu().numpy(), gWb) and np.array_equal(gxd.cpu().numpy(), gX)
+    assert L.Conv1dCalculateGradientDevice(h, dp(gd), dp(gxd), dp(dd)) == 0 and L.nntk_hip_synchronize() == 0
+    np.testing.assert_allclose(gd.cpu().numpy(), 2 * gWb, rtol=1e-6, atol=1e-6 * max(1.0, float(np.abs(gWb).max())))
+    assert L.Conv1dCalculateGradientDevice(h, None, dp(gxd), dp(dd)) == -1
+    L.ConvGradientDestroy(g); L.Conv1dDestroy(h)
 
 
 def test_dense_and_batchnorm_training_device_forms_equal_the_host_forms(gpu):

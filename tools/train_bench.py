@@ -38,6 +38,13 @@ def main():
     g = L.Conv1dCreateGradient(cfg, tc)
     timed("Conv1d(40->128,k5) B=64 T=1000", lambda: L.Conv1dApplyTrainingBatch(h, P(x), P(y)), lambda: L.Conv1dCalculateGradient(h, g, P(d)),
           "%.1f GFLOP fwd" % (2e-9 * B * (T - k + 1) * Cin * k * Cout))
+    import torch
+    torch.cuda.set_device(0)
+    dpc = lambda t: C.c_void_p(t.data_ptr())
+    xd, dd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(d).cuda(), torch.empty(B, T - k + 1, Cout, device="cuda")
+    gd, gx = torch.zeros(Cout * Cin * k + Cout, device="cuda"), torch.empty(B, T, Cin, device="cuda")
+    timed("Conv1d(40->128,k5) B=64 T=1000, device pointers", lambda: (L.Conv1dApplyTrainingBatchDevice(h, dpc(xd), dpc(yd)), L.nntk_hip_synchronize()),
+          lambda: (L.Conv1dCalculateGradientDevice(h, dpc(gd), dpc(gx), dpc(dd)), L.nntk_hip_synchronize()), "same")
     L.ConvGradientDestroy(g); L.Conv1dDestroy(h)
     # BatchNorm over the conv output
     F, count = 128, 996
