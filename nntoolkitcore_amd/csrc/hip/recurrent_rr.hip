@@ -243,7 +243,10 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
     constexpr int NST = KX + KH;                      // k steps one wavefront multiplies per half
     constexpr int S_RED = 0, S_PUB = 1;
     constexpr int S_XSPL = KX > 2 ? KX : 2;
-    constexpr int S_E1 = NST >= 8 ? RR_S_E1 : 3;
+#ifndef RR_S_E1_XLATE
+#define RR_S_E1_XLATE 2           // the KX = 4 shapes (x requests behind the poll) may arrive from k step 2 on: 6.82 -> 6.66 us per step; 4: 8.3 -- the chain is that tight
+#endif
+    constexpr int S_E1 = KX > 2 ? RR_S_E1_XLATE : RR_S_E1;
     // X_LATE (KX = 4): the eight x requests of a half-step touch 32 rows each (2 x 16 bytes per row and request): they hold the
     // address path for ~2 k cycles and take ~3 us to return, and the poll's vmcnt(0) at S_E2 waited for them (stamps: 6 k cycles
     // in that k step).  They go out AFTER the poll instead, at the end of the half-step, and have the next half-step up to its
@@ -256,9 +259,9 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
     // vector-memory operations a wave issues between a publication (S_PUB) and its arrival (S_E1): the own-sequence operand
     // requests of k steps S_PUB .. S_E1 - 1 and the x request at S_XSPL -- what the arrival's counted wait leaves in flight
     constexpr int own_lo = S_PUB + NPRE < KH ? S_PUB + NPRE : KH, own_hi = S_E1 + NPRE < KH ? S_E1 + NPRE : KH;
-    constexpr int N_X_AFTER_PUB = X_LATE ? 0 : 2 * KX;
+    constexpr int N_X_AFTER_PUB = (X_LATE || S_XSPL >= S_E1) ? 0 : 2 * KX;      // (S_XSPL == S_E1: the arrival precedes the x requests in its k step)
     constexpr int N_AFTER_PUB = 3 * (own_hi - own_lo) + N_X_AFTER_PUB;
-    static_assert(NST >= 5 && S_E1 < S_E2 && S_E1 > S_PUB && S_XSPL >= KX && (X_LATE ? S_XSPL < S_E2 - RR_POLL_LEAD : S_XSPL < S_E1) &&
+    static_assert(NST >= 5 && S_E1 < S_E2 && S_E1 > S_PUB && S_XSPL >= KX && S_XSPL < S_E2 - RR_POLL_LEAD &&
                   S_XSPL > S_PUB && KH - NPRE <= S_E2, "slice schedule");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     rr_v4u *ULs = reinterpret_cast<rr_v4u *>(smem);                       // [4][KH][2] blocks (not with ULR)

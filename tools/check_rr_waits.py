@@ -14,7 +14,7 @@ def main():
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "rr.s")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-Wno-unused-function",
-                               "--cuda-device-only", "-S", SRC, "-o", out], stderr=subprocess.DEVNULL)
+                               "--cuda-device-only", "-S", SRC, "-o", out] + os.environ.get("RR_EXTRA", "").split(), stderr=subprocess.DEVNULL)
         txt = open(out).read()
     bad = total = 0
     for kname in re.findall(r'^(_Z1[34](?:lstm|gru)_rr_kernel\w+):', txt, re.M):
