@@ -5,7 +5,7 @@ R=$(cd $(dirname $0)/.. && pwd)
 S=$R/gpurun_out/$1; P=$R/profiles/$2
 for w in stack gru conv spectrogram conv_exact stack_exact gru_fused; do [ -s $S/bench_$w.json ] && cp $S/bench_$w.json ${P}_bench_$w.json; done
 for w in stack gru conv spectrogram elementwise lstm_train; do
-  f=$(ls $S/prof_$w/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f ${P}_${w}_kernel_stats.csv
+  f=$(ls -t $S/prof_$w/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f ${P}_${w}_kernel_stats.csv
 done
 for f in pmc_traffic pmc_traffic_gru pmc_traffic_conv pmc_traffic_spectrogram pmc_sq pmc_sq_gru; do [ -s $S/$f.json ] && cp $S/$f.json ${P}_$f.json; done
 [ -s $S/split_error.log ] && cp $S/split_error.log ${P}_split_error.log
