@@ -22,6 +22,7 @@ struct NntkOptions {
     int rec_stream = -1;         // small-batch streaming kernel (0 off)
     int rec_fused2 = -1;         // fused two-layer GRU kernel (0 off)
     int rec_rr = -1;             // register-resident split-bf16 LSTM kernel with the fused input projection (0 off, 1 also for small batches)
+    int train_outer_plain = -1;  // weight-gradient products of plain matrices on the VALU-free MFMA kernel (0: the general one; A/B)
     int train_bptt = -1;         // GRU / LSTM gradient: the whole BPTT loop in one persistent kernel (0: two launches per timestep)
     int spec_ppw = 0;            // frame pairs per wavefront in K1 (0 = auto)
     int spec_variant = -1;       // 1: log-mel as two kernels (K1, then the GEMM) instead of the fused output stage (A/B, tests)

@@ -45,6 +45,7 @@ static const OptDesc g_opt_table[] = {
     {"rec_fused2", "NNTK_REC_FUSED2", &NntkOptions::rec_fused2},
     {"rec_rr", "NNTK_REC_RR", &NntkOptions::rec_rr},
     {"train_bptt", "NNTK_TRAIN_BPTT", &NntkOptions::train_bptt},
+    {"train_outer_plain", "NNTK_TRAIN_OUTER_PLAIN", &NntkOptions::train_outer_plain},
     {"spec_ppw", "NNTK_SPEC_PPW", &NntkOptions::spec_ppw},
     {"spec_variant", "NNTK_SPEC_VARIANT", &NntkOptions::spec_variant},
     {"spec_dma", "NNTK_SPEC_DMA", &NntkOptions::spec_dma},

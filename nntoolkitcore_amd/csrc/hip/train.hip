@@ -684,6 +684,79 @@ __global__ __launch_bounds__(256) void outer_mfma_kernel(const float *__restrict
         }
 }
 
+// The same product for PLAIN row-major operands (rps = rows), with (almost) no vector-ALU instruction in the loop: an f32 MFMA and a
+// VALU instruction never overlap on gfx950, and the general kernel above spends ~25 VALU per row pair on predicates and 64-bit
+// pointer arithmetic (0.39 of the MFMA pipe at LSTM-512's d_U).  Here every load is a buffer load whose per-lane offset never
+// changes: column masks are baked into the offsets (out-of-range = 0), the row advance moves the descriptor's base and shrinks its
+// range on the scalar unit, so rows past the slice's end fall out of range by themselves.  SHIFT (A = h_prev: row (b, t) reads
+// h_{t-1}, zero at t = 0) costs a select per operand and a counter update per row pair.
+template <bool SHIFT>
+__global__ __launch_bounds__(256) void outer_mfma_plain_kernel(const float *__restrict__ A, const float *__restrict__ Bm, float *__restrict__ partial,
+                                                               long rows, int I, int K, int T) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = lane & 31, kk = lane >> 5;
+    const int i0 = blockIdx.y * OUTER_TILE + (wv >> 1) * 64, k0 = blockIdx.x * OUTER_TILE + (wv & 1) * 64;
+    if (i0 >= I || k0 >= K) return;
+    const long r0 = rows * blockIdx.z / gridDim.z, r1 = rows * (blockIdx.z + 1) / gridDim.z;
+    const int OOB = 0x7ffffff0;
+    const int va0 = i0 + c < I ? (kk * I + i0 + c) * 4 : OOB, va1 = i0 + 32 + c < I ? (kk * I + i0 + 32 + c) * 4 : OOB;
+    const int vb0 = k0 + c < K ? (kk * K + k0 + c) * 4 : OOB, vb1 = k0 + 32 + c < K ? (kk * K + k0 + 32 + c) * 4 : OOB;
+    const bool do_bs = blockIdx.y == 0 && (wv >> 1) == 0;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[x][y][v] = 0.f;
+    float bs0 = 0.f, bs1 = 0.f;
+    int tt = SHIFT ? (int)((r0 + kk) % T) : 1;
+    // bases of the slice (A one row earlier with SHIFT: that row is only read where t > 0); the ranges end with the slice
+    const char *abase = reinterpret_cast<const char *>(A + (r0 - (SHIFT ? 1 : 0)) * (long)I);
+    const char *bbase = reinterpret_cast<const char *>(Bm + r0 * (long)K);
+    long aleft = (r1 - r0) * (long)I * 4, bleft = (r1 - r0) * (long)K * 4;
+    const long astep = 2L * I * 4, bstep = 2L * K * 4;
+    for (long rb = r0; rb < r1; rb += 8) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)abase, 0, (int)(aleft > 0 ? (aleft < 0x7fffffffL ? aleft : 0x7fffffffL) : 0), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rbd = __builtin_amdgcn_make_buffer_rsrc((void *)bbase, 0, (int)(bleft > 0 ? (bleft < 0x7fffffffL ? bleft : 0x7fffffffL) : 0), 0x00020000);
+            const bool live = !SHIFT || tt != 0;
+            const float a0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, live ? va0 : OOB, 0, 0));
+            const float a1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, live ? va1 : OOB, 0, 0));
+            const float b0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rbd, vb0, 0, 0));
+            const float b1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rbd, vb1, 0, 0));
+            if (do_bs) { bs0 += b0; bs1 += b1; }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            abase += astep; bbase += bstep; aleft -= astep; bleft -= bstep;
+            if (SHIFT) { tt += 2; if (tt >= T) tt -= T; if (tt >= T) tt -= T; }     // T = 1 needs both
+        }
+    }
+    float *dst = partial + (size_t)blockIdx.z * (I + 1) * K;
+    if (do_bs) {
+        bs0 += __shfl_xor(bs0, 32, 64); bs1 += __shfl_xor(bs1, 32, 64);
+        if (kk == 0) {
+            if (k0 + c < K) dst[(size_t)I * K + k0 + c] = bs0;
+            if (k0 + 32 + c < K) dst[(size_t)I * K + k0 + 32 + c] = bs1;
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int k = k0 + 32 * y + c;
+            if (k >= K) continue;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int i = i0 + 32 * x + 8 * (v >> 2) + 4 * kk + (v & 3);
+                if (i < I) dst[(size_t)i * K + k] = acc[x][y][v];
+            }
+        }
+}
+
 extern "C" size_t nntk_shim_outer_scratch_floats(int I, int K) { return (size_t)OUTER_SLICES * (I + 1) * K; }
 // partial [slices][I + 1][K] (row I: column sums of Bm); returns the number of slices written, 0 when the shape is not taken
 int nntk_outer_mfma_launch(const float *d_A, const float *d_B, float *d_partial, long rows, int I, int K, int a_shift_T,
@@ -695,8 +768,16 @@ int nntk_outer_mfma_launch(const float *d_A, const float *d_B, float *d_partial,
     if (slices > OUTER_SLICES) slices = OUTER_SLICES;
     if ((long)slices > rows / 64) slices = (int)(rows / 64);
     if (slices < 1) slices = 1;
-    hipLaunchKernelGGL(outer_mfma_kernel, dim3((unsigned)tk, (unsigned)ti, (unsigned)slices), dim3(256), 0, nntk_stream(),
-                       d_A, d_B, d_partial, rows, I, K, a_shift_T, rps, seq_pitch, row_pitch);
+    const bool plain = rps >= rows && row_pitch == I && (double)(rows / slices + 2) * (I > K ? I : K) * 4 < 2.0e9 && nntk_options().train_outer_plain != 0;
+    if (plain && a_shift_T > 0)
+        hipLaunchKernelGGL(outer_mfma_plain_kernel<true>, dim3((unsigned)tk, (unsigned)ti, (unsigned)slices), dim3(256), 0, nntk_stream(),
+                           d_A, d_B, d_partial, rows, I, K, a_shift_T);
+    else if (plain)
+        hipLaunchKernelGGL(outer_mfma_plain_kernel<false>, dim3((unsigned)tk, (unsigned)ti, (unsigned)slices), dim3(256), 0, nntk_stream(),
+                           d_A, d_B, d_partial, rows, I, K, 1);
+    else
+        hipLaunchKernelGGL(outer_mfma_kernel, dim3((unsigned)tk, (unsigned)ti, (unsigned)slices), dim3(256), 0, nntk_stream(),
+                           d_A, d_B, d_partial, rows, I, K, a_shift_T, rps, seq_pitch, row_pitch);
     return slices;
 }
 extern "C" int nntk_shim_outer_accumulate(const float *d_A, const float *d_B, float *d_C, float *d_c, float *d_scratch,
