@@ -309,8 +309,9 @@ def test_streaming_last_state_only_and_reset(gpu):
 
 # ---- fused two-layer GRU (BASELINE configs[3]) ----
 
+@pytest.mark.parametrize("mode", ["auto", 1])        # auto: two register-resident launches when both layers qualify (B >= 32); 1: the fused kernel
 @pytest.mark.parametrize("B,I,H,T,seq", [(70, 128, 256, 40, True), (3, 24, 64, 17, True), (130, 16, 128, 9, False), (65, 40, 256, 5, True)])
-def test_fused_two_layer_gru_matches_two_calls_and_oracle(gpu, B, I, H, T, seq):
+def test_fused_two_layer_gru_matches_two_calls_and_oracle(gpu, B, I, H, T, seq, mode):
     """GRUStack2ApplyDevice: both layers in ONE persistent launch, layer 2 one step behind.  Against the oracle, and
     against the two single-layer calls: equal within the layer tolerance (layer 2's input projection is summed in the
     MFMA's k order instead of the GEMM kernel's), and the fused form itself is reproducible and shard-independent."""
@@ -322,22 +323,28 @@ def test_fused_two_layer_gru_matches_two_calls_and_oracle(gpu, B, I, H, T, seq):
     g1, g2 = NL.GRU(I, H, True, T), NL.GRU(H, H, seq, T)
     g1.set_weights(W1, U1, bi1, bh1); g2.set_weights(W2, U2, bi2, bh2)
     ref = O.gru(O.gru(x, W1, U1, bi1, bh1), W2, U2, bi2, bh2, return_sequences=seq)
+    capi.set_option("rec_fused2", mode)
     fused = NL.gru_stack2_apply(g1, g2, x)
+    if mode == 1:
+        assert capi.load().nntk_hip_last_recurrent_kernel().decode().startswith("gru2_persistent_kernel")
     capi.set_option("rec_fused2", 0)
     two = NL.gru_stack2_apply(g1, g2, x)                       # falls back to the two calls
-    capi.set_option("rec_fused2", "auto")
+    capi.set_option("rec_fused2", mode)
     e_f, e_t, e_ft = float(np.abs(fused - ref).max()), float(np.abs(two - ref).max()), float(np.abs(fused - two).max())
     print("fused GRU stack B=%d H=%d T=%d: vs oracle %.2e (two calls %.2e), fused vs two calls %.2e" % (B, H, T, e_f, e_t, e_ft))
     assert e_f < 1e-5 and e_t < 1e-5 and e_ft < 5e-6
     xd = torch.from_numpy(x).cuda()
     a = NL.gru_stack2_apply_device(g1, g2, xd).cpu().numpy()
     assert np.array_equal(a, fused)                            # reproducible
-    lo = NL.gru_stack2_apply_device(g1, g2, xd[: B // 2 + 1].contiguous()).cpu().numpy()
-    assert np.array_equal(lo, fused[: B // 2 + 1])             # a shard gives the same bits as the whole batch
+    if mode == 1 or B // 2 + 1 >= 32 or B < 32:                # (auto: a shard below 32 sequences leaves the register-resident kernels)
+        lo = NL.gru_stack2_apply_device(g1, g2, xd[: B // 2 + 1].contiguous()).cpu().numpy()
+        assert np.array_equal(lo, fused[: B // 2 + 1])         # a shard gives the same bits as the whole batch
+    capi.set_option("rec_fused2", "auto")
     g1.destroy(); g2.destroy()
 
 
-def test_fused_two_layer_gru_several_launches_and_ragged_batch(gpu):
+@pytest.mark.parametrize("mode", ["auto", 1])
+def test_fused_two_layer_gru_several_launches_and_ragged_batch(gpu, mode):
     """B = 1100 at H = 256: 18 batch tiles of 64 rows (the last one holds 12) x 16 column tiles = 288 workgroups > 256
     CUs, so the call is TWO persistent launches (16 + 2 batch tiles) sharing one counter / hand-off area -- against the
     oracle on rows of both launches and of the ragged tile, and bit-identical to the same rows run as smaller batches."""
@@ -350,6 +357,7 @@ def test_fused_two_layer_gru_several_launches_and_ragged_batch(gpu):
     g1, g2 = NL.GRU(I, H, True, T), NL.GRU(H, H, True, T)
     g1.set_weights(W1, U1, bi1, bh1); g2.set_weights(W2, U2, bi2, bh2)
     xd = torch.from_numpy(x).cuda()
+    capi.set_option("rec_fused2", mode)
     y = NL.gru_stack2_apply_device(g1, g2, xd)
     assert capi.load().nntk_hip_device_status() == 0
     rows = [0, 63, 64, 1023, 1024, 1087, 1088, 1099]
@@ -359,6 +367,7 @@ def test_fused_two_layer_gru_several_launches_and_ragged_batch(gpu):
     np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
     tail = NL.gru_stack2_apply_device(g1, g2, xd[1000:].contiguous())           # rows 1000..1099 as their own batch
     assert torch.equal(tail, y[1000:])
+    capi.set_option("rec_fused2", "auto")
     g1.destroy(); g2.destroy()
 
 
