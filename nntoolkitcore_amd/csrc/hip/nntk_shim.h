@@ -185,7 +185,7 @@ int nntk_shim_lstm_rr_pack_raw(const float *d_U /*[H][4H]*/, const float *d_W /*
 /* training forward on the same kernel (zero initial state): h [B][T][H] and the BPTT caches c [B][T][H], zifgo [B][T][8H] */
 /* GRU on the same kernels (gru_rr_kernel): image from the four-slot matrices, d_b4 [4H]; see recurrent_rr.hip */
 int nntk_shim_gru_rr(const float *d_x, const float *d_img, const float *d_b4, const float *d_h0, float *d_out, float *d_hT,
-                     float *d_work, int B, int T, int in, int H, int return_sequences);
+                     float *d_work, int B, int T, int in, int H, int return_sequences, int x_tm, int out_tm);
 int nntk_shim_gru_rr_train_forward(const float *d_x, const float *d_img, const float *d_b4, float *d_h, float *d_hU, float *d_Zg,
                                    float *d_work, int B, int T, int in, int H);
 int nntk_shim_lstm_rr_train_forward(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,

@@ -165,6 +165,7 @@ struct RRParams {
     float *cT, *hT;            // [B][H] or NULL
     float *out;                // [B][T][H] or [B][H]
     unsigned *flags;           // [NBT][2 halves][RR_FLAGS], zeroed before the launch
+    int x_tm, out_tm;          // x / the sequence output in time-major layout ([T][B][.]: the tensor between two stacked layers)
     float *c_cache;            // training forward (TRAIN): cell state of every step [B][T][H] ...
     float *z_cache;            // ... and pre-activations | activations [B][T][8H] (lstm.c:426-475 keeps them for BPTT)
     unsigned *fault;
@@ -329,10 +330,16 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void *)p.hb, 0, hb_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.hb + p.hb_parity_bytes), 0, hb_bytes, 0x00020000);
     const int lane16 = lane * 16;
-    // x: the tile's rows [b0, b0 + rows_valid) of [B][T][in]; rows past the batch are out of range (zeros)
-    const long x_row_bytes = (long)p.T * p.in * 4;
-    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + (size_t)b0 * p.T * p.in), 0,
-                                                                          (int)(rows_valid * x_row_bytes), 0x00020000);
+    // x: the tile's rows [b0, b0 + rows_valid) of [B][T][in] -- or of the time-major [T][B][in] a stacked layer hands over
+    // (p.x_tm: a row's timesteps are then B * in apart and the tile's 32 rows of one step are contiguous: coalesced requests).
+    // Rows past the batch are masked PER LANE AND HALF (xok): the half rides in the scalar offset, which the range check does
+    // not see, so the descriptor's range alone would let half 1 read up to 32 rows past the end of the tensor.
+    const long x_row_bytes = p.x_tm ? (long)p.in * 4 : (long)p.T * p.in * 4;
+    const long x_step_bytes = p.x_tm ? (long)p.B * p.in * 4 : (long)p.in * 4;
+    const long x_range = p.x_tm ? (long)(T - 1) * x_step_bytes + rows_valid * x_row_bytes : rows_valid * x_row_bytes;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + (size_t)b0 * (x_row_bytes / 4)), 0,
+                                                                          (int)(x_range < 0x7fffffffL ? x_range : 0x7fffffffL), 0x00020000);
+    const bool xok0 = n < rows_valid, xok1 = 32 + n < rows_valid;
     int xvo[KX][2];
 #pragma unroll
     for (int ix = 0; ix < KX; ++ix)
@@ -344,11 +351,15 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
     // publication: lane (n, kh) of the publishing wave owns hidden units 8 kh .. 8 kh + 7 of row n -- one B fragment of the
     // consumers; output rows past the batch fall outside the descriptor; hand-off rows past the batch are written too
     // (padding rows compute on zero inputs: finite, read only by themselves)
-    const long o_row_bytes = (long)(p.return_sequences ? p.T : 1) * H * 4;
+    // (p.out_tm: the sequence output goes out time-major, [T][B][H], for the next layer of a stack -- rows are then masked per lane)
+    const long o_row_bytes = p.out_tm ? (long)H * 4 : (long)(p.return_sequences ? p.T : 1) * H * 4;
+    const long o_step_bytes = p.out_tm ? (long)p.B * H * 4 : (long)H * 4;
+    const long o_range = p.out_tm ? (long)(T - 1) * o_step_bytes + rows_valid * o_row_bytes : rows_valid * o_row_bytes;
     const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(p.out + (size_t)b0 * (p.return_sequences ? p.T : 1) * H), 0, (int)(rows_valid * o_row_bytes), 0x00020000);
+        (void *)(p.out + (size_t)b0 * (o_row_bytes / 4)), 0, (int)(o_range < 0x7fffffffL ? o_range : 0x7fffffffL), 0x00020000);
     const int out_vo = (int)(n * o_row_bytes) + (16 * ct + 8 * kh) * 4;
     const int out_half = (int)(32 * o_row_bytes);
+    const int out_step = (int)o_step_bytes;
     RR_BARRIER();
 
     using I0 = std::integral_constant<int, 0>;
@@ -377,11 +388,12 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
         }
     };
     auto issue_x = [&](int half, int t) __attribute__((always_inline)) {
-        const int so = (int)((half * 32) * x_row_bytes) + t * p.in * 4;
+        const int so = (int)((half * 32) * x_row_bytes) + t * (int)x_step_bytes;
+        const bool ok = half ? xok1 : xok0;
 #pragma unroll
         for (int ix = 0; ix < KX; ++ix)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) xr[ix][q] = __builtin_amdgcn_raw_buffer_load_b128(rsx, xvo[ix][q], so, 0);
+            for (int q = 0; q < 2; ++q) xr[ix][q] = __builtin_amdgcn_raw_buffer_load_b128(rsx, ok ? xvo[ix][q] : RR_OOB, so, 0);
     };
     auto split_x = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -500,7 +512,7 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
             const rr_v4u o0 = *reinterpret_cast<const rr_v4u *>(hx + n * RR_HX_LD + 8 * kh);
             const rr_v4u o1 = *reinterpret_cast<const rr_v4u *>(hx + n * RR_HX_LD + 8 * kh + 4);
             if (p.return_sequences && !RR_DBG(1024)) {
-                const int vo = out_vo + half * out_half + t * H * 4;       // soffset immediate, as above
+                const int vo = (half ? xok1 : xok0) ? out_vo + half * out_half + t * out_step : RR_OOB;       // soffset immediate, as above
                 __builtin_amdgcn_raw_buffer_store_b128(o0, rso, vo, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(o1, rso, vo + 16, 0, 0);
             }
@@ -766,7 +778,8 @@ extern "C" int nntk_shim_lstm_rr_pack_raw(const float *d_U, const float *d_W, fl
 // 0 = launched; 1 = shape / configuration not taken (the caller runs projection GEMM + rec_persistent_kernel); -1 = error
 static int lstm_rr_launch(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,
                           const float *d_h0, const float *d_c0, float *d_out, float *d_hT, float *d_cT,
-                          float *d_work, int B, int T, int in, int H, int return_sequences, float *d_c_cache, float *d_z_cache, int cell);
+                          float *d_work, int B, int T, int in, int H, int return_sequences, float *d_c_cache, float *d_z_cache, int cell,
+                          int x_tm = 0, int out_tm = 0);
 
 extern "C" int nntk_shim_lstm_rr(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,
                                  const float *d_h0, const float *d_c0, float *d_out, float *d_hT, float *d_cT,
@@ -775,9 +788,12 @@ extern "C" int nntk_shim_lstm_rr(const float *d_x, const float *d_img, const flo
 }
 // GRU on the same kernel frame (gru_rr_kernel): d_img packed from the four-slot matrices [U_z | U_r | U_h | 0] / [W_z | W_r | 0 | W_h],
 // d_b4 [4H] = b_i,z + b_h,z | b_i,r + b_h,r | b_h,h | b_i,h.  The f32 state register starts from h_0 (which is also the published operand).
+// x_tm / out_tm: d_x is [T][B][in] / the sequence output is written as [T][B][H] (the tensor between two stacked layers: a tile's 32 rows of
+// one timestep are then contiguous, and the consumer's x requests are coalesced -- GRUStack2ApplyDevice)
 extern "C" int nntk_shim_gru_rr(const float *d_x, const float *d_img, const float *d_b4, const float *d_h0, float *d_out, float *d_hT,
-                                float *d_work, int B, int T, int in, int H, int return_sequences) {
-    return lstm_rr_launch(d_x, d_img, d_b4, nullptr, d_h0, d_h0, d_out, d_hT, nullptr, d_work, B, T, in, H, return_sequences, nullptr, nullptr, 1);
+                                float *d_work, int B, int T, int in, int H, int return_sequences, int x_tm, int out_tm) {
+    return lstm_rr_launch(d_x, d_img, d_b4, nullptr, d_h0, d_h0, d_out, d_hT, nullptr, d_work, B, T, in, H, return_sequences, nullptr, nullptr, 1,
+                          x_tm, out_tm);
 }
 // GRU training forward: zero initial state, h of every step to d_h [B][T][H], caches d_hU [B][T][H] (h.U_h + b_h) and d_Zg [B][T][6H]
 extern "C" int nntk_shim_gru_rr_train_forward(const float *d_x, const float *d_img, const float *d_b4, float *d_h, float *d_hU, float *d_Zg,
@@ -792,8 +808,12 @@ extern "C" int nntk_shim_lstm_rr_train_forward(const float *d_x, const float *d_
 
 static int lstm_rr_launch(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,
                           const float *d_h0, const float *d_c0, float *d_out, float *d_hT, float *d_cT,
-                          float *d_work, int B, int T, int in, int H, int return_sequences, float *d_c_cache, float *d_z_cache, int cell) {
+                          float *d_work, int B, int T, int in, int H, int return_sequences, float *d_c_cache, float *d_z_cache, int cell,
+                          int x_tm, int out_tm) {
     if (B <= 0 || T <= 0) return 0;
+    // time-major tensors are addressed across the whole batch with 32-bit buffer offsets
+    if (x_tm && (double)T * B * in * 4 >= 2.0e9) return 1;
+    if (out_tm && (!return_sequences || (double)T * B * H * 4 >= 2.0e9)) return 1;
     const NntkOptions &opt = nntk_options();
     if (opt.rec_rr == 0 || opt.rec_persistent == 0 || nntk_persistent_disabled()) return 1;
     int KH, KX;
@@ -840,6 +860,7 @@ static int lstm_rr_launch(const float *d_x, const float *d_img, const float *d_b
     q.hb = (char *)d_work; q.hb_parity_bytes = parity;
     q.c0 = d_c0; q.cT = d_cT; q.hT = d_hT; q.out = d_out;
     q.c_cache = d_c_cache; q.z_cache = d_z_cache;
+    q.x_tm = x_tm; q.out_tm = out_tm;
     q.fault = fault;
     q.spin_ticks = (unsigned long long)(opt.rec_spin_us > 0 ? opt.rec_spin_us : 0) * 100ull;
     q.B = B; q.T = T; q.H = H; q.in = in; q.NCT = NCT; q.return_sequences = return_sequences;

@@ -226,7 +226,7 @@ static int gru_rr_build_image(int in, int H, const float *W, const float *U, con
     free(tmp);                                              /* (nntk_shim_upload has copied it) */
     return rc ? -1 : 0;
 }
-static int core_try_gru_rr(rec_core *c, const int *acts, const float *d_in, float *d_out, int B, int stateful) {
+static int core_try_gru_rr(rec_core *c, const int *acts, const float *d_in, float *d_out, int B, int stateful, int x_tm, int out_tm) {
     int on = -1;
     (void)nntk_shim_get_option("rec_rr", &on);
     if (on == 0 || c->G != 3 || !gru_std_acts(acts)) return 1;
@@ -242,7 +242,7 @@ static int core_try_gru_rr(rec_core *c, const int *acts, const float *d_in, floa
     if (!d_work) return -1;
     const float *h0 = stateful ? c->d_h[c->cur] : NULL;
     float *hT = stateful ? c->d_h[c->cur ^ 1] : NULL;
-    return nntk_shim_gru_rr(d_in, c->d_rr, c->d_b4, h0, d_out, hT, d_work, B, c->T, in, H, c->return_sequences);
+    return nntk_shim_gru_rr(d_in, c->d_rr, c->d_b4, h0, d_out, hT, d_work, B, c->T, in, H, c->return_sequences, x_tm, out_tm);
 }
 
 /* stateful != 0: continue from / store into the handle's state (B must be 1) */
@@ -255,7 +255,7 @@ static int core_apply_device(rec_core *c, int is_lstm, int use_bh, const int *ac
         if (rc <= 0) return rc;
     }
     if (!is_lstm && G == 3) {
-        int rc = core_try_gru_rr(c, acts, d_in, d_out, B, stateful);
+        int rc = core_try_gru_rr(c, acts, d_in, d_out, B, stateful, 0, 0);
         if (rc <= 0) return rc;
     }
     float *d_xw = nntk_devbuf_reserve(&c->d_xw, (size_t)T * B * G * H);
@@ -699,6 +699,20 @@ int GRUStack2ApplyDevice(GRU l1, GRU l2, const float *d_input, float *d_output, 
     /* not taken by the fused kernel: the two layers one after the other, through a scratch inter-layer tensor */
     float *d_mid = nntk_devbuf_reserve(&c1->d_out, (size_t)B * T * H);
     if (!d_mid) return -1;
+    if (rr_pair) {
+        /* the inter-layer tensor TIME-MAJOR ([T][B][H]): layer 2's x requests then touch 32 contiguous rows instead of 32 rows 1 MB apart
+         * (they sat on its hand-off chain: DESIGN K4b); same arithmetic, same bits as the two layer calls */
+        int a1[3], a2[3];
+        float s1[3], s2[3];
+        if (gru_acts(l1, a1, s1) || gru_acts(l2, a2, s2)) return -1;
+        int rc = core_try_gru_rr(c1, a1, d_input, d_mid, B, 0, 0, 1);
+        if (rc < 0) return -1;
+        if (rc == 0) {
+            rc = core_try_gru_rr(c2, a2, d_mid, d_output, B, 0, 1, 0);
+            if (rc <= 0) return rc;
+            /* layer 2 not taken after all (cannot happen for a pair that qualified): redo layer 1 in the batch-major layout below */
+        }
+    }
     if (GRUApplyDevice(l1, d_input, d_mid, batch)) return -1;
     return GRUApplyDevice(l2, d_mid, d_output, batch);
 }
