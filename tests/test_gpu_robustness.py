@@ -422,11 +422,11 @@ def test_conv1d_training_forward_and_gradient(gpu, B, T, Cin, Cout, k, s):
     xt, Wt = torch.tensor(x).double().requires_grad_(True), torch.tensor(W).double().requires_grad_(True)
     bt = torch.zeros(Cout).double().requires_grad_(True)
     F.conv1d(xt.transpose(1, 2), Wt, bt, stride=s).transpose(1, 2)[:, :Tout].backward(torch.tensor(dout).double())
-    tol = 3e-6 * np.sqrt(B * Tout)
+    tol = 1.5e-7 * np.sqrt(B * Tout)                     # measured on MI355X: <= 3.6e-8 x sqrt(B Tout) x scale; bound = that x 4
     for name, got, ora, t64 in (("dW", gw, dW, Wt.grad.numpy()), ("db", gb, db, bt.grad.numpy()), ("dX", gx, dX, xt.grad.numpy())):
         sc = max(1.0, float(np.abs(t64).max()))
         e_o, e_t = float(np.abs(got - ora).max()), float(np.abs(got - t64).max())
-        print("conv grad %s (%d,%d,%d,%d,%d,%d): vs oracle %.2e, vs torch float64 %.2e" % (name, B, T, Cin, Cout, k, s, e_o, e_t))
+        print("conv grad %s (%d,%d,%d,%d,%d,%d): vs oracle %.2e, vs torch float64 %.2e (scale %.1f)" % (name, B, T, Cin, Cout, k, s, e_o, e_t, sc))
         assert e_o <= tol * sc and e_t <= tol * sc
     # a second call accumulates d_W / d_b and rewrites d_X
     L.Conv1dCalculateGradient(h, g, dout.ctypes.data_as(capi.fp))

@@ -106,12 +106,12 @@ def test_dense_training_forward_and_gradient(gpu, B, n_in, n_out, act, v):
         at = {None: zt, "sigmoid": torch.sigmoid(zt), "tanh": torch.tanh(zt), "softmax": torch.softmax(zt, 1)}[act]
         at.backward(torch.tensor(dout).double())
         refs.append(("torch float64", Wt.grad.numpy(), bt.grad.numpy(), xt.grad.numpy()))
-    tol = 4e-6 * np.sqrt(max(B, n_out))
+    tol = 2e-7 * np.sqrt(max(B, n_out))                  # measured on MI355X: <= 6.1e-8 x sqrt(max(B, n_out)) x scale; bound = that x 3.3
     for nm, rW, rb, rX in refs:
         for part, got, ref in (("dW", gW, rW), ("db", gb, rb), ("dX", gX, rX)):
             sc = max(1.0, float(np.abs(ref).max()))
             err = float(np.abs(got - ref).max())
-            print("dense grad %s vs %s (%d,%d,%d,%s): %.2e" % (part, nm, B, n_in, n_out, act, err))
+            print("dense grad %s vs %s (%d,%d,%d,%s): %.2e (scale %.1f)" % (part, nm, B, n_in, n_out, act, err, sc))
             assert err <= tol * sc, (part, nm, err)
     # a second call accumulates d_W / d_b onto the block and rewrites d_X
     L.DenseCalculateGradient(h, g, P(dout))
@@ -310,7 +310,7 @@ def test_gru_training_forward_and_bptt(gpu, B, T, n_in, H, seq, acts):
         hh = torch.stack(outs, 1)
         (hh if seq else hh[:, -1]).backward(torch.tensor(dout).double())
         refs.append(("torch float64", tuple(t_.grad.numpy() for t_ in (Wt, Ut, bit, bht, xt))))
-    tol = 5e-6 * np.sqrt(B * T)
+    tol = 2e-7 * np.sqrt(B * T)                          # measured on MI355X: <= 5.0e-8 x sqrt(B T) x scale (oracle), 3.8e-8 (torch float64); x 4
     for nm, ref in refs:
         for part, a, b_ in zip(("dW", "dU", "dbi", "dbh", "dX"), got, ref):
             sc = max(1.0, float(np.abs(b_).max()))
@@ -388,7 +388,7 @@ def test_lstm_training_forward_and_bptt(gpu, B, T, n_in, H, seq, v2, acts):
         (hh if seq else hh[:, -1]).backward(torch.tensor(dout).double())
         # without v2 the forward never reads b_h, but the reference still reports d_b_h = dgates (lstm.c:415)
         refs.append(("torch float64", (Wt.grad.numpy(), Ut.grad.numpy(), bit.grad.numpy(), bht.grad.numpy() if v2 else bit.grad.numpy(), xt.grad.numpy())))
-    tol = 5e-6 * np.sqrt(B * T)
+    tol = 2e-7 * np.sqrt(B * T)                          # measured on MI355X: <= 4.6e-8 x sqrt(B T) x scale (oracle), 3.8e-8 (torch float64); x 4
     for nm, ref in refs:
         for part, a, b_ in zip(("dW", "dU", "dbi", "dbh", "dX"), got, ref):
             sc = max(1.0, float(np.abs(b_).max()))
@@ -524,11 +524,12 @@ def test_rnn_training_forward_and_bptt(gpu, B, T, n_in, H, seq, v2, act):
         hh = torch.stack(outs, 1)
         (hh if seq else hh[:, -1]).backward(torch.tensor(dout).double())
         refs.append(("torch float64", (Wt.grad.numpy(), Ut.grad.numpy(), bit.grad.numpy(), bht.grad.numpy() if v2 else bit.grad.numpy(), xt.grad.numpy())))
-    tol = 5e-6 * np.sqrt(B * T)
+    tol = 2e-7 * np.sqrt(B * T)                          # measured on MI355X: <= 4.1e-8 x sqrt(B T) x scale; x 4
     for nm, ref in refs:
         for part, a, b_ in zip(("dW", "dU", "dbi", "dbh", "dX"), got, ref):
             sc = max(1.0, float(np.abs(b_).max()))
             err = float(np.abs(a - b_).max())
+            print("rnn grad %s vs %s (%d,%d,%d,%d): %.2e (scale %.1f)" % (part, nm, B, T, n_in, H, err, sc))
             assert err <= tol * sc, (part, nm, err)
     hi = L.RNNCreateForInference(cfg)
     assert L.RNNApplyTrainingBatch(hi, P(x), P(y)) == -1
