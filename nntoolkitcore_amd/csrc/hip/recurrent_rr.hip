@@ -512,7 +512,7 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
             const rr_v4u o0 = *reinterpret_cast<const rr_v4u *>(hx + n * RR_HX_LD + 8 * kh);
             const rr_v4u o1 = *reinterpret_cast<const rr_v4u *>(hx + n * RR_HX_LD + 8 * kh + 4);
             if (p.return_sequences && !RR_DBG(1024)) {
-                const int vo = (half ? xok1 : xok0) ? out_vo + half * out_half + t * out_step : RR_OOB;       // soffset immediate, as above
+                const int vo = (half ? xok1 : xok0) ? out_vo + half * out_half + t * out_step : 0x7fff0000;   // (past every range, room for + 16); soffset immediate, as above
                 __builtin_amdgcn_raw_buffer_store_b128(o0, rso, vo, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(o1, rso, vo + 16, 0, 0);
             }

@@ -966,7 +966,7 @@ __global__ __launch_bounds__(256) void bptt_persistent_kernel(BpttParams p) {
         __syncthreads();
         if (s_stop) return;                                      // uniform: every wave of the workgroup leaves
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const int ao = a_live ? ((n * T + t) * K + k0 + 4 * q) * 4 : 0x7ffffff0;      // out of range: the load returns 0
+        const int ao = a_live ? ((n * T + t) * K + k0 + 4 * q) * 4 : 0x7fff0000;      // out of range (the tile is < 2e9 bytes): the load returns 0; room for + kbi * 64
         // all of the wave's operand loads are requested before the first MFMA: one memory round trip per step, not one per
         // batch of loads (the rows were written through moments ago, so every load goes out to memory)
         bp_v4u a[NB];
