@@ -251,8 +251,10 @@ def pmc_traffic(kernel_prefix, B):
     value -- returned ONLY when the profile is stamped with the hash of the sources this library was built from
     and the same utterances per GPU; otherwise (None, why)."""
     import glob
-    from nntoolkitcore_amd._build import source_hash
-    want = source_hash()
+    from nntoolkitcore_amd import capi
+    # the hash the LOADED library carries (embedded at build time), not the source tree's: a stale .so must not borrow a
+    # newer profile's counters
+    want = (capi.load().nntk_build_source_hash() or b"").decode()
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
         try:
             d = json.load(open(path))

@@ -8,7 +8,7 @@
  * convention), so an application that includes the reference headers links
  * against libnntoolkitcore_hip.so unchanged.  Each block cites the reference
  * header it replaces.  The struct layouts are checked against the reference's
- * real headers by tests/test_abi.py (golden: tests/golden/ref_probe.json).
+ * real headers by tests/test_abi_and_symbols.py (golden: tests/golden/ref_probe.json).
  *
  * PART 2 is ADDITIVE: batched [batch, time, feature] entry points, device-pointer
  * variants (so a stack chains on the GPU without host round trips), fused
@@ -98,7 +98,9 @@ ConvGradient *Conv1dCreateGradient(Conv1dConfig config, ConvTrainingConfig train
 void ConvGradientDestroy(ConvGradient *gradient);
 int  Conv1dApplyTrainingBatch(Conv1d filter, const float *input /*[mini_batch,T,Cin]*/, float *output);   /* -1 on an inference handle */
 void Conv1dCalculateGradient(Conv1d filter, ConvGradient *gradient, const float *d_out /*[mini_batch,Tout,Cout]*/);
-/* Additive device-pointer forms (tensors stay in HBM, asynchronous on the calling thread's stream; same kernels, same bits):
+/* Additive device-pointer forms (tensors stay in HBM; enqueued on the calling thread's stream, but NOT asynchronous: each call
+ * uploads the current weight block and waits for that copy, so it returns with the stream drained up to the upload; kernel-side
+ * faults surface through nntk_hip_synchronize() / nntk_hip_device_status(); same kernels, same bits):
  * d_input must stay valid until the gradient call; d_grad_Wb = W [Cout][Cin][k] | b [Cout] is ADDED to, d_dX overwritten. */
 int  Conv1dApplyTrainingBatchDevice(Conv1d filter, const float *d_input /*[mini_batch,T,Cin]*/, float *d_output);
 int  Conv1dCalculateGradientDevice(Conv1d filter, float *d_grad_Wb, float *d_dX, const float *d_dout);
@@ -172,7 +174,8 @@ GRU  GRUCreateForTraining(GRUConfig config, GRUTrainingConfig training_config);
 GRUGradient *GRUGradientCreate(GRUConfig config, GRUTrainingConfig training_config);
 int  GRUApplyTrainingBatch(GRU filter, const float *input, float *output);      /* -1 on an inference-mode handle (gru.c:247) */
 void GRUCalculateGradient(GRU filter, GRUGradient *gradients, float *d_out);
-/* Additive device-pointer forms (tensors stay in HBM, asynchronous on the calling thread's stream): d_input [B][T][in] must
+/* Additive device-pointer forms (tensors stay in HBM; enqueued on the calling thread's stream -- each call synchronises the stream
+ * once for its weight upload, see Conv1dApplyTrainingBatchDevice; poll nntk_hip_device_status() for faults): d_input [B][T][in] must
  * stay valid until the gradient call; d_grad = W [in][3H] | U [H][3H] | b_i [3H] | b_h [3H] (the layout of the gradient block)
  * is ADDED to, d_dX [B][T][in] is overwritten.  Same kernels as the host-pointer forms: bit-identical results. */
 int  GRUApplyTrainingBatchDevice(GRU filter, const float *d_input, float *d_output);
@@ -384,6 +387,7 @@ int         nntk_hip_synchronize(void);               /* waits for the calling t
                                                          launch faulted since the last check (see below) */
 const char *nntk_last_error(void);                    /* "" when the last call succeeded */
 const char *nntk_version(void);
+const char *nntk_build_source_hash(void);        /* sha256/16 of the sources THIS binary was built from (nntoolkitcore_amd/_build.py) */
 /* Threading (as the reference: distinct handles are independent, a handle is not re-entrant -- conv_1d.c:41,
  * gru.c:86, lstm.c:97): the current stream and the error string are per host thread; two threads may drive two
  * handles on two streams at the same time.  One handle is used by one thread and on one stream at a time

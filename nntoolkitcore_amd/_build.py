@@ -73,6 +73,16 @@ def build(force=False, verbose=False):
             jobs.append([HIPCC, "-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-Wall",
                          "-Wno-unused-function"] + os.environ.get("NNTK_EXTRA_HIPFLAGS", "").split() +
                         ["-c", src, "-o", obj])
+    # the identity of the sources this library is built from, embedded so that a consumer (bench.py's roofline.traffic gate) asks the
+    # LOADED binary, not the source tree: a stale .so next to edited sources must not borrow the new sources' profile
+    bid_src = os.path.join(OBJ, "build_id.c")
+    bid_obj = os.path.join(OBJ, "build_id.c.o")
+    bid_txt = 'const char *nntk_build_source_hash(void) { return "%s"; }\n' % source_hash()
+    objs.append(bid_obj)
+    if force or not os.path.exists(bid_src) or open(bid_src).read() != bid_txt or not os.path.exists(bid_obj):
+        with open(bid_src, "w") as fh:
+            fh.write(bid_txt)
+        jobs.append(["gcc", "-O2", "-fPIC", "-fvisibility=default", "-c", bid_src, "-o", bid_obj])
     if jobs:
         # the translation units are independent: compile them side by side (the two conv1d units take minutes each)
         from concurrent.futures import ThreadPoolExecutor

@@ -283,6 +283,7 @@ SIGNATURES = {
     "nntk_hip_synchronize": (C.c_int, []),
     "nntk_last_error": (C.c_char_p, []),
     "nntk_version": (C.c_char_p, []),
+    "nntk_build_source_hash": (C.c_char_p, []),
     "nntk_hip_set_option": (C.c_int, [C.c_char_p, C.c_char_p]),
     "nntk_hip_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "nntk_hip_device_status": (C.c_int, []),

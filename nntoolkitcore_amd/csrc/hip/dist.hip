@@ -105,7 +105,9 @@ int nntk_shim_dist_broadcast_host(float *block, size_t n, int root) {
 // Data-parallel training ("where gradient all-reduce over xGMI would first appear"): in-place SUM of a gradient
 // block over the ranks.  Device form: asynchronous on the calling thread's stream -- a caller overlaps one layer's all-reduce
 // with the next layer's backward pass by issuing them from two threads / streams (nntk_hip_set_stream); the device-pointer
-// gradient calls (<Layer>CalculateGradientDevice) leave their blocks in HBM for exactly this.  Host form: staged and blocking.
+// gradient calls (<Layer>CalculateGradientDevice) leave their blocks in HBM for exactly this (note that those calls themselves
+// synchronise their stream once per call for the weight upload -- nntoolkitcore_hip.h -- so the overlap is between two host threads
+// on two streams, not inside one stream).  Host form: staged and blocking.
 // Without a communicator both are no-ops (world size 1: the sum over one rank).
 int nntk_shim_dist_allreduce_device(float *d_block, size_t n) {
     std::lock_guard<std::mutex> lk(g_mutex);

@@ -42,6 +42,7 @@ typedef struct {
     float *d_wp, *d_bi, *d_ut, *d_bh;
     float *d_wt;                /* W^T packed like U^T (only when in == H): layer-2 operand of the fused two-layer GRU */
     int wt_valid;
+    int rr_exact_only;          /* W or U holds a value the bf16 split cannot represent (non-finite, > 3.39e38, denormal): exact kernels only */
     float *d_rr;                /* LSTM: weight images of the register-resident split-bf16 kernel (recurrent_rr.hip), made on first use */
     int rr_valid;
     float *d_b4, *d_b4_train;   /* GRU on those kernels: the four-slot bias vector (core_try_gru_rr; the training forward's copy) */
@@ -60,6 +61,21 @@ typedef struct {
     unsigned seq;
     nntk_devbuf d_in, d_out, d_xw, d_work, d_work_rr, d_rr_stage;
 } rec_core;
+
+/* 1 if the block holds a value the split-bf16 x 3 contraction cannot represent exactly: non-finite, above bf16's largest finite
+ * value (bf16(x) = inf, and inf - inf = NaN in the split), or denormal (the bf16 MFMA flushes it).  The reference's f32 chain
+ * (core/default_ops.cc:224-231) saturates or carries such values; the register-resident kernels would turn them into NaN, so a
+ * flagged block keeps the exact-f32 kernels -- the same rule conv / dense / mel weights follow (runtime.c).  Branch-free so that
+ * gcc vectorises it: the training forwards run it on every mini-batch. */
+__attribute__((optimize("O3"))) static int rr_unsplittable(const float *v, size_t n) {
+    const unsigned *u = (const unsigned *)v;
+    unsigned bad = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const unsigned a = u[i] & 0x7fffffffu;
+        bad |= (unsigned)(a > 0x7f7f0000u) | (unsigned)(a - 1u < 0x007fffffu);
+    }
+    return bad != 0;
+}
 
 static int core_init(rec_core *c, int G, RecurrentConfig base) {
     memset(c, 0, sizeof(*c));
@@ -118,6 +134,7 @@ static int core_upload(rec_core *c) {
     if (rc) return rc;
     c->wt_valid = 0;
     c->rr_valid = 0;
+    c->rr_exact_only = rr_unsplittable(c->weights->W, (size_t)c->in * G * H + (size_t)H * G * H);      /* W | U are contiguous */
     nntk_wblock_mark_uploaded(&c->wb);
     return 0;
 }
@@ -159,10 +176,14 @@ static int core_broadcast(rec_core *c, int root) {
     return core_upload(c);
 }
 
-/* LSTM batches of at least this many sequences take the register-resident split-bf16 kernel (recurrent_rr.hip: x W fused
- * into the step, no [T, B, 4H] tensor); smaller ones are latency-bound on the hand-off chain, where the exact-f32
- * kernel -- whose chain the streaming path reproduces bit for bit -- is as fast.  Option rec_rr = 1 takes it always. */
-#define NNTK_RR_MIN_BATCH 32
+/* Which recurrent kernel a call takes depends on the layer's SHAPE, its activations and the FORM of the call -- never on the
+ * number of sequences in it: a row's bits must not change with the batch (or shard) it arrives in (round 3 had a
+ * B >= 32 threshold here, which made a 130-utterance batch sharded over 8 GPUs differ from the single-GPU run).
+ *   zero-state batch forms ([B, T, in]: *ApplyInferenceBatch, *ApplyDevice, GRUStack2Apply*, the training forwards), qualifying
+ *     shape, standard activations, splittable weights  ->  the register-resident split-bf16 kernels (recurrent_rr.hip), any B;
+ *   the reference's stateful single-sequence call (*ApplyInference: carried h / c)  ->  the exact-f32 kernels, whose chain the
+ *     streaming kernel (T <= 32) reproduces bit for bit, so cutting a stream into calls of any length gives the same bits.
+ * Option rec_rr = 1 takes the register-resident kernels for the stateful call too; 0 never takes them. */
 
 static int lstm_std_acts(const int *acts) {
     return acts[0] == NNTK_ACT_SIGMOID && acts[1] == NNTK_ACT_SIGMOID && acts[2] == NNTK_ACT_TANH &&
@@ -173,8 +194,8 @@ static int lstm_std_acts(const int *acts) {
 static int core_try_lstm_rr(rec_core *c, int use_bh, const int *acts, const float *d_in, float *d_out, int B, int stateful) {
     int on = -1;
     (void)nntk_shim_get_option("rec_rr", &on);
-    if (on == 0 || c->G != 4 || !lstm_std_acts(acts)) return 1;
-    if (on != 1 && B < NNTK_RR_MIN_BATCH) return 1;
+    if (on == 0 || c->G != 4 || !lstm_std_acts(acts) || c->rr_exact_only) return 1;
+    if (on != 1 && stateful) return 1;
     size_t img = nntk_shim_lstm_rr_image_floats(c->H, c->in);
     if (!img) return 1;
     if (!c->rr_valid) {
@@ -229,13 +250,16 @@ static int gru_rr_build_image(int in, int H, const float *W, const float *U, con
 static int core_try_gru_rr(rec_core *c, const int *acts, const float *d_in, float *d_out, int B, int stateful, int x_tm, int out_tm) {
     int on = -1;
     (void)nntk_shim_get_option("rec_rr", &on);
-    if (on == 0 || c->G != 3 || !gru_std_acts(acts)) return 1;
-    if (on != 1 && B < NNTK_RR_MIN_BATCH) return 1;
+    if (on == 0 || c->G != 3 || !gru_std_acts(acts) || c->rr_exact_only) return 1;
+    if (on != 1 && stateful) return 1;
     const int H = c->H, in = c->in;
     size_t img = nntk_shim_lstm_rr_image_floats(H, in);
     if (!img) return 1;
     if (!c->rr_valid) {
-        if (gru_rr_build_image(in, H, c->weights->W, c->weights->U, c->weights->b_i, c->weights->b_h, &c->d_rr, img, &c->d_b4, &c->d_rr_stage)) return -1;
+        /* from the SHADOW, i.e. the weight version core_upload packed d_wp / d_ut from: the device-pointer calls do not look for
+         * host edits (SyncWeights is their contract), and an un-synced edit must not reach this kernel alone */
+        const float *sW = c->wb.shadow, *sU = sW + (size_t)in * 3 * H, *sbi = sU + (size_t)H * 3 * H, *sbh = sbi + 3 * (size_t)H;
+        if (gru_rr_build_image(in, H, sW, sU, sbi, sbh, &c->d_rr, img, &c->d_b4, &c->d_rr_stage)) return -1;
         c->rr_valid = 1;
     }
     float *d_work = nntk_devbuf_reserve(&c->d_work_rr, nntk_shim_lstm_rr_work_floats(B, H));
@@ -517,12 +541,12 @@ static int gru_train_forward_dev(GRU filter, const float *d_x) {
     if (!d_h || !d_Zg || !d_hU || !d_raw) return -1;
     if (nntk_shim_upload(d_raw, c->wb.host, nw * sizeof(float))) return -1;          /* W | U | b_i | b_h, caller layout */
     const float *dW = d_raw, *dU = dW + (size_t)in * 3 * H, *dbi = dU + (size_t)H * 3 * H, *dbh = dbi + 3 * (size_t)H;
-    /* default activations, mini-batches of >= 32 sequences: ONE launch of the register-resident kernel with the caches written from
+    /* default activations, any mini-batch: ONE launch of the register-resident kernel with the caches written from
      * its gate phase (recurrent_rr.hip gru_rr_kernel<.., TRAIN>); its image is re-packed from the current weights every call */
     int ran = 0, rr_on = -1;
     (void)nntk_shim_get_option("rec_rr", &rr_on);
     size_t img = nntk_shim_lstm_rr_image_floats(H, in);
-    if (rr_on != 0 && img && gru_std_acts(acts) && (B >= NNTK_RR_MIN_BATCH || rr_on == 1)) {
+    if (rr_on != 0 && img && gru_std_acts(acts) && !rr_unsplittable(c->wb.host, (size_t)in * 3 * H + (size_t)H * 3 * H)) {
         float *d_wk = nntk_devbuf_reserve(&c->d_work_rr, nntk_shim_lstm_rr_work_floats(B, H));
         if (!d_wk) return -1;
         if (gru_rr_build_image(in, H, c->weights->W, c->weights->U, c->weights->b_i, c->weights->b_h, &c->d_rr_train, img, &c->d_b4_train, &c->d_rr_stage)) return -1;
@@ -611,7 +635,8 @@ void GRUCalculateGradient(GRU filter, GRUGradient *gradient, float *d_out) {
     nntk_shim_download(gradient->d_X, d_dX, rows * in * sizeof(float));
 }
 /* device-pointer form: d_grad = W [in][3H] | U [H][3H] | b_i [3H] | b_h [3H] (the gradient block's layout) is ADDED to, d_dX
- * [B][T][in] overwritten; d_dout [B][T][H] or [B][H].  Asynchronous on the calling thread's stream. */
+ * [B][T][in] overwritten; d_dout [B][T][H] or [B][H].  Enqueued on the calling thread's stream (the forward call that precedes it
+ * synchronised that stream once for its weight upload). */
 int GRUCalculateGradientDevice(GRU filter, float *d_grad, float *d_dX, const float *d_dout) {
     nntk_shim_clear_error();
     if (!filter || !d_grad || !d_dX || !d_dout) NNTK_FAIL("GRUCalculateGradientDevice: NULL argument");
@@ -682,7 +707,7 @@ int GRUStack2ApplyDevice(GRU l1, GRU l2, const float *d_input, float *d_output, 
     int rr_on = -1, fused_on = -1;
     (void)nntk_shim_get_option("rec_rr", &rr_on);
     (void)nntk_shim_get_option("rec_fused2", &fused_on);
-    const int rr_pair = rr_on != 0 && (B >= NNTK_RR_MIN_BATCH || rr_on == 1) && d1 && d2 &&
+    const int rr_pair = rr_on != 0 && d1 && d2 && !c1->rr_exact_only && !c2->rr_exact_only &&
                         nntk_shim_lstm_rr_image_floats(c1->H, c1->in) && nntk_shim_lstm_rr_image_floats(c2->H, c2->in);
     if (d1 && d2 && c2->H == H && !(rr_pair && fused_on != 1)) {
         if (core_ensure_wt(c2)) return -1;
@@ -861,13 +886,13 @@ static int lstm_train_forward_dev(LSTM filter, const float *d_x) {
     if (!d_h || !d_z || !d_c || !d_raw) return -1;
     if (nntk_shim_upload(d_raw, c->wb.host, nw * sizeof(float))) return -1;          /* W | U | b_i | b_h, caller layout */
     const float *dW = d_raw, *dU = dW + (size_t)in * 4 * H, *dbi = dU + (size_t)H * 4 * H, *dbh = dbi + 4 * (size_t)H;
-    /* standard activations, mini-batches of >= 32 sequences: the register-resident inference kernel with the caches written
+    /* standard activations, any mini-batch: the register-resident inference kernel with the caches written
      * from its gate phase (recurrent_rr.hip, TRAIN): ONE launch instead of T; its weight images are packed on the device from
      * the block just uploaded (the weights change with every optimiser step).  Otherwise: one launch per timestep. */
     int ran = 0, rr_on = -1;
     (void)nntk_shim_get_option("rec_rr", &rr_on);
     size_t img = nntk_shim_lstm_rr_image_floats(H, in);
-    if (rr_on != 0 && img && lstm_std_acts(acts) && (B >= NNTK_RR_MIN_BATCH || rr_on == 1)) {
+    if (rr_on != 0 && img && lstm_std_acts(acts) && !rr_unsplittable(c->wb.host, (size_t)in * 4 * H + (size_t)H * 4 * H)) {
         if (!c->d_rr_train && !(c->d_rr_train = (float *)nntk_shim_malloc(img * sizeof(float)))) return -1;
         float *d_wk = nntk_devbuf_reserve(&c->d_work_rr, nntk_shim_lstm_rr_work_floats(B, H));
         if (!d_wk) return -1;

@@ -15,7 +15,7 @@
  *   - window functions: pinned against the reference's own signal/window.c
  *     compiled in place (oracle/_ref, see oracle/Makefile target `ref`).
  *   - config geometry + struct ABI: pinned against the reference headers
- *     (oracle/ref_abi_probe.c compiled against /root/reference headers).
+ *     (oracle/ref_probe.c compiled against /root/reference headers).
  *   - compute paths (conv/bn/act/gru/lstm/dense/spectrogram): PARITY UNPINNED
  *     by the reference.  The reference ships no tests, fixtures or golden
  *     vectors, and its Linux backend cannot be built here: core/default_ops.cc
@@ -23,7 +23,7 @@
  *     submodules (.gitmodules:1-6) that are absent from this image.  The
  *     restatement is instead cross-checked against independent implementations
  *     (torch.nn.GRU/LSTM/conv1d, scipy.signal.spectrogram, numpy) in
- *     tests/test_oracle_*.py.
+ *     tests/test_oracle.py.
  *
  * Third-party arithmetic restated from published algorithms:
  *   - Eigen (gitlab.com/libeigen/eigen, commit unpinned in the reference):

@@ -35,3 +35,5 @@ def test_lstm_rr_counted_waits_match_the_isa():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_rr_waits.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 mismatches" in r.stdout
+    # ... and the flag poll's register is left alone between its asm load and its asm wait, no scratch in any rr kernel
+    assert "0 violations" in r.stdout and " 0 flag polls" not in r.stdout

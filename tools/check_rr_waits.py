@@ -39,7 +39,64 @@ def main():
                         print("%s: wait vmcnt(%s) at +%d but %d vector-memory instructions follow the publication" % (kname, m.group(1), j, younger))
                     break
     print("lstm_rr_kernel / gru_rr_kernel: %d counted waits checked, %d mismatches" % (total, bad))
-    return 1 if bad or total == 0 else 0
+    pbad, ptotal = check_polls(txt)
+    print("lstm_rr_kernel / gru_rr_kernel: %d flag polls checked, %d violations" % (ptotal, pbad))
+    return 1 if bad or total == 0 or pbad or ptotal == 0 else 0
+
+
+def regs_of(tok):
+    """VGPR numbers an operand token names: v12 -> {12}, v[14:15] -> {14, 15}"""
+    m = re.match(r'v\[(\d+):(\d+)\]', tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r'v(\d+)$', tok)
+    return {int(m.group(1))} if m else set()
+
+
+def check_polls(txt):
+    """The flag poll is two asm statements a k step apart: `global_load_dword vN, ..., off sc1` (poll_a) and `s_waitcnt vmcnt(0)` with
+    vN as an in/out operand (poll_b).  The compiler does not know vN is in flight in between, so nothing enforces that it leaves the
+    register alone.  Checked here for every poll of every instantiation: between the load and the first asm vmcnt(0) wait
+    that follows it, no instruction names vN as an operand and no branch is taken; and no rr kernel uses scratch (a spill of vN would
+    be a hidden read + write)."""
+    bad = total = 0
+    for kname in re.findall(r'^(_Z1[34](?:lstm|gru)_rr_kernel\w+):', txt, re.M):
+        a = txt.index("\n" + kname + ":")
+        s = txt[a:txt.index("s_endpgm", a)].split("\n")
+        m = re.search(r'\.amdhsa_kernel %s\b.*?\.end_amdhsa_kernel' % re.escape(kname), txt, re.S)
+        if m:
+            ps = re.search(r'\.amdhsa_private_segment_fixed_size (\d+)', m.group(0))
+            if ps and int(ps.group(1)) != 0:
+                bad += 1
+                print("%s: private_segment_fixed_size %s (scratch in use: a spill may touch the poll register)" % (kname, ps.group(1)))
+        for i, l in enumerate(s):
+            t = l.strip()
+            pm = re.match(r'global_load_dword (v\d+), v\[\d+:\d+\], off sc1$', t)
+            if not (pm and "ASMSTART" in s[i - 1]):
+                continue
+            total += 1
+            reg = int(pm.group(1)[1:])
+            closed = False
+            for j in range(i + 1, min(i + 400, len(s))):
+                u = s[j].strip()
+                if not u or u.startswith(";") or u.startswith("."):
+                    if re.match(r'\.LBB', u):
+                        print("%s: a branch target between the flag load (v%d) and its wait" % (kname, reg)); bad += 1; closed = True
+                        break
+                    continue
+                if u == "s_waitcnt vmcnt(0)" and "ASMSTART" in s[j - 1]:
+                    closed = True
+                    break
+                if re.match(r's_(c?branch|setpc|swappc|call)', u):
+                    print("%s: `%s` between the flag load (v%d) and its wait" % (kname, u, reg)); bad += 1; closed = True
+                    break
+                ops = re.split(r'[,\s]+', u)[1:]
+                if any(reg in regs_of(o) for o in ops):
+                    print("%s: `%s` touches v%d while the flag load is in flight" % (kname, u, reg)); bad += 1; closed = True
+                    break
+            if not closed:
+                print("%s: no asm vmcnt(0) wait within 400 lines of the flag load into v%d" % (kname, reg)); bad += 1
+    return bad, total
 
 
 if __name__ == "__main__":
