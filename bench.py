@@ -152,6 +152,11 @@ def unpack(flat, parts):
 
 # ---------------------------------------------------------------- workloads ---
 
+def capi_lib():
+    from nntoolkitcore_amd import capi
+    return capi.load()
+
+
 class Workload:
     """Builds the layer handles through the reference-shaped C API and runs one step."""
 
@@ -190,8 +195,14 @@ class Workload:
             self.tdd = NL.TimeDistributedDense(Tc, 512, 1000)
             self.tdd.set_weights(w["tdd_W"], w["tdd_b"])
             self.layers += [self.lstm, self.tdd]
-            self.lstm_out = torch.empty((B, Tc, 512), device=dev)
             self.tdd_out = torch.empty((B, Tc, 1000), device=dev)
+            # default: the LSTM hands its output to the dense layer in frag3 form (already split for the split-bf16 contraction, MFMA
+            # fragment order -- the LSTM kernel's own hand-off buffer); NNTK_BENCH_STACK_F32=1: through an f32 tensor, as round 3 did
+            self.f32_route = bool(int(os.environ.get("NNTK_BENCH_STACK_F32", "0")))
+            if self.f32_route:
+                self.lstm_out = torch.empty((B, Tc, 512), device=dev)
+            else:
+                self.lstm_f3 = torch.empty(capi_lib().nntk_frag3_floats(B, Tc, 512), device=dev)
         if name == "gru":
             self.g1 = NL.GRU(128, 256, True, frames)
             self.g2 = NL.GRU(256, 256, True, frames)
@@ -221,9 +232,14 @@ class Workload:
         if self.name == "stack":
             self.conv.apply_device(self.spec_out, out=self.conv_out, bn=self.bn, act=self.relu)
             mark("conv_bn_relu")
-            self.lstm.apply_device(self.conv_out, out=self.lstm_out)
-            mark("lstm")
-            self.tdd.apply_device(self.lstm_out, out=self.tdd_out)
+            if self.f32_route:
+                self.lstm.apply_device(self.conv_out, out=self.lstm_out)
+                mark("lstm")
+                self.tdd.apply_device(self.lstm_out, out=self.tdd_out)
+            else:       # = LSTMTimeDistributedDenseApplyDevice, as its two halves so that each gets its own HIP-event phase
+                self.NL.recurrent_apply_device_frag3(self.lstm, x=self.conv_out, want_f32=False, out_f3=self.lstm_f3)
+                mark("lstm")
+                self.NL.tdd_apply_device_frag3(self.tdd, self.lstm_f3, self.B, out=self.tdd_out)
             mark("tdd")
         if self.name == "conv":
             self.conv.apply_device(self.x, out=self.conv_out, bn=self.bn, act=self.relu)

@@ -519,6 +519,27 @@ int bd_reverse_input_batch_device(const float *d_input, float *d_output, Recurre
 int bd_reverse_backward_batch_device(const float *d_input, float *d_output, RecurrentConfig config, int batch);
 int bd_merge_concat_device(const float *d_forward, const float *d_backward, float *d_output, RecurrentConfig config, int batch);
 int bd_merge_sum_device(const float *d_forward, const float *d_backward, float *d_output, RecurrentConfig config, int batch);
+/* ---- frag3 tensors: activations already split for the split-bf16 x 3 contraction ---------------------------------------------
+ * The default contraction of conv / dense / recurrent layers multiplies every f32 operand as three bf16 terms (x = hi + mid + lo,
+ * exactly).  A FRAG3 tensor is a [batch][T][C] f32 tensor stored as those three images in MFMA fragment order:
+ * [T][2 ceil(batch / 64)][ceil(C / 16)][3] blocks of 1 KB, block = 32 batch rows x 16 channels, lane 32 kh + n of a wavefront holding
+ * channels 16 ks + 8 kh .. + 7 of batch row 32 ht + n as 8 consecutive bf16 (padding rows / channels are zeros).  6 bytes per value
+ * instead of 4; in exchange a consumer's operand fetch is a run of coalesced 1 KB loads straight into MFMA registers (no LDS
+ * staging, no split, no per-row requests).  The register-resident GRU / LSTM kernels produce their output in this form for free
+ * (it is their inter-workgroup hand-off) and read their input from it; the dense GEMM reads it as its A operand.
+ * The format is exact: unpack(pack(x)) == x for finite x, so every *Frag3 call equals its f32 counterpart BIT FOR BIT.
+ *   <GRU|LSTM>ApplyDeviceFrag3: input as f32 (d_input) or frag3 (d_input_frag3), one of them NULL; output as f32 (d_output), frag3
+ *   (d_output_frag3, needs return_sequences) or both, unused ones NULL.  Zero initial state per sequence.  Shapes the register-resident
+ *   kernels do not take run the other kernels through f32 scratch -- the call is valid for every layer.
+ *   LSTMTimeDistributedDenseApplyDevice = LSTMApplyDevice then TimeDistributedDenseApplyDevice without the f32 tensor in between. */
+size_t nntk_frag3_floats(int batch, int T, int C);                       /* size of a frag3 tensor, in floats */
+int nntk_frag3_pack_device(const float *d_x /*[batch,T,C]*/, float *d_frag3, int batch, int T, int C);
+int nntk_frag3_unpack_device(const float *d_frag3, float *d_x /*[batch,T,C]*/, int batch, int T, int C);
+int GRUApplyDeviceFrag3(GRU filter, const float *d_input, const float *d_input_frag3, float *d_output, float *d_output_frag3, int batch);
+int LSTMApplyDeviceFrag3(LSTM filter, const float *d_input, const float *d_input_frag3, float *d_output, float *d_output_frag3, int batch);
+int TimeDistributedDenseApplyDeviceFrag3(TimeDistributedDense filter, const float *d_input_frag3 /*[batch,ts,in]*/, float *d_output, int batch);
+int LSTMTimeDistributedDenseApplyDevice(LSTM lstm, TimeDistributedDense tdd, const float *d_input /*[batch,T,in]*/,
+                                        float *d_output /*[batch,T,out]*/, int batch);
 int DenseApplyDevice(Dense filter, const float *d_input /*[rows,in]*/, float *d_output /*[rows,out]*/, int rows);
 int TimeDistributedDenseApplyDevice(TimeDistributedDense filter, const float *d_input, float *d_output, int batch);
 

@@ -336,6 +336,14 @@ SIGNATURES = {
     "GRUStack2ApplyDevice": (C.c_int, [vp, vp, vp, vp, C.c_int]),
     "GRUStack2ApplyInferenceBatch": (C.c_int, [vp, vp, fp, fp, C.c_int]),
     "LSTMApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
+    # frag3 tensors (additive)
+    "nntk_frag3_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "nntk_frag3_pack_device": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int]),
+    "nntk_frag3_unpack_device": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int]),
+    "GRUApplyDeviceFrag3": (C.c_int, [vp, vp, vp, vp, vp, C.c_int]),
+    "LSTMApplyDeviceFrag3": (C.c_int, [vp, vp, vp, vp, vp, C.c_int]),
+    "TimeDistributedDenseApplyDeviceFrag3": (C.c_int, [vp, vp, vp, C.c_int]),
+    "LSTMTimeDistributedDenseApplyDevice": (C.c_int, [vp, vp, vp, vp, C.c_int]),
     "RNNApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
     "bd_reverse_input_batch_device": (C.c_int, [vp, vp, RecurrentConfig, C.c_int]),
     "bd_reverse_backward_batch_device": (C.c_int, [vp, vp, RecurrentConfig, C.c_int]),

@@ -174,25 +174,38 @@ int nntk_shim_lstm(const float *d_xw, const float *d_ut, const float *d_bh,
                    const float *d_h0, const float *d_c0, float *d_out, float *d_hT, float *d_cT,
                    float *d_work, int B, int T, int H, int return_sequences, const int acts[5], const float act_scales[5]);
 
-/* Register-resident split-bf16 LSTM with the input projection fused into the step (recurrent_rr.hip): standard
- * activations, H % 16 == 0, 64 <= H <= 512, in % 8 == 0, in <= 128.  d_x [B][T][in]; d_img = weight images made by
+/* Register-resident split-bf16 recurrent kernels with the input projection fused into the step (recurrent_rr.hip): standard
+ * activations, H % 16 == 0, 64 <= H <= 512, in <= 128 (in <= 256 when H <= 256); f32 input: in % 8 == 0; frag3 input: any in.
+ * d_x [B][T][in] f32 -- or NULL with d_xf3 = the same tensor in frag3 form (frag3.hip); d_img = weight images made by
  * nntk_shim_lstm_rr_pack from the per-gate U^T (d_ut) and the packed W^T (d_wp); d_bh NULL for the one-bias form.
- * nntk_shim_lstm_rr returns 1 when the shape / configuration is not taken (nothing launched). */
-size_t nntk_shim_lstm_rr_image_floats(int H, int in);           /* 0: shape not taken */
+ * d_hseq (nntk_shim_rr_hseq_floats) receives the layer output of every step in frag3 form -- it is the kernels' hand-off buffer;
+ * d_out (f32) may be NULL when the caller consumes d_hseq.  d_work: nntk_shim_lstm_rr_work_floats.
+ * nntk_shim_lstm_rr / nntk_shim_gru_rr return 1 when the shape / configuration is not taken (nothing launched). */
+size_t nntk_shim_lstm_rr_image_floats(int H, int in);           /* 0: shape not taken (f32 input) */
+size_t nntk_shim_rr_image_floats_xf(int H, int in);             /* 0: shape not taken (frag3 input) */
 size_t nntk_shim_lstm_rr_work_floats(int B, int H);
+size_t nntk_shim_rr_hseq_floats(int B, int T, int H);
 int nntk_shim_lstm_rr_pack(const float *d_ut, const float *d_wp, float *d_img, int H, int in);
 int nntk_shim_lstm_rr_pack_raw(const float *d_U /*[H][4H]*/, const float *d_W /*[in][4H]*/, float *d_img, int H, int in);
-/* training forward on the same kernel (zero initial state): h [B][T][H] and the BPTT caches c [B][T][H], zifgo [B][T][8H] */
 /* GRU on the same kernels (gru_rr_kernel): image from the four-slot matrices, d_b4 [4H]; see recurrent_rr.hip */
-int nntk_shim_gru_rr(const float *d_x, const float *d_img, const float *d_b4, const float *d_h0, float *d_out, float *d_hT,
-                     float *d_work, int B, int T, int in, int H, int return_sequences, int x_tm, int out_tm);
+int nntk_shim_gru_rr(const float *d_x, const void *d_xf3, const float *d_img, const float *d_b4, const float *d_h0, float *d_out,
+                     float *d_hseq, float *d_hT, float *d_work, int B, int T, int in, int H, int return_sequences, int x_tm, int out_tm);
 int nntk_shim_gru_rr_train_forward(const float *d_x, const float *d_img, const float *d_b4, float *d_h, float *d_hU, float *d_Zg,
-                                   float *d_work, int B, int T, int in, int H);
+                                   float *d_hseq, float *d_work, int B, int T, int in, int H);
 int nntk_shim_lstm_rr_train_forward(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,
-                                    float *d_h, float *d_c, float *d_zifgo, float *d_work, int B, int T, int in, int H);
-int nntk_shim_lstm_rr(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,
-                      const float *d_h0, const float *d_c0, float *d_out, float *d_hT, float *d_cT,
+                                    float *d_h, float *d_c, float *d_zifgo, float *d_hseq, float *d_work, int B, int T, int in, int H);
+int nntk_shim_lstm_rr(const float *d_x, const void *d_xf3, const float *d_img, const float *d_bi, const float *d_bh,
+                      const float *d_h0, const float *d_c0, float *d_out, float *d_hseq, float *d_hT, float *d_cT,
                       float *d_work, int B, int T, int in, int H, int return_sequences);
+
+/* ---- frag3 tensors (frag3.hip): a [B][T][C] f32 tensor as three bf16 images (x = hi + mid + lo exactly) in MFMA fragment order,
+ * [T][2 ceil(B / 64)][ceil(C / 16)][3] blocks of 1 KB.  nntk_shim_dense_frag3: out [B][T][N] = act(h . W + b) with h in frag3 form and
+ * d_wp the packed weights of a Dense layer; returns 1 when the shape is not taken. */
+size_t nntk_shim_frag3_floats(int B, int T, int C);
+int nntk_shim_frag3_pack(const float *d_x, void *d_frag, int B, int T, int C);
+int nntk_shim_frag3_unpack(const void *d_frag, float *d_x, int B, int T, int C);
+int nntk_shim_dense_frag3(const void *d_frag, const float *d_wp, const float *d_bias, int act_kind, float relu_a,
+                          float *d_out, int B, int T, int K, int N);
 
 /* fused two-layer GRU (standard activations, zero initial state, both layers H units): layer 2's input projection and
  * recurrence run inside layer 1's persistent launch, one step behind.  d_wt2 = W2^T packed like U^T.  Returns 1 when

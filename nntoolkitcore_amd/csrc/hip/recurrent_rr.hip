@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void rr_pack_kernel(const float *__restrict__ 
     }
 }
 
-// h_0 [B][H] f32 -> the split hand-off layout of parity 0: block (((bt * 2 + half) * NKS + ks) * 3 + m), lane (n, kh)
+// h_0 [B][H] f32 -> the split hand-off layout of the h_0 slot: block (((bt * 2 + half) * NKS + ks) * 3 + m), lane (n, kh); NKS = H / 16
 __global__ __launch_bounds__(256) void rr_tile_h0_kernel(const float *__restrict__ h0, rr_v4u *__restrict__ hb, int B, int H, int NKS) {
     const long total = (long)((B + 63) / 64) * 2 * (H / 16) * 64;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -159,8 +159,13 @@ struct RRParams {
     const float *x;            // [B][T][in]
     const rr_v4u *img;         // weight images (rr_pack_kernel)
     const float *bi, *bh;      // [4H]; bh NULL when !v2
-    char *hb;                  // [2 parities][hb_parity_bytes] split hand-off buffers; parity 0 holds h_0
-    size_t hb_parity_bytes;
+    // split hand-off = the layer output in FRAG3 form (frag3.hip): h0f [NHT][NKS][3] blocks of 1 KB holds h_0; hseq [T][NHT][NKS][3]
+    // receives h_t of every step (step t reads h_{t-1}: t == 0 from h0f, else from hseq + (t - 1) * hstep) -- T-deep, so the
+    // published fragments ARE a tensor the next layer can consume (a stacked GRU's x operand, the dense GEMM's A operand)
+    char *h0f, *hseq;
+    size_t hstep;              // bytes per timestep of hseq = NHT_total * NKS * 3072, NKS = H / 16
+    const char *xf3;           // XF: x as a frag3 tensor [T][NHT][NKSx][3] blocks, NKSx = ceil(in / 16) (instead of p.x)
+    size_t xstep;
     const float *c0;           // [B][H] or NULL (zeros)
     float *cT, *hT;            // [B][H] or NULL
     float *out;                // [B][T][H] or [B][H]
@@ -171,6 +176,7 @@ struct RRParams {
     unsigned *fault;
     unsigned long long spin_ticks;
     int B, T, H, in, NBT, NCT, b_base, return_sequences;
+    int NKSx;                  // k steps of 16 the x frag3 tensor stores per row block
 #ifdef NNTK_REC_STAMPS
     unsigned long long *stamp; // [T][2 halves][16] s_memtime of workgroup 0, wave 0 (diagnostics build only)
 #endif
@@ -201,6 +207,7 @@ struct RRParams {
 #define RR_PIN_A(v) do {} while (0)
 #endif
 #define RR_OOB 0x7ffffff0          // out-of-range vector offset: a buffer load returns 0, a buffer store is dropped
+#define RR_OOB_F 0x7f000000        // the same for the frag3 blocks, whose instructions add up to 3 KB of immediate offset (no wrap); steps < this
 
 // The kernel is a software pipeline of HALF-STEPS.  Half-step s multiplies half Y = s & 1 at timestep t = s >> 1 (its
 // operand fetched during half-step s - 1) and, sliced between the k steps of that MFMA sequence, FINISHES half X = 1 - Y,
@@ -237,10 +244,13 @@ struct RRParams {
 // that is the LSTM's c_t holds the GRU's own f32 h_t.
 // ULR (in > 128, H <= 256): U's low image lives in registers (32 VGPRs at KH = 4) instead of LDS, which makes room for the
 // 96 KB of W images a 256-wide input needs.
-template <int KH, int KX, bool TRAIN, int CELL>
+// XF: x arrives as a frag3 tensor (frag3.hip: already split into its three bf16 images, in THIS kernel's B-fragment order, 32-row
+// blocks of one timestep contiguous): 3 KX coalesced 1 KB requests per half-step straight into the MFMA operand registers instead
+// of 2 KX requests that touch 32 rows each plus the 44-instruction split (DESIGN K4b "what the x part costs": the requests, not
+// the split, were 0.5 us of a 6.7 us step).  Each half owns an operand set, requested a whole half-step ahead.
+template <int KH, int KX, bool TRAIN, int CELL, bool XF>
 __device__ __forceinline__ void rr_body(const RRParams &p) {
     constexpr bool ULR = KX > 2;
-    constexpr int NKS = 4 * KH;                       // k steps of the hand-off buffer (>= H / 16)
     constexpr int NST = KX + KH;                      // k steps one wavefront multiplies per half
     constexpr int S_RED = 0, S_PUB = 1;
     constexpr int S_XSPL = KX > 2 ? KX : 2;
@@ -260,7 +270,8 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
     // vector-memory operations a wave issues between a publication (S_PUB) and its arrival (S_E1): the own-sequence operand
     // requests of k steps S_PUB .. S_E1 - 1 and the x request at S_XSPL -- what the arrival's counted wait leaves in flight
     constexpr int own_lo = S_PUB + NPRE < KH ? S_PUB + NPRE : KH, own_hi = S_E1 + NPRE < KH ? S_E1 + NPRE : KH;
-    constexpr int N_X_AFTER_PUB = (X_LATE || S_XSPL >= S_E1) ? 0 : 2 * KX;      // (S_XSPL == S_E1: the arrival precedes the x requests in its k step)
+    constexpr int NXR = XF ? 3 * KX : 2 * KX;         // vector-memory requests of one x fetch
+    constexpr int N_X_AFTER_PUB = (X_LATE || S_XSPL >= S_E1) ? 0 : NXR;      // (S_XSPL == S_E1: the arrival precedes the x requests in its k step)
     constexpr int N_AFTER_PUB = 3 * (own_hi - own_lo) + N_X_AFTER_PUB;
     static_assert(NST >= 5 && S_E1 < S_E2 && S_E1 > S_PUB && S_XSPL >= KX && S_XSPL < S_E2 - RR_POLL_LEAD &&
                   S_XSPL > S_PUB && KH - NPRE <= S_E2, "slice schedule");
@@ -279,6 +290,7 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
     const int bt_abs = p.b_base / 64 + bt;
     const int b0 = p.b_base + bt * 64;
     const int H = p.H, T = p.T;
+    const int NKS = H >> 4;                          // k steps the hand-off stores per row block (H % 16 == 0)
     const int rows_valid = p.B - b0 < 64 ? p.B - b0 : 64;
 
     // ---- resident operands ----
@@ -326,10 +338,20 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
             cst[half][e] = (p.c0 && row < p.B && jf + e < H) ? p.c0[(size_t)row * H + jf + e] : 0.0f;
         }
     // ---- buffer descriptors and per-lane offsets (everything that must be clipped rides in the range-checked vector offset) ----
-    const int hb_bytes = (int)p.hb_parity_bytes;
-    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void *)p.hb, 0, hb_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.hb + p.hb_parity_bytes), 0, hb_bytes, 0x00020000);
+    const int hb_bytes = (int)p.hstep;
+    // the hand-off of step t: read h_{t-1} (t == 0: the h_0 slot), write h_t -- one descriptor per timestep, 32-bit offsets inside it
+    auto rs_rd = [&](int t) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(t ? p.hseq + (size_t)(t - 1) * p.hstep : p.h0f), 0, hb_bytes, 0x00020000);
+    };
+    auto rs_wr = [&](int t) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(p.hseq + (size_t)t * p.hstep), 0, hb_bytes, 0x00020000);
+    };
     const int lane16 = lane * 16;
+    // k steps past H / 16 (H between the compiled depths: 4 KH * 16 > H) are not stored: their fragments read as zeros through an
+    // out-of-range vector offset
+    int hvo[KH];
+#pragma unroll
+    for (int i = 0; i < KH; ++i) hvo[i] = w * KH + i < NKS ? lane16 : RR_OOB_F;
     // x: the tile's rows [b0, b0 + rows_valid) of [B][T][in] -- or of the time-major [T][B][in] a stacked layer hands over
     // (p.x_tm: a row's timesteps are then B * in apart and the tile's 32 rows of one step are contiguous: coalesced requests).
     // Rows past the batch are masked PER LANE AND HALF (xok): the half rides in the scalar offset, which the range check does
@@ -346,7 +368,8 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int k = (w * KX + ix) * 16 + 8 * kh + 4 * q;
-            xvo[ix][q] = k < p.in ? (int)(n * x_row_bytes) + k * 4 : RR_OOB;
+            xvo[ix][q] = XF ? (w * KX + ix < p.NKSx ? lane16 : RR_OOB_F)        // (XF: only [ix][0] is used: the block's lane offset)
+                            : k < p.in ? (int)(n * x_row_bytes) + k * 4 : RR_OOB;
         }
     // publication: lane (n, kh) of the publishing wave owns hidden units 8 kh .. 8 kh + 7 of row n -- one B fragment of the
     // consumers; output rows past the batch fall outside the descriptor; hand-off rows past the batch are written too
@@ -367,8 +390,8 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
     using Tt = std::true_type;
     using Ff = std::false_type;
     rr_v4u hf[2][KH][3];           // the h operand of each half
-    rr_v4u xr[KX][2];              // raw x_t (f32) of the half that multiplies next
-    rr_bf16x8 xf[KX][3];           // ... and its three bf16 images
+    rr_v4u xr[XF ? 1 : KX][2];     // raw x_t (f32) of the half that multiplies next (not with XF)
+    rr_bf16x8 xf[XF ? 2 : 1][KX][3];   // ... and its three bf16 images; XF: one set per half, filled by the loads themselves
 
     // The operand's 3 KH fragment loads are SPREAD over the MFMA sequences instead of issued in one burst: a 1 KB wave-wide load
     // occupies the CU's address path for ~16 cycles and the four wavefronts (in lockstep) share that path, so a burst of 24
@@ -378,24 +401,37 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
     auto issue_h = [&](auto half_tag, int t, int j0, int j1) __attribute__((always_inline)) {      // fragments [j0, j1): constants once unrolled
         constexpr int half = decltype(half_tag)::value;
         const int so = ((bt_abs * 2 + half) * NKS + w * KH) * 3 * 1024;
+        const __amdgpu_buffer_rsrc_t rs = rs_rd(t);
 #pragma unroll
         for (int blk = 0; blk < 3 * KH; ++blk) {
             if (blk < j0 || blk >= j1) continue;
             // four 1 KB blocks per scalar offset: the rest of the address rides in the instruction's immediate
             const int i = blk / 3, m = blk % 3;
-            if (t & 1) hf[half][i][m] = __builtin_amdgcn_raw_buffer_load_b128(rs1, lane16 + (blk & 3) * 1024, so + (blk >> 2) * 4096, 16 /* sc1 */);
-            else       hf[half][i][m] = __builtin_amdgcn_raw_buffer_load_b128(rs0, lane16 + (blk & 3) * 1024, so + (blk >> 2) * 4096, 16 /* sc1 */);
+            hf[half][i][m] = __builtin_amdgcn_raw_buffer_load_b128(rs, hvo[i] + (blk & 3) * 1024, so + (blk >> 2) * 4096, 16 /* sc1 */);
         }
     };
-    auto issue_x = [&](int half, int t) __attribute__((always_inline)) {
-        const int so = (int)((half * 32) * x_row_bytes) + t * (int)x_step_bytes;
-        const bool ok = half ? xok1 : xok0;
+    auto issue_x = [&](auto half_tag, int t) __attribute__((always_inline)) {
+        constexpr int half = decltype(half_tag)::value;
+        if constexpr (XF) {
+            // the half's own operand set: its MFMAs of this half-step are done, x_{t} of its NEXT step lands where they read from
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.xf3 + (size_t)t * p.xstep), 0, (int)p.xstep, 0x00020000);
+            const int so = ((bt_abs * 2 + half) * p.NKSx + w * KX) * 3 * 1024;
 #pragma unroll
-        for (int ix = 0; ix < KX; ++ix)
+            for (int ix = 0; ix < KX; ++ix)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) xr[ix][q] = __builtin_amdgcn_raw_buffer_load_b128(rsx, ok ? xvo[ix][q] : RR_OOB, so, 0);
+                for (int m = 0; m < 3; ++m)
+                    xf[half][ix][m] = __builtin_bit_cast(rr_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, xvo[ix][0] + ((3 * ix + m) & 3) * 1024, so + ((3 * ix + m) >> 2) * 4096, 0));
+        } else {
+            const int so = (int)((half * 32) * x_row_bytes) + t * (int)x_step_bytes;
+            const bool ok = half ? xok1 : xok0;
+#pragma unroll
+            for (int ix = 0; ix < KX; ++ix)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) xr[ix][q] = __builtin_amdgcn_raw_buffer_load_b128(rsx, ok ? xvo[ix][q] : RR_OOB, so, 0);
+        }
     };
     auto split_x = [&]() __attribute__((always_inline)) {
+        if constexpr (XF) return;
 #pragma unroll
         for (int ix = 0; ix < KX; ++ix) {
             float v[8];
@@ -406,7 +442,7 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
             }
             rr_v4u a, b, c;
             rr_split8(v, a, b, c);
-            xf[ix][0] = __builtin_bit_cast(rr_bf16x8, a); xf[ix][1] = __builtin_bit_cast(rr_bf16x8, b); xf[ix][2] = __builtin_bit_cast(rr_bf16x8, c);
+            xf[0][ix][0] = __builtin_bit_cast(rr_bf16x8, a); xf[0][ix][1] = __builtin_bit_cast(rr_bf16x8, b); xf[0][ix][2] = __builtin_bit_cast(rr_bf16x8, c);
         }
     };
     // ---- the finish of a half, in slices ----
@@ -498,20 +534,16 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
             // soffset followed by a VALU write of its data registers stores the overwritten value in some lanes on MI355X, and
             // the compiler inserts no wait state for that form (tools/check_store_hazard.py, tests/test_isa_lint.py)
             const int vo = lane16 + (((bt_abs * 2 + half) * NKS + ct) * 3) * 1024;
-            if (RR_DBG(128)) {
-            } else if ((t + 1) & 1) {
-                __builtin_amdgcn_raw_buffer_store_b128(a, rs1, vo, 0, 16 /* sc1 */);
-                __builtin_amdgcn_raw_buffer_store_b128(b, rs1, vo + 1024, 0, 16);
-                __builtin_amdgcn_raw_buffer_store_b128(c, rs1, vo + 2048, 0, 16);
-            } else {
-                __builtin_amdgcn_raw_buffer_store_b128(a, rs0, vo, 0, 16);
-                __builtin_amdgcn_raw_buffer_store_b128(b, rs0, vo + 1024, 0, 16);
-                __builtin_amdgcn_raw_buffer_store_b128(c, rs0, vo + 2048, 0, 16);
+            if (!RR_DBG(128)) {
+                const __amdgpu_buffer_rsrc_t rs = rs_wr(t);
+                __builtin_amdgcn_raw_buffer_store_b128(a, rs, vo, 0, 16 /* sc1 */);
+                __builtin_amdgcn_raw_buffer_store_b128(b, rs, vo + 1024, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(c, rs, vo + 2048, 0, 16);
             }
         } else if (w == 2 * half + 1) {                 // the output wave: the same row pieces in f32
             const rr_v4u o0 = *reinterpret_cast<const rr_v4u *>(hx + n * RR_HX_LD + 8 * kh);
             const rr_v4u o1 = *reinterpret_cast<const rr_v4u *>(hx + n * RR_HX_LD + 8 * kh + 4);
-            if (p.return_sequences && !RR_DBG(1024)) {
+            if (p.return_sequences && p.out && !RR_DBG(1024)) {      // (p.out NULL: the caller takes the layer output in frag3 form -- hseq -- only)
                 const int vo = (half ? xok1 : xok0) ? out_vo + half * out_half + t * out_step : 0x7fff0000;   // (past every range, room for + 16); soffset immediate, as above
                 __builtin_amdgcn_raw_buffer_store_b128(o0, rso, vo, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(o1, rso, vo + 16, 0, 0);
@@ -521,7 +553,7 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
                 asm volatile("" : "+s"(b0e));             // opaque: keeps these addresses from being computed (and spilled) ahead of the loop
                 const int row = b0e + half * 32 + n;
                 if (row < p.B) {
-                    if (!p.return_sequences) {
+                    if (!p.return_sequences && p.out) {
                         float *o = p.out + (size_t)row * H + 16 * ct + 8 * kh;
                         *reinterpret_cast<rr_v4u *>(o) = o0; *reinterpret_cast<rr_v4u *>(o + 4) = o1;
                     }
@@ -617,7 +649,7 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
                 if (NEXT && POLL && !RR_DBG(4)) poll_b(X, tX + 1);
             }
             if (s == S_E2 && NEXT && !RR_DBG(1)) issue_h(XT{}, tX + 1, 0, 3 * NPRE);          // head of X's next operand
-            if (s == S_E2 && X_LATE && XLIVE && !RR_DBG(8)) issue_x(Y, t + 1);                // (xr is free since this half-step's S_XSPL)
+            if (s == S_E2 && X_LATE && XLIVE && !RR_DBG(8)) issue_x(y_tag, t + 1);            // (xr is free since this half-step's S_XSPL)
             if (s + NPRE < KH && !RR_DBG(1)) issue_h(y_tag, t, 3 * (s + NPRE), 3 * (s + NPRE + 1));       // THIS half's operand, k step s + NPRE (published long ago)
             // ---- multiply ----
             if (RR_DBG(16)) {
@@ -626,7 +658,7 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
                 for (int pr = 0; pr < 6; ++pr)
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
-                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[mt][PA[pr]], xf[s][PB[pr]], acc[mt], 0, 0, 0);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[mt][PA[pr]], xf[XF ? Y : 0][s][PB[pr]], acc[mt], 0, 0, 0);
             } else {
                 const int i = s - KX;
                 rr_bf16x8 b[3];
@@ -644,7 +676,7 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
             // half's x_{t+1} -- a whole half-step ahead of its use
             if (s == S_XSPL) {
                 if (NEXT && !RR_DBG(8)) split_x();
-                if (!X_LATE && XLIVE && !RR_DBG(8)) issue_x(Y, t + 1);  // the arrival's counted wait counts these requests
+                if (!X_LATE && XLIVE && !RR_DBG(8)) issue_x(y_tag, t + 1);  // the arrival's counted wait counts these requests
             }
 #ifndef RR_NO_INTERLEAVE
             // spread this k step's vector-memory instructions between its MFMAs (2 MFMAs, then at most 1 memory operation,
@@ -684,10 +716,10 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
     };
 
     // prologue: operands of half A, step 0 (h_0 sits in parity 0: no poll); x_0 of half B
-    issue_x(0, 0);
+    issue_x(I0{}, 0);
     issue_h(I0{}, 0, 0, 3 * NPRE);
     split_x();
-    issue_x(1, 0);
+    issue_x(I1{}, 0);
     if (T > 1) {
         half_step(I0{}, Ff{}, Tt{}, Ff{}, Ff{}, Tt{}, 0, -1);                   // A(0); fetch B(0)
         half_step(I1{}, Tt{}, Tt{}, Tt{}, Ff{}, Tt{}, 0, 0);                    // B(0); finish A(0); fetch A(1)
@@ -716,14 +748,16 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
         }
     }
 }
-template <int KH, int KX, bool TRAIN = false>
-__global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) { rr_body<KH, KX, TRAIN, 0>(p); }
-template <int KH, int KX, bool TRAIN = false>
-__global__ __launch_bounds__(256) void gru_rr_kernel(RRParams p) { rr_body<KH, KX, TRAIN, 1>(p); }
+template <int KH, int KX, bool TRAIN = false, bool XF = false>
+__global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) { rr_body<KH, KX, TRAIN, 0, XF>(p); }
+template <int KH, int KX, bool TRAIN = false, bool XF = false>
+__global__ __launch_bounds__(256) void gru_rr_kernel(RRParams p) { rr_body<KH, KX, TRAIN, 1, XF>(p); }
 
 // ---- host side --------------------------------------------------------------------------------------------------
-static bool rr_shape(int H, int in, int *KH, int *KX) {
-    if (H < 64 || H > 512 || (H % 16) != 0 || in < 8 || (in % 8) != 0) return false;
+// xf: x arrives as a frag3 tensor (any in: the pack kernel zero-pads to whole k steps); else f32 rows read 16 bytes at a time
+static bool rr_shape(int H, int in, bool xf, int *KH, int *KX) {
+    if (H < 64 || H > 512 || (H % 16) != 0 || in < 1) return false;
+    if (!xf && (in < 8 || (in % 8) != 0)) return false;
     *KH = H <= 256 ? 4 : 8;
     // in <= 256 (KX = 4) needs 96 KB of LDS for the W images: it fits once U's low image moves to registers, which the register
     // budget allows at KH = 4 (H <= 256) only
@@ -733,22 +767,31 @@ static bool rr_shape(int H, int in, int *KH, int *KX) {
 static size_t rr_lds_bytes(int KH, int KX) {
     return (size_t)((KX > 2 ? 0 : 4 * KH * 2) + 4 * KX * 6 + 32) * 1024 + 32 * RR_HX_LD * 4;
 }
-static size_t rr_parity_bytes(int B, int KH) { return (size_t)((B + 63) / 64) * 2 * (4 * KH) * 3 * 1024; }
+// one timestep of the frag3 hand-off / layer output: [NHT = 2 * batch tiles][H / 16 k steps][3 images] blocks of 1 KB
+static size_t rr_step_bytes(int B, int H) { return (size_t)((B + 63) / 64) * 2 * (H / 16) * 3 * 1024; }
 
 extern "C" size_t nntk_shim_lstm_rr_image_floats(int H, int in) {
     int KH, KX;
-    if (!rr_shape(H, in, &KH, &KX)) return 0;
+    if (!rr_shape(H, in, false, &KH, &KX)) return 0;
     return (size_t)((H + 15) / 16) * rr_blocks_per_ct(KH, KX) * 256;        // 1 KB blocks, in floats
 }
-extern "C" size_t nntk_shim_lstm_rr_work_floats(int B, int H) {
-    const int KH = H <= 256 ? 4 : 8;
-    const size_t nbt = (size_t)(B + 63) / 64;
-    return 2 * rr_parity_bytes(B, KH) / 4 + 2 * nbt * RR_FLAGS;
+// the same for a layer whose input arrives in frag3 form (any in up to the LDS limit)
+extern "C" size_t nntk_shim_rr_image_floats_xf(int H, int in) {
+    int KH, KX;
+    if (!rr_shape(H, in, true, &KH, &KX)) return 0;
+    return (size_t)((H + 15) / 16) * rr_blocks_per_ct(KH, KX) * 256;
 }
+// d_work: the h_0 slot (one timestep of the hand-off) followed by the flag words
+extern "C" size_t nntk_shim_lstm_rr_work_floats(int B, int H) {
+    const size_t nbt = (size_t)(B + 63) / 64;
+    return rr_step_bytes(B, H) / 4 + 2 * nbt * RR_FLAGS;
+}
+// d_hseq: T timesteps of the hand-off = the layer output as a frag3 tensor (same size as nntk_shim_frag3_floats(B, T, H))
+extern "C" size_t nntk_shim_rr_hseq_floats(int B, int T, int H) { return (size_t)T * (rr_step_bytes(B, H) / 4); }
 // d_ut / d_wp: the per-gate U^T and packed W^T the other kernels use (host: core_upload); d_img: nntk_shim_lstm_rr_image_floats
 extern "C" int nntk_shim_lstm_rr_pack(const float *d_ut, const float *d_wp, float *d_img, int H, int in) {
     int KH, KX;
-    if (!rr_shape(H, in, &KH, &KX)) return nntk_fail_msg("lstm_rr_pack: shape not taken by the register-resident kernel");
+    if (!rr_shape(H, in, true, &KH, &KX)) return nntk_fail_msg("lstm_rr_pack: shape not taken by the register-resident kernel");
     const int Hj_p = (H + 15) & ~15, Hk_p = (H + 31) & ~31;
     int Kin_p, N_p;
     nntk_shim_conv_pack_sizes(in, 4 * H, 1, &Kin_p, &N_p);
@@ -764,7 +807,7 @@ extern "C" int nntk_shim_lstm_rr_pack(const float *d_ut, const float *d_wp, floa
 // the same images from the caller-layout weights U [H][4H], W [in][4H] already on the device (training forward)
 extern "C" int nntk_shim_lstm_rr_pack_raw(const float *d_U, const float *d_W, float *d_img, int H, int in) {
     int KH, KX;
-    if (!rr_shape(H, in, &KH, &KX)) return nntk_fail_msg("lstm_rr_pack_raw: shape not taken by the register-resident kernel");
+    if (!rr_shape(H, in, true, &KH, &KX)) return nntk_fail_msg("lstm_rr_pack_raw: shape not taken by the register-resident kernel");
     const int NCT = (H + 15) / 16;
     const long total = (long)NCT * rr_blocks_per_ct(KH, KX) * 64;
     long g = (total + 255) / 256;
@@ -776,65 +819,74 @@ extern "C" int nntk_shim_lstm_rr_pack_raw(const float *d_U, const float *d_W, fl
 }
 
 // 0 = launched; 1 = shape / configuration not taken (the caller runs projection GEMM + rec_persistent_kernel); -1 = error
-static int lstm_rr_launch(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,
-                          const float *d_h0, const float *d_c0, float *d_out, float *d_hT, float *d_cT,
-                          float *d_work, int B, int T, int in, int H, int return_sequences, float *d_c_cache, float *d_z_cache, int cell,
-                          int x_tm = 0, int out_tm = 0);
+// d_x: f32 [B][T][in] (or time-major with x_tm), or NULL with d_xf3 = the same tensor in frag3 form (nntk_shim_frag3_pack);
+// d_out: f32 layer output or NULL (the caller takes it in frag3 form: d_hseq); d_hseq: nntk_shim_rr_hseq_floats(B, T, H) floats
+struct RRIo {
+    const float *x; const void *xf3; float *out; float *hseq; float *work;
+    const float *h0, *c0; float *hT, *cT; float *c_cache, *z_cache;
+    int x_tm, out_tm;
+};
+static int rr_launch(const RRIo &io, const float *d_img, const float *d_bi, const float *d_bh,
+                     int B, int T, int in, int H, int return_sequences, int cell);
 
-extern "C" int nntk_shim_lstm_rr(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,
-                                 const float *d_h0, const float *d_c0, float *d_out, float *d_hT, float *d_cT,
+extern "C" int nntk_shim_lstm_rr(const float *d_x, const void *d_xf3, const float *d_img, const float *d_bi, const float *d_bh,
+                                 const float *d_h0, const float *d_c0, float *d_out, float *d_hseq, float *d_hT, float *d_cT,
                                  float *d_work, int B, int T, int in, int H, int return_sequences) {
-    return lstm_rr_launch(d_x, d_img, d_bi, d_bh, d_h0, d_c0, d_out, d_hT, d_cT, d_work, B, T, in, H, return_sequences, nullptr, nullptr, 0);
+    RRIo io = {d_x, d_xf3, d_out, d_hseq, d_work, d_h0, d_c0, d_hT, d_cT, nullptr, nullptr, 0, 0};
+    return rr_launch(io, d_img, d_bi, d_bh, B, T, in, H, return_sequences, 0);
 }
 // GRU on the same kernel frame (gru_rr_kernel): d_img packed from the four-slot matrices [U_z | U_r | U_h | 0] / [W_z | W_r | 0 | W_h],
 // d_b4 [4H] = b_i,z + b_h,z | b_i,r + b_h,r | b_h,h | b_i,h.  The f32 state register starts from h_0 (which is also the published operand).
-// x_tm / out_tm: d_x is [T][B][in] / the sequence output is written as [T][B][H] (the tensor between two stacked layers: a tile's 32 rows of
-// one timestep are then contiguous, and the consumer's x requests are coalesced -- GRUStack2ApplyDevice)
-extern "C" int nntk_shim_gru_rr(const float *d_x, const float *d_img, const float *d_b4, const float *d_h0, float *d_out, float *d_hT,
-                                float *d_work, int B, int T, int in, int H, int return_sequences, int x_tm, int out_tm) {
-    return lstm_rr_launch(d_x, d_img, d_b4, nullptr, d_h0, d_h0, d_out, d_hT, nullptr, d_work, B, T, in, H, return_sequences, nullptr, nullptr, 1,
-                          x_tm, out_tm);
+// x_tm / out_tm: d_x is [T][B][in] / the sequence output is written as [T][B][H]
+extern "C" int nntk_shim_gru_rr(const float *d_x, const void *d_xf3, const float *d_img, const float *d_b4, const float *d_h0, float *d_out,
+                                float *d_hseq, float *d_hT, float *d_work, int B, int T, int in, int H, int return_sequences, int x_tm, int out_tm) {
+    RRIo io = {d_x, d_xf3, d_out, d_hseq, d_work, d_h0, d_h0, d_hT, nullptr, nullptr, nullptr, x_tm, out_tm};
+    return rr_launch(io, d_img, d_b4, nullptr, B, T, in, H, return_sequences, 1);
 }
 // GRU training forward: zero initial state, h of every step to d_h [B][T][H], caches d_hU [B][T][H] (h.U_h + b_h) and d_Zg [B][T][6H]
 extern "C" int nntk_shim_gru_rr_train_forward(const float *d_x, const float *d_img, const float *d_b4, float *d_h, float *d_hU, float *d_Zg,
-                                              float *d_work, int B, int T, int in, int H) {
-    return lstm_rr_launch(d_x, d_img, d_b4, nullptr, nullptr, nullptr, d_h, nullptr, nullptr, d_work, B, T, in, H, 1, d_hU, d_Zg, 1);
+                                              float *d_hseq, float *d_work, int B, int T, int in, int H) {
+    RRIo io = {d_x, nullptr, d_h, d_hseq, d_work, nullptr, nullptr, nullptr, nullptr, d_hU, d_Zg, 0, 0};
+    return rr_launch(io, d_img, d_b4, nullptr, B, T, in, H, 1, 1);
 }
 // training forward: zero initial state, h of every step to d_h [B][T][H], caches d_c [B][T][H] and d_zifgo [B][T][8H]
 extern "C" int nntk_shim_lstm_rr_train_forward(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,
-                                               float *d_h, float *d_c, float *d_zifgo, float *d_work, int B, int T, int in, int H) {
-    return lstm_rr_launch(d_x, d_img, d_bi, d_bh, nullptr, nullptr, d_h, nullptr, nullptr, d_work, B, T, in, H, 1, d_c, d_zifgo, 0);
+                                               float *d_h, float *d_c, float *d_zifgo, float *d_hseq, float *d_work, int B, int T, int in, int H) {
+    RRIo io = {d_x, nullptr, d_h, d_hseq, d_work, nullptr, nullptr, nullptr, nullptr, d_c, d_zifgo, 0, 0};
+    return rr_launch(io, d_img, d_bi, d_bh, B, T, in, H, 1, 0);
 }
 
-static int lstm_rr_launch(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,
-                          const float *d_h0, const float *d_c0, float *d_out, float *d_hT, float *d_cT,
-                          float *d_work, int B, int T, int in, int H, int return_sequences, float *d_c_cache, float *d_z_cache, int cell,
-                          int x_tm, int out_tm) {
+template <int KH, int KX>
+static void (*rr_pick(int cell, bool train, bool xf))(RRParams) {
+    if (cell == 1) return train ? gru_rr_kernel<KH, KX, true, false> : xf ? gru_rr_kernel<KH, KX, false, true> : gru_rr_kernel<KH, KX, false, false>;
+    return train ? lstm_rr_kernel<KH, KX, true, false> : xf ? lstm_rr_kernel<KH, KX, false, true> : lstm_rr_kernel<KH, KX, false, false>;
+}
+
+static int rr_launch(const RRIo &io, const float *d_img, const float *d_bi, const float *d_bh,
+                     int B, int T, int in, int H, int return_sequences, int cell) {
     if (B <= 0 || T <= 0) return 0;
+    const bool xf = io.xf3 != nullptr;
+    const bool train = io.c_cache != nullptr;
+    if (xf && (train || io.x_tm)) return 1;
+    if (!xf && !io.x) return nntk_fail_msg("lstm_rr: no input");
+    if (!io.hseq || !io.work) return nntk_fail_msg("lstm_rr: no hand-off buffer");
     // time-major tensors are addressed across the whole batch with 32-bit buffer offsets
-    if (x_tm && (double)T * B * in * 4 >= 2.0e9) return 1;
-    if (out_tm && (!return_sequences || (double)T * B * H * 4 >= 2.0e9)) return 1;
+    if (io.x_tm && (double)T * B * in * 4 >= 2.0e9) return 1;
+    if (io.out_tm && (!return_sequences || !io.out || (double)T * B * H * 4 >= 2.0e9)) return 1;
     const NntkOptions &opt = nntk_options();
     if (opt.rec_rr == 0 || opt.rec_persistent == 0 || nntk_persistent_disabled()) return 1;
     int KH, KX;
-    if (!rr_shape(H, in, &KH, &KX)) return 1;
-    if ((((size_t)d_x) & 15) != 0 || (in % 4) != 0) return 1;
+    if (!rr_shape(H, in, xf, &KH, &KX)) return 1;
+    if (!xf && ((((size_t)io.x) & 15) != 0 || (in % 4) != 0)) return 1;
     const int NCT = H / 16;
     // the x and out rows of one 64-row batch tile are addressed with 32-bit buffer offsets
     if ((double)64 * T * in * 4 >= 2.0e9 || (double)64 * T * H * 4 >= 2.0e9) return 1;
     void (*kern)(RRParams) = nullptr;
-    const bool train = d_c_cache != nullptr;
-    if (cell == 1) {
-        if (KH == 8 && KX == 2) kern = train ? gru_rr_kernel<8, 2, true> : gru_rr_kernel<8, 2>;
-        else if (KH == 8 && KX == 1) kern = train ? gru_rr_kernel<8, 1, true> : gru_rr_kernel<8, 1>;
-        else if (KH == 4 && KX == 4) kern = train ? gru_rr_kernel<4, 4, true> : gru_rr_kernel<4, 4>;
-        else if (KH == 4 && KX == 2) kern = train ? gru_rr_kernel<4, 2, true> : gru_rr_kernel<4, 2>;
-        else if (KH == 4 && KX == 1) kern = train ? gru_rr_kernel<4, 1, true> : gru_rr_kernel<4, 1>;
-    } else if (KH == 8 && KX == 2) kern = train ? lstm_rr_kernel<8, 2, true> : lstm_rr_kernel<8, 2>;
-    else if (KH == 8 && KX == 1) kern = train ? lstm_rr_kernel<8, 1, true> : lstm_rr_kernel<8, 1>;
-    else if (KH == 4 && KX == 4) kern = train ? lstm_rr_kernel<4, 4, true> : lstm_rr_kernel<4, 4>;
-    else if (KH == 4 && KX == 2) kern = train ? lstm_rr_kernel<4, 2, true> : lstm_rr_kernel<4, 2>;
-    else if (KH == 4 && KX == 1) kern = train ? lstm_rr_kernel<4, 1, true> : lstm_rr_kernel<4, 1>;
+    if (KH == 8 && KX == 2) kern = rr_pick<8, 2>(cell, train, xf);
+    else if (KH == 8 && KX == 1) kern = rr_pick<8, 1>(cell, train, xf);
+    else if (KH == 4 && KX == 4) kern = rr_pick<4, 4>(cell, train, xf);
+    else if (KH == 4 && KX == 2) kern = rr_pick<4, 2>(cell, train, xf);
+    else if (KH == 4 && KX == 1) kern = rr_pick<4, 1>(cell, train, xf);
     if (!kern) return 1;
     const size_t lds = rr_lds_bytes(KH, KX);
     if (lds > 160 * 1024) return 1;
@@ -844,23 +896,27 @@ static int lstm_rr_launch(const float *d_x, const float *d_img, const float *d_b
     if (tiles_per_launch < 1) return 1;
     unsigned *fault = nntk_fault_word();
     if (!fault) return 1;
-    const size_t parity = rr_parity_bytes(B, KH);
-    if (parity >= 0x7ffffff0ULL) return 1;
+    const size_t step = rr_step_bytes(B, H);
+    if (step >= (size_t)RR_OOB_F) return 1;
     const int nbt_total = (B + 63) / 64;
-    unsigned *flags = reinterpret_cast<unsigned *>(d_work + 2 * parity / 4);
-    // both parities cleared (k steps >= H / 16 must stay zero), h_0 split into parity 0, flags zeroed
-    if (nntk_shim_memset(d_work, 0, 2 * parity + (size_t)nbt_total * 2 * RR_FLAGS * sizeof(unsigned))) return -1;
-    if (d_h0) {
+    const size_t xstep = (size_t)nbt_total * 2 * ((in + 15) / 16) * 3 * 1024;
+    if (xf && xstep >= (size_t)RR_OOB_F) return 1;
+    unsigned *flags = reinterpret_cast<unsigned *>(io.work + step / 4);
+    // the h_0 slot (zeros, or h_0 split below) and the flags; the T-deep part needs no clearing: every block a step reads has been
+    // written by the step before it (k steps the hand-off does not store read as zeros through out-of-range offsets)
+    if (nntk_shim_memset(io.work, 0, step + (size_t)nbt_total * 2 * RR_FLAGS * sizeof(unsigned))) return -1;
+    if (io.h0) {
         long g = ((long)nbt_total * 2 * NCT * 64 + 255) / 256;
         if (g > 2048) g = 2048;
-        hipLaunchKernelGGL(rr_tile_h0_kernel, dim3((unsigned)g), dim3(256), 0, nntk_stream(), d_h0, (rr_v4u *)d_work, B, H, 4 * KH);
+        hipLaunchKernelGGL(rr_tile_h0_kernel, dim3((unsigned)g), dim3(256), 0, nntk_stream(), io.h0, (rr_v4u *)io.work, B, H, H / 16);
     }
     RRParams q;
-    q.x = d_x; q.img = (const rr_v4u *)d_img; q.bi = d_bi; q.bh = d_bh;
-    q.hb = (char *)d_work; q.hb_parity_bytes = parity;
-    q.c0 = d_c0; q.cT = d_cT; q.hT = d_hT; q.out = d_out;
-    q.c_cache = d_c_cache; q.z_cache = d_z_cache;
-    q.x_tm = x_tm; q.out_tm = out_tm;
+    q.x = io.x; q.img = (const rr_v4u *)d_img; q.bi = d_bi; q.bh = d_bh;
+    q.h0f = (char *)io.work; q.hseq = (char *)io.hseq; q.hstep = step;
+    q.xf3 = (const char *)io.xf3; q.xstep = xstep; q.NKSx = (in + 15) / 16;
+    q.c0 = io.c0; q.cT = io.cT; q.hT = io.hT; q.out = io.out;
+    q.c_cache = io.c_cache; q.z_cache = io.z_cache;
+    q.x_tm = io.x_tm; q.out_tm = io.out_tm;
     q.fault = fault;
     q.spin_ticks = (unsigned long long)(opt.rec_spin_us > 0 ? opt.rec_spin_us : 0) * 100ull;
     q.B = B; q.T = T; q.H = H; q.in = in; q.NCT = NCT; q.return_sequences = return_sequences;

@@ -115,6 +115,30 @@ int DenseApplyDevice(Dense filter, const float *d_input, float *d_output, int ro
     return dense_rows_device(filter, d_input, d_output, rows);
 }
 
+/* rows (b, t) of a frag3 tensor [B][T][in]: the register-direct GEMM (frag3.hip dense_frag3_kernel) when it takes the shape, else the
+ * tensor is unpacked (exactly) and the ordinary GEMM runs -- same split products in the same order, same bits */
+static int dense_frag3_device(Dense f, const float *d_in_f3, float *d_out, int B, int T) {
+    if (B <= 0 || T <= 0) return 0;
+    ActivationFunction act = f->config.activation;
+    int kind = nntk_act_kind(act);
+    if (kind == NNTK_ACT_CUSTOM) NNTK_FAIL("dense: custom host-callback activation cannot run on the device");
+    const int fused = nntk_act_fusable(act);
+    int rc = nntk_shim_dense_frag3(d_in_f3, f->d_wp, f->d_bias, fused ? kind : NNTK_ACT_IDENTITY, act ? act->relu_a : 1.f, d_out,
+                                   B, T, f->config.input_size, f->config.output_size);
+    if (rc < 0) return -1;
+    if (rc == 1) {
+        float *xs = nntk_devbuf_reserve(&f->d_in, (size_t)B * T * f->config.input_size);
+        if (!xs || nntk_shim_frag3_unpack(d_in_f3, xs, B, T, f->config.input_size)) return -1;
+        return dense_rows_device(f, xs, d_out, (long)B * T);
+    }
+    if (!fused) {
+        if ((long)act->input_size * act->vector_size != f->config.output_size)
+            NNTK_FAIL("dense: softmax input_size * vector_size must equal the dense output_size");
+        return nntk_shim_activation(NNTK_ACT_SOFTMAX, 1.f, act->vector_size, d_out, d_out, (long)B * T * f->config.output_size);
+    }
+    return 0;
+}
+
 static int dense_rows_host(Dense f, const float *input, float *output, long rows) {
     if (rows <= 0) return 0;
     if (dense_ensure(f, 1)) return -1;
@@ -362,6 +386,30 @@ int TimeDistributedDenseApplyInferenceBatch(TimeDistributedDense filter, const f
     nntk_shim_clear_error();
     if (!filter) NNTK_FAIL("TimeDistributedDenseApplyInferenceBatch: NULL handle");
     return dense_rows_host(filter->dense, input, output, (long)batch * filter->config.ts);
+}
+/* additive: the input as a frag3 tensor [batch][ts][input_size] (nntk_frag3_pack_device, or a recurrent layer's frag3 output) */
+int TimeDistributedDenseApplyDeviceFrag3(TimeDistributedDense filter, const float *d_input_frag3, float *d_output, int batch) {
+    nntk_shim_clear_error();
+    if (!filter || !d_input_frag3 || !d_output) NNTK_FAIL("TimeDistributedDenseApplyDeviceFrag3: NULL argument");
+    if (dense_ensure(filter->dense, 0)) return -1;
+    return dense_frag3_device(filter->dense, d_input_frag3, d_output, batch, filter->config.ts);
+}
+/* additive: LSTM (return_sequences) -> TimeDistributedDense without an f32 tensor in between.  The LSTM's hand-off buffer is its
+ * output in frag3 form; the dense GEMM reads it as its A operand.  Results = LSTMApplyDevice then TimeDistributedDenseApplyDevice,
+ * bit for bit (the frag3 images are the f32 values exactly, and the GEMM sums the same products in the same order). */
+int LSTMTimeDistributedDenseApplyDevice(LSTM lstm, TimeDistributedDense tdd, const float *d_input, float *d_output, int batch) {
+    nntk_shim_clear_error();
+    if (!lstm || !tdd || !d_input || !d_output) NNTK_FAIL("LSTMTimeDistributedDenseApplyDevice: NULL argument");
+    int T, in, H, seq;
+    nntk_lstm_dims(lstm, &T, &in, &H, &seq);
+    if (!seq || tdd->config.ts != T || tdd->dense->config.input_size != H)
+        NNTK_FAIL("LSTMTimeDistributedDenseApplyDevice: the LSTM must return sequences and feed the dense layer (ts = timesteps, input_size = H)");
+    if (batch <= 0) return 0;
+    float *d_h3 = nntk_lstm_frag3_scratch(lstm, batch);
+    if (!d_h3) return -1;
+    if (LSTMApplyDeviceFrag3(lstm, d_input, NULL, NULL, d_h3, batch)) return -1;
+    if (dense_ensure(tdd->dense, 0)) return -1;
+    return dense_frag3_device(tdd->dense, d_h3, d_output, batch, T);
 }
 int TimeDistributedDenseApplyDevice(TimeDistributedDense filter, const float *d_input, float *d_output, int batch) {
     nntk_shim_clear_error();

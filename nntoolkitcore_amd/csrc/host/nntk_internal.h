@@ -76,6 +76,10 @@ const float *nntk_mel_weights(MelFilterBank bank);   /* host [nbins, n_mels] */
 int nntk_spectrogram_apply_mel_device(Spectrogram filter, const float *d_input, float *d_output, int batch,
                                       const int *d_mel_tab, const float *d_mel_w, int n_mels, float eps, int do_log);
 
+/* recurrent.c, for the fused LSTM -> TimeDistributedDense call in dense.c */
+void nntk_lstm_dims(LSTM f, int *T, int *in, int *H, int *return_sequences);
+float *nntk_lstm_frag3_scratch(LSTM f, int batch);       /* the handle's own frag3 output buffer [batch][T][H] */
+
 void nntk_set_error(const char *msg);
 #define NNTK_FAIL(msg) do { nntk_set_error(msg); return -1; } while (0)
 

@@ -60,6 +60,8 @@ typedef struct {
     volatile unsigned *flag;
     unsigned seq;
     nntk_devbuf d_in, d_out, d_xw, d_work, d_work_rr, d_rr_stage;
+    nntk_devbuf d_hseq;         /* register-resident kernels: their T-deep hand-off = the layer output in frag3 form (when the caller supplies no buffer) */
+    nntk_devbuf d_xf3;          /* ... and the input packed into frag3 form (when the call packs it) */
 } rec_core;
 
 /* 1 if the block holds a value the split-bf16 x 3 contraction cannot represent exactly: non-finite, above bf16's largest finite
@@ -109,6 +111,7 @@ static void core_free(rec_core *c) {
     nntk_shim_host_free(c->pin_in); nntk_shim_host_free(c->pin_out); nntk_shim_host_free((void *)c->flag);
     nntk_shim_free(c->d_done);
     nntk_devbuf_free(&c->d_in); nntk_devbuf_free(&c->d_out); nntk_devbuf_free(&c->d_xw); nntk_devbuf_free(&c->d_work); nntk_devbuf_free(&c->d_work_rr); nntk_devbuf_free(&c->d_rr_stage);
+    nntk_devbuf_free(&c->d_hseq); nntk_devbuf_free(&c->d_xf3);
     nntk_wblock_free(&c->wb);
     free(c->weights);
 }
@@ -190,25 +193,61 @@ static int lstm_std_acts(const int *acts) {
            acts[3] == NNTK_ACT_SIGMOID && acts[4] == NNTK_ACT_TANH;
 }
 
+/* How a call on the register-resident kernels takes its input and hands over its output.  The kernels' hand-off buffer is T-deep and
+ * in FRAG3 form (frag3.hip: three bf16 images in MFMA fragment order), so the layer output exists in that form anyway; a consumer that
+ * reads frag3 (the next layer of a stack, the dense GEMM) takes it from there and d_out may be NULL. */
+typedef struct {
+    const float *d_in;      /* f32 [B][T][in], or NULL when d_in_f3 is given */
+    const float *d_in_f3;   /* the input in frag3 form, or NULL */
+    float *d_out;           /* f32 output, or NULL */
+    float *d_out_f3;        /* frag3 output [B][T][H] (nntk_frag3_floats), or NULL: handle scratch */
+} rr_io;
+
+/* decides the x form and provides it: 0 = f32 rows, 1 = frag3 (*xf3 set; packed here when the caller passed f32), 2 = shape not taken */
+static int rr_input(rec_core *c, const rr_io *io, int B, const float **xf3) {
+    *xf3 = io->d_in_f3;
+    const int f32_ok = io->d_in && nntk_shim_lstm_rr_image_floats(c->H, c->in) != 0;
+    const int xf_ok = nntk_shim_rr_image_floats_xf(c->H, c->in) != 0;
+    if (io->d_in_f3) return xf_ok ? 1 : 2;
+    int mode = -1;
+    (void)nntk_shim_get_option("rec_xf", &mode);
+    /* 1: always pack (one extra pass over x, then coalesced requests and no split inside the step); 0: only when the f32 path cannot
+     * take the shape (in % 8 != 0); auto: pack once the call is big enough for the pass to pay (measured at the stack's LSTM, 512 x 996
+     * x 128: 6.50 -> 6.16 ms including the pack).  The two x forms give the same bits (the split is exact and the kernels sum the same
+     * products in the same order -- tests/test_gpu_frag3.py), so this is a speed choice that may depend on the size of the call. */
+    if (f32_ok && (mode == 0 || (mode < 0 && (long)B * c->T < 8192))) return 0;
+    if (!xf_ok || !io->d_in) return 2;
+    float *buf = nntk_devbuf_reserve(&c->d_xf3, nntk_shim_frag3_floats(B, c->T, c->in));
+    if (!buf) return -1;
+    if (nntk_shim_frag3_pack(io->d_in, buf, B, c->T, c->in)) return -1;
+    *xf3 = buf;
+    return 1;
+}
+
 /* 0 = ran; 1 = not taken; -1 = error */
-static int core_try_lstm_rr(rec_core *c, int use_bh, const int *acts, const float *d_in, float *d_out, int B, int stateful) {
+static int core_try_lstm_rr(rec_core *c, int use_bh, const int *acts, const rr_io *io, int B, int stateful) {
     int on = -1;
     (void)nntk_shim_get_option("rec_rr", &on);
     if (on == 0 || c->G != 4 || !lstm_std_acts(acts) || c->rr_exact_only) return 1;
     if (on != 1 && stateful) return 1;
-    size_t img = nntk_shim_lstm_rr_image_floats(c->H, c->in);
-    if (!img) return 1;
+    if (!nntk_shim_rr_image_floats_xf(c->H, c->in)) return 1;
+    const float *xf3 = NULL;
+    const int xm = rr_input(c, io, B, &xf3);
+    if (xm < 0) return -1;
+    if (xm == 2) return 1;
+    size_t img = nntk_shim_rr_image_floats_xf(c->H, c->in);
     if (!c->rr_valid) {
         if (!c->d_rr && !(c->d_rr = (float *)nntk_shim_malloc(img * sizeof(float)))) return -1;
         if (nntk_shim_lstm_rr_pack(c->d_ut, c->d_wp, c->d_rr, c->H, c->in)) return -1;
         c->rr_valid = 1;
     }
     float *d_work = nntk_devbuf_reserve(&c->d_work_rr, nntk_shim_lstm_rr_work_floats(B, c->H));
-    if (!d_work) return -1;
+    float *d_hseq = io->d_out_f3 ? io->d_out_f3 : nntk_devbuf_reserve(&c->d_hseq, nntk_shim_rr_hseq_floats(B, c->T, c->H));
+    if (!d_work || !d_hseq) return -1;
     const float *h0 = stateful ? c->d_h[c->cur] : NULL, *c0 = stateful ? c->d_c[c->cur] : NULL;
     float *hT = stateful ? c->d_h[c->cur ^ 1] : NULL, *cT = stateful ? c->d_c[c->cur ^ 1] : NULL;
-    return nntk_shim_lstm_rr(d_in, c->d_rr, c->d_bi, use_bh ? c->d_bh : NULL, h0, c0, d_out, hT, cT, d_work,
-                             B, c->T, c->in, c->H, c->return_sequences);
+    return nntk_shim_lstm_rr(xm ? NULL : io->d_in, xm ? xf3 : NULL, c->d_rr, c->d_bi, use_bh ? c->d_bh : NULL, h0, c0, io->d_out, d_hseq,
+                             hT, cT, d_work, B, c->T, c->in, c->H, c->return_sequences);
 }
 
 /* GRU on the register-resident split-bf16 kernels (recurrent_rr.hip gru_rr_kernel).  The three gates ride in four slots,
@@ -247,14 +286,18 @@ static int gru_rr_build_image(int in, int H, const float *W, const float *U, con
     free(tmp);                                              /* (nntk_shim_upload has copied it) */
     return rc ? -1 : 0;
 }
-static int core_try_gru_rr(rec_core *c, const int *acts, const float *d_in, float *d_out, int B, int stateful, int x_tm, int out_tm) {
+static int core_try_gru_rr(rec_core *c, const int *acts, const rr_io *io, int B, int stateful) {
     int on = -1;
     (void)nntk_shim_get_option("rec_rr", &on);
     if (on == 0 || c->G != 3 || !gru_std_acts(acts) || c->rr_exact_only) return 1;
     if (on != 1 && stateful) return 1;
     const int H = c->H, in = c->in;
-    size_t img = nntk_shim_lstm_rr_image_floats(H, in);
+    size_t img = nntk_shim_rr_image_floats_xf(H, in);
     if (!img) return 1;
+    const float *xf3 = NULL;
+    const int xm = rr_input(c, io, B, &xf3);
+    if (xm < 0) return -1;
+    if (xm == 2) return 1;
     if (!c->rr_valid) {
         /* from the SHADOW, i.e. the weight version core_upload packed d_wp / d_ut from: the device-pointer calls do not look for
          * host edits (SyncWeights is their contract), and an un-synced edit must not reach this kernel alone */
@@ -263,10 +306,12 @@ static int core_try_gru_rr(rec_core *c, const int *acts, const float *d_in, floa
         c->rr_valid = 1;
     }
     float *d_work = nntk_devbuf_reserve(&c->d_work_rr, nntk_shim_lstm_rr_work_floats(B, H));
-    if (!d_work) return -1;
+    float *d_hseq = io->d_out_f3 ? io->d_out_f3 : nntk_devbuf_reserve(&c->d_hseq, nntk_shim_rr_hseq_floats(B, c->T, H));
+    if (!d_work || !d_hseq) return -1;
     const float *h0 = stateful ? c->d_h[c->cur] : NULL;
     float *hT = stateful ? c->d_h[c->cur ^ 1] : NULL;
-    return nntk_shim_gru_rr(d_in, c->d_rr, c->d_b4, h0, d_out, hT, d_work, B, c->T, in, H, c->return_sequences, x_tm, out_tm);
+    return nntk_shim_gru_rr(xm ? NULL : io->d_in, xm ? xf3 : NULL, c->d_rr, c->d_b4, h0, io->d_out, d_hseq, hT, d_work, B, c->T, in, H,
+                            c->return_sequences, 0, 0);
 }
 
 /* stateful != 0: continue from / store into the handle's state (B must be 1) */
@@ -274,12 +319,13 @@ static int core_apply_device(rec_core *c, int is_lstm, int use_bh, const int *ac
                              const float *d_in, float *d_out, int B, int stateful) {
     int G = c->G, H = c->H, T = c->T;
     if (B <= 0 || T <= 0) return 0;
+    const rr_io io = { d_in, NULL, d_out, NULL };
     if (is_lstm) {
-        int rc = core_try_lstm_rr(c, use_bh, acts, d_in, d_out, B, stateful);
+        int rc = core_try_lstm_rr(c, use_bh, acts, &io, B, stateful);
         if (rc <= 0) return rc;
     }
     if (!is_lstm && G == 3) {
-        int rc = core_try_gru_rr(c, acts, d_in, d_out, B, stateful, 0, 0);
+        int rc = core_try_gru_rr(c, acts, &io, B, stateful);
         if (rc <= 0) return rc;
     }
     float *d_xw = nntk_devbuf_reserve(&c->d_xw, (size_t)T * B * G * H);
@@ -297,6 +343,32 @@ static int core_apply_device(rec_core *c, int is_lstm, int use_bh, const int *ac
     if (is_lstm)
         return nntk_shim_lstm(d_xw, c->d_ut, bh, h0, c0, d_out, hT, cT, d_work, B, T, H, c->return_sequences, acts, scales);
     return nntk_shim_gru(d_xw, c->d_ut, bh, h0, d_out, hT, d_work, B, T, H, c->return_sequences, acts, scales);
+}
+
+/* Device call with frag3 tensors on either side (additive API: <Layer>ApplyDeviceFrag3).  Zero state per sequence.  The
+ * register-resident kernels take and produce the format natively; every other kernel goes through f32 scratch tensors (frag3 is
+ * exact: unpack(pack(x)) == x), so the call works for every shape and the results do not depend on the route. */
+static int core_apply_device_f3(rec_core *c, int is_lstm, int use_bh, const int *acts, const float *scales,
+                                const float *d_in, const float *d_in_f3, float *d_out, float *d_out_f3, int B) {
+    if (B <= 0 || c->T <= 0) return 0;
+    if (!d_in && !d_in_f3) NNTK_FAIL("ApplyDeviceFrag3: no input tensor");
+    if (!d_out && !d_out_f3) NNTK_FAIL("ApplyDeviceFrag3: no output tensor");
+    if (d_out_f3 && !c->return_sequences) NNTK_FAIL("ApplyDeviceFrag3: a frag3 output needs return_sequences");
+    const rr_io io = { d_in, d_in_f3, d_out, d_out_f3 };
+    int rc = 1;
+    if (is_lstm) rc = core_try_lstm_rr(c, use_bh, acts, &io, B, 0);
+    else if (c->G == 3) rc = core_try_gru_rr(c, acts, &io, B, 0);
+    if (rc <= 0) return rc;
+    const float *x = d_in;
+    if (!x) {
+        float *xs = nntk_devbuf_reserve(&c->d_in, (size_t)B * c->T * c->in);
+        if (!xs || nntk_shim_frag3_unpack(d_in_f3, xs, B, c->T, c->in)) return -1;
+        x = xs;
+    }
+    float *o = d_out;
+    if (!o && !(o = nntk_devbuf_reserve(&c->d_out, (size_t)B * c->T * c->H))) return -1;
+    if (core_apply_device(c, is_lstm, use_bh, acts, scales, x, o, B, 0)) return -1;
+    return d_out_f3 ? nntk_shim_frag3_pack(o, d_out_f3, B, c->T, c->H) : 0;
 }
 
 /* The reference's own call shape -- one sequence, carried state, a handful of timesteps (gru.c:189-204,
@@ -550,7 +622,9 @@ static int gru_train_forward_dev(GRU filter, const float *d_x) {
         float *d_wk = nntk_devbuf_reserve(&c->d_work_rr, nntk_shim_lstm_rr_work_floats(B, H));
         if (!d_wk) return -1;
         if (gru_rr_build_image(in, H, c->weights->W, c->weights->U, c->weights->b_i, c->weights->b_h, &c->d_rr_train, img, &c->d_b4_train, &c->d_rr_stage)) return -1;
-        int rc = nntk_shim_gru_rr_train_forward(d_x, c->d_rr_train, c->d_b4_train, d_h, d_hU, d_Zg, d_wk, B, T, in, H);
+        float *d_hs = nntk_devbuf_reserve(&c->d_hseq, nntk_shim_rr_hseq_floats(B, T, H));
+        if (!d_hs) return -1;
+        int rc = nntk_shim_gru_rr_train_forward(d_x, c->d_rr_train, c->d_b4_train, d_h, d_hU, d_Zg, d_hs, d_wk, B, T, in, H);
         if (rc < 0) return -1;
         ran = rc == 0;
     }
@@ -671,6 +745,15 @@ int GRUApplyDevice(GRU filter, const float *d_input, float *d_output, int batch)
     if (core_ensure(&filter->core, 0)) return -1;
     return core_apply_device(&filter->core, 0, 1, acts, sc, d_input, d_output, batch, 0);
 }
+int GRUApplyDeviceFrag3(GRU filter, const float *d_input, const float *d_input_frag3, float *d_output, float *d_output_frag3, int batch) {
+    nntk_shim_clear_error();
+    int acts[3];
+    float sc[3];
+    if (!filter) NNTK_FAIL("GRUApplyDeviceFrag3: NULL handle");
+    if (gru_acts(filter, acts, sc)) return -1;
+    if (core_ensure(&filter->core, 0)) return -1;
+    return core_apply_device_f3(&filter->core, 0, 1, acts, sc, d_input, d_input_frag3, d_output, d_output_frag3, batch);
+}
 int GRUResetState(GRU filter) {
     nntk_shim_clear_error();
     if (!filter) NNTK_FAIL("GRUResetState: NULL handle");
@@ -708,7 +791,7 @@ int GRUStack2ApplyDevice(GRU l1, GRU l2, const float *d_input, float *d_output, 
     (void)nntk_shim_get_option("rec_rr", &rr_on);
     (void)nntk_shim_get_option("rec_fused2", &fused_on);
     const int rr_pair = rr_on != 0 && d1 && d2 && !c1->rr_exact_only && !c2->rr_exact_only &&
-                        nntk_shim_lstm_rr_image_floats(c1->H, c1->in) && nntk_shim_lstm_rr_image_floats(c2->H, c2->in);
+                        nntk_shim_rr_image_floats_xf(c1->H, c1->in) && nntk_shim_rr_image_floats_xf(c2->H, c2->in);
     if (d1 && d2 && c2->H == H && !(rr_pair && fused_on != 1)) {
         if (core_ensure_wt(c2)) return -1;
         float *d_xw = nntk_devbuf_reserve(&c1->d_xw, (size_t)T * B * 3 * H);
@@ -721,23 +804,28 @@ int GRUStack2ApplyDevice(GRU l1, GRU l2, const float *d_input, float *d_output, 
                                 B, T, H, c2->return_sequences);
         if (rc <= 0) return rc;
     }
-    /* not taken by the fused kernel: the two layers one after the other, through a scratch inter-layer tensor */
-    float *d_mid = nntk_devbuf_reserve(&c1->d_out, (size_t)B * T * H);
-    if (!d_mid) return -1;
+    /* the register-resident pair: layer 1 publishes h1_t ALREADY SPLIT, in layer 2's operand order, into a T-deep buffer -- its own
+     * hand-off, so not one store more than a single layer issues -- and layer 2 reads that buffer as its x operand: 12 coalesced 1 KB
+     * requests per half-step, no f32 inter-layer tensor, no split in the consumer (DESIGN K4b).  The values are the f32 h1_t exactly
+     * (hi + mid + lo), so the result equals GRUApplyDevice(l1) then GRUApplyDevice(l2) bit for bit. */
     if (rr_pair) {
-        /* the inter-layer tensor TIME-MAJOR ([T][B][H]): layer 2's x requests then touch 32 contiguous rows instead of 32 rows 1 MB apart
-         * (they sat on its hand-off chain: DESIGN K4b); same arithmetic, same bits as the two layer calls */
         int a1[3], a2[3];
         float s1[3], s2[3];
         if (gru_acts(l1, a1, s1) || gru_acts(l2, a2, s2)) return -1;
-        int rc = core_try_gru_rr(c1, a1, d_input, d_mid, B, 0, 0, 1);
+        float *d_h1 = nntk_devbuf_reserve(&c1->d_hseq, nntk_shim_rr_hseq_floats(B, T, H));
+        if (!d_h1) return -1;
+        const rr_io io1 = { d_input, NULL, NULL, d_h1 };
+        int rc = core_try_gru_rr(c1, a1, &io1, B, 0);
         if (rc < 0) return -1;
         if (rc == 0) {
-            rc = core_try_gru_rr(c2, a2, d_mid, d_output, B, 0, 1, 0);
+            const rr_io io2 = { NULL, d_h1, d_output, NULL };
+            rc = core_try_gru_rr(c2, a2, &io2, B, 0);
             if (rc <= 0) return rc;
-            /* layer 2 not taken after all (cannot happen for a pair that qualified): redo layer 1 in the batch-major layout below */
+            /* layer 2 not taken after all (cannot happen for a pair that qualified): both layers again, through an f32 tensor */
         }
     }
+    float *d_mid = nntk_devbuf_reserve(&c1->d_out, (size_t)B * T * H);
+    if (!d_mid) return -1;
     if (GRUApplyDevice(l1, d_input, d_mid, batch)) return -1;
     return GRUApplyDevice(l2, d_mid, d_output, batch);
 }
@@ -897,7 +985,9 @@ static int lstm_train_forward_dev(LSTM filter, const float *d_x) {
         float *d_wk = nntk_devbuf_reserve(&c->d_work_rr, nntk_shim_lstm_rr_work_floats(B, H));
         if (!d_wk) return -1;
         if (nntk_shim_lstm_rr_pack_raw(dU, dW, c->d_rr_train, H, in)) return -1;
-        int rc = nntk_shim_lstm_rr_train_forward(d_x, c->d_rr_train, dbi, filter->config.v2 ? dbh : NULL, d_h, d_c, d_z, d_wk, B, T, in, H);
+        float *d_hs = nntk_devbuf_reserve(&c->d_hseq, nntk_shim_rr_hseq_floats(B, T, H));
+        if (!d_hs) return -1;
+        int rc = nntk_shim_lstm_rr_train_forward(d_x, c->d_rr_train, dbi, filter->config.v2 ? dbh : NULL, d_h, d_c, d_z, d_hs, d_wk, B, T, in, H);
         if (rc < 0) return -1;
         ran = rc == 0;
     }
@@ -1011,6 +1101,22 @@ int LSTMApplyDevice(LSTM filter, const float *d_input, float *d_output, int batc
     if (lstm_acts(filter, acts, sc)) return -1;
     if (core_ensure(&filter->core, 0)) return -1;
     return core_apply_device(&filter->core, 1, filter->config.v2, acts, sc, d_input, d_output, batch, 0);
+}
+int LSTMApplyDeviceFrag3(LSTM filter, const float *d_input, const float *d_input_frag3, float *d_output, float *d_output_frag3, int batch) {
+    nntk_shim_clear_error();
+    int acts[5];
+    float sc[5];
+    if (!filter) NNTK_FAIL("LSTMApplyDeviceFrag3: NULL handle");
+    if (lstm_acts(filter, acts, sc)) return -1;
+    if (core_ensure(&filter->core, 0)) return -1;
+    return core_apply_device_f3(&filter->core, 1, filter->config.v2, acts, sc, d_input, d_input_frag3, d_output, d_output_frag3, batch);
+}
+/* accessors for the fused LSTM -> TimeDistributedDense call (dense.c) */
+void nntk_lstm_dims(LSTM f, int *T, int *in, int *H, int *return_sequences) {
+    *T = f->core.T; *in = f->core.in; *H = f->core.H; *return_sequences = f->core.return_sequences ? 1 : 0;
+}
+float *nntk_lstm_frag3_scratch(LSTM f, int batch) {
+    return nntk_devbuf_reserve(&f->core.d_hseq, nntk_shim_rr_hseq_floats(batch, f->core.T, f->core.H));
 }
 /* lstm.c:270-274 (lstm_zero_state) */
 int LSTMResetState(LSTM filter) {

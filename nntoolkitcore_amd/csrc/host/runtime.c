@@ -51,6 +51,19 @@ int nntk_device_download(float *dst_host, const float *src_device, size_t n_floa
     return nntk_shim_download(dst_host, src_device, n_floats * sizeof(float));
 }
 
+/* ---- frag3 tensors (frag3.hip) ---- */
+size_t nntk_frag3_floats(int batch, int T, int C) { return nntk_shim_frag3_floats(batch, T, C); }
+int nntk_frag3_pack_device(const float *d_x, float *d_frag3, int batch, int T, int C) {
+    nntk_shim_clear_error();
+    if (!d_x || !d_frag3) NNTK_FAIL("nntk_frag3_pack_device: NULL argument");
+    return nntk_shim_frag3_pack(d_x, d_frag3, batch, T, C);
+}
+int nntk_frag3_unpack_device(const float *d_frag3, float *d_x, int batch, int T, int C) {
+    nntk_shim_clear_error();
+    if (!d_x || !d_frag3) NNTK_FAIL("nntk_frag3_unpack_device: NULL argument");
+    return nntk_shim_frag3_unpack(d_frag3, d_x, batch, T, C);
+}
+
 /* ---- weight blocks ---- */
 int nntk_wblock_init(nntk_wblock *wb, size_t n_floats) {
     wb->n = n_floats;

@@ -227,6 +227,58 @@ def gru_stack2_apply_device(g1, g2, x, out=None):
     return out
 
 
+# ---- frag3 tensors (nntoolkitcore_hip.h: activations pre-split for the split-bf16 x 3 contraction, MFMA fragment order) ----
+
+def frag3_pack_device(x):
+    """[B, T, C] f32 device tensor -> its frag3 form (a flat f32-typed device buffer of nntk_frag3_floats(B, T, C) floats)."""
+    B, T, Cc = x.shape
+    L = capi.load()
+    out = x.new_empty(L.nntk_frag3_floats(B, T, Cc))
+    check(L.nntk_frag3_pack_device(_dp(x), _dp(out), B, T, Cc), "nntk_frag3_pack_device")
+    return out
+
+
+def frag3_unpack_device(f3, B, T, Cc):
+    """frag3 buffer -> [B, T, C] f32 device tensor (exact: hi + mid + lo)."""
+    out = f3.new_empty((B, T, Cc))
+    check(capi.load().nntk_frag3_unpack_device(_dp(f3), _dp(out), B, T, Cc), "nntk_frag3_unpack_device")
+    return out
+
+
+def recurrent_apply_device_frag3(layer, x=None, x_f3=None, batch=None, want_f32=True, want_f3=False, out=None, out_f3=None):
+    """<GRU|LSTM>ApplyDeviceFrag3: input as f32 `x` [B, T, in] or frag3 `x_f3` (then `batch` is required); returns (out_f32 | None,
+    out_frag3 | None).  `out` / `out_f3`: preallocated outputs (they imply want_f32 / want_f3)."""
+    L = capi.load()
+    fn = L.LSTMApplyDeviceFrag3 if isinstance(layer, LSTM) else L.GRUApplyDeviceFrag3
+    B = x.shape[0] if x is not None else batch
+    src = x if x is not None else x_f3
+    H, T = layer.cfg.base.output_feature_channels, layer.cfg.base.timesteps
+    if out is None and want_f32:
+        out = src.new_empty((B, T, H) if layer.cfg.base.return_sequences else (B, H))
+    out3 = out_f3
+    if out3 is None and want_f3:
+        out3 = src.new_empty(L.nntk_frag3_floats(B, T, H))
+    check(fn(layer.h, _dp(x) if x is not None else None, _dp(x_f3) if x_f3 is not None else None,
+             _dp(out) if out is not None else None, _dp(out3) if out3 is not None else None, B), "ApplyDeviceFrag3")
+    return out, out3
+
+
+def tdd_apply_device_frag3(tdd, x_f3, batch, out=None):
+    """TimeDistributedDenseApplyDeviceFrag3: the input [batch, ts, in] in frag3 form."""
+    if out is None:
+        out = x_f3.new_empty((batch, tdd.cfg.ts, tdd.cfg.dense.output_size))
+    check(capi.load().TimeDistributedDenseApplyDeviceFrag3(tdd.h, _dp(x_f3), _dp(out), batch), "TimeDistributedDenseApplyDeviceFrag3")
+    return out
+
+
+def lstm_tdd_apply_device(lstm, tdd, x, out=None):
+    """LSTMTimeDistributedDenseApplyDevice: LSTM (return_sequences) -> TimeDistributedDense with the tensor in between in frag3 form."""
+    if out is None:
+        out = x.new_empty((x.shape[0], tdd.cfg.ts, tdd.cfg.dense.output_size))
+    check(capi.load().LSTMTimeDistributedDenseApplyDevice(lstm.h, tdd.h, _dp(x), _dp(out), x.shape[0]), "LSTMTimeDistributedDenseApplyDevice")
+    return out
+
+
 def gru_stack2_apply(g1, g2, x):
     """GRUStack2ApplyInferenceBatch on host arrays [B, T, in]."""
     x = _f32(x)

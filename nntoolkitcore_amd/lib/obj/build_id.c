@@ -1,1 +1,1 @@
-const char *nntk_build_source_hash(void) { return "d237a3674eb64242"; }
+const char *nntk_build_source_hash(void) { return "4338d8fc158faf39"; }

@@ -89,6 +89,67 @@ def test_lstm_rr_shards_are_bit_identical_and_rows_are_isolated(gpu):
     lstm.destroy()
 
 
+@pytest.mark.parametrize("cell", ["lstm", "gru"])
+def test_rr_shards_of_any_size_equal_the_whole_batch(gpu, cell):
+    """the kernel is chosen from the layer's shape and activations, never from the number of sequences in the call
+    (round 3 switched kernels at B = 32, so 130 utterances over 8 GPUs differed from the single-GPU run).  B = 40 split 20 / 20,
+    130 split into 8 shards of 16-17, and a single row: all bit-identical to the whole batch."""
+    import torch
+    r = rng(41)
+    I, H, T = 128, 256, 9
+    G = 4 if cell == "lstm" else 3
+    W, U, bi, bh = u(r, I, G * H, sc=I ** -0.5), u(r, H, G * H, sc=H ** -0.5), u(r, G * H, sc=0.1), u(r, G * H, sc=0.1)
+    layer = NL.LSTM(I, H, True, T, v2=True) if cell == "lstm" else NL.GRU(I, H, True, T)
+    layer.set_weights(W, U, bi, bh)
+    L = capi.load()
+    for B, cuts in ((40, [0, 20, 40]), (130, [0, 17, 34, 51, 67, 83, 99, 115, 130]), (33, [0, 1, 33])):
+        xd = torch.from_numpy(u(r, B, T, I)).cuda()
+        whole = layer.apply_device(xd).clone()
+        assert L.nntk_hip_last_recurrent_kernel().decode().startswith(cell + "_rr_kernel")
+        parts = torch.cat([layer.apply_device(xd[a:b].contiguous()).clone() for a, b in zip(cuts[:-1], cuts[1:])])
+        assert L.nntk_hip_last_recurrent_kernel().decode().startswith(cell + "_rr_kernel")       # ... also for a shard of one row
+        assert torch.equal(whole, parts), (cell, B)
+    layer.destroy()
+
+
+@pytest.mark.parametrize("cell", ["lstm", "gru"])
+@pytest.mark.parametrize("bad,where", [(np.inf, "W"), (-np.inf, "W"), (3.4e38, "U"), (1e-40, "U")])
+def test_recurrent_weights_the_split_cannot_hold_run_on_the_exact_kernels(gpu, cell, bad, where):
+    """a W or U value the bf16 split cannot represent (non-finite, above bf16's largest finite value, denormal) would go
+    through the register-resident kernels' split as hi = inf, rest = inf - inf = NaN, where the reference's f32 chain gives a
+    saturated, finite gate.  Such a block is found at upload and keeps the exact-f32 kernels: "auto" equals rec_rr = 0 bit for bit
+    and matches the oracle; clean weights go back to the register-resident kernel."""
+    import torch
+    r = rng(43)
+    B, I, H, T = 48, 64, 128, 6
+    G = 4 if cell == "lstm" else 3
+    W, U, bi, bh = u(r, I, G * H, sc=I ** -0.5), u(r, H, G * H, sc=H ** -0.5), u(r, G * H, sc=0.1), u(r, G * H, sc=0.1)
+    Wb, Ub = W.copy(), U.copy()
+    (Wb if where == "W" else Ub)[3, 7] = bad                       # gate block 0 (i / z), hidden unit 7: a sigmoid saturates it
+    x = u(r, B, T, I)
+    layer = NL.LSTM(I, H, True, T, v2=True) if cell == "lstm" else NL.GRU(I, H, True, T)
+    layer.set_weights(Wb, Ub, bi, bh)
+    L = capi.load()
+    xd = torch.from_numpy(x).cuda()
+    auto = layer.apply_device(xd).cpu().numpy()
+    assert not L.nntk_hip_last_recurrent_kernel().decode().startswith(cell + "_rr_kernel")
+    capi.set_option("rec_rr", 0)
+    exact = layer.apply_device(xd).cpu().numpy()
+    capi.set_option("rec_rr", "auto")
+    assert np.array_equal(auto, exact, equal_nan=True)
+    ofn = O.lstm if cell == "lstm" else O.gru
+    ref = ofn(x, Wb, Ub, bi, bh, **({"v2": True} if cell == "lstm" else {}))
+    ref = ref[0] if isinstance(ref, tuple) else ref
+    assert np.array_equal(np.isfinite(auto), np.isfinite(ref))
+    fin = np.isfinite(ref)
+    np.testing.assert_allclose(auto[fin], ref[fin], rtol=1e-5, atol=1e-5)
+    layer.set_weights(W, U, bi, bh)
+    layer.sync_weights()                                           # (device-pointer calls do not look for host edits)
+    layer.apply_device(xd)
+    assert L.nntk_hip_last_recurrent_kernel().decode().startswith(cell + "_rr_kernel")
+    layer.destroy()
+
+
 def test_lstm_rr_carried_state_and_final_state(gpu):
     """h_0 / c_0 taken from, and h_T / c_T left in, the handle (the reference's stateful single-sequence API, lstm.c:241-268)
     through the register-resident kernel (rec_rr = 1 forces it for B = 1; rec_stream = 0 keeps the call off the streaming

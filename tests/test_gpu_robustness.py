@@ -309,7 +309,7 @@ def test_streaming_last_state_only_and_reset(gpu):
 
 # ---- fused two-layer GRU (BASELINE configs[3]) ----
 
-@pytest.mark.parametrize("mode", ["auto", 1])        # auto: two register-resident launches when both layers qualify (B >= 32); 1: the fused kernel
+@pytest.mark.parametrize("mode", ["auto", 1])        # auto: two register-resident launches when both layers' shapes qualify (any B); 1: the fused kernel
 @pytest.mark.parametrize("B,I,H,T,seq", [(70, 128, 256, 40, True), (3, 24, 64, 17, True), (130, 16, 128, 9, False), (65, 40, 256, 5, True)])
 def test_fused_two_layer_gru_matches_two_calls_and_oracle(gpu, B, I, H, T, seq, mode):
     """GRUStack2ApplyDevice: both layers in ONE persistent launch, layer 2 one step behind.  Against the oracle, and
@@ -336,9 +336,10 @@ def test_fused_two_layer_gru_matches_two_calls_and_oracle(gpu, B, I, H, T, seq, 
     xd = torch.from_numpy(x).cuda()
     a = NL.gru_stack2_apply_device(g1, g2, xd).cpu().numpy()
     assert np.array_equal(a, fused)                            # reproducible
-    if mode == 1 or B // 2 + 1 >= 32 or B < 32:                # (auto: a shard below 32 sequences leaves the register-resident kernels)
-        lo = NL.gru_stack2_apply_device(g1, g2, xd[: B // 2 + 1].contiguous()).cpu().numpy()
-        assert np.array_equal(lo, fused[: B // 2 + 1])         # a shard gives the same bits as the whole batch
+    # a shard gives the same bits as the whole batch, whatever its size (the kernel choice depends on shape and activations only)
+    for n in (B // 2 + 1, min(B, 5)):
+        lo = NL.gru_stack2_apply_device(g1, g2, xd[:n].contiguous()).cpu().numpy()
+        assert np.array_equal(lo, fused[:n])
     capi.set_option("rec_fused2", "auto")
     g1.destroy(); g2.destroy()
 
