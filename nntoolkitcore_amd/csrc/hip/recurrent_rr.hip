@@ -180,7 +180,23 @@ struct RRParams {
 #ifdef NNTK_REC_STAMPS
     unsigned long long *stamp; // [T][2 halves][16] s_memtime of workgroup 0, wave 0 (diagnostics build only)
 #endif
+#ifdef NNTK_RR_BOUNDS
+    unsigned long long *bounds; // [8]: see RR_BOUND below (diagnostics build only)
+#endif
 };
+
+// -DNNTK_RR_BOUNDS (tools/rr_bounds_check.py, tests/test_gpu_lstm_rr.py): every request the kernel sends towards a CALLER-visible tensor
+// records the last byte it really touches -- lanes whose vector offset falls outside the descriptor's range touch nothing and are
+// skipped, exactly as the hardware skips them -- as an offset from the tensor's base: word 0 x (f32 rows), 1 x (frag3), 2 f32 output,
+// 3 frag3 hand-off / output (hseq), 4 the h_0 slot.  The host compares them with the tensors' sizes.  Round 3 closed a read past the
+// end of x that the buffer range check could not see (the half-tile rode in the scalar offset); this makes such a read visible.
+#ifdef NNTK_RR_BOUNDS
+#define RR_BOUND(word, base_off, vo, so, range, bytes) do { \
+        if (p.bounds && (unsigned)(vo) < (unsigned)(range)) \
+            atomicMax(p.bounds + (word), (unsigned long long)(base_off) + (unsigned long long)(unsigned)(vo) + (unsigned long long)(so) + (bytes)); } while (0)
+#else
+#define RR_BOUND(word, base_off, vo, so, range, bytes) do {} while (0)
+#endif
 
 #ifdef NNTK_REC_STAMPS
 #define RR_STAMP(half, t, i) do { if (p.stamp && blockIdx.x == 0 && w == 0 && lane == 0) \
@@ -408,6 +424,7 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
             // four 1 KB blocks per scalar offset: the rest of the address rides in the instruction's immediate
             const int i = blk / 3, m = blk % 3;
             hf[half][i][m] = __builtin_amdgcn_raw_buffer_load_b128(rs, hvo[i] + (blk & 3) * 1024, so + (blk >> 2) * 4096, 16 /* sc1 */);
+            RR_BOUND(t ? 3 : 4, t ? (size_t)(t - 1) * p.hstep : 0, hvo[i] + (blk & 3) * 1024, so + (blk >> 2) * 4096, hb_bytes, 16);
         }
     };
     auto issue_x = [&](auto half_tag, int t) __attribute__((always_inline)) {
@@ -420,14 +437,20 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
             for (int ix = 0; ix < KX; ++ix)
 #pragma unroll
                 for (int m = 0; m < 3; ++m)
+                {
                     xf[half][ix][m] = __builtin_bit_cast(rr_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, xvo[ix][0] + ((3 * ix + m) & 3) * 1024, so + ((3 * ix + m) >> 2) * 4096, 0));
+                    RR_BOUND(1, (size_t)t * p.xstep, xvo[ix][0] + ((3 * ix + m) & 3) * 1024, so + ((3 * ix + m) >> 2) * 4096, p.xstep, 16);
+                }
         } else {
             const int so = (int)((half * 32) * x_row_bytes) + t * (int)x_step_bytes;
             const bool ok = half ? xok1 : xok0;
 #pragma unroll
             for (int ix = 0; ix < KX; ++ix)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) xr[ix][q] = __builtin_amdgcn_raw_buffer_load_b128(rsx, ok ? xvo[ix][q] : RR_OOB, so, 0);
+                for (int q = 0; q < 2; ++q) {
+                    xr[ix][q] = __builtin_amdgcn_raw_buffer_load_b128(rsx, ok ? xvo[ix][q] : RR_OOB, so, 0);
+                    RR_BOUND(0, (size_t)b0 * x_row_bytes, ok ? xvo[ix][q] : RR_OOB, so, x_range < 0x7fffffffL ? x_range : 0x7fffffffL, 16);
+                }
         }
     };
     auto split_x = [&]() __attribute__((always_inline)) {
@@ -539,6 +562,7 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
                 __builtin_amdgcn_raw_buffer_store_b128(a, rs, vo, 0, 16 /* sc1 */);
                 __builtin_amdgcn_raw_buffer_store_b128(b, rs, vo + 1024, 0, 16);
                 __builtin_amdgcn_raw_buffer_store_b128(c, rs, vo + 2048, 0, 16);
+                RR_BOUND(3, (size_t)t * p.hstep, vo + 2048, 0, hb_bytes, 16);
             }
         } else if (w == 2 * half + 1) {                 // the output wave: the same row pieces in f32
             const rr_v4u o0 = *reinterpret_cast<const rr_v4u *>(hx + n * RR_HX_LD + 8 * kh);
@@ -547,6 +571,7 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
                 const int vo = (half ? xok1 : xok0) ? out_vo + half * out_half + t * out_step : 0x7fff0000;   // (past every range, room for + 16); soffset immediate, as above
                 __builtin_amdgcn_raw_buffer_store_b128(o0, rso, vo, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(o1, rso, vo + 16, 0, 0);
+                RR_BOUND(2, (size_t)b0 * o_row_bytes, vo + 16, 0, o_range < 0x7fffffffL ? o_range : 0x7fffffffL, 16);
             }
             if (LAST) {
                 int b0e = b0;
@@ -754,6 +779,18 @@ template <int KH, int KX, bool TRAIN = false, bool XF = false>
 __global__ __launch_bounds__(256) void gru_rr_kernel(RRParams p) { rr_body<KH, KX, TRAIN, 1, XF>(p); }
 
 // ---- host side --------------------------------------------------------------------------------------------------
+#ifdef NNTK_RR_BOUNDS
+static unsigned long long *g_rr_bounds = nullptr;
+// copies the eight recorded extents to the host and clears them (diagnostics build only; synchronises the device)
+extern "C" int nntk_shim_rr_bounds_fetch(unsigned long long out[8]) {
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    if (!g_rr_bounds) return 0;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpy(out, g_rr_bounds, 64, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    (void)hipMemset(g_rr_bounds, 0, 64);
+    return 0;
+}
+#endif
 // xf: x arrives as a frag3 tensor (any in: the pack kernel zero-pads to whole k steps); else f32 rows read 16 bytes at a time
 static bool rr_shape(int H, int in, bool xf, int *KH, int *KX) {
     if (H < 64 || H > 512 || (H % 16) != 0 || in < 1) return false;
@@ -927,6 +964,15 @@ static int rr_launch(const RRIo &io, const float *d_img, const float *d_bi, cons
         if (hipMalloc((void **)&q.stamp, (size_t)T * 32 * 8) != hipSuccess) return nntk_fail_msg("stamp alloc");
         (void)hipMemset(q.stamp, 0, (size_t)T * 32 * 8);
     }
+#endif
+#ifdef NNTK_RR_BOUNDS
+    static unsigned long long *g_bounds = nullptr;
+    if (!g_bounds) {
+        if (hipMalloc((void **)&g_bounds, 64) != hipSuccess) return nntk_fail_msg("bounds alloc");
+        (void)hipMemset(g_bounds, 0, 64);
+    }
+    q.bounds = g_bounds;
+    g_rr_bounds = g_bounds;
 #endif
     const int span = nntk_prof_span_begin(NNTK_SPAN_REC);
     nntk_persistent_launch_begin();

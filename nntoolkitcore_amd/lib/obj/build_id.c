@@ -1,1 +1,1 @@
-const char *nntk_build_source_hash(void) { return "4338d8fc158faf39"; }
+const char *nntk_build_source_hash(void) { return "163ccbb2551cf199"; }

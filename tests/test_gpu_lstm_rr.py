@@ -230,8 +230,10 @@ def test_achieved_error_lstm_rr_512_T996(gpu):
 
 
 def test_full_size_lstm_rr_stack_shard(gpu):
-    """B = 512 x T = 996: the bench's own launch (8 batch tiles x 32 column tiles = all 256 CUs), rows of the first and
-    last tile and of both halves against the oracle."""
+    """B = 512 x T = 996: the bench's own launch (8 batch tiles x 32 column tiles = all 256 CUs).  Rows of the first and last tile
+    and of both halves against the oracle; and, as a race detector for the kernel's hand-off protocol (flag words, counted drains,
+    peeled half-steps), over the WHOLE batch: a second run equal bit for bit, every input / output form of the kernel (f32 rows and
+    frag3 on either side) equal bit for bit, and the exact-f32 persistent kernel within the summation-order bound."""
     import torch
     r = rng(512)
     B, I, H, T = 512, 128, 512, 996
@@ -240,15 +242,80 @@ def test_full_size_lstm_rr_stack_shard(gpu):
     W, U, bi, bh = uw(I, I, 4 * H), uw(H, H, 4 * H), uw(H, 4 * H), uw(H, 4 * H)
     lstm = NL.LSTM(I, H, True, T, v2=True)
     lstm.set_weights(W, U, bi, bh)
-    y = lstm.apply_device(x)
-    assert capi.load().nntk_hip_device_status() == 0
+    L = capi.load()
+    y = lstm.apply_device(x).clone()                 # default route at this size: x packed into frag3, XF instantiation
+    assert L.nntk_hip_device_status() == 0 and L.nntk_hip_last_recurrent_kernel().decode() == "lstm_rr_kernel<8,2>"
     rows = [0, 40, 300, 479, 511]
     ref = O.lstm(x[rows].cpu().numpy(), W, U, bi, bh, v2=True)
     ref = ref[0] if isinstance(ref, tuple) else ref
     e = float(np.abs(y[rows].cpu().numpy() - ref).max())
     print("lstm_rr B=512 T=996: max abs err vs oracle %.2e" % e)
     assert e < 3e-6
+    assert torch.equal(lstm.apply_device(x), y)      # reproducible over the whole batch
+    capi.set_option("rec_xf", 0)                     # the f32-row input form of the kernel
+    assert torch.equal(lstm.apply_device(x), y)
+    capi.set_option("rec_xf", "auto")
+    _, f3 = NL.recurrent_apply_device_frag3(lstm, x=x, want_f32=False, want_f3=True)     # the bench's form: frag3 output only
+    assert torch.equal(NL.frag3_unpack_device(f3, B, T, H), y)
+    del f3
+    capi.set_option("rec_rr", 0)                     # exact-f32 persistent kernel + projection GEMM: another summation order
+    ex = lstm.apply_device(x)
+    capi.set_option("rec_rr", "auto")
+    assert L.nntk_hip_last_recurrent_kernel().decode().startswith("rec_persistent_kernel")
+    d = float((ex - y).abs().max())
+    print("lstm_rr vs exact-f32 persistent kernel, whole batch: max abs diff %.2e" % d)
+    assert d < 1e-5
+    assert L.nntk_hip_device_status() == 0
     lstm.destroy()
+
+
+def test_single_gpu_at_the_named_batch_of_4096(gpu):
+    """north_star quotes the recurrent kernel "at batch 4096 x 1000 frames": 4096 utterances on ONE GPU are 64 batch tiles = 8
+    back-to-back launches of the 256-workgroup kernel sharing the hand-off and flag buffers (T = 100 keeps the oracle rows cheap;
+    the launch structure is the full-size one).  Rows of the first and the last launch against the oracle, a 512-row shard equal
+    to the whole batch bit for bit, the fused LSTM -> TimeDistributedDense call equal to the two calls (lstm.c:426-475)."""
+    import torch
+    r = rng(4096)
+    B, I, H, T, N = 4096, 128, 512, 100, 1000
+    x = torch.randn(B, T, I, device="cuda", generator=torch.Generator(device="cuda").manual_seed(6))
+    uw = lambda fan, *s: r.uniform(-fan ** -0.5, fan ** -0.5, s).astype(np.float32)
+    W, U, bi, bh = uw(I, I, 4 * H), uw(H, H, 4 * H), uw(H, 4 * H), uw(H, 4 * H)
+    Wd, bd = uw(H, H, N), uw(H, N)
+    lstm = NL.LSTM(I, H, True, T, v2=True)
+    lstm.set_weights(W, U, bi, bh)
+    tdd = NL.TimeDistributedDense(T, H, N)
+    tdd.set_weights(Wd, bd)
+    L = capi.load()
+    y = lstm.apply_device(x).clone()
+    assert L.nntk_hip_device_status() == 0 and L.nntk_hip_last_recurrent_kernel().decode() == "lstm_rr_kernel<8,2>"
+    rows = [0, 63, 511, 512, 3584, 4000, 4095]
+    ref = O.lstm(x[rows].cpu().numpy(), W, U, bi, bh, v2=True)
+    ref = ref[0] if isinstance(ref, tuple) else ref
+    e = float(np.abs(y[rows].cpu().numpy() - ref).max())
+    print("lstm_rr B=4096 T=100 (8 launches): max abs err vs oracle %.2e" % e)
+    assert e < 3e-6
+    assert torch.equal(lstm.apply_device(x[3584:].contiguous()), y[3584:])       # the last launch's rows as a batch of their own
+    z2 = tdd.apply_device(y)
+    z1 = NL.lstm_tdd_apply_device(lstm, tdd, x)
+    assert torch.equal(z1, z2)
+    zr = O.time_distributed_dense(ref[-1], Wd, bd)
+    np.testing.assert_allclose(z1[4095].cpu().numpy(), zr, rtol=1e-4, atol=1e-5)
+    assert L.nntk_hip_device_status() == 0
+    lstm.destroy(); tdd.destroy()
+
+
+def test_rr_requests_stay_inside_their_tensors(gpu):
+    """a diagnostics build of the library (recurrent_rr.hip -DNNTK_RR_BOUNDS) records the last byte every request
+    of gru_rr_kernel / lstm_rr_kernel really touches; ragged last tiles (B = 33, 65, 130, 1) through all four input / output forms
+    must stay inside [0, size) of x, the f32 output, the frag3 tensors and the h_0 slot.  Runs in a child process (its own library)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "rr_bounds_check.py")], capture_output=True, text=True, timeout=900)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "rr bounds: 0 violation(s)" in r.stdout
 
 
 def test_lstm_rr_fault_is_reported_and_heals(gpu):
