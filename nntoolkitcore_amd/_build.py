@@ -14,7 +14,7 @@ OBJ = os.path.join(PKG, "lib", "obj")
 LIB = os.path.join(PKG, "lib", "libnntoolkitcore_hip.so")
 
 HOST_SRC = ["runtime.c", "activation.c", "conv_1d.c", "recurrent.c", "dense.c", "spectrogram.c", "mel.c", "train.c"]
-HIP_SRC = ["runtime.hip", "conv1d.hip", "conv1d_s2.hip", "recurrent.hip", "recurrent_rr.hip", "frag3.hip", "spectrogram.hip", "dist.hip", "conv1d_grad.hip", "train.hip"]
+HIP_SRC = ["runtime.hip", "conv1d.hip", "conv1d_s2.hip", "recurrent.hip", "recurrent_rr.hip", "recurrent_rr4.hip", "frag3.hip", "spectrogram.hip", "dist.hip", "conv1d_grad.hip", "train.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
@@ -26,7 +26,7 @@ def source_hash():
     h = hashlib.sha256()
     files = [os.path.join(CSRC, "host", f) for f in HOST_SRC] + [os.path.join(CSRC, "hip", f) for f in HIP_SRC]
     files += [os.path.join(CSRC, "hip", "nntk_shim.h"), os.path.join(CSRC, "hip", "nntk_common.hpp"),
-              os.path.join(CSRC, "hip", "conv1d_kernels.hpp"),
+              os.path.join(CSRC, "hip", "conv1d_kernels.hpp"), os.path.join(CSRC, "hip", "recurrent_rr_common.hpp"),
               os.path.join(CSRC, "host", "nntk_internal.h"), os.path.join(ROOT, "include", "nntoolkitcore_hip.h")]
     for f in sorted(files):
         h.update(os.path.basename(f).encode())
@@ -56,6 +56,7 @@ def build(force=False, verbose=False):
                os.path.join(CSRC, "hip", "nntk_shim.h"),
                os.path.join(CSRC, "hip", "nntk_common.hpp"),
                os.path.join(CSRC, "hip", "conv1d_kernels.hpp"),
+               os.path.join(CSRC, "hip", "recurrent_rr_common.hpp"),
                os.path.join(CSRC, "host", "nntk_internal.h")]
     objs, jobs = [], []
     for f in HOST_SRC:

@@ -161,6 +161,8 @@ __global__ __launch_bounds__(256) void dense_frag3_kernel(DF3Params p) {
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
     const int tile = (local / p.n_tiles) * 8 + xcd;
     if (tile >= p.m_tiles) return;
+    // (Measured and not kept: staggering the first round of workgroups by 2.5 - 20 us per phase so that the CUs' epilogues -- 64 MB of
+    // stores in a burst while every MFMA pipe idles -- fall into each other's main loops: 2.60 ms with and without, tools/r04j.sh.)
     const int n0 = (local % p.n_tiles) * BN;
     const long rb0 = (long)tile * BM_RB + wm * TM;    // this wave's first row block
     const int NKS = p.NKS;

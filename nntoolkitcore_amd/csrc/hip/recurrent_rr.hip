@@ -33,49 +33,7 @@
 // Numerics: the contraction is the split form of conv1d.hip (error <= the f32 chain's against float64); gates are the
 // exp2 / rcp forms of nntk_common.hpp.  Not bit-identical to rec_persistent_kernel (another summation order), same
 // tolerance; results do not depend on the batch tile a row lands in, so shards equal the whole batch bit for bit.
-#include "nntk_common.hpp"
-#include <stdio.h>
-#include <stdlib.h>
-#include <type_traits>
-
-typedef __bf16 rr_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 rr_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float rr_f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned rr_v4u __attribute__((ext_vector_type(4)));
-
-#define RR_FLAGS 64               // flag words per (batch tile, half): one per column tile (<= 32), padded to one wave-wide load
-#ifndef RR_POLL_LEAD
-#define RR_POLL_LEAD 1           // the flags are requested this many k steps before they are looked at
-#endif
-#ifndef RR_NPRE
-#define RR_NPRE 2                // operand k steps requested ahead, at the end of the other half's sequence (the rest: own sequence)
-#endif
-#ifndef RR_S_E1
-#define RR_S_E1 3                // k step at which a half's publication is taken to have drained (tools/rr_stamps.py)
-#endif
-
-#define RR_HX_LD 20               // floats per row of the h exchange image (16-byte aligned rows)
-
-__device__ __forceinline__ unsigned rr_cvt_pk(float a, float b) {       // RNE, a in the low half
-    return __builtin_bit_cast(unsigned, __builtin_convertvector((rr_f32x2){a, b}, rr_bf16x2));
-}
-// x = hi + mid + lo exactly (8 + 8 + 8 significand bits), two elements at a time
-__device__ __forceinline__ void rr_split_pair(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo) {
-    hi = rr_cvt_pk(x0, x1);
-    const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
-    mid = rr_cvt_pk(r0, r1);
-    const float s0 = r0 - __uint_as_float(mid << 16), s1 = r1 - __uint_as_float(mid & 0xffff0000u);
-    lo = rr_cvt_pk(s0, s1);
-}
-// eight consecutive f32 -> the three 16-byte bf16 fragments
-__device__ __forceinline__ void rr_split8(const float (&v)[8], rr_v4u &hi, rr_v4u &mid, rr_v4u &lo) {
-    unsigned h[4], m[4], l[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) rr_split_pair(v[2 * i], v[2 * i + 1], h[i], m[i], l[i]);
-    hi = (rr_v4u){h[0], h[1], h[2], h[3]};
-    mid = (rr_v4u){m[0], m[1], m[2], m[3]};
-    lo = (rr_v4u){l[0], l[1], l[2], l[3]};
-}
+#include "recurrent_rr_common.hpp"
 
 // ---- weight images ------------------------------------------------------------------------------------------------
 // Tile row c (0..63) of column tile ct  <->  gate g = (c >> 3) & 3, hidden unit j = 16 ct + 8 ((c >> 2) & 1) + 4 (c >> 5) + (c & 3):
@@ -154,76 +112,6 @@ __global__ __launch_bounds__(256) void rr_tile_h0_kernel(const float *__restrict
         dst[0] = hi; dst[64] = mid; dst[128] = lo;
     }
 }
-
-struct RRParams {
-    const float *x;            // [B][T][in]
-    const rr_v4u *img;         // weight images (rr_pack_kernel)
-    const float *bi, *bh;      // [4H]; bh NULL when !v2
-    // split hand-off = the layer output in FRAG3 form (frag3.hip): h0f [NHT][NKS][3] blocks of 1 KB holds h_0; hseq [T][NHT][NKS][3]
-    // receives h_t of every step (step t reads h_{t-1}: t == 0 from h0f, else from hseq + (t - 1) * hstep) -- T-deep, so the
-    // published fragments ARE a tensor the next layer can consume (a stacked GRU's x operand, the dense GEMM's A operand)
-    char *h0f, *hseq;
-    size_t hstep;              // bytes per timestep of hseq = NHT_total * NKS * 3072, NKS = H / 16
-    const char *xf3;           // XF: x as a frag3 tensor [T][NHT][NKSx][3] blocks, NKSx = ceil(in / 16) (instead of p.x)
-    size_t xstep;
-    const float *c0;           // [B][H] or NULL (zeros)
-    float *cT, *hT;            // [B][H] or NULL
-    float *out;                // [B][T][H] or [B][H]
-    unsigned *flags;           // [NBT][2 halves][RR_FLAGS], zeroed before the launch
-    int x_tm, out_tm;          // x / the sequence output in time-major layout ([T][B][.]: the tensor between two stacked layers)
-    float *c_cache;            // training forward (TRAIN): cell state of every step [B][T][H] ...
-    float *z_cache;            // ... and pre-activations | activations [B][T][8H] (lstm.c:426-475 keeps them for BPTT)
-    unsigned *fault;
-    unsigned long long spin_ticks;
-    int B, T, H, in, NBT, NCT, b_base, return_sequences;
-    int NKSx;                  // k steps of 16 the x frag3 tensor stores per row block
-#ifdef NNTK_REC_STAMPS
-    unsigned long long *stamp; // [T][2 halves][16] s_memtime of workgroup 0, wave 0 (diagnostics build only)
-#endif
-#ifdef NNTK_RR_BOUNDS
-    unsigned long long *bounds; // [8]: see RR_BOUND below (diagnostics build only)
-#endif
-};
-
-// -DNNTK_RR_BOUNDS (tools/rr_bounds_check.py, tests/test_gpu_lstm_rr.py): every request the kernel sends towards a CALLER-visible tensor
-// records the last byte it really touches -- lanes whose vector offset falls outside the descriptor's range touch nothing and are
-// skipped, exactly as the hardware skips them -- as an offset from the tensor's base: word 0 x (f32 rows), 1 x (frag3), 2 f32 output,
-// 3 frag3 hand-off / output (hseq), 4 the h_0 slot.  The host compares them with the tensors' sizes.  Round 3 closed a read past the
-// end of x that the buffer range check could not see (the half-tile rode in the scalar offset); this makes such a read visible.
-#ifdef NNTK_RR_BOUNDS
-#define RR_BOUND(word, base_off, vo, so, range, bytes) do { \
-        if (p.bounds && (unsigned)(vo) < (unsigned)(range)) \
-            atomicMax(p.bounds + (word), (unsigned long long)(base_off) + (unsigned long long)(unsigned)(vo) + (unsigned long long)(so) + (bytes)); } while (0)
-#else
-#define RR_BOUND(word, base_off, vo, so, range, bytes) do {} while (0)
-#endif
-
-#ifdef NNTK_REC_STAMPS
-#define RR_STAMP(half, t, i) do { if (p.stamp && blockIdx.x == 0 && w == 0 && lane == 0) \
-        p.stamp[((size_t)(t) * 2 + (half)) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define RR_STAMP(half, t, i) do {} while (0)
-#endif
-
-// timing ablations only (WRONG results; tools/rr_ablate.sh builds one library per mask): -DNNTK_RR_DBG=<mask>,
-// 1 no operand loads, 2 no finish, 4 no arrive / poll, 8 no x, 16 no MFMAs, 32 no partial-sum writes,
-// 64 no gate arithmetic, 128 no publication (split + stores), 256 no partial-sum reads, 512 no workgroup barriers, 1024 no output stores.  Compile-time on
-// purpose: a run-time mask changed the register allocation of the whole kernel (2x slower with the mask at 0).
-#ifdef NNTK_RR_DBG
-#define RR_DBG(bit) ((NNTK_RR_DBG) & (bit))
-#else
-#define RR_DBG(bit) 0
-#endif
-
-// raw barrier: LDS traffic ordered, vector-memory operations (the operand prefetch!) left in flight
-#define RR_BARRIER() do { if (!RR_DBG(512)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
-#ifndef RR_NO_PIN
-#define RR_PIN_A(v) asm volatile("" : "+a"(v))      // accumulator-file registers: MFMA operands only, never copied about
-#else
-#define RR_PIN_A(v) do {} while (0)
-#endif
-#define RR_OOB 0x7ffffff0          // out-of-range vector offset: a buffer load returns 0, a buffer store is dropped
-#define RR_OOB_F 0x7f000000        // the same for the frag3 blocks, whose instructions add up to 3 KB of immediate offset (no wrap); steps < this
 
 // The kernel is a software pipeline of HALF-STEPS.  Half-step s multiplies half Y = s & 1 at timestep t = s >> 1 (its
 // operand fetched during half-step s - 1) and, sliced between the k steps of that MFMA sequence, FINISHES half X = 1 - Y,
@@ -820,8 +708,8 @@ extern "C" size_t nntk_shim_rr_image_floats_xf(int H, int in) {
 }
 // d_work: the h_0 slot (one timestep of the hand-off) followed by the flag words
 extern "C" size_t nntk_shim_lstm_rr_work_floats(int B, int H) {
-    const size_t nbt = (size_t)(B + 63) / 64;
-    return rr_step_bytes(B, H) / 4 + 2 * nbt * RR_FLAGS;
+    const size_t nht = (size_t)(B + 127) / 128 * 4;        // flag words for whole 128-row tiles (the four-stream kernels' unit)
+    return rr_step_bytes(B, H) / 4 + nht * RR_FLAGS;
 }
 // d_hseq: T timesteps of the hand-off = the layer output as a frag3 tensor (same size as nntk_shim_frag3_floats(B, T, H))
 extern "C" size_t nntk_shim_rr_hseq_floats(int B, int T, int H) { return (size_t)T * (rr_step_bytes(B, H) / 4); }
@@ -858,7 +746,9 @@ extern "C" int nntk_shim_lstm_rr_pack_raw(const float *d_U, const float *d_W, fl
 // 0 = launched; 1 = shape / configuration not taken (the caller runs projection GEMM + rec_persistent_kernel); -1 = error
 // d_x: f32 [B][T][in] (or time-major with x_tm), or NULL with d_xf3 = the same tensor in frag3 form (nntk_shim_frag3_pack);
 // d_out: f32 layer output or NULL (the caller takes it in frag3 form: d_hseq); d_hseq: nntk_shim_rr_hseq_floats(B, T, H) floats
+int nntk_rr4_launch(RRParams q, const float *d_img4, int cell, size_t *launches);      // recurrent_rr4.hip
 struct RRIo {
+    const float *img4;        // images of the four-stream kernels (nntk_shim_rr4_pack) or NULL
     const float *x; const void *xf3; float *out; float *hseq; float *work;
     const float *h0, *c0; float *hT, *cT; float *c_cache, *z_cache;
     int x_tm, out_tm;
@@ -866,30 +756,30 @@ struct RRIo {
 static int rr_launch(const RRIo &io, const float *d_img, const float *d_bi, const float *d_bh,
                      int B, int T, int in, int H, int return_sequences, int cell);
 
-extern "C" int nntk_shim_lstm_rr(const float *d_x, const void *d_xf3, const float *d_img, const float *d_bi, const float *d_bh,
+extern "C" int nntk_shim_lstm_rr(const float *d_x, const void *d_xf3, const float *d_img, const float *d_img4, const float *d_bi, const float *d_bh,
                                  const float *d_h0, const float *d_c0, float *d_out, float *d_hseq, float *d_hT, float *d_cT,
                                  float *d_work, int B, int T, int in, int H, int return_sequences) {
-    RRIo io = {d_x, d_xf3, d_out, d_hseq, d_work, d_h0, d_c0, d_hT, d_cT, nullptr, nullptr, 0, 0};
+    RRIo io = {d_img4, d_x, d_xf3, d_out, d_hseq, d_work, d_h0, d_c0, d_hT, d_cT, nullptr, nullptr, 0, 0};
     return rr_launch(io, d_img, d_bi, d_bh, B, T, in, H, return_sequences, 0);
 }
 // GRU on the same kernel frame (gru_rr_kernel): d_img packed from the four-slot matrices [U_z | U_r | U_h | 0] / [W_z | W_r | 0 | W_h],
 // d_b4 [4H] = b_i,z + b_h,z | b_i,r + b_h,r | b_h,h | b_i,h.  The f32 state register starts from h_0 (which is also the published operand).
 // x_tm / out_tm: d_x is [T][B][in] / the sequence output is written as [T][B][H]
-extern "C" int nntk_shim_gru_rr(const float *d_x, const void *d_xf3, const float *d_img, const float *d_b4, const float *d_h0, float *d_out,
+extern "C" int nntk_shim_gru_rr(const float *d_x, const void *d_xf3, const float *d_img, const float *d_img4, const float *d_b4, const float *d_h0, float *d_out,
                                 float *d_hseq, float *d_hT, float *d_work, int B, int T, int in, int H, int return_sequences, int x_tm, int out_tm) {
-    RRIo io = {d_x, d_xf3, d_out, d_hseq, d_work, d_h0, d_h0, d_hT, nullptr, nullptr, nullptr, x_tm, out_tm};
+    RRIo io = {d_img4, d_x, d_xf3, d_out, d_hseq, d_work, d_h0, d_h0, d_hT, nullptr, nullptr, nullptr, x_tm, out_tm};
     return rr_launch(io, d_img, d_b4, nullptr, B, T, in, H, return_sequences, 1);
 }
 // GRU training forward: zero initial state, h of every step to d_h [B][T][H], caches d_hU [B][T][H] (h.U_h + b_h) and d_Zg [B][T][6H]
 extern "C" int nntk_shim_gru_rr_train_forward(const float *d_x, const float *d_img, const float *d_b4, float *d_h, float *d_hU, float *d_Zg,
                                               float *d_hseq, float *d_work, int B, int T, int in, int H) {
-    RRIo io = {d_x, nullptr, d_h, d_hseq, d_work, nullptr, nullptr, nullptr, nullptr, d_hU, d_Zg, 0, 0};
+    RRIo io = {nullptr, d_x, nullptr, d_h, d_hseq, d_work, nullptr, nullptr, nullptr, nullptr, d_hU, d_Zg, 0, 0};
     return rr_launch(io, d_img, d_b4, nullptr, B, T, in, H, 1, 1);
 }
 // training forward: zero initial state, h of every step to d_h [B][T][H], caches d_c [B][T][H] and d_zifgo [B][T][8H]
 extern "C" int nntk_shim_lstm_rr_train_forward(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,
                                                float *d_h, float *d_c, float *d_zifgo, float *d_hseq, float *d_work, int B, int T, int in, int H) {
-    RRIo io = {d_x, nullptr, d_h, d_hseq, d_work, nullptr, nullptr, nullptr, nullptr, d_c, d_zifgo, 0, 0};
+    RRIo io = {nullptr, d_x, nullptr, d_h, d_hseq, d_work, nullptr, nullptr, nullptr, nullptr, d_c, d_zifgo, 0, 0};
     return rr_launch(io, d_img, d_bi, d_bh, B, T, in, H, 1, 0);
 }
 
@@ -941,7 +831,7 @@ static int rr_launch(const RRIo &io, const float *d_img, const float *d_bi, cons
     unsigned *flags = reinterpret_cast<unsigned *>(io.work + step / 4);
     // the h_0 slot (zeros, or h_0 split below) and the flags; the T-deep part needs no clearing: every block a step reads has been
     // written by the step before it (k steps the hand-off does not store read as zeros through out-of-range offsets)
-    if (nntk_shim_memset(io.work, 0, step + (size_t)nbt_total * 2 * RR_FLAGS * sizeof(unsigned))) return -1;
+    if (nntk_shim_memset(io.work, 0, step + (size_t)((B + 127) / 128) * 4 * RR_FLAGS * sizeof(unsigned))) return -1;
     if (io.h0) {
         long g = ((long)nbt_total * 2 * NCT * 64 + 255) / 256;
         if (g > 2048) g = 2048;
@@ -957,12 +847,13 @@ static int rr_launch(const RRIo &io, const float *d_img, const float *d_bi, cons
     q.fault = fault;
     q.spin_ticks = (unsigned long long)(opt.rec_spin_us > 0 ? opt.rec_spin_us : 0) * 100ull;
     q.B = B; q.T = T; q.H = H; q.in = in; q.NCT = NCT; q.return_sequences = return_sequences;
+    q.NHT = nbt_total * 2;
 #ifdef NNTK_REC_STAMPS
     q.stamp = nullptr;
     const char *stamp_path = getenv("NNTK_REC_STAMP_FILE");
     if (stamp_path) {
-        if (hipMalloc((void **)&q.stamp, (size_t)T * 32 * 8) != hipSuccess) return nntk_fail_msg("stamp alloc");
-        (void)hipMemset(q.stamp, 0, (size_t)T * 32 * 8);
+        if (hipMalloc((void **)&q.stamp, (size_t)(T + 1) * 64 * 8) != hipSuccess) return nntk_fail_msg("stamp alloc");
+        (void)hipMemset(q.stamp, 0, (size_t)(T + 1) * 64 * 8);
     }
 #endif
 #ifdef NNTK_RR_BOUNDS
@@ -976,6 +867,18 @@ static int rr_launch(const RRIo &io, const float *d_img, const float *d_bi, cons
 #endif
     const int span = nntk_prof_span_begin(NNTK_SPAN_REC);
     nntk_persistent_launch_begin();
+    // four half-streams per workgroup (recurrent_rr4.hip): same bits, built to hide the hand-off chain of the H <= 256 shapes -- and
+    // measured SLOWER than this family on every shape (GRU-256 pair 14.4 vs 10.9 ms, LSTM-512 7.8 vs 6.2: a half-step carries ~2.7 k
+    // cycles of finish / poll / barrier work whatever its MFMA count, and four short half-steps pay it twice as often; stamps in
+    // profiles/r04_rr4_stamps.log, DESIGN K4c).  Kept behind rec_rr4 = 1 as the record of that experiment; auto = off.
+    size_t launches = (size_t)(nbt_total + tiles_per_launch - 1) / tiles_per_launch;
+    int took4 = 1;
+    if (xf && !train && io.img4 && opt.rec_rr4 == 1 && !io.out_tm) {
+        q.flags = flags;
+        took4 = nntk_rr4_launch(q, io.img4, cell, &launches);
+        if (took4 < 0) { nntk_persistent_launch_end(); return -1; }
+    }
+    if (took4 == 1)
     for (int bt0 = 0; bt0 < nbt_total; bt0 += tiles_per_launch) {
         const int nbt = nbt_total - bt0 < tiles_per_launch ? nbt_total - bt0 : tiles_per_launch;
         q.NBT = nbt; q.b_base = bt0 * 64;
@@ -985,20 +888,20 @@ static int rr_launch(const RRIo &io, const float *d_img, const float *d_bi, cons
     const int copy_rc = nntk_fault_enqueue_copy();
     nntk_persistent_launch_end();
     if (copy_rc) return -1;
-    nntk_prof_span_end(span, (nbt_total + tiles_per_launch - 1) / tiles_per_launch, T);
+    nntk_prof_span_end(span, (long)launches, T);
 #ifdef NNTK_REC_STAMPS
     if (q.stamp) {
         (void)hipStreamSynchronize(nntk_stream());
-        unsigned long long *hs = (unsigned long long *)malloc((size_t)T * 32 * 8);
-        (void)hipMemcpy(hs, q.stamp, (size_t)T * 32 * 8, hipMemcpyDeviceToHost);
+        unsigned long long *hs = (unsigned long long *)malloc((size_t)(T + 1) * 64 * 8);
+        (void)hipMemcpy(hs, q.stamp, (size_t)(T + 1) * 64 * 8, hipMemcpyDeviceToHost);
         FILE *f = fopen(stamp_path, "wb");
-        if (f) { fwrite(hs, 8, (size_t)T * 32, f); fclose(f); }
+        if (f) { fwrite(hs, 8, (size_t)(T + 1) * 64, f); fclose(f); }
         free(hs); (void)hipFree(q.stamp);
     }
 #endif
     NNTK_LAUNCH_CHECK("lstm_rr_kernel");
     static const char *const names[2][2][3] = {{{"lstm_rr_kernel<4,1>", "lstm_rr_kernel<4,2>", "lstm_rr_kernel<4,4>"}, {"lstm_rr_kernel<8,1>", "lstm_rr_kernel<8,2>", ""}},
                                                {{"gru_rr_kernel<4,1>", "gru_rr_kernel<4,2>", "gru_rr_kernel<4,4>"}, {"gru_rr_kernel<8,1>", "gru_rr_kernel<8,2>", ""}}};
-    nntk_set_last_rec_kernel(names[cell == 1][KH == 8][KX == 1 ? 0 : KX == 2 ? 1 : 2]);
+    if (took4 == 1) nntk_set_last_rec_kernel(names[cell == 1][KH == 8][KX == 1 ? 0 : KX == 2 ? 1 : 2]);
     return 0;
 }

@@ -43,6 +43,7 @@ typedef struct {
     float *d_wt;                /* W^T packed like U^T (only when in == H): layer-2 operand of the fused two-layer GRU */
     int wt_valid;
     int rr_exact_only;          /* W or U holds a value the bf16 split cannot represent (non-finite, > 3.39e38, denormal): exact kernels only */
+    float *d_rr4;               /* the same weights as images of the four-stream kernels (recurrent_rr4.hip), packed with d_rr */
     float *d_rr;                /* LSTM: weight images of the register-resident split-bf16 kernel (recurrent_rr.hip), made on first use */
     int rr_valid;
     float *d_b4, *d_b4_train;   /* GRU on those kernels: the four-slot bias vector (core_try_gru_rr; the training forward's copy) */
@@ -106,7 +107,7 @@ static int core_init(rec_core *c, int G, RecurrentConfig base) {
 static void core_free(rec_core *c) {
     nntk_shim_synchronize();
     nntk_shim_free(c->d_wp); nntk_shim_free(c->d_bi); nntk_shim_free(c->d_ut); nntk_shim_free(c->d_bh); nntk_shim_free(c->d_wt);
-    nntk_shim_free(c->d_rr); nntk_shim_free(c->d_rr_train); nntk_shim_free(c->d_b4); nntk_shim_free(c->d_b4_train);
+    nntk_shim_free(c->d_rr); nntk_shim_free(c->d_rr4); nntk_shim_free(c->d_rr_train); nntk_shim_free(c->d_b4); nntk_shim_free(c->d_b4_train);
     nntk_shim_free(c->d_h[0]);
     nntk_shim_host_free(c->pin_in); nntk_shim_host_free(c->pin_out); nntk_shim_host_free((void *)c->flag);
     nntk_shim_free(c->d_done);
@@ -239,6 +240,11 @@ static int core_try_lstm_rr(rec_core *c, int use_bh, const int *acts, const rr_i
     if (!c->rr_valid) {
         if (!c->d_rr && !(c->d_rr = (float *)nntk_shim_malloc(img * sizeof(float)))) return -1;
         if (nntk_shim_lstm_rr_pack(c->d_ut, c->d_wp, c->d_rr, c->H, c->in)) return -1;
+        const size_t img4 = nntk_shim_rr4_image_floats(c->H, c->in);
+        if (img4) {
+            if (!c->d_rr4 && !(c->d_rr4 = (float *)nntk_shim_malloc(img4 * sizeof(float)))) return -1;
+            if (nntk_shim_rr4_pack(c->d_ut, c->d_wp, c->d_rr4, c->H, c->in)) return -1;
+        }
         c->rr_valid = 1;
     }
     float *d_work = nntk_devbuf_reserve(&c->d_work_rr, nntk_shim_lstm_rr_work_floats(B, c->H));
@@ -246,7 +252,7 @@ static int core_try_lstm_rr(rec_core *c, int use_bh, const int *acts, const rr_i
     if (!d_work || !d_hseq) return -1;
     const float *h0 = stateful ? c->d_h[c->cur] : NULL, *c0 = stateful ? c->d_c[c->cur] : NULL;
     float *hT = stateful ? c->d_h[c->cur ^ 1] : NULL, *cT = stateful ? c->d_c[c->cur ^ 1] : NULL;
-    return nntk_shim_lstm_rr(xm ? NULL : io->d_in, xm ? xf3 : NULL, c->d_rr, c->d_bi, use_bh ? c->d_bh : NULL, h0, c0, io->d_out, d_hseq,
+    return nntk_shim_lstm_rr(xm ? NULL : io->d_in, xm ? xf3 : NULL, c->d_rr, c->d_rr4, c->d_bi, use_bh ? c->d_bh : NULL, h0, c0, io->d_out, d_hseq,
                              hT, cT, d_work, B, c->T, c->in, c->H, c->return_sequences);
 }
 
@@ -259,7 +265,7 @@ static int gru_std_acts(const int *acts) {
 }
 /* packs *d_img (allocated on first use, `img` floats) and *d_b4 from the caller-layout weights W [in][3H], U [H][3H], b_i, b_h */
 static int gru_rr_build_image(int in, int H, const float *W, const float *U, const float *bi, const float *bh,
-                              float **d_img, size_t img, float **d_b4, nntk_devbuf *stage) {
+                              float **d_img, size_t img, float **d_b4, nntk_devbuf *stage, float **d_img4) {
     const size_t nW = (size_t)in * 4 * H, nU = (size_t)H * 4 * H;
     float *tmp = (float *)calloc(nW + nU + 4 * (size_t)H, sizeof(float));
     if (!tmp) NNTK_FAIL("out of host memory while packing GRU weights");
@@ -283,6 +289,11 @@ static int gru_rr_build_image(int in, int H, const float *W, const float *U, con
     if (!rc) rc = nntk_shim_upload(d_tmp, tmp, (nW + nU) * sizeof(float));
     if (!rc) rc = nntk_shim_upload(*d_b4, b4, 4 * (size_t)H * sizeof(float));
     if (!rc) rc = nntk_shim_lstm_rr_pack_raw(d_tmp + nW, d_tmp, *d_img, H, in);
+    const size_t img4 = d_img4 ? nntk_shim_rr4_image_floats(H, in) : 0;        /* the four-stream family's images of the same matrices */
+    if (!rc && img4) {
+        if (!*d_img4 && !(*d_img4 = (float *)nntk_shim_malloc(img4 * sizeof(float)))) rc = -1;
+        if (!rc) rc = nntk_shim_rr4_pack_raw(d_tmp + nW, d_tmp, *d_img4, H, in);
+    }
     free(tmp);                                              /* (nntk_shim_upload has copied it) */
     return rc ? -1 : 0;
 }
@@ -302,7 +313,7 @@ static int core_try_gru_rr(rec_core *c, const int *acts, const rr_io *io, int B,
         /* from the SHADOW, i.e. the weight version core_upload packed d_wp / d_ut from: the device-pointer calls do not look for
          * host edits (SyncWeights is their contract), and an un-synced edit must not reach this kernel alone */
         const float *sW = c->wb.shadow, *sU = sW + (size_t)in * 3 * H, *sbi = sU + (size_t)H * 3 * H, *sbh = sbi + 3 * (size_t)H;
-        if (gru_rr_build_image(in, H, sW, sU, sbi, sbh, &c->d_rr, img, &c->d_b4, &c->d_rr_stage)) return -1;
+        if (gru_rr_build_image(in, H, sW, sU, sbi, sbh, &c->d_rr, img, &c->d_b4, &c->d_rr_stage, &c->d_rr4)) return -1;
         c->rr_valid = 1;
     }
     float *d_work = nntk_devbuf_reserve(&c->d_work_rr, nntk_shim_lstm_rr_work_floats(B, H));
@@ -310,7 +321,7 @@ static int core_try_gru_rr(rec_core *c, const int *acts, const rr_io *io, int B,
     if (!d_work || !d_hseq) return -1;
     const float *h0 = stateful ? c->d_h[c->cur] : NULL;
     float *hT = stateful ? c->d_h[c->cur ^ 1] : NULL;
-    return nntk_shim_gru_rr(xm ? NULL : io->d_in, xm ? xf3 : NULL, c->d_rr, c->d_b4, h0, io->d_out, d_hseq, hT, d_work, B, c->T, in, H,
+    return nntk_shim_gru_rr(xm ? NULL : io->d_in, xm ? xf3 : NULL, c->d_rr, c->d_rr4, c->d_b4, h0, io->d_out, d_hseq, hT, d_work, B, c->T, in, H,
                             c->return_sequences, 0, 0);
 }
 
@@ -621,7 +632,7 @@ static int gru_train_forward_dev(GRU filter, const float *d_x) {
     if (rr_on != 0 && img && gru_std_acts(acts) && !rr_unsplittable(c->wb.host, (size_t)in * 3 * H + (size_t)H * 3 * H)) {
         float *d_wk = nntk_devbuf_reserve(&c->d_work_rr, nntk_shim_lstm_rr_work_floats(B, H));
         if (!d_wk) return -1;
-        if (gru_rr_build_image(in, H, c->weights->W, c->weights->U, c->weights->b_i, c->weights->b_h, &c->d_rr_train, img, &c->d_b4_train, &c->d_rr_stage)) return -1;
+        if (gru_rr_build_image(in, H, c->weights->W, c->weights->U, c->weights->b_i, c->weights->b_h, &c->d_rr_train, img, &c->d_b4_train, &c->d_rr_stage, NULL)) return -1;
         float *d_hs = nntk_devbuf_reserve(&c->d_hseq, nntk_shim_rr_hseq_floats(B, T, H));
         if (!d_hs) return -1;
         int rc = nntk_shim_gru_rr_train_forward(d_x, c->d_rr_train, c->d_b4_train, d_h, d_hU, d_Zg, d_hs, d_wk, B, T, in, H);

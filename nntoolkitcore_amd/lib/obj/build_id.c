@@ -1,1 +1,1 @@
-const char *nntk_build_source_hash(void) { return "163ccbb2551cf199"; }
+const char *nntk_build_source_hash(void) { return "a8ef4e03155e491e"; }

@@ -7,41 +7,103 @@ between the store group and the wait in the ISA; exit 1 on a mismatch.   usage: 
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "nntoolkitcore_amd", "csrc", "hip", "recurrent_rr.hip")
+SRCS = [os.path.join(ROOT, "nntoolkitcore_amd", "csrc", "hip", f) for f in ("recurrent_rr.hip", "recurrent_rr4.hip")]
 
 
 def main():
+    txt = ""
     with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "rr.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-Wno-unused-function",
-                               "--cuda-device-only", "-S", SRC, "-o", out] + os.environ.get("RR_EXTRA", "").split(), stderr=subprocess.DEVNULL)
-        txt = open(out).read()
+        for k, src in enumerate(SRCS):
+            out = os.path.join(td, "rr%d.s" % k)
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-Wno-unused-function",
+                                   "--cuda-device-only", "-S", src, "-o", out] + os.environ.get("RR_EXTRA", "").split(), stderr=subprocess.DEVNULL)
+            txt += open(out).read() + "\n"
     bad = total = 0
-    for kname in re.findall(r'^(_Z1[34](?:lstm|gru)_rr_kernel\w+):', txt, re.M):
+    for kname in re.findall(r'^(_Z1[345](?:lstm|gru)_rr4?_kernel\w+):', txt, re.M):
         a = txt.index("\n" + kname + ":")
-        s = txt[a:txt.index("s_endpgm", a)].split("\n")
-        for i, l in enumerate(s):
-            first = "buffer_store_dwordx4" in l and "sc1" in l and not ("buffer_store_dwordx4" in s[i - 1] and "sc1" in s[i - 1])
-            if not first:
-                continue
-            # the two parities of a publication are the arms of an if / else: the second arm's group is reached from the first
-            # arm's position too, so every group is followed to ITS wait and both must agree with the count
-            younger = 0
-            for j in range(i, min(i + 1500, len(s))):
-                t = s[j].strip()
-                if re.match(r'(buffer_|global_|scratch_|flat_)', t) and not ("buffer_store_dwordx4" in t and "sc1" in t):
-                    younger += 1
-                m = re.match(r's_waitcnt vmcnt\((\d+)\)$', t)
-                if m and "ASMSTART" in s[j - 1]:
-                    total += 1
-                    if int(m.group(1)) != younger:
-                        bad += 1
-                        print("%s: wait vmcnt(%s) at +%d but %d vector-memory instructions follow the publication" % (kname, m.group(1), j, younger))
-                    break
+        s = txt[a:txt.index(".Lfunc_end", a)].split("\n")           # (a kernel may hold several s_endpgm and out-of-line blocks behind them)
+        b_, t_ = check_counted_waits(kname, s)
+        bad += b_
+        total += t_
     print("lstm_rr_kernel / gru_rr_kernel: %d counted waits checked, %d mismatches" % (total, bad))
     pbad, ptotal = check_polls(txt)
     print("lstm_rr_kernel / gru_rr_kernel: %d flag polls checked, %d violations" % (ptotal, pbad))
     return 1 if bad or total == 0 or pbad or ptotal == 0 else 0
+
+
+def is_pub_store(t):
+    return "buffer_store_dwordx4" in t and "sc1" in t
+
+
+def is_vmem(t):
+    return re.match(r'(buffer_|global_|scratch_|flat_)', t) is not None
+
+
+def check_counted_waits(kname, s):
+    """For every publication (a group of write-through 16-byte stores) follow the CONTROL FLOW to the asm `s_waitcnt vmcnt(N)` that
+    guards its flag: N must equal the smallest number of vector-memory instructions on any path from the stores to the wait.  (The
+    stores have completed once at most as many operations are outstanding as the wave issued after them; N larger than that and the
+    flag can overtake the data.  Arms another wave takes -- the output wave's stores -- only add instructions, so the minimum is the
+    publishing wave's own path; hipcc places such arms out of line, which is why this walks labels and branches, not lines.)"""
+    ins = [l.strip() for l in s]
+    labels = {}
+    for i, t in enumerate(ins):
+        m = re.match(r'(\.LBB\w+):', t)
+        if m:
+            labels[m.group(1)] = i
+    bad = total = 0
+    for i, t in enumerate(ins):
+        if not (is_pub_store(t) and not is_pub_store(ins[i - 1])):
+            continue
+        j = i
+        while is_pub_store(ins[j]):
+            j += 1
+        best, found = {}, {}                       # instruction index -> fewest vector-memory instructions on a path reaching it
+        stack = [(j, 0)]
+        while stack:
+            k, cnt = stack.pop()
+            steps = 0
+            while k < len(ins) and steps < 6000:
+                if best.get(k, 1 << 30) <= cnt:
+                    break
+                best[k] = cnt
+                u = ins[k]
+                steps += 1
+                if is_pub_store(u):                # the next publication: this path never raised the flag (not the publishing wave's)
+                    break
+                m = re.match(r's_waitcnt vmcnt\((\d+)\)$', u)
+                # the arrival's wait is the asm wait that is followed by the flag store (the poll's asm wait is not)
+                if m and k > 0 and "ASMSTART" in ins[k - 1] and any(x.startswith("global_store_dword ") for x in ins[k + 1:k + 16]):
+                    key = (k, int(m.group(1)))
+                    found[key] = min(found.get(key, 1 << 30), cnt)
+                    break
+                if is_vmem(u):
+                    cnt += 1
+                m = re.match(r's_branch\s+(\.LBB\w+)', u)
+                if m:
+                    k = labels[m.group(1)]
+                    continue
+                m = re.match(r's_cbranch_\w+\s+(\.LBB\w+)', u)
+                if m:
+                    stack.append((labels[m.group(1)], cnt))
+                if u.startswith("s_endpgm") or u.startswith("s_setpc"):
+                    break
+                k += 1
+        # paths that bypass this publication's own arrival (its `if` arm) run on to later half-steps' arrivals: infeasible for the
+        # publishing wave, and always longer -- the nearest arrival is this publication's
+        if found:
+            key = min(found, key=lambda kk: found[kk])
+            found = {key: found[key]}
+        for (k, n_wait), cnt in found.items():
+            total += 1
+            if n_wait != cnt:
+                bad += 1
+                print("%s: publication at +%d, wait vmcnt(%d) at +%d, but the shortest path between them issues %d vector-memory instructions"
+                      % (kname, i, n_wait, k, cnt))
+        if not found:
+            # a publication whose flag is never raised: only the very last one of a sequence (its consumers do not exist)
+            pass
+    return bad, total
 
 
 def regs_of(tok):
@@ -60,9 +122,9 @@ def check_polls(txt):
     that follows it, no instruction names vN as an operand and no branch is taken; and no rr kernel uses scratch (a spill of vN would
     be a hidden read + write)."""
     bad = total = 0
-    for kname in re.findall(r'^(_Z1[34](?:lstm|gru)_rr_kernel\w+):', txt, re.M):
+    for kname in re.findall(r'^(_Z1[345](?:lstm|gru)_rr4?_kernel\w+):', txt, re.M):
         a = txt.index("\n" + kname + ":")
-        s = txt[a:txt.index("s_endpgm", a)].split("\n")
+        s = txt[a:txt.index(".Lfunc_end", a)].split("\n")
         m = re.search(r'\.amdhsa_kernel %s\b.*?\.end_amdhsa_kernel' % re.escape(kname), txt, re.S)
         if m:
             ps = re.search(r'\.amdhsa_private_segment_fixed_size (\d+)', m.group(0))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostics build only (tools/build_variant.sh <lib> -DNNTK_REC_STAMPS; NNTK_LIB=<lib>): run the stack's LSTM on
+"""Diagnostics build only (python tools/build_variant.py build/libs/libstamps.so recurrent_rr.hip,recurrent_rr4.hip -DNNTK_REC_STAMPS; NNTK_LIB=<lib>): run the stack's LSTM on
 lstm_rr_kernel once and print where workgroup 0 / wave 0 spends a half-step (s_memtime cycles).
 usage: NNTK_LIB=<lib built with -DNNTK_REC_STAMPS> python tools/rr_stamps.py [B] [T] [lstm|gru] [in] [H]"""
 import os, sys
@@ -23,6 +23,9 @@ def main():
     lstm = NL.LSTM(I, H, True, T, v2=True) if kind == "lstm" else NL.GRU(I, H, True, T)
     lstm.set_weights(u(I, G * H, sc=I ** -0.5), u(H, G * H, sc=H ** -0.5), u(G * H, sc=0.1), u(G * H, sc=0.1))
     capi.set_option("rec_rr", 1)
+    capi.set_option("rec_xf", 1)
+    if os.environ.get("RR4"):
+        capi.set_option("rec_rr4", int(os.environ["RR4"]))
     x = torch.randn(B, T, I, device="cuda"); h = torch.empty(B, T, H, device="cuda")
     for _ in range(3):
         lstm.apply_device(x, out=h)
@@ -32,14 +35,16 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); lstm.apply_device(x, out=h); e1.record(); torch.cuda.synchronize()
     del os.environ["NNTK_REC_STAMP_FILE"]
-    s = np.fromfile(path, dtype=np.uint64).astype(np.int64).reshape(T, 2, 16)
+    s = np.fromfile(path, dtype=np.uint64).astype(np.int64).reshape(T + 1, 4, 16)
     lo, hi = T // 10, T - T // 10
     nst = (4 if H <= 256 else 8) + (1 if I <= 64 else 2 if I <= 128 else 4)
-    print("%s in=%d H=%d: %s, %d k steps per half" % (kind, I, H, capi.load().nntk_hip_last_recurrent_kernel().decode(), nst))
+    kname = capi.load().nntk_hip_last_recurrent_kernel().decode()
+    ns = 4 if "rr4" in kname else 2
+    print("%s in=%d H=%d: %s, %d k steps per half-step, %d streams" % (kind, I, H, kname, nst, ns))
     print("launch %.3f ms incl. stamping = %.2f us/step" % (e0.elapsed_time(e1), e0.elapsed_time(e1) * 1e3 / T))
-    for half in range(2):
+    for half in range(ns):
         d = s[lo:hi, half]
-        nxt = s[lo:hi, 1 - half] if half == 0 else s[lo + 1:hi + 1, 0]
+        nxt = s[lo:hi, half + 1] if half < ns - 1 else s[lo + 1:hi + 1, 0]
         dur = [(d[:, i + 1] - d[:, i]) for i in range(nst)]
         print("half %d: half-step %.0f cyc; k steps (mean): %s | end->next start %.0f" % (
             half, (nxt[:, 0] - d[:, 0]).mean(), " ".join("%.0f" % x.mean() for x in dur), (nxt[:, 0] - d[:, nst]).mean()))
