@@ -33,6 +33,7 @@ struct NntkOptions {
     int bn_fast = 0;             // reciprocal-multiply BatchNorm (not the reference's divide)
     int gemm_tm_batch = -1;      // tile time-major GEMM outputs over the batch
     int conv_a4 = 1;             // 16-byte window loads also for channel counts that are not multiples of 4 (0: 4-byte loads there)
+    int conv_flatk = -1;         // flat-K split convolution for Cin % 8 == 0, Cin % 16 != 0 (conv1d_flatk.hip); 0 off
     int conv_store = -1;         // GEMM epilogue: -1 auto, 0 row form (4-byte stores), 1 quad form (16-byte stores); bit-identical
     int gemm_split_bf16 = -1;    // 3-way split-bf16 contraction: -1 auto (conv / dense / TDD / mel, not the recurrent xW), 0 never, 1 all
     int gemm_wide = -1;          // 128 x 256 tile for wide dense GEMMs on the split path (0 off)

@@ -88,6 +88,11 @@ int  nntk_shim_conv1d(const float *d_in, const float *d_wp, const float *d_bias,
                       int B, int T, int Cin, int Cout, int k, int stride, int Tout, int out_mode);
 
 /* ---- training, first slice: Conv1dCalculateGradient (conv_1d.c:185-245); untuned VALU kernels, deterministic ---- */
+/* flat-K split convolution (conv1d_flatk.hip; stride 1, Cin % 8 == 0, Cin % 16 != 0): d_wpf = [Cout_p][Kf_p] with K = tap * Cin + channel,
+ * Kf_p = k * Cin rounded up to 16, followed by its split images (nntk_upload_packed_weights).  Returns 1 when not taken. */
+int nntk_shim_conv1d_flatk(const float *d_in, const float *d_wpf, const float *d_bias, const float *d_bn,
+                           float bn_eps, int act_kind, float relu_a, float *d_out,
+                           int B, int T, int Cin, int Cout, int k, int Tout);
 size_t nntk_shim_conv1d_grad_scratch_floats(int Cin, int Cout, int k);
 int nntk_shim_conv1d_grad(const float *d_in, const float *d_W, const float *d_dout, float *d_dW, float *d_db,
                           float *d_dX, float *d_scratch, int B, int T, int Cin, int Cout, int k, int stride, int Tout);

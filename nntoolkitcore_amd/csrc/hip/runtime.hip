@@ -56,6 +56,7 @@ static const OptDesc g_opt_table[] = {
     {"gemm_tm_batch", "NNTK_GEMM_TM_BATCH", &NntkOptions::gemm_tm_batch},
     {"gemm_split_bf16", "NNTK_GEMM_SPLIT_BF16", &NntkOptions::gemm_split_bf16},
     {"conv_store", "NNTK_CONV_STORE", &NntkOptions::conv_store},
+    {"conv_flatk", "NNTK_CONV_FLATK", &NntkOptions::conv_flatk},
     {"conv_a4", "NNTK_CONV_A4", &NntkOptions::conv_a4},
     {"gemm_wide", "NNTK_GEMM_WIDE", &NntkOptions::gemm_wide},
     {"conv_dbg", "NNTK_CONV_DBG", &NntkOptions::conv_dbg},

@@ -1,1 +1,1 @@
-const char *nntk_build_source_hash(void) { return "a8ef4e03155e491e"; }
+const char *nntk_build_source_hash(void) { return "aa70aa6219aa52c3"; }

@@ -1039,3 +1039,54 @@ def test_public_dft_api_matches_kissfft_restatement_and_numpy(gpu, n, forward):
     L.join_complex_split(C.byref(sp_out), back.ctypes.data, n)
     np.testing.assert_array_equal(back[:, 0], ore); np.testing.assert_array_equal(back[:, 1], oim)
     L.DFTSetupDestroy(s)
+
+
+@pytest.mark.parametrize("B,cin,cout,k,T,fused", [
+    (3, 40, 128, 5, 300, True),       # BASELINE configs[2] shape: K = 200 -> 13 k steps instead of the chunked kernel's 15
+    (2, 24, 64, 3, 131, False),       # BN = 64 tile, ragged last row tile, K = 72 -> 80: the last k step's second half is padding
+    (5, 8, 128, 9, 140, True),        # one 8-channel group per tap: every k step straddles two taps
+    (1, 56, 256, 2, 257, False),      # two column tiles
+    (4, 104, 192, 4, 129, True),      # three 64-wide column tiles; 13 groups of 8 per tap
+])
+def test_flat_k_convolution_matches_oracle_and_the_chunked_kernel(gpu, B, cin, cout, k, T, fused):
+    """conv1d_flatk.hip (conv_1d.c:122-147 semantics): stride-1 convolutions whose channel count is a multiple of 8 but not of 16 walk
+    K = tap * Cin + channel without per-tap padding.  Against the oracle; against the chunked split kernel (conv_flatk = 0: same
+    contraction, K in another order -- a few f32 roundings apart); shard-independent and reproducible; a NaN / inf input stays in
+    exactly the outputs whose window holds it (the K padding's operand is a zero slot, not a neighbouring row)."""
+    import torch
+    r = rng(cin * 31 + cout + k)
+    x, W, b = u(r, B, T, cin), u(r, cout, cin, k, sc=(cin * k) ** -0.5), u(r, cout, sc=0.2)
+    conv = NL.Conv1d(cin, cout, k, 1, T)
+    conv.set_weights(W, b)
+    Tc = conv.out_shape[0]
+    bn = relu = None
+    ref = O.conv1d(x, W, b, 1)
+    if fused:
+        bn, relu = NL.BatchNorm(cout, 1e-3, Tc), NL.Activation("relu", Tc * cout, 1.0)
+        g, be, mu, var = 1 + u(r, cout, sc=0.5), u(r, cout, sc=0.5), u(r, cout, sc=0.1), 1 + u(r, cout, sc=0.5)
+        bn.set_weights(g, be, mu, var)
+        ref = O.activation(O.ACT_RELU, O.batch_norm(ref, g, be, mu, var, 1e-3))
+    xd = torch.from_numpy(x).cuda()
+    flat = conv.apply_device(xd, bn=bn, act=relu).clone()
+    capi.set_option("conv_flatk", 0)
+    chunked = conv.apply_device(xd, bn=bn, act=relu).clone()
+    capi.set_option("conv_flatk", "auto")
+    close(flat.cpu().numpy(), ref)
+    assert not torch.equal(flat, chunked)                       # the option really selected the other kernel
+    assert float((flat - chunked).abs().max()) < 4e-6
+    assert torch.equal(conv.apply_device(xd, bn=bn, act=relu), flat)
+    assert torch.equal(conv.apply_device(xd[B - 1:].contiguous(), bn=bn, act=relu), flat[B - 1:])
+    xp = xd.clone()
+    xp[0, 50, 3] = float("nan")
+    xp[B - 1, 100, cin - 1] = float("inf")
+    bad = conv.apply_device(xp, bn=bn, act=relu)
+    touched = torch.zeros(B, Tc, dtype=torch.bool, device="cuda")
+    touched[0, max(0, 50 - k + 1):51] = True
+    touched[B - 1, max(0, 100 - k + 1):101] = True
+    assert torch.equal(bad[~touched], flat[~touched])
+    assert not torch.isfinite(bad[touched]).all(dim=-1).any() or fused       # (ReLU turns -inf into 0: the unfused form must be all non-finite)
+    if not fused:
+        assert (~torch.isfinite(bad[touched])).any(dim=-1).all()
+    for o in (conv, bn, relu):
+        if o:
+            o.destroy()
