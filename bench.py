@@ -623,6 +623,9 @@ def main():
             "parallelism": "utterance shards, dp%d, no data-path collective" % world,
             "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
             "ranks_seen": ranks_seen,
+            "lstm_to_tdd": ("f32 tensor" if getattr(wl, "f32_route", True) else
+                            "frag3 tensor: the LSTM kernel's T-deep hand-off buffer (h already split into three bf16 images, MFMA fragment order) "
+                            "is the dense GEMM's A operand; bit-identical to the f32 route") if a.workload == "stack" else None,
             "gemm": gemm_mode() + " for conv / TDD" + (
                 ("; LSTM: " + prof["rec_kernel"] + " (split-bf16x3 recurrence with the input projection fused into the step)")
                 if prof.get("rec_kernel", "").startswith("lstm_rr") else

@@ -535,6 +535,11 @@ int bd_merge_sum_device(const float *d_forward, const float *d_backward, float *
 size_t nntk_frag3_floats(int batch, int T, int C);                       /* size of a frag3 tensor, in floats */
 int nntk_frag3_pack_device(const float *d_x /*[batch,T,C]*/, float *d_frag3, int batch, int T, int C);
 int nntk_frag3_unpack_device(const float *d_frag3, float *d_x /*[batch,T,C]*/, int batch, int T, int C);
+/* Which kernel family the batch forms of this layer take, and -- when it is not the register-resident one -- why (shape, activations,
+ * weights, options): a human-readable line, valid until the calling thread's next call of the same function.  Depends on the layer
+ * only, never on the batch size. */
+const char *GRUKernelPlan(GRU filter);
+const char *LSTMKernelPlan(LSTM filter);
 int GRUApplyDeviceFrag3(GRU filter, const float *d_input, const float *d_input_frag3, float *d_output, float *d_output_frag3, int batch);
 int LSTMApplyDeviceFrag3(LSTM filter, const float *d_input, const float *d_input_frag3, float *d_output, float *d_output_frag3, int batch);
 int TimeDistributedDenseApplyDeviceFrag3(TimeDistributedDense filter, const float *d_input_frag3 /*[batch,ts,in]*/, float *d_output, int batch);

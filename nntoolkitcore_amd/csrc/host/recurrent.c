@@ -11,6 +11,7 @@
  * lstm.c:264-265): h/c persist in the handle between calls; the batched forms
  * start every sequence from zeros (gru.c:260, lstm.c:439).
  */
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -380,6 +381,29 @@ static int core_apply_device_f3(rec_core *c, int is_lstm, int use_bh, const int 
     if (!o && !(o = nntk_devbuf_reserve(&c->d_out, (size_t)B * c->T * c->H))) return -1;
     if (core_apply_device(c, is_lstm, use_bh, acts, scales, x, o, B, 0)) return -1;
     return d_out_f3 ? nntk_shim_frag3_pack(o, d_out_f3, B, c->T, c->H) : 0;
+}
+
+/* Which kernel family the zero-state batch forms of a layer will take, and why not the fast one when they will not: a caller can see a
+ * performance cliff (a shape outside the register-resident kernels runs 1.3-1.8x slower) before it measures one.  The answer depends on
+ * the layer only -- shape, activations, weights -- never on the batch (see the comment above core_try_lstm_rr). */
+static const char *core_plan(rec_core *c, int std_acts, char *buf, size_t n) {
+    int on = -1;
+    (void)nntk_shim_get_option("rec_rr", &on);
+    const int f32_ok = nntk_shim_lstm_rr_image_floats(c->H, c->in) != 0, xf_ok = nntk_shim_rr_image_floats_xf(c->H, c->in) != 0;
+    const char *cell = c->G == 4 ? "lstm" : c->G == 3 ? "gru" : "rnn";
+    const char *why = NULL;
+    if (c->G == 1) why = "the RNN cell has no register-resident kernel";
+    else if (on == 0) why = "option rec_rr = 0";
+    else if (!std_acts) why = "non-default gate activations";
+    else if (c->wb.uploaded && c->rr_exact_only) why = "a weight the bf16 split cannot hold (non-finite, > 3.39e38 or denormal)";
+    else if (!xf_ok) why = (c->H % 16) ? "H % 16 != 0" : (c->H < 64 || c->H > 512) ? "H outside 64..512" : "input wider than 128 (256 when H <= 256)";
+    if (why)
+        snprintf(buf, n, "%s: exact-f32 kernels (projection GEMM + rec_persistent_kernel, per-timestep kernels when that does not fit) -- %s", cell, why);
+    else
+        snprintf(buf, n, "%s: %s_rr_kernel<%d,%d> (register-resident split-bf16 x 3, input projection fused)%s; the stateful single-sequence call keeps the exact-f32 kernels",
+                 cell, cell, c->H <= 256 ? 4 : 8, c->in <= 64 ? 1 : c->in <= 128 ? 2 : 4,
+                 f32_ok ? "" : "; in % 8 != 0: the input is packed into frag3 form first");
+    return buf;
 }
 
 /* The reference's own call shape -- one sequence, carried state, a handful of timesteps (gru.c:189-204,
@@ -765,6 +789,13 @@ int GRUApplyDeviceFrag3(GRU filter, const float *d_input, const float *d_input_f
     if (core_ensure(&filter->core, 0)) return -1;
     return core_apply_device_f3(&filter->core, 0, 1, acts, sc, d_input, d_input_frag3, d_output, d_output_frag3, batch);
 }
+const char *GRUKernelPlan(GRU filter) {
+    static _Thread_local char buf[320];
+    if (!filter) return "";
+    int a[3]; float sc[3];
+    if (gru_acts(filter, a, sc)) return "gru: invalid gate activations";
+    return core_plan(&filter->core, gru_std_acts(a), buf, sizeof buf);
+}
 int GRUResetState(GRU filter) {
     nntk_shim_clear_error();
     if (!filter) NNTK_FAIL("GRUResetState: NULL handle");
@@ -1128,6 +1159,13 @@ void nntk_lstm_dims(LSTM f, int *T, int *in, int *H, int *return_sequences) {
 }
 float *nntk_lstm_frag3_scratch(LSTM f, int batch) {
     return nntk_devbuf_reserve(&f->core.d_hseq, nntk_shim_rr_hseq_floats(batch, f->core.T, f->core.H));
+}
+const char *LSTMKernelPlan(LSTM filter) {
+    static _Thread_local char buf[320];
+    if (!filter) return "";
+    int a[5]; float sc[5];
+    if (lstm_acts(filter, a, sc)) return "lstm: invalid gate activations";
+    return core_plan(&filter->core, lstm_std_acts(a), buf, sizeof buf);
 }
 /* lstm.c:270-274 (lstm_zero_state) */
 int LSTMResetState(LSTM filter) {

@@ -1,1 +1,1 @@
-const char *nntk_build_source_hash(void) { return "aa70aa6219aa52c3"; }
+const char *nntk_build_source_hash(void) { return "8e92769b938acdf1"; }

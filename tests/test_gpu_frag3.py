@@ -167,3 +167,23 @@ def test_fused_lstm_tdd_equals_the_two_calls_and_the_oracle(gpu, B, I, H, T, N):
     np.testing.assert_allclose(one.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
     assert capi.load().nntk_hip_device_status() == 0
     lstm.destroy(); tdd.destroy()
+
+
+def test_kernel_plan_names_the_kernel_family_and_the_reason(gpu):
+    """GRUKernelPlan / LSTMKernelPlan: the family a layer's batch forms take is a property of the layer, and the query says why a layer
+    misses the register-resident kernels (VERDICT r03 #6: make the perf cliff visible)."""
+    import torch
+    L = capi.load()
+    r = rng(3)
+    cases = [("lstm", 128, 512, "lstm_rr_kernel<8,2>"), ("gru", 256, 256, "gru_rr_kernel<4,4>"), ("lstm", 100, 128, "frag3"),
+             ("lstm", 24, 40, "H % 16"), ("gru", 300, 512, "wider"), ("lstm", 8, 640, "outside")]
+    for cell, I, H, want in cases:
+        layer = NL.LSTM(I, H, True, 4, v2=True) if cell == "lstm" else NL.GRU(I, H, True, 4)
+        G = 4 if cell == "lstm" else 3
+        layer.set_weights(u(r, I, G * H, sc=0.1), u(r, H, G * H, sc=0.1), u(r, G * H, sc=0.1), u(r, G * H, sc=0.1))
+        plan = (L.LSTMKernelPlan if cell == "lstm" else L.GRUKernelPlan)(layer.h).decode()
+        assert want in plan, plan
+        layer.apply_device(torch.from_numpy(u(r, 3, 4, I)).cuda())
+        ran_rr = L.nntk_hip_last_recurrent_kernel().decode().startswith(cell + "_rr_kernel")
+        assert ran_rr == ("_rr_kernel" in plan), (plan, L.nntk_hip_last_recurrent_kernel())
+        layer.destroy()

@@ -9,7 +9,12 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from nntoolkitcore_amd._build import source_hash  # noqa: E402
+from nntoolkitcore_amd import capi  # noqa: E402
+
+
+def source_hash():
+    """the hash the BUILT library carries (the profile belongs to the binary that ran, not to the source tree)"""
+    return (capi.load().nntk_build_source_hash() or b"").decode()
 
 
 def agg(d, counter):
