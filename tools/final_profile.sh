@@ -19,6 +19,11 @@ timeout -k 10 300 python tools/conv_probe.py gemm_split_bf16=0,1 2>&1 | grep -v 
 timeout -k 10 300 python tools/train_bench.py 2>&1 | grep -v amdgpu.ids > $O/train_bench.log; cat $O/train_bench.log
 timeout -k 10 300 python tools/rec_ab.py 1024 500 2>&1 | grep -v amdgpu.ids > $O/rec_ab.log; cat $O/rec_ab.log
 NNTK_REC_FUSED2=1 timeout -k 10 300 python bench.py --workload gru --no-cpu-baseline > $O/bench_gru_fused.json 2> /dev/null; tail -c 200 $O/bench_gru_fused.json; echo
+# north_star's own batch on ONE GPU (4096 utterances = 8 back-to-back launches of the 256-workgroup LSTM kernel), and the round-3 route
+timeout -k 10 300 python bench.py --batch-per-gpu 4096 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_stack_b4096.json 2> $O/bench_stack_b4096.err; tail -c 300 $O/bench_stack_b4096.json; echo
+NNTK_BENCH_STACK_F32=1 NNTK_REC_XF=0 timeout -k 10 300 python bench.py --no-cpu-baseline > $O/bench_stack_f32route.json 2> /dev/null; tail -c 200 $O/bench_stack_f32route.json; echo
+NNTK_CONV_FLATK=0 timeout -k 10 300 python bench.py --workload conv --no-cpu-baseline > $O/bench_conv_chunked.json 2> /dev/null; tail -c 200 $O/bench_conv_chunked.json; echo
+NNTK_REC_RR4=1 timeout -k 10 300 python bench.py --workload gru --no-cpu-baseline > $O/bench_gru_rr4.json 2> /dev/null; tail -c 200 $O/bench_gru_rr4.json; echo
 fi
 [ "$PART" = bench ] && { ls $O; exit 0; }
 cd /tmp && export TMPDIR=/tmp
