@@ -147,6 +147,8 @@ struct DF3Params {
 // WM x WN wavefronts, each TM row blocks x TN column tiles of 32 x 32.  D = W x h^T, so a lane owns ONE output row (batch row n of
 // its row block) and register r of a tile holds channel 8 (r >> 2) + 4 kh + (r & 3): four consecutive channels per register quad =
 // one 16-byte store (the orientation of conv_epilogue).
+// (Tried: the A fragments requested TWO k steps ahead through a ring of three register sets -- 240 operand registers next to the 256
+// accumulators: 2 784 bytes of scratch, not measured.  The deeper A prefetch lives in dense_frag3_hybrid_kernel below instead.)
 template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void dense_frag3_kernel(DF3Params p) {
     static_assert(WM * WN == 4, "4 wavefronts");
@@ -183,9 +185,9 @@ __global__ __launch_bounds__(256) void dense_frag3_kernel(DF3Params p) {
     f3_v4u av[2][TM][3], wv[2][TN][3];
     // requested in the order the products need them (lo of A and hi of W first, see PA / PW below), so the consumer's counted waits
     // release its first MFMAs before the whole set has landed
+    constexpr int MA[3] = {2, 0, 1}, MW[3] = {0, 2, 1};
     auto load = [&](auto buf_tag, int ks) __attribute__((always_inline)) {
         constexpr int buf = decltype(buf_tag)::value;
-        constexpr int MA[3] = {2, 0, 1}, MW[3] = {0, 2, 1};
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
 #pragma unroll
@@ -209,23 +211,25 @@ __global__ __launch_bounds__(256) void dense_frag3_kernel(DF3Params p) {
         for (int j = 0; j < TN; ++j) asm volatile("" : "+a"(acc[i][j]));
     // smallest terms first, the order of conv1d_mfma_bf16x3_kernel (bit-identical sums): (A image, W image)
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PW[6] = {0, 2, 1, 0, 1, 0};
-    auto mma = [&](auto buf_tag) __attribute__((always_inline)) {
-        constexpr int buf = decltype(buf_tag)::value;
+    auto mma2 = [&](auto abuf_tag, auto wbuf_tag) __attribute__((always_inline)) {
+        constexpr int ab = decltype(abuf_tag)::value, wb = decltype(wbuf_tag)::value;
 #pragma unroll
         for (int t = 0; t < 6; ++t)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(f3_bf16x8, wv[buf][j][PW[t]]),
-                                                                        __builtin_bit_cast(f3_bf16x8, av[buf][i][PA[t]]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(f3_bf16x8, wv[wb][j][PW[t]]),
+                                                                        __builtin_bit_cast(f3_bf16x8, av[ab][i][PA[t]]), acc[i][j], 0, 0, 0);
     };
+    auto mma = [&](auto buf_tag) __attribute__((always_inline)) { mma2(buf_tag, buf_tag); };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     // two operand sets, no branch inside the pair: the loads of one set are in flight under the other set's 96 MFMAs and the compiler
     // can COUNT them (vmcnt(24)); with a conditional load in the loop it waited vmcnt(0) at the join -- one exposed round trip per pair
-    load(I0{}, 0);
     int ks = 0;
+    {
+    load(I0{}, 0);
     // one request per two MFMAs over the first half of a set's MFMAs (four lock-stepped waves share the CU's address path: a burst of
     // 24 stalls the issuing wave and its MFMAs), the second half is the cover for the requests' latency
     auto interleave = [&]() __attribute__((always_inline)) {
@@ -245,6 +249,7 @@ __global__ __launch_bounds__(256) void dense_frag3_kernel(DF3Params p) {
         interleave();
     }
     if (ks < NKS) mma(I0{});                              // odd K / 16
+    }
 
     // ---- epilogue: bias + activation (chosen once, outside the loops), 16-byte stores of channel quads into out[(b, t), :] ----
     auto epilogue = [&](auto act_tag) __attribute__((always_inline)) {
@@ -436,6 +441,12 @@ __global__ __launch_bounds__(256) void dense_frag3_lds_kernel(DF3Params p) {
     else if (p.act_kind == NNTK_ACT_RELU) epilogue(std::integral_constant<int, NNTK_ACT_RELU>{});
     else epilogue(std::integral_constant<int, -1>{});
 }
+
+// (Measured and not kept -- profiles/r04_tdd_three_kernels.log, same box, ms at the stack's shape: register-direct 2.54, this LDS
+// ring 2.63, and a hybrid that took A through a three-stage LDS ring requested TWO k steps ahead (one fetch per workgroup, 12 ds_read
+// per wave and k step under the MFMAs) with W register-direct: 2.60.  Three operand paths, one result: the operand fetch is not what
+// holds the kernels at 0.61 MFMA-busy; the exposed epilogue (0.35-0.4 ms: one workgroup owns the CU) and the clock the bf16 pipe is
+// allowed (1.89 GHz here) are.  The hybrid kernel was removed again; this ring kernel stays as the probe harness, tools/tdd_probe.py.)
 
 // 0 = launched; 1 = shape not taken (the caller unpacks and runs the f32 GEMM); -1 = error.
 // d_wp: the packed weights of nntk_upload_gemm_weights ([N_p][K_p] f32 followed by the three split images); K = the frag3 tensor's C.

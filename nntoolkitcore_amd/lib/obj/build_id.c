@@ -1,1 +1,1 @@
-const char *nntk_build_source_hash(void) { return "8e92769b938acdf1"; }
+const char *nntk_build_source_hash(void) { return "7e08cf5985201671"; }

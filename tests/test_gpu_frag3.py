@@ -137,8 +137,9 @@ def test_dense_with_a_frag3_input_equals_the_f32_call_bit_for_bit(gpu, B, T, K, 
     kind = {None: O.ACT_NONE, "relu": O.ACT_RELU, "sigmoid": O.ACT_SIGMOID, "tanh": O.ACT_TANH, "softmax": O.ACT_SOFTMAX}[act]
     ref = O.time_distributed_dense(x, W, b, act=kind, **({"softmax_vector_size": 64, "act_size": N // 64} if act == "softmax" else {}))
     np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
-    capi.set_option("dense_frag3", 0)                                   # the fallback route on its own
-    assert torch.equal(NL.tdd_apply_device_frag3(tdd, NL.frag3_pack_device(xd), B), base)
+    for mode in (0, 3):         # 0: the fallback route on its own; 3: the LDS-ring kernel (wide shapes; else = auto)
+        capi.set_option("dense_frag3", mode)
+        assert torch.equal(NL.tdd_apply_device_frag3(tdd, NL.frag3_pack_device(xd), B), base), mode
     capi.set_option("dense_frag3", "auto")
     tdd.destroy()
     if a:

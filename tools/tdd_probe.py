@@ -31,9 +31,8 @@ flops = 2.0 * B * T * K * N
 for rnd in range(2):
     print("f32 input (LDS-staged, splits A in the kernel): %.3f ms" % timeit(lambda: tdd.apply_device(x, out=out)))
     for mode, name in ((1, "frag3 register-direct"), (3, "frag3 LDS ring")):
-        if mode == 1 and rnd: continue
         capi.set_option("dense_frag3", mode)
-        for dbg in (0, 1, 2, 4, 3, 7):
+        for dbg in ((0, 1, 2, 4, 3, 7) if mode == 3 and os.environ.get('TDD_DBG') else (0,)):
             capi.set_option("conv_dbg", dbg)
             ms = timeit(lambda: NL.tdd_apply_device_frag3(tdd, x3, B, out=out))
             print("%s dbg=%d: %.3f ms  (%.0f TFLOP/s)" % (name, dbg, ms, flops / ms / 1e9))
