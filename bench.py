@@ -311,7 +311,11 @@ def roofline_for(wl, phase_ms, prof):
         ms = phase_ms["conv_bn_relu"]
         ach = flops / (ms * 1e-3) / 1e12
         hbm_frac = bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-        traffic, traffic_source = pmc_traffic("conv1d_mfma_kernel" if gemm_mode() == "exact-f32" else "conv1d_mfma_bf16x3_kernel", B)
+        from nntoolkitcore_amd import capi
+        # channel counts that are multiples of 8 but not of 16 take the flat-K kernel (conv1d_flatk.hip) at stride 1 unless conv_flatk = 0
+        flatk = gemm_mode() != "exact-f32" and capi.get_option("conv_flatk") != 0 and cin % 8 == 0 and cin % 16 != 0 and wl.conv.cfg.stride == 1
+        split_kernel = "conv1d_flatk_bf16x3_kernel" if flatk else "conv1d_mfma_bf16x3_kernel"
+        traffic, traffic_source = pmc_traffic("conv1d_mfma_kernel" if gemm_mode() == "exact-f32" else split_kernel, B)
         if gemm_mode() == "exact-f32":
             return {"kernel": "conv1d_mfma_kernel<2,2,2,2>", "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source, "ms_per_launch": ms,
@@ -319,7 +323,7 @@ def roofline_for(wl, phase_ms, prof):
         # split-bf16x3: six bf16 MFMA products per f32 product, so the MFMA ceiling in ALGORITHMIC flops is the dense
         # bf16 peak / 6 (still above the HBM ceiling's time here: 125 us vs 86 us at config 3)
         peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
-        return {"kernel": "conv1d_mfma_bf16x3_kernel<2,2,2,2>", "bound": "mfma", "achieved": ach, "peak": peak,
+        return {"kernel": split_kernel + ("<2,true>" if flatk else "<2,2,2,2>"), "bound": "mfma", "achieved": ach, "peak": peak,
                 "peak_note": "dense bf16 MFMA peak / 6 products per f32 product", "unit": "TFLOP/s", "frac": ach / peak,
                 "traffic": traffic, "traffic_source": traffic_source, "ms_per_launch": ms, "algorithmic_flops": flops,
                 "algorithmic_bytes": bytes_, "hbm_frac": hbm_frac, "frac_of_exact_f32_mfma_peak": ach / F32_MFMA_PEAK_TFLOPS}
@@ -349,7 +353,7 @@ def roofline_for(wl, phase_ms, prof):
                 "timesteps_per_launch": tpl, "us_per_timestep": ms * 1e3 / tpl,
                 "mfma_pipe_cycles_per_timestep": mfma_cycles,
                 "launches_per_step": prof.get("rec_launches_per_step")}
-    if last.startswith("gru_rr_kernel") and wl.name == "gru":
+    if (last.startswith("gru_rr_kernel") or last.startswith("gru_rr4_kernel")) and wl.name == "gru":
         # the two stacked GRU-256 layers as two launches of the register-resident split-bf16 kernel (input projections fused):
         # rec_launch_ms is the AVERAGE of the two, so are the algorithmic flops ([h | x_t] x [U ; W], three gates, T steps)
         n_l = prof.get("rec_launches_per_step") or 2.0
@@ -357,8 +361,9 @@ def roofline_for(wl, phase_ms, prof):
         flops = (flops_l1 + flops_l2) / 2
         ach = flops / (ms * 1e-3) / 1e12
         peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
-        traffic, traffic_source = pmc_traffic("gru_rr_kernel", B)
-        return {"kernel": "gru_rr_kernel<4,2> (layer 1) + gru_rr_kernel<4,4> (layer 2)", "bound": "mfma", "achieved": ach, "peak": peak,
+        fam = "gru_rr4_kernel" if last.startswith("gru_rr4") else "gru_rr_kernel"
+        traffic, traffic_source = pmc_traffic(fam, B)
+        return {"kernel": "%s<4,2> (layer 1) + %s<4,4> (layer 2)" % (fam, fam), "bound": "mfma", "achieved": ach, "peak": peak,
                 "peak_note": "dense bf16 MFMA peak / 6 products per f32 product (split-bf16 x 3 contraction); one gate slot in four "
                              "multiplies a zero weight block (the GRU's candidate gate keeps its x and h parts apart), not counted as flops",
                 "unit": "TFLOP/s", "frac": ach / peak, "frac_of_exact_f32_mfma_peak": ach / F32_MFMA_PEAK_TFLOPS,
@@ -629,7 +634,7 @@ def main():
             "gemm": gemm_mode() + " for conv / TDD" + (
                 ("; LSTM: " + prof["rec_kernel"] + " (split-bf16x3 recurrence with the input projection fused into the step)")
                 if prof.get("rec_kernel", "").startswith("lstm_rr") else
-                ("; GRU layers: gru_rr_kernel (split-bf16x3 recurrences with the input projections fused into the step)")
+                ("; GRU layers: gru_rr_kernel (split-bf16x3 recurrences with the input projections fused into the step; layer 1 hands h over in frag3 form)")
                 if prof.get("rec_kernel", "").startswith("gru_rr") else
                 ("; exact-f32 for the recurrent input projection and recurrences" if a.workload in ("stack", "gru") else "")),
             "gemm_accuracy": ("f32 results: error vs a float64 contraction <= the exact-f32 MFMA chain's on every BASELINE shape "

@@ -156,12 +156,16 @@ template <int KH, int KX, bool TRAIN, int CELL, bool XF>
 __device__ __forceinline__ void rr_body(const RRParams &p) {
     constexpr bool ULR = KX > 2;
     constexpr int NST = KX + KH;                      // k steps one wavefront multiplies per half
-    constexpr int S_RED = 0, S_PUB = 1;
-    constexpr int S_XSPL = KX > 2 ? KX : 2;
+#ifndef RR_S_RED
+#define RR_S_RED 0               // k step of the reduce + gates slice; 1 (KH = 8: the half-step's first 12 MFMAs issue before its barrier) measured
+                                 // 1-4 % SLOWER on LSTM-512 (6.30-6.46 vs 6.19-6.23 ms, same box, alternating processes: profiles/r04_lstm_sred_ab.log)
+#endif
+    constexpr int S_RED = (RR_S_RED) && KH == 8 ? 1 : 0, S_PUB = S_RED + 1;       // (the KH = 4 shapes have no k step to spare)
+    constexpr int S_XSPL = KX > 2 ? KX : S_PUB + 1;
 #ifndef RR_S_E1_XLATE
 #define RR_S_E1_XLATE 2           // the KX = 4 shapes (x requests behind the poll) may arrive from k step 2 on: 6.82 -> 6.66 us per step; 4: 8.3 -- the chain is that tight
 #endif
-    constexpr int S_E1 = KX > 2 ? RR_S_E1_XLATE : RR_S_E1;
+    constexpr int S_E1 = (KX > 2 ? RR_S_E1_XLATE : RR_S_E1) + S_RED;
     // X_LATE (KX = 4): the eight x requests of a half-step touch 32 rows each (2 x 16 bytes per row and request): they hold the
     // address path for ~2 k cycles and take ~3 us to return, and the poll's vmcnt(0) at S_E2 waited for them (stamps: 6 k cycles
     // in that k step).  They go out AFTER the poll instead, at the end of the half-step, and have the next half-step up to its

@@ -1,1 +1,1 @@
-const char *nntk_build_source_hash(void) { return "7e08cf5985201671"; }
+const char *nntk_build_source_hash(void) { return "297ae9bd0d034931"; }

@@ -139,3 +139,46 @@ def test_reference_style_training_loop_learns(tmp_path, built_lib, gpu):
     losses = [float(l.split()[-1]) for l in out.stdout.splitlines() if l.startswith("step")]
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert len(losses) == 40 and losses[-1] < 0.6 * losses[0]
+
+
+# ---- the additive frag3 entry points from C ----
+FRAG3_SRC = os.path.join(ROOT, "tests", "c_api", "frag3_caller.c")
+
+
+def _build_frag3(tmp_path):
+    exe = str(tmp_path / "frag3_caller")
+    libdir = os.path.dirname(capi.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=gnu11", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), FRAG3_SRC,
+                           "-L", libdir, "-lnntoolkitcore_hip", "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined", "-o", exe])
+    return exe
+
+
+def test_frag3_c_caller_compiles_and_links(tmp_path, built_lib):
+    assert os.path.exists(_build_frag3(tmp_path))
+
+
+@pytest.mark.gpu
+def test_frag3_c_caller_routes_agree_bitwise_and_match_the_oracle(tmp_path, built_lib, gpu):
+    """LSTM -> TimeDistributedDense from C three ways (f32 device calls, LSTMTimeDistributedDenseApplyDevice, the piece-by-piece
+    frag3 calls): identical bits, and the oracle's values (lstm.c:426-475, time_distributed_dense.c:52-58)."""
+    import oracle as O
+    exe = _build_frag3(tmp_path)
+    r = np.random.default_rng(41)
+    B, T, I, H, V = 70, 9, 40, 128, 256
+    u = lambda *s, sc=1.0: r.uniform(-sc, sc, s).astype(np.float32)
+    x, W, U, bi, bh = u(B, T, I), u(I, 4 * H, sc=I ** -0.5), u(H, 4 * H, sc=H ** -0.5), u(4 * H, sc=0.1), u(4 * H, sc=0.1)
+    dW, db = u(H, V, sc=H ** -0.5), u(V, sc=0.1)
+    for name, arr in dict(x=x, W=W, U=U, bi=bi, bh=bh, dW=dW, db=db).items():
+        arr.tofile(str(tmp_path / (name + ".bin")))
+    (tmp_path / "shape.txt").write_text("%d %d %d %d %d\n" % (B, T, I, H, V))
+    env = dict(os.environ)
+    torch_lib = os.path.join(os.path.dirname(__import__("torch").__file__), "lib")
+    env["LD_LIBRARY_PATH"] = torch_lib + ":" + env.get("LD_LIBRARY_PATH", "")
+    out = subprocess.run([exe, str(tmp_path)], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "lstm_rr_kernel<4,1>" in out.stdout, out.stdout            # LSTMKernelPlan names the family
+    ys = {k: np.fromfile(str(tmp_path / ("out_%s.bin" % k)), np.float32).reshape(B, T, V) for k in ("f32", "fused", "frag3")}
+    assert np.array_equal(ys["f32"], ys["fused"]) and np.array_equal(ys["f32"], ys["frag3"])
+    h = O.lstm(x, W, U, bi, bh, v2=True)
+    assert np.abs(np.fromfile(str(tmp_path / "out_h.bin"), np.float32).reshape(B, T, H) - h).max() < 1e-5
+    assert np.abs(ys["fused"] - O.time_distributed_dense(h, dW, db)).max() < 2e-5

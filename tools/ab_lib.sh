@@ -1,11 +1,10 @@
 #!/bin/bash
-# Compare two builds of the library on the SAME box: tools/ab_lib.sh <workload> <libA.so> <libB.so> [rounds]
-# (each library runs in its own process; interleaved A B A B to average drift)
-W=$1; A=$2; B=$3; R=${4:-2}
-for i in $(seq $R); do
-  for L in $A $B; do
-    NNTK_LIB=$L python bench.py --workload $W --no-cpu-baseline --steps 8 --warmup 3 2>/dev/null | python -c "
+# A/B of library variants (tools/build_variant.py) on one box, alternating processes: bash tools/ab_lib.sh <workload> <rounds> <lib> <lib> ...
+W=$1; R=$2; shift 2
+for r in $(seq 1 $R); do
+  for L in "$@"; do
+    NNTK_LIB=$L timeout -k 10 200 python bench.py --workload $W --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$L', 'ms=%.3f'%d['ms_per_step'], d['phase_ms'])"
+d=json.loads(sys.stdin.read()); print('$L', round(d['ms_per_step'],3), d['phase_ms'], round(d['roofline']['ms_per_launch'],3))"
   done
 done
