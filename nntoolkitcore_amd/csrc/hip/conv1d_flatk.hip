@@ -14,9 +14,11 @@
 
 // WDIRECT: the weight fragments go global (L2) -> registers, every wave fetching the TN column tiles it multiplies, one k step ahead:
 // no weight LDS, NO barrier in the K loop (the window is read-only after its staging), 32 KB of LDS per workgroup instead of 57.
-template <int TN, bool WDIRECT>
+// TM: 32-position tiles per wave (2: 128 output positions per workgroup; 4: 256 -- the weight stream per output halves)
+template <int TN, bool WDIRECT, int TM = 2>
 __global__ __launch_bounds__(256, 2) void conv1d_flatk_bf16x3_kernel(ConvParams p, int KS /* k steps of 16 */) {
-    constexpr int WN = 2, TM = 2;
+    constexpr int WN = 2;
+    constexpr int BM = 2 * TM * 32;
     constexpr int BN = WN * TN * 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char *lds = reinterpret_cast<char *>(smem);
@@ -36,7 +38,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_flatk_bf16x3_kernel(ConvParams 
     const int tile = (local / p.n_tiles) * 8 + xcd;
     if (tile >= p.m_tiles) return;
     const int b = tile / p.tiles_per_seq;
-    const int x0 = (tile % p.tiles_per_seq) * CONV_BM;
+    const int x0 = (tile % p.tiles_per_seq) * BM;
     const int n0 = (local % p.n_tiles) * BN;
 
     // ---- weights: wave w stages column tile w (+ 4 c) of the workgroup's BN / 32: one 1 KB block per image and k step ----
@@ -171,16 +173,20 @@ extern "C" int nntk_shim_conv1d_flatk(const float *d_in, const float *d_wpf, con
     int Cin_p;
     nntk_shim_conv_pack_sizes(Cin, Cout, k, &Cin_p, &p.Cout_p);
     p.Cin_p = Cin_p;
-    p.tiles_per_seq = (Tout + CONV_BM - 1) / CONV_BM;
+    // (256-position tiles -- TM = 4: half the weight stream per output, 229 VGPRs, two workgroups per CU -- measured SLOWER at configs[2]:
+    // 0.438 vs 0.388 ms, same box; the kernel lives on waves in flight, not on L2 bytes.  conv_flatk = 4 selects them for A/B.)
+    const int KS = (k * Cin + 15) / 16;
+    const bool big = opt.conv_flatk == 4 && p.Cout_p % 128 == 0 && (size_t)(255 + k) * 6 * Cin + 16 + 6 * 128 * sizeof(float) <= 72 * 1024;
+    const int BM = big ? 256 : CONV_BM;
+    p.tiles_per_seq = (Tout + BM - 1) / BM;
     p.out_mode = 0;
-    p.rows_a = CONV_BM - 1 + k;
+    p.rows_a = BM - 1 + k;
     p.bn_fast = opt.bn_fast == 1 ? 1 : 0;
     p.store16 = Cout % 4 == 0 && ((size_t)d_out & 15) == 0;
     p.quad = 1;
 #ifdef NNTK_CONV_DBG
     p.dbg = 0;
 #endif
-    const int KS = (k * Cin + 15) / 16;
     if (p.Cout_p % 64 != 0 || (long)p.Cout_p * KS * 16 * 6 >= (long)CONV_OOB || (long)(p.rows_a + 1) * Cin * 4 >= (long)CONV_OOB) return 1;
     const bool bn128 = p.Cout_p % 128 == 0;
     const int BN = bn128 ? 128 : 64;
@@ -191,7 +197,8 @@ extern "C" int nntk_shim_conv1d_flatk(const float *d_in, const float *d_wpf, con
     p.n_tiles = p.Cout_p / BN;
     const long blocks = (long)((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
     if ((long)B * p.tiles_per_seq > 0x7fffffffL / 8 || blocks > 0x7fffffffL) return 1;
-    void (*kern)(ConvParams, int) = bn128 ? (wdirect ? conv1d_flatk_bf16x3_kernel<2, true> : conv1d_flatk_bf16x3_kernel<2, false>)
+    void (*kern)(ConvParams, int) = big ? conv1d_flatk_bf16x3_kernel<2, true, 4>
+                                  : bn128 ? (wdirect ? conv1d_flatk_bf16x3_kernel<2, true> : conv1d_flatk_bf16x3_kernel<2, false>)
                                           : (wdirect ? conv1d_flatk_bf16x3_kernel<1, true> : conv1d_flatk_bf16x3_kernel<1, false>);
     if (lds > 64 * 1024 && nntk_set_max_dynamic_lds((const void *)kern, lds)) return -1;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, nntk_stream(), p, KS);

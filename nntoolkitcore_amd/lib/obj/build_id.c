@@ -1,1 +1,1 @@
-const char *nntk_build_source_hash(void) { return "297ae9bd0d034931"; }
+const char *nntk_build_source_hash(void) { return "6e0eac64d3350386"; }
