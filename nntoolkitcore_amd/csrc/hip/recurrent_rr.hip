@@ -25,10 +25,31 @@
 //     fetch elapses, and the other way round.  The events of the idle half (drain + arrival of what it published, poll
 //     for its next operand, operand loads) are placed INSIDE the multiplying half's MFMA sequence.
 //
-// Hand-off protocol: the placement-independent recipe of the CDNA4 guide (Guideline 16 R1, sc1 row): write-through
-// (sc1) 16-byte stores, every storing wave waits vmcnt(0), the waves meet (here: an LDS counter, the wave whose add is
-// last signals), ONE lane adds to an agent-scope counter; the consumer polls from one lane (relaxed, s_sleep) and every
-// load of handed-off bytes is an sc1 buffer load.  Spins are bounded and poison the counter (runtime.hip fault word).
+// Hand-off protocols.  Both follow the placement-independent recipe of the CDNA4 guide (Guideline 16 R1, sc1 row): write-through
+// (sc1) 16-byte stores by the producer, every load of handed-off bytes an sc1 buffer load.  They differ in how a consumer learns
+// that a block has been written:
+//   * FLAGS (KH = 8, the LSTM-512 class): the publishing wave waits until its stores have drained (a counted vmcnt), then stores
+//     t + 1 into its column tile's flag word; a consumer wave reads the batch tile's flags with one wave-wide sc1 load before it
+//     requests the operand.  Cheapest in instructions; the chain publication -> drain -> flag -> poll -> operand request -> operand
+//     is ~5 k cycles, which a 10-k-step half-step covers.
+//   * PENDING PATTERN (KH = 4, H <= 256): that chain is LONGER than a 6..8-k-step half-step (stamps, DESIGN K4b round 4: the
+//     half-step took as long as the chain, 5.15 k cycles against 2.3 k of MFMA time), so these shapes drop the flag: a block that
+//     has not been written yet holds the word 0xffffffff in every position, a published block never does (the publisher maps the
+//     one bf16 pair that would -- two NaNs with all payload bits set -- to another NaN), and the consumer simply requests the
+//     operand and LOOKS at it: every word of every fragment of a k step is compared (v_max3 over 12 words, in the shadow of the
+//     previous k step's MFMAs), and a k step that still holds a pending word is requested again (rare; bounded like every spin).
+//     No drain wait, no flag hop, no poll; per-word comparison, so no assumption about how a 16-byte store becomes visible.
+//     Who writes the pattern: the T-deep hand-off is also the layer's OUTPUT, so it cannot be cleared behind the consumers.  The
+//     host presets the first two timesteps; after that the workgroup that owns a block marks its block of step t + 2 while it
+//     publishes step t.  Why a stale block of an earlier launch can never be taken for data: a consumer requests blocks of step
+//     t + 2 only after it has multiplied step t + 1's operand, i.e. after it has SEEN every producer's data of step t + 1; a
+//     producer issues that data a whole step (>= 4 workgroup barriers and > 20 consumed operand loads, whose in-order vmcnt waits
+//     also retire the older mark stores) after its marks of step t + 2; both are write-through stores of the same workgroup to
+//     memory.  So "data(t + 1) visible" implies "mark(t + 2) visible", and from then on the block reads as pending until its own
+//     data lands on top of the mark.  The marks are issued by the OTHER half's publishing wave, which is idle in that slice: it has
+//     retired them (the vmcnt waits of the operand loads it consumes in every k step) two steps of workgroup barriers before the
+//     publishing wave issues the data for the same addresses.
+// Spins are bounded and poison the counter (runtime.hip fault word).
 //
 // Numerics: the contraction is the split form of conv1d.hip (error <= the f32 chain's against float64); gates are the
 // exp2 / rcp forms of nntk_common.hpp.  Not bit-identical to rec_persistent_kernel (another summation order), same
@@ -117,12 +138,16 @@ __global__ __launch_bounds__(256) void rr_tile_h0_kernel(const float *__restrict
 // operand fetched during half-step s - 1) and, sliced between the k steps of that MFMA sequence, FINISHES half X = 1 - Y,
 // whose partial sums half-step s - 1 left in LDS:
 //   k step S_RED   barrier; partial sums of X read and added (fixed order); gates; h written to the exchange image
-//          S_PUB   barrier; 16 lanes per wave assemble 8 consecutive hidden units of a row, split them into the three bf16
-//                  images and publish them write-through
+//          S_PUB   barrier; the publishing wave reads 8 consecutive hidden units of a row, already split into the three bf16
+//                  images by the lanes that computed them, and publishes them write-through
 //          S_XSPL  x_t of X's next step split into its three images; x_{t+1} of Y requested (a whole half-step ahead)
-//          S_E1    the publication has had S_E1 - S_PUB k steps to drain: vmcnt(0), then every wave raises ITS OWN flag
-//          S_E2-1  every wave requests the 128 flags (4 waves x 32 column tiles) of X's next operand: two loads
-//          S_E2    check them (spin only if one is missing), store the f32 layer output of X, request the 24 operand fragments
+//   FLAGS:
+//          S_E1    the publication has had S_E1 - S_PUB k steps to drain: counted vmcnt, then the publishing wave raises its flag
+//          S_E2-1  every wave requests the flags of X's next operand
+//          S_E2    check them (spin only if one is missing), request the head of X's next operand
+//   PENDING PATTERN:
+//          S_HEAD  request the head of X's next operand (no earlier than the data can be there: RR_HEAD_LEAD)
+//          every h k step: the NEXT k step's fragments are looked at (probe_h); a pending one is settled before its MFMAs
 // so that the vector ALU, LDS and memory work of one half runs in the shadow of the other half's MFMAs (an MFMA holds the
 // issue port 8 of its 32 cycles).  Every vector-memory operation is a branch-free buffer operation (lanes that must not
 // load / store get an out-of-range offset), so the steady-state half-step is straight-line code apart from the poll.
@@ -132,9 +157,9 @@ __global__ __launch_bounds__(256) void rr_tile_h0_kernel(const float *__restrict
 // them issued five quarter-filled store instructions per half-step, and a store occupies the shared address path as long
 // whatever it carries (measured: publication + output stores cost 1.06 us of a 7.0 us step that way).
 //
-// Signalling is by FLAG WORDS, not by an arrival counter: the publishing wave of column tile ct stores (t + 1) write-through
-// into flags[batch tile][half][ct] once its publishing stores have drained, and every consumer wave reads the batch tile's
-// flags with one wave-wide sc1 load.  Against the agent-scope counter of rec_persistent_kernel this removes the
+// FLAGS protocol: signalling is by FLAG WORDS, not by an arrival counter: the publishing wave of column tile ct stores (t + 1)
+// write-through into flags[batch tile][half][ct] once its publishing stores have drained, and every consumer wave reads the batch
+// tile's flags with one wave-wide sc1 load.  Against the agent-scope counter of rec_persistent_kernel this removes the
 // serialisation of 32 read-modify-writes at the memory side (~12 ns each) and the cross-wave gather in front of the add,
 // and makes the arrival a plain store.  Valid by the guide's sc1 hand-off table: the flag covers exactly the stores of the
 // wave that raises it, after that wave's vmcnt wait.
@@ -162,32 +187,43 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
 #endif
     constexpr int S_RED = (RR_S_RED) && KH == 8 ? 1 : 0, S_PUB = S_RED + 1;       // (the KH = 4 shapes have no k step to spare)
     constexpr int S_XSPL = KX > 2 ? KX : S_PUB + 1;
+    // Hand-off protocol (see the header comment): PEND = the published fragments carry their own validity (KH = 4 shapes, whose
+    // half-step is shorter than the flag chain), else flag words (KH = 8: the chain fits, and the flags cost fewer instructions)
+#ifndef RR_PEND
+#define RR_PEND (KH == 4)
+#endif
+    constexpr bool PEND = RR_PEND;
 #ifndef RR_S_E1_XLATE
 #define RR_S_E1_XLATE 2           // the KX = 4 shapes (x requests behind the poll) may arrive from k step 2 on: 6.82 -> 6.66 us per step; 4: 8.3 -- the chain is that tight
 #endif
-    constexpr int S_E1 = (KX > 2 ? RR_S_E1_XLATE : RR_S_E1) + S_RED;
+    constexpr int S_E1 = (KX > 2 ? RR_S_E1_XLATE : RR_S_E1) + S_RED;                  // (flag protocol only)
     // X_LATE (KX = 4): the eight x requests of a half-step touch 32 rows each (2 x 16 bytes per row and request): they hold the
     // address path for ~2 k cycles and take ~3 us to return, and the poll's vmcnt(0) at S_E2 waited for them (stamps: 6 k cycles
     // in that k step).  They go out AFTER the poll instead, at the end of the half-step, and have the next half-step up to its
     // S_XSPL to arrive.
     constexpr bool X_LATE = KX > 2;
     constexpr int S_E2 = NST - 1;
-    // Operand schedule: the fragments of h k step i are requested NPRE k steps ... see issue_h below: i < NPRE at S_E2 of the
-    // OTHER half's sequence (after the poll), i >= NPRE at k step i - NPRE of the half's own sequence (needed at KX + i).
+#ifndef RR_HEAD_LEAD
+#define RR_HEAD_LEAD 1            // PEND: the head of the other half's next operand goes out this many k steps before the half-step's last one
+#endif                            // (GRU-256 pair: 0: 10.6, 1: 10.2, 2: 11.2, 3: 12.0 ms -- earlier than that the fragments are still pending and the second look costs a round trip)
+    constexpr int S_HEAD = !PEND ? S_E2 : S_E2 - RR_HEAD_LEAD > S_PUB ? S_E2 - RR_HEAD_LEAD : S_PUB + 1;
+    // Operand schedule: the fragments of h k step i are requested NPRE k steps ... see issue_h below: i < NPRE at S_HEAD of the
+    // OTHER half's sequence (flag protocol: after the poll), i >= NPRE at k step i - NPRE of the half's own sequence (needed at KX + i).
     constexpr int NPRE = RR_NPRE < KH ? RR_NPRE : KH;
-    // vector-memory operations a wave issues between a publication (S_PUB) and its arrival (S_E1): the own-sequence operand
-    // requests of k steps S_PUB .. S_E1 - 1 and the x request at S_XSPL -- what the arrival's counted wait leaves in flight
+    // flag protocol: vector-memory operations a wave issues between a publication (S_PUB) and its arrival (S_E1): the own-sequence
+    // operand requests of k steps S_PUB .. S_E1 - 1 and the x request at S_XSPL -- what the arrival's counted wait leaves in flight
     constexpr int own_lo = S_PUB + NPRE < KH ? S_PUB + NPRE : KH, own_hi = S_E1 + NPRE < KH ? S_E1 + NPRE : KH;
     constexpr int NXR = XF ? 3 * KX : 2 * KX;         // vector-memory requests of one x fetch
     constexpr int N_X_AFTER_PUB = (X_LATE || S_XSPL >= S_E1) ? 0 : NXR;      // (S_XSPL == S_E1: the arrival precedes the x requests in its k step)
     constexpr int N_AFTER_PUB = 3 * (own_hi - own_lo) + N_X_AFTER_PUB;
-    static_assert(NST >= 5 && S_E1 < S_E2 && S_E1 > S_PUB && S_XSPL >= KX && S_XSPL < S_E2 - RR_POLL_LEAD &&
-                  S_XSPL > S_PUB && KH - NPRE <= S_E2, "slice schedule");
+    static_assert(NST >= 5 && S_XSPL >= KX && S_XSPL > S_PUB && KH - NPRE <= S_E2 && S_HEAD > S_PUB && S_HEAD <= S_E2, "slice schedule");
+    static_assert(PEND ? S_XSPL < S_E2 : (S_E1 < S_E2 && S_E1 > S_PUB && S_XSPL < S_E2 - RR_POLL_LEAD), "slice schedule");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     rr_v4u *ULs = reinterpret_cast<rr_v4u *>(smem);                       // [4][KH][2] blocks (not with ULR)
     rr_v4u *WXs = ULs + (ULR ? 0 : 4 * KH * 2 * 64);                      // [4][KX][2][3] blocks
     rr_v4u *red = WXs + 4 * KX * 6 * 64;                                  // [dst 4][src 4][2] blocks: split-K exchange
-    float *hx = reinterpret_cast<float *>(red + 32 * 64);                 // [32][RR_HX_LD] h exchange
+    float *hx = reinterpret_cast<float *>(red + 32 * 64);                 // [32][RR_HX_LD] h exchange (f32: the output wave's rows)
+    unsigned *hs = reinterpret_cast<unsigned *>(hx + 32 * RR_HX_LD);      // [3 images][32][RR_HS_LD] the same h, already split (the publishing wave's rows)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -411,6 +447,17 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
             ac[0][e] = ig; ac[1][e] = fg; ac[2][e] = gg; ac[3][e] = og;
         }
         *reinterpret_cast<float2 *>(hx + n * RR_HX_LD + jl) = make_float2(hn[0], hn[1]);
+        // every lane splits its own two hidden units (11 instructions in each of the four waves, here in the reduce slice, instead of 44
+        // in the publishing wave between its barrier and its stores: that wave's half-steps were ~400 cycles longer than the others')
+        if (!RR_DBG(128)) {
+            unsigned sh, sm, sl;
+            rr_split_pair(hn[0], hn[1], sh, sm, sl);
+            // PEND: no published word may equal the "not yet written" pattern (two bf16 NaNs with every payload bit set): such a pair
+            // becomes another NaN
+            if (PEND) { sh = min(sh, 0xfffffffeu); sm = min(sm, 0xfffffffeu); sl = min(sl, 0xfffffffeu); }
+            unsigned *d = hs + n * RR_HS_LD + (jl >> 1);
+            d[0] = sh; d[32 * RR_HS_LD] = sm; d[2 * 32 * RR_HS_LD] = sl;
+        }
         if (TRAIN && CELL == 1) {
             const int row = b0 + half * 32 + n;
             if (row < p.B && jf + 1 < H + 1) {
@@ -439,12 +486,14 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
         constexpr int half = decltype(half_tag)::value;
         constexpr bool LAST = decltype(last_tag)::value;     // the half's last step: final state / last output leave from here
         RR_BARRIER();                                   // the half's h row pieces are in `hx`
-        if (w == 2 * half) {                            // the publishing wave: split, three full write-through stores
-            const float4 h_lo = *reinterpret_cast<const float4 *>(hx + n * RR_HX_LD + 8 * kh);
-            const float4 h_hi = *reinterpret_cast<const float4 *>(hx + n * RR_HX_LD + 8 * kh + 4);
-            const float v[8] = {h_lo.x, h_lo.y, h_lo.z, h_lo.w, h_hi.x, h_hi.y, h_hi.z, h_hi.w};
+        if (w == 2 * half) {                            // the publishing wave: three full write-through stores
             rr_v4u a, b, c;
-            if (!RR_DBG(128)) rr_split8(v, a, b, c);
+            if (!RR_DBG(128)) {
+                const unsigned *src = hs + n * RR_HS_LD + 4 * kh;
+                a = *reinterpret_cast<const rr_v4u *>(src);
+                b = *reinterpret_cast<const rr_v4u *>(src + 32 * RR_HS_LD);
+                c = *reinterpret_cast<const rr_v4u *>(src + 2 * 32 * RR_HS_LD);
+            }
             // the block's offset rides in the VECTOR offset and soffset stays immediate 0: a wide buffer store with an SGPR
             // soffset followed by a VALU write of its data registers stores the overwritten value in some lanes on MI355X, and
             // the compiler inserts no wait state for that form (tools/check_store_hazard.py, tests/test_isa_lint.py)
@@ -480,8 +529,22 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
                     }
                 }
             }
+        } else if (PEND && w == ((2 * half + 2) & 3)) {
+            // the OTHER half's publishing wave (idle in this slice) marks this column tile's blocks of step t + 2 pending (see "Hand-off
+            // protocol" above); past the last step the offset is out of range and the stores are dropped
+            if (!RR_DBG(128)) {
+                const int vo = lane16 + (((bt_abs * 2 + half) * NKS + ct) * 3) * 1024;
+                const __amdgpu_buffer_rsrc_t rs2 = rs_wr(t + 2 < T ? t + 2 : t);
+                const int vo2 = t + 2 < T ? vo : RR_OOB_F;
+                const rr_v4u pend = {RR_PENDING, RR_PENDING, RR_PENDING, RR_PENDING};
+                __builtin_amdgcn_raw_buffer_store_b128(pend, rs2, vo2, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(pend, rs2, vo2 + 1024, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(pend, rs2, vo2 + 2048, 0, 16);
+                RR_BOUND(3, (size_t)(t + 2 < T ? t + 2 : t) * p.hstep, vo2 + 2048, 0, hb_bytes, 16);
+            }
         }
     };
+    // ---- flag protocol (!PEND) ----
     unsigned *const flags0 = p.flags + (size_t)bt * 2 * RR_FLAGS, *const flags1 = flags0 + RR_FLAGS;
     // arrival (publishing wave only): its publishing stores have drained -> raise the column tile's flag (write-through store
     // of t + 1).  Counted wait: the x request and the own-sequence operand requests issued after the publication stay in flight.
@@ -524,6 +587,39 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
         }
     };
 
+    // ---- pending-pattern protocol (PEND) ----
+    // validity of a fetched k step: no word of its three fragments is the pending pattern.  The fast path is 7 vector-ALU
+    // instructions and an untaken branch per k step; a fragment that is still pending is requested again (bounded; a peer that gave up
+    // has raised the fault word and ends every other spin at once).  spin_ticks == 0 is fault injection (tests): behave as if the
+    // first look had found nothing and the budget had run out.
+    // probe_h looks (the mask of lanes that hold a pending word), settle_h acts on it: the look at k step i + 1 is computed at the END
+    // of k step i, in the shadow of its last MFMAs, so the multiply of k step i + 1 starts behind one scalar compare
+    auto probe_h = [&](auto half_tag, int i) __attribute__((always_inline)) {
+        constexpr int half = decltype(half_tag)::value;
+        unsigned mx = 0;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const rr_v4u v = hf[half][i][m];
+            mx = max(mx, max(max(v.x, v.y), max(v.z, v.w)));
+        }
+        return __builtin_amdgcn_ballot_w64(mx == RR_PENDING);
+    };
+    const unsigned long long inject = p.spin_ticks == 0 ? ~0ull : 0ull;
+    auto settle_h = [&](auto half_tag, int t, int i, unsigned long long pend) __attribute__((always_inline)) {
+        if (__builtin_expect((pend | inject) != 0, 0)) {
+            const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+            bool expired = p.spin_ticks == 0;
+            while (!expired) {
+                issue_h(half_tag, t, 3 * i, 3 * i + 3);
+                if (probe_h(half_tag, i) == 0) break;
+                if (__hip_atomic_load(p.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { expired = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+                expired = __builtin_amdgcn_s_memrealtime() - t_start > p.spin_ticks;
+            }
+            if (expired && lane == 0) __hip_atomic_fetch_or(p.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+
     // one half-step: multiply half Y at step t; FIN: finish half X = 1 - Y (its step tX) on the way; NEXT: fetch X's operand of
     // step tX + 1 (POLL: it was published inside this launch)
     auto half_step = [&](auto y_tag, auto fin_tag, auto next_tag, auto poll_tag, auto last_tag, auto xlive_tag, int t, int tX) __attribute__((always_inline)) {
@@ -532,7 +628,9 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
         using XT = std::integral_constant<int, 1 - Y>;
         constexpr int X = 1 - Y;
         constexpr bool FIN = decltype(fin_tag)::value, NEXT = decltype(next_tag)::value, POLL = decltype(poll_tag)::value;
+        constexpr bool YCHK = PEND;      // this half's operand is checked where it is used (at run time: from its second step on)
         f32x16 acc[2];
+        unsigned long long pend_next = 0;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -560,12 +658,12 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
             // ---- slices of the other half's finish and of its next fetch ----
             if (s == S_RED && FIN && !RR_DBG(2)) { fin_reduce(); fin_gates(XT{}, tX); }
             if (s == S_PUB && FIN && !RR_DBG(2)) { fin_publish(XT{}, last_tag, tX); }
-            if (s == S_E1 && FIN && !RR_DBG(4)) { arrive(X, tX, xlive_tag); }
-            if (s == S_E2 - RR_POLL_LEAD && NEXT && POLL && !RR_DBG(4)) poll_a(X);
-            if (s == S_E2) {
-                if (NEXT && POLL && !RR_DBG(4)) poll_b(X, tX + 1);
+            if (!PEND) {
+                if (s == S_E1 && FIN && !RR_DBG(4)) { arrive(X, tX, xlive_tag); }
+                if (s == S_E2 - RR_POLL_LEAD && NEXT && POLL && !RR_DBG(4)) poll_a(X);
+                if (s == S_E2 && NEXT && POLL && !RR_DBG(4)) poll_b(X, tX + 1);
             }
-            if (s == S_E2 && NEXT && !RR_DBG(1)) issue_h(XT{}, tX + 1, 0, 3 * NPRE);          // head of X's next operand
+            if (s == S_HEAD && NEXT && !RR_DBG(1)) issue_h(XT{}, tX + 1, 0, 3 * NPRE);        // head of X's next operand (PEND: speculative, checked where it is used)
             if (s == S_E2 && X_LATE && XLIVE && !RR_DBG(8)) issue_x(y_tag, t + 1);            // (xr is free since this half-step's S_XSPL)
             if (s + NPRE < KH && !RR_DBG(1)) issue_h(y_tag, t, 3 * (s + NPRE), 3 * (s + NPRE + 1));       // THIS half's operand, k step s + NPRE (published long ago)
             // ---- multiply ----
@@ -578,6 +676,7 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
                         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[mt][PA[pr]], xf[XF ? Y : 0][s][PB[pr]], acc[mt], 0, 0, 0);
             } else {
                 const int i = s - KX;
+                if (YCHK && t > 0 && !RR_DBG(4) && !RR_DBG(1)) settle_h(y_tag, t, i, pend_next);   // (step 0 reads the h_0 slot, written before the launch)
                 rr_bf16x8 b[3];
 #pragma unroll
                 for (int m = 0; m < 3; ++m) b[m] = __builtin_bit_cast(rr_bf16x8, hf[Y][i][m]);
@@ -589,6 +688,7 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
                         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b[PB[pr]], acc[mt], 0, 0, 0);
                     }
             }
+            if (YCHK && s + 1 >= KX && s + 1 < NST && !RR_DBG(4) && !RR_DBG(1)) pend_next = probe_h(y_tag, s + 1 - KX);
             // x_t of the half that multiplies next: split (this half's own x part has been multiplied), then request this
             // half's x_{t+1} -- a whole half-step ahead of its use
             if (s == S_XSPL) {
@@ -694,7 +794,7 @@ static bool rr_shape(int H, int in, bool xf, int *KH, int *KX) {
     return *KX != 0;
 }
 static size_t rr_lds_bytes(int KH, int KX) {
-    return (size_t)((KX > 2 ? 0 : 4 * KH * 2) + 4 * KX * 6 + 32) * 1024 + 32 * RR_HX_LD * 4;
+    return (size_t)((KX > 2 ? 0 : 4 * KH * 2) + 4 * KX * 6 + 32) * 1024 + 32 * RR_HX_LD * 4 + 3 * 32 * RR_HS_LD * 4;
 }
 // one timestep of the frag3 hand-off / layer output: [NHT = 2 * batch tiles][H / 16 k steps][3 images] blocks of 1 KB
 static size_t rr_step_bytes(int B, int H) { return (size_t)((B + 63) / 64) * 2 * (H / 16) * 3 * 1024; }
@@ -836,6 +936,9 @@ static int rr_launch(const RRIo &io, const float *d_img, const float *d_bi, cons
     // the h_0 slot (zeros, or h_0 split below) and the flags; the T-deep part needs no clearing: every block a step reads has been
     // written by the step before it (k steps the hand-off does not store read as zeros through out-of-range offsets)
     if (nntk_shim_memset(io.work, 0, step + (size_t)((B + 127) / 128) * 4 * RR_FLAGS * sizeof(unsigned))) return -1;
+    // pending-pattern protocol (KH = 4 kernels; harmless for the others, which overwrite it before their flags let anyone look): the first
+    // two timesteps of the hand-off start out "pending"; from there on every publishing wave marks its own blocks two steps ahead
+    if (nntk_shim_memset(io.hseq, 0xff, step * (size_t)(T < 2 ? T : 2))) return -1;
     if (io.h0) {
         long g = ((long)nbt_total * 2 * NCT * 64 + 255) / 256;
         if (g > 2048) g = 2048;

@@ -23,6 +23,13 @@ typedef unsigned rr_v4u __attribute__((ext_vector_type(4)));
 #define RR_S_E1 3                // k step at which a half's publication is taken to have drained (tools/rr_stamps.py)
 #endif
 
+// "not yet written" pattern of the frag3 hand-off (recurrent_rr.hip): a published word never equals it
+#define RR_PENDING 0xffffffffu
+__device__ __forceinline__ rr_v4u rr_not_pending(rr_v4u v) {
+    return (rr_v4u){min(v.x, 0xfffffffeu), min(v.y, 0xfffffffeu), min(v.z, 0xfffffffeu), min(v.w, 0xfffffffeu)};
+}
+
+#define RR_HS_LD 12               // dwords per row of a split h exchange image (8 used; 16-byte aligned rows, two-way bank spread)
 #define RR_HX_LD 20               // floats per row of the h exchange image (16-byte aligned rows)
 
 __device__ __forceinline__ unsigned rr_cvt_pk(float a, float b) {       // RNE, a in the low half
@@ -30,6 +37,7 @@ __device__ __forceinline__ unsigned rr_cvt_pk(float a, float b) {       // RNE, 
 }
 // x = hi + mid + lo exactly (8 + 8 + 8 significand bits), two elements at a time
 __device__ __forceinline__ void rr_split_pair(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo) {
+#pragma clang fp contract(off)    // the residuals are those of the ROUNDED x (inlined behind x = a * b, x - hi must not become fma(a, b, -hi))
     hi = rr_cvt_pk(x0, x1);
     const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
     mid = rr_cvt_pk(r0, r1);

@@ -1,1 +1,1 @@
-const char *nntk_build_source_hash(void) { return "6e0eac64d3350386"; }
+const char *nntk_build_source_hash(void) { return "726e45298310815f"; }

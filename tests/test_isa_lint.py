@@ -37,3 +37,6 @@ def test_lstm_rr_counted_waits_match_the_isa():
     assert "0 mismatches" in r.stdout
     # ... and the flag poll's register is left alone between its asm load and its asm wait, no scratch in any rr kernel
     assert "0 violations" in r.stdout and " 0 flag polls" not in r.stdout
+    # ... and the KH = 4 instantiations, which hand over without flags (pending pattern): every look covers all twelve words of a
+    # k step's three fragments, no flag-protocol drain is left in them, no scratch
+    assert "0 defects" in r.stdout and " 0 pending-pattern looks" not in r.stdout

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""ISA check for lstm_rr_kernel's COUNTED vmcnt wait (recurrent_rr.hip, `arrive`): the publishing wave waits for its three
+"""ISA checks for the hand-off protocols of recurrent_rr.hip / recurrent_rr4.hip.  Flag protocol: lstm_rr_kernel's COUNTED vmcnt wait (recurrent_rr.hip, `arrive`): the publishing wave waits for its three
 write-through stores with s_waitcnt vmcnt(N), N = the vector-memory instructions it issues between those stores and the wait.
 If the compiler drops or adds one (dead x loads in the last half-steps did), N is wrong: too large and the flag can overtake the
 data.  This script compiles the file and, for every such wait of every instantiation, counts the vector-memory instructions
@@ -28,7 +28,9 @@ def main():
     print("lstm_rr_kernel / gru_rr_kernel: %d counted waits checked, %d mismatches" % (total, bad))
     pbad, ptotal = check_polls(txt)
     print("lstm_rr_kernel / gru_rr_kernel: %d flag polls checked, %d violations" % (ptotal, pbad))
-    return 1 if bad or total == 0 or pbad or ptotal == 0 else 0
+    qbad, qtotal = check_pending(txt)
+    print("lstm_rr_kernel / gru_rr_kernel: %d pending-pattern looks checked, %d defects" % (qtotal, qbad))
+    return 1 if bad or total == 0 or pbad or ptotal == 0 or qbad or qtotal == 0 else 0
 
 
 def is_pub_store(t):
@@ -158,6 +160,52 @@ def check_polls(txt):
                     break
             if not closed:
                 print("%s: no asm vmcnt(0) wait within 400 lines of the flag load into v%d" % (kname, reg)); bad += 1
+    return bad, total
+
+
+def check_pending(txt):
+    """The KH = 4 instantiations hand h over WITHOUT flags: a consumer looks at the fragments it fetched and takes a word of 0xffffffff
+    for "not written yet" (recurrent_rr.hip, probe_h / settle_h).  That is only sound if every WORD of the three fragments of a k step
+    is looked at (nothing is assumed about how a 16-byte store becomes visible).  For each such kernel: every `v_cmp_eq_u32 -1, vN`
+    sits on top of a v_max_u32 / v_max3_u32 tree with exactly twelve leaf registers; there are at least 2 x 4 k steps x 2 halves of
+    them (the steady-state loop and the peeled last half-steps, fast path + the second look of the slow path); the kernel contains no
+    asm vmcnt wait (the flag protocol's drain) and uses no scratch.  (Which registers hold a fragment changes from one peeled copy to
+    the next, so the leaves are not traced back to the loads; the bit-for-bit shard / whole-batch tests do that at run time.)"""
+    bad = total = 0
+    for kname in re.findall(r'^(_Z1[34](?:lstm|gru)_rr_kernelILi4E\w+):', txt, re.M):
+        a = txt.index("\n" + kname + ":")
+        s = [l.strip() for l in txt[a:txt.index(".Lfunc_end", a)].split("\n")]
+        m = re.search(r'\.amdhsa_kernel %s\b.*?\.end_amdhsa_kernel' % re.escape(kname), txt, re.S)
+        ps = re.search(r'\.amdhsa_private_segment_fixed_size (\d+)', m.group(0)) if m else None
+        if ps and int(ps.group(1)) != 0:
+            bad += 1
+            print("%s: scratch in use" % kname)
+        looks = 0
+        for i, t in enumerate(s):
+            cm = re.match(r'v_cmp_eq_u32_e\d+ \S+ -1, v(\d+)$', t)
+            if not cm:
+                continue
+            total += 1
+            looks += 1
+            want = {int(cm.group(1))}
+            for j in range(i - 1, max(i - 40, 0), -1):
+                mm = re.match(r'v_max3?_u32(?:_e\d+)? v(\d+), (.*)$', s[j])
+                if not mm or int(mm.group(1)) not in want:
+                    continue
+                want.discard(int(mm.group(1)))
+                for o in re.split(r',\s*', mm.group(2)):
+                    r = regs_of(o.strip())
+                    if len(r) == 1:
+                        want |= r                  # (a source that no earlier max in the window defines stays in `want`: a leaf)
+            if len(want) != 12:
+                bad += 1
+                print("%s: the look at +%d covers %d registers %s, not the twelve words of three fragments" % (kname, i, len(want), sorted(want)))
+        if looks < 32:
+            bad += 1
+            print("%s: only %d looks" % (kname, looks))
+        if any("ASMSTART" in s[k - 1] and re.match(r's_waitcnt vmcnt', t) for k, t in enumerate(s)):
+            bad += 1
+            print("%s: an asm vmcnt wait (the flag protocol) in a pending-pattern kernel" % kname)
     return bad, total
 
 
