@@ -448,7 +448,10 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
         }
         *reinterpret_cast<float2 *>(hx + n * RR_HX_LD + jl) = make_float2(hn[0], hn[1]);
         // every lane splits its own two hidden units (11 instructions in each of the four waves, here in the reduce slice, instead of 44
-        // in the publishing wave between its barrier and its stores: that wave's half-steps were ~400 cycles longer than the others')
+        // in the publishing wave between its barrier and its stores: that wave's half-steps were ~400 cycles longer than the others').
+        // (Publishing from here as well -- every lane storing its own word of the fragment slot, three write-through 4-byte stores, no
+        // LDS round trip and no publishing wave -- was measured SLOWER with the pending-pattern protocol: GRU-256 pair 10.33 vs 9.90 ms,
+        // profiles/r04_rr_direct_publication.log: the quarter-filled stores reach the consumers later than three full 1 KB ones.)
         if (!RR_DBG(128)) {
             unsigned sh, sm, sl;
             rr_split_pair(hn[0], hn[1], sh, sm, sl);
