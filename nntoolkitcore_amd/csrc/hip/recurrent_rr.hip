@@ -623,6 +623,19 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
         }
     };
 
+    // ---- split-K exchange: wave `dst` finishes registers 4 g + 2 (dst & 1) + {0, 1} of tile dst >> 1 (read in the NEXT half-step) ----
+    auto exchange = [&](const f32x16 (&acc)[2], int d0, int d1) __attribute__((always_inline)) {
+        if (RR_DBG(32)) return;
+#pragma unroll
+        for (int dst = 0; dst < 4; ++dst) {
+            if (dst < d0 || dst >= d1) continue;
+            const int mt = dst >> 1, o = 2 * (dst & 1);
+            const rr_v4u q0 = {__float_as_uint(acc[mt][o]), __float_as_uint(acc[mt][o + 1]), __float_as_uint(acc[mt][4 + o]), __float_as_uint(acc[mt][5 + o])};
+            const rr_v4u q1 = {__float_as_uint(acc[mt][8 + o]), __float_as_uint(acc[mt][9 + o]), __float_as_uint(acc[mt][12 + o]), __float_as_uint(acc[mt][13 + o])};
+            red[((dst * 4 + w) * 2 + 0) * 64 + lane] = q0;
+            red[((dst * 4 + w) * 2 + 1) * 64 + lane] = q1;
+        }
+    };
     // one half-step: multiply half Y at step t; FIN: finish half X = 1 - Y (its step tX) on the way; NEXT: fetch X's operand of
     // step tX + 1 (POLL: it was published inside this launch)
     auto half_step = [&](auto y_tag, auto fin_tag, auto next_tag, auto poll_tag, auto last_tag, auto xlive_tag, int t, int tX) __attribute__((always_inline)) {
@@ -659,6 +672,8 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
                 for (int mt = 0; mt < 2; ++mt) ulo[mt] = __builtin_bit_cast(rr_bf16x8, ULs[((w * KH + (s - KX)) * 2 + mt) * 64 + lane]);
             }
             // ---- slices of the other half's finish and of its next fetch ----
+            // (issuing 2 / 4 / 6 of this k step's x products BEFORE the reduce slice's barrier -- they do not depend on it -- measured
+            // +0.1 ms on LSTM-512 and nothing on GRU-256: profiles/r04_rr_exchange_ab.log)
             if (s == S_RED && FIN && !RR_DBG(2)) { fin_reduce(); fin_gates(XT{}, tX); }
             if (s == S_PUB && FIN && !RR_DBG(2)) { fin_publish(XT{}, last_tag, tX); }
             if (!PEND) {
@@ -683,6 +698,19 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
                 rr_bf16x8 b[3];
 #pragma unroll
                 for (int m = 0; m < 3; ++m) b[m] = __builtin_bit_cast(rr_bf16x8, hf[Y][i][m]);
+                if (s == NST - 1) {
+                    // the half-step's last k step runs tile by tile (the same six products per tile in the same order): tile 0's
+                    // partial sums leave for the exchange while tile 1 still multiplies
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                        for (int pr = 0; pr < 6; ++pr) {
+                            const rr_bf16x8 av = PA[pr] == 2 ? ulo[mt] : uh[i][mt][PA[pr]];
+                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b[PB[pr]], acc[mt], 0, 0, 0);
+                        }
+                        if (mt == 0) exchange(acc, 0, 2);
+                    }
+                } else {
 #pragma unroll
                 for (int pr = 0; pr < 6; ++pr)
 #pragma unroll
@@ -690,6 +718,7 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
                         const rr_bf16x8 av = PA[pr] == 2 ? ulo[mt] : uh[i][mt][PA[pr]];
                         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b[PB[pr]], acc[mt], 0, 0, 0);
                     }
+                }
             }
             if (YCHK && s + 1 >= KX && s + 1 < NST && !RR_DBG(4) && !RR_DBG(1)) pend_next = probe_h(y_tag, s + 1 - KX);
             // x_t of the half that multiplies next: split (this half's own x part has been multiplied), then request this
@@ -710,29 +739,33 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
                 if (j & 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
             }
 #else
+            if (s == NST - 1) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {             // tile 1's MFMAs, tile 0's four LDS writes and the rest of the requests between them
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            } else {
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            }
             }
 #endif
 #endif
             __builtin_amdgcn_sched_barrier(0);            // a slice stays with its k step
         }
         RR_STAMP(Y, t, NST);
-        // ---- split-K exchange: wave `dst` finishes registers 4 g + 2 (dst & 1) + {0, 1} of tile dst >> 1 (read in the NEXT half-step) ----
-        if (!RR_DBG(32))
-#pragma unroll
-        for (int dst = 0; dst < 4; ++dst) {
-#ifdef RR_RED_SKIP_OWN
-            if (dst == w) continue;                       // uniform branch: a wave keeps its own part in registers ... (see fin_reduce)
-#endif
-            const int mt = dst >> 1, o = 2 * (dst & 1);
-            const rr_v4u q0 = {__float_as_uint(acc[mt][o]), __float_as_uint(acc[mt][o + 1]), __float_as_uint(acc[mt][4 + o]), __float_as_uint(acc[mt][5 + o])};
-            const rr_v4u q1 = {__float_as_uint(acc[mt][8 + o]), __float_as_uint(acc[mt][9 + o]), __float_as_uint(acc[mt][12 + o]), __float_as_uint(acc[mt][13 + o])};
-            red[((dst * 4 + w) * 2 + 0) * 64 + lane] = q0;
-            red[((dst * 4 + w) * 2 + 1) * 64 + lane] = q1;
-        }
+        // (tile 1's half of the split-K exchange; tile 0's went out inside the last k step)
+        exchange(acc, 2, 4);
     };
 
     // prologue: operands of half A, step 0 (h_0 sits in parity 0: no poll); x_0 of half B
