@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void rr_tile_h0_kernel(const float *__restrict
 //          S_XSPL  x_t of X's next step split into its three images; x_{t+1} of Y requested (a whole half-step ahead)
 //   FLAGS:
 //          S_E1    the publication has had S_E1 - S_PUB k steps to drain: counted vmcnt, then the publishing wave raises its flag
-//          S_E2-1  every wave requests the flags of X's next operand
+//          S_E2-2  every wave requests the flags of X's next operand (POLL_LEAD)
 //          S_E2    check them (spin only if one is missing), request the head of X's next operand
 //   PENDING PATTERN:
 //          S_HEAD  request the head of X's next operand (no earlier than the data can be there: RR_HEAD_LEAD)
@@ -217,7 +217,14 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
     constexpr int N_X_AFTER_PUB = (X_LATE || S_XSPL >= S_E1) ? 0 : NXR;      // (S_XSPL == S_E1: the arrival precedes the x requests in its k step)
     constexpr int N_AFTER_PUB = 3 * (own_hi - own_lo) + N_X_AFTER_PUB;
     static_assert(NST >= 5 && S_XSPL >= KX && S_XSPL > S_PUB && KH - NPRE <= S_E2 && S_HEAD > S_PUB && S_HEAD <= S_E2, "slice schedule");
-    static_assert(PEND ? S_XSPL < S_E2 : (S_E1 < S_E2 && S_E1 > S_PUB && S_XSPL < S_E2 - RR_POLL_LEAD), "slice schedule");
+    // flag protocol: the flags are requested POLL_LEAD k steps before they are looked at.  Two k steps (~1 k cycles) cover the load's round
+    // trip; with one the check waited for it: LSTM-512 5.94-5.98 -> 5.78-5.85 ms in four alternating rounds, three k steps 5.82-5.85
+    // (profiles/r04_rr_poll_lead_ab.log)
+#ifndef RR_POLL_LEAD_RR
+#define RR_POLL_LEAD_RR (NST >= 9 ? 2 : RR_POLL_LEAD)
+#endif
+    constexpr int POLL_LEAD = RR_POLL_LEAD_RR;
+    static_assert(PEND ? S_XSPL < S_E2 : (S_E1 < S_E2 && S_E1 > S_PUB && S_XSPL < S_E2 - POLL_LEAD), "slice schedule");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     rr_v4u *ULs = reinterpret_cast<rr_v4u *>(smem);                       // [4][KH][2] blocks (not with ULR)
     rr_v4u *WXs = ULs + (ULR ? 0 : 4 * KH * 2 * 64);                      // [4][KX][2][3] blocks
@@ -561,7 +568,7 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
                 __hip_atomic_store((half ? flags1 : flags0) + ct, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
-    // every wave polls for itself: one sc1 load covers the batch tile's flags; requested RR_POLL_LEAD k steps before it is looked at
+    // every wave polls for itself: one sc1 load covers the batch tile's flags; requested POLL_LEAD k steps before it is looked at
     unsigned pv0 = 0;
     const bool flag_live = lane < p.NCT;               // lanes past the last column tile read padding words (always 0)
     auto poll_a = [&](int half) __attribute__((always_inline)) {
@@ -678,7 +685,7 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
             if (s == S_PUB && FIN && !RR_DBG(2)) { fin_publish(XT{}, last_tag, tX); }
             if (!PEND) {
                 if (s == S_E1 && FIN && !RR_DBG(4)) { arrive(X, tX, xlive_tag); }
-                if (s == S_E2 - RR_POLL_LEAD && NEXT && POLL && !RR_DBG(4)) poll_a(X);
+                if (s == S_E2 - POLL_LEAD && NEXT && POLL && !RR_DBG(4)) poll_a(X);
                 if (s == S_E2 && NEXT && POLL && !RR_DBG(4)) poll_b(X, tX + 1);
             }
             if (s == S_HEAD && NEXT && !RR_DBG(1)) issue_h(XT{}, tX + 1, 0, 3 * NPRE);        // head of X's next operand (PEND: speculative, checked where it is used)
