@@ -318,14 +318,16 @@ def test_rr_requests_stay_inside_their_tensors(gpu):
     assert "rr bounds: 0 violation(s)" in r.stdout
 
 
-def test_lstm_rr_fault_is_reported_and_heals(gpu):
+@pytest.mark.parametrize("H", [128, 512])
+def test_lstm_rr_fault_is_reported_and_heals(gpu, H):
     """The register-resident kernel needs all its workgroups resident, like the other persistent kernels: a poll that runs
     out of budget (forced with rec_spin_us = 0) raises the sticky fault word.  Device-pointer callers see -1 at the next
-    synchronize; the host-pointer call repeats itself on the per-timestep kernels and returns correct results."""
+    synchronize; the host-pointer call repeats itself on the per-timestep kernels and returns correct results.
+    H = 128: the pending-pattern hand-off (a look at a fetched fragment gives up); H = 512: the flag protocol (a flag poll gives up)."""
     import torch
     L = capi.load()
     r = rng(91)
-    B, I, H, T = 70, 64, 128, 12
+    B, I, T = 70, 64, 12
     x = u(r, B, T, I)
     W, U, bi, bh = lstm_weights(r, I, H)
     ref = O.lstm(x, W, U, bi, bh, v2=True)

@@ -592,6 +592,10 @@ def test_full_size_config4_two_layer_gru(gpu):
     L = capi.load()
     yr = NL.gru_stack2_apply_device(g1, g2, x).clone()
     assert L.nntk_hip_last_recurrent_kernel().decode() == "gru_rr_kernel<4,4>" and torch.equal(yr, y)
+    # race detector for the hand-off without flags (pending pattern, H <= 256) at the full grid of 256 workgroups: a second run and a
+    # 512-row shard (another set of batch tiles, half the workgroups) equal the first run bit for bit over the whole batch
+    assert torch.equal(NL.gru_stack2_apply_device(g1, g2, x), yr)
+    assert torch.equal(NL.gru_stack2_apply_device(g1, g2, x[512:].contiguous()), yr[512:])
     capi.set_option("rec_fused2", 1)
     yf = NL.gru_stack2_apply_device(g1, g2, x)
     capi.set_option("rec_fused2", "auto")
