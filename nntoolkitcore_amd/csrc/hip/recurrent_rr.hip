@@ -341,6 +341,8 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
     using Tt = std::true_type;
     using Ff = std::false_type;
     rr_v4u hf[2][KH][3];           // the h operand of each half
+    constexpr bool ULPRE = !ULR && KH == 8;
+    rr_bf16x8 ulo_n[2];            // ULPRE: U's low image of the next h k step (LDS -> registers one k step ahead)
     rr_v4u xr[XF ? 1 : KX][2];     // raw x_t (f32) of the half that multiplies next (not with XF)
     rr_bf16x8 xf[XF ? 2 : 1][KX][3];   // ... and its three bf16 images; XF: one set per half, filled by the loads themselves
 
@@ -676,7 +678,9 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
                 for (int mt = 0; mt < 2; ++mt) ulo[mt] = ulr[s - KX][mt];
             } else {
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) ulo[mt] = __builtin_bit_cast(rr_bf16x8, ULs[((w * KH + (s - KX)) * 2 + mt) * 64 + lane]);
+                for (int mt = 0; mt < 2; ++mt)
+                    ulo[mt] = ULPRE ? ulo_n[mt]           // requested during the previous k step (below)
+                                    : __builtin_bit_cast(rr_bf16x8, ULs[((w * KH + (s - KX)) * 2 + mt) * 64 + lane]);
             }
             // ---- slices of the other half's finish and of its next fetch ----
             // (issuing 2 / 4 / 6 of this k step's x products BEFORE the reduce slice's barrier -- they do not depend on it -- measured
@@ -728,6 +732,13 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
                 }
             }
             if (YCHK && s + 1 >= KX && s + 1 < NST && !RR_DBG(4) && !RR_DBG(1)) pend_next = probe_h(y_tag, s + 1 - KX);
+            // U's low image of the NEXT k step: an LDS round trip (~100+ cycles with four waves reading) ahead of the product that
+            // needs it (the second of the six).  KH = 8: LSTM-512 6.04 -> 5.98 ms in four alternating rounds; nothing at KH = 4
+            // (profiles/r04_rr_ulo_prefetch_ab.log; the same for W's images in the x k steps: no difference on either shape)
+            if (ULPRE && s + 1 >= KX && s + 1 < NST) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) ulo_n[mt] = __builtin_bit_cast(rr_bf16x8, ULs[((w * KH + (s + 1 - KX)) * 2 + mt) * 64 + lane]);
+            }
             // x_t of the half that multiplies next: split (this half's own x part has been multiplied), then request this
             // half's x_{t+1} -- a whole half-step ahead of its use
             if (s == S_XSPL) {
