@@ -12,5 +12,6 @@ for f in pmc_traffic pmc_traffic_gru pmc_traffic_conv pmc_traffic_spectrogram pm
 [ -s $S/conv_probe_ab.log ] && cp $S/conv_probe_ab.log ${P}_conv_probe_split_vs_exact.log
 [ -s $S/train_bench.log ] && cp $S/train_bench.log ${P}_train_bench.log
 [ -s $S/rec_ab.log ] && cp $S/rec_ab.log ${P}_rec_ab.log
+[ -s $S/rr_repeat_check.log ] && cp $S/rr_repeat_check.log ${P}_rr_repeat_check.log
 [ -s $S/elementwise.log ] && grep -v "rocprofv3\|amdgpu.ids\|output_stream\|tool.cpp" $S/elementwise.log > ${P}_elementwise.log
 ls $R/profiles | grep "^$2_" | wc -l

@@ -17,6 +17,7 @@ NNTK_GEMM_SPLIT_BF16=0 timeout -k 10 300 python bench.py --no-cpu-baseline > $O/
 timeout -k 10 300 python tools/split_error.py 2>&1 | grep -v amdgpu.ids > $O/split_error.log; timeout -k 10 200 python tools/split_error.py --stress 2>&1 | grep -v amdgpu.ids >> $O/split_error.log; echo split_error $?
 timeout -k 10 300 python tools/conv_probe.py gemm_split_bf16=0,1 2>&1 | grep -v amdgpu.ids > $O/conv_probe_ab.log; cat $O/conv_probe_ab.log
 timeout -k 10 300 python tools/train_bench.py 2>&1 | grep -v amdgpu.ids > $O/train_bench.log; cat $O/train_bench.log
+timeout -k 10 300 python tools/rr_repeat_check.py 40 2>&1 | grep -v amdgpu.ids > $O/rr_repeat_check.log; tail -1 $O/rr_repeat_check.log
 timeout -k 10 300 python tools/rec_ab.py 1024 500 2>&1 | grep -v amdgpu.ids > $O/rec_ab.log; cat $O/rec_ab.log
 NNTK_REC_FUSED2=1 timeout -k 10 300 python bench.py --workload gru --no-cpu-baseline > $O/bench_gru_fused.json 2> /dev/null; tail -c 200 $O/bench_gru_fused.json; echo
 # north_star's own batch on ONE GPU (4096 utterances = 8 back-to-back launches of the 256-workgroup LSTM kernel), and the round-3 route
@@ -42,6 +43,9 @@ for wb in gru:1024 conv:1024 spectrogram:256; do
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_$w -- python3 $R/bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_fetch_$w.log 2>&1; echo fetch_$w $?
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_$w -- python3 $R/bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_write_$w.log 2>&1; echo write_$w $?
 done
+# memory-path counters (L1 / L2 requests, hit rates) of the stack kernels; summarised by hand into profiles/r04_pmc_mem.json this round.
+# (TA_* / TCP_PENDING_STALL counters in one pass made rocprofv3 run into the 300 s limit on this pool: left out.)
+timeout -k 10 300 rocprofv3 --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_BUSY_avr TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum --kernel-trace --output-format csv -d $O/pmc_mem -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_mem.log 2>&1; echo mem $?
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_elementwise -- python3 $R/tools/elementwise_bench.py > $O/elementwise.log 2>&1; cat $O/elementwise.log | grep -v amdgpu.ids
 for f in $(ls $O/prof_elementwise/*/*kernel_stats.csv 2>/dev/null); do cut -c1-150 $f | head -7; done
 cd $R
