@@ -353,7 +353,7 @@ def roofline_for(wl, phase_ms, prof):
                 "timesteps_per_launch": tpl, "us_per_timestep": ms * 1e3 / tpl,
                 "mfma_pipe_cycles_per_timestep": mfma_cycles,
                 "launches_per_step": prof.get("rec_launches_per_step")}
-    if (last.startswith("gru_rr_kernel") or last.startswith("gru_rr4_kernel")) and wl.name == "gru":
+    if (last.startswith("gru_rr_kernel") or last.startswith("gru_fk_kernel")) and wl.name == "gru":
         # the two stacked GRU-256 layers as two launches of the register-resident split-bf16 kernel (input projections fused):
         # rec_launch_ms is the AVERAGE of the two, so are the algorithmic flops ([h | x_t] x [U ; W], three gates, T steps)
         n_l = prof.get("rec_launches_per_step") or 2.0
@@ -361,9 +361,10 @@ def roofline_for(wl, phase_ms, prof):
         flops = (flops_l1 + flops_l2) / 2
         ach = flops / (ms * 1e-3) / 1e12
         peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
-        fam = "gru_rr4_kernel" if last.startswith("gru_rr4") else "gru_rr_kernel"
+        fam = "gru_fk_kernel" if last.startswith("gru_fk") else "gru_rr_kernel"
         traffic, traffic_source = pmc_traffic(fam, B)
-        return {"kernel": "%s<4,2> (layer 1) + %s<4,4> (layer 2)" % (fam, fam), "bound": "mfma", "achieved": ach, "peak": peak,
+        shapes = ("<16,8,4>", "<16,16,2>") if fam == "gru_fk_kernel" else ("<4,2>", "<4,4>")
+        return {"kernel": "%s%s (layer 1) + %s%s (layer 2)" % (fam, shapes[0], fam, shapes[1]), "bound": "mfma", "achieved": ach, "peak": peak,
                 "peak_note": "dense bf16 MFMA peak / 6 products per f32 product (split-bf16 x 3 contraction); one gate slot in four "
                              "multiplies a zero weight block (the GRU's candidate gate keeps its x and h parts apart), not counted as flops",
                 "unit": "TFLOP/s", "frac": ach / peak, "frac_of_exact_f32_mfma_peak": ach / F32_MFMA_PEAK_TFLOPS,

@@ -14,7 +14,7 @@ OBJ = os.path.join(PKG, "lib", "obj")
 LIB = os.path.join(PKG, "lib", "libnntoolkitcore_hip.so")
 
 HOST_SRC = ["runtime.c", "activation.c", "conv_1d.c", "recurrent.c", "dense.c", "spectrogram.c", "mel.c", "train.c"]
-HIP_SRC = ["runtime.hip", "conv1d.hip", "conv1d_s2.hip", "conv1d_flatk.hip", "recurrent.hip", "recurrent_rr.hip", "recurrent_rr4.hip", "frag3.hip", "spectrogram.hip", "dist.hip", "conv1d_grad.hip", "train.hip"]
+HIP_SRC = ["runtime.hip", "conv1d.hip", "conv1d_s2.hip", "conv1d_flatk.hip", "recurrent.hip", "recurrent_rr.hip", "recurrent_fk.hip", "frag3.hip", "spectrogram.hip", "dist.hip", "conv1d_grad.hip", "train.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 

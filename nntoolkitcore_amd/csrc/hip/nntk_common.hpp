@@ -23,7 +23,7 @@ struct NntkOptions {
     int rec_fused2 = -1;         // fused two-layer GRU kernel (0 off)
     int rec_rr = -1;             // register-resident split-bf16 LSTM kernel with the fused input projection (0 off, 1 also for small batches)
     int rec_xf = -1;             // register-resident kernels: f32 input packed into frag3 form first (1 always, 0 only when the f32 path cannot take the shape; auto: see recurrent.c)
-    int rec_rr4 = -1;            // four-stream register-resident kernels (recurrent_rr4.hip): 1 whenever the shape allows; auto = off (measured slower, DESIGN K4c)
+    int rec_fk = -1;             // 1: full-K register-resident kernels (recurrent_fk.hip) for the shapes they take; auto = off while they do not beat the split-K family
     int dense_frag3 = -1;        // dense GEMM with a frag3 A operand (0: consumers unpack to f32 and run the LDS-staged GEMM)
     int train_outer_plain = -1;  // weight-gradient products of plain matrices on the VALU-free MFMA kernel (0: the general one; A/B)
     int train_bptt = -1;         // GRU / LSTM gradient: the whole BPTT loop in one persistent kernel (0: two launches per timestep)

@@ -193,10 +193,11 @@ size_t nntk_shim_rr_hseq_floats(int B, int T, int H);
 int nntk_shim_lstm_rr_pack(const float *d_ut, const float *d_wp, float *d_img, int H, int in);
 int nntk_shim_lstm_rr_pack_raw(const float *d_U /*[H][4H]*/, const float *d_W /*[in][4H]*/, float *d_img, int H, int in);
 /* GRU on the same kernels (gru_rr_kernel): image from the four-slot matrices, d_b4 [4H]; see recurrent_rr.hip */
-/* four half-streams per workgroup (recurrent_rr4.hip): own weight images d_img4 (NULL: family not used); taken for frag3 input */
-size_t nntk_shim_rr4_image_floats(int H, int in);               /* 0: shape not taken */
-int nntk_shim_rr4_pack(const float *d_ut, const float *d_wp, float *d_img4, int H, int in);
-int nntk_shim_rr4_pack_raw(const float *d_U /*[H][4H]*/, const float *d_W /*[in][4H]*/, float *d_img4, int H, int in);
+/* full-K family (recurrent_fk.hip: no split-K; H <= 256, frag3 input): own weight images d_img4 (NULL: family not used).  A shape this
+ * family takes ALWAYS runs on it (the host packs an f32 input into frag3 form first), so a row's bits never depend on the call's size */
+size_t nntk_shim_fk_image_floats(int H, int in);                /* 0: shape not taken (or option rec_fk = 0) */
+int nntk_shim_fk_pack(const float *d_ut, const float *d_wp, float *d_img4, int H, int in);
+int nntk_shim_fk_pack_raw(const float *d_U /*[H][4H]*/, const float *d_W /*[in][4H]*/, float *d_img4, int H, int in);
 int nntk_shim_gru_rr(const float *d_x, const void *d_xf3, const float *d_img, const float *d_img4, const float *d_b4, const float *d_h0, float *d_out,
                      float *d_hseq, float *d_hT, float *d_work, int B, int T, int in, int H, int return_sequences, int x_tm, int out_tm);
 int nntk_shim_gru_rr_train_forward(const float *d_x, const float *d_img, const float *d_b4, float *d_h, float *d_hU, float *d_Zg,

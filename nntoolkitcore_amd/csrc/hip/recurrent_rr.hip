@@ -904,9 +904,9 @@ extern "C" int nntk_shim_lstm_rr_pack_raw(const float *d_U, const float *d_W, fl
 // 0 = launched; 1 = shape / configuration not taken (the caller runs projection GEMM + rec_persistent_kernel); -1 = error
 // d_x: f32 [B][T][in] (or time-major with x_tm), or NULL with d_xf3 = the same tensor in frag3 form (nntk_shim_frag3_pack);
 // d_out: f32 layer output or NULL (the caller takes it in frag3 form: d_hseq); d_hseq: nntk_shim_rr_hseq_floats(B, T, H) floats
-int nntk_rr4_launch(RRParams q, const float *d_img4, int cell, size_t *launches);      // recurrent_rr4.hip
+int nntk_fk_launch(RRParams q, const float *d_imgfk, int cell, size_t *launches);      // recurrent_fk.hip
 struct RRIo {
-    const float *img4;        // images of the four-stream kernels (nntk_shim_rr4_pack) or NULL
+    const float *img4;        // images of the full-K kernels (nntk_shim_fk_pack) or NULL
     const float *x; const void *xf3; float *out; float *hseq; float *work;
     const float *h0, *c0; float *hT, *cT; float *c_cache, *z_cache;
     int x_tm, out_tm;
@@ -1028,15 +1028,12 @@ static int rr_launch(const RRIo &io, const float *d_img, const float *d_bi, cons
 #endif
     const int span = nntk_prof_span_begin(NNTK_SPAN_REC);
     nntk_persistent_launch_begin();
-    // four half-streams per workgroup (recurrent_rr4.hip): same bits, built to hide the hand-off chain of the H <= 256 shapes -- and
-    // measured SLOWER than this family on every shape (GRU-256 pair 14.4 vs 10.9 ms, LSTM-512 7.8 vs 6.2: a half-step carries ~2.7 k
-    // cycles of finish / poll / barrier work whatever its MFMA count, and four short half-steps pay it twice as often; stamps in
-    // profiles/r04_rr4_stamps.log, DESIGN K4c).  Kept behind rec_rr4 = 1 as the record of that experiment; auto = off.
+    // H <= 256 with a 128- / 256-wide input (frag3 form): the full-K family (recurrent_fk.hip: no split-K, gates in the accumulator lanes)
     size_t launches = (size_t)(nbt_total + tiles_per_launch - 1) / tiles_per_launch;
     int took4 = 1;
-    if (xf && !train && io.img4 && opt.rec_rr4 == 1 && !io.out_tm) {
+    if (xf && !train && io.img4 && !io.out_tm) {
         q.flags = flags;
-        took4 = nntk_rr4_launch(q, io.img4, cell, &launches);
+        took4 = nntk_fk_launch(q, io.img4, cell, &launches);
         if (took4 < 0) { nntk_persistent_launch_end(); return -1; }
     }
     if (took4 == 1)

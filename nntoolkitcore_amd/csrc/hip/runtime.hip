@@ -45,7 +45,7 @@ static const OptDesc g_opt_table[] = {
     {"rec_fused2", "NNTK_REC_FUSED2", &NntkOptions::rec_fused2},
     {"rec_rr", "NNTK_REC_RR", &NntkOptions::rec_rr},
     {"rec_xf", "NNTK_REC_XF", &NntkOptions::rec_xf},
-    {"rec_rr4", "NNTK_REC_RR4", &NntkOptions::rec_rr4},
+    {"rec_fk", "NNTK_REC_FK", &NntkOptions::rec_fk},
     {"dense_frag3", "NNTK_DENSE_FRAG3", &NntkOptions::dense_frag3},
     {"train_bptt", "NNTK_TRAIN_BPTT", &NntkOptions::train_bptt},
     {"train_outer_plain", "NNTK_TRAIN_OUTER_PLAIN", &NntkOptions::train_outer_plain},

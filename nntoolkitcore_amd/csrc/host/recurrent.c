@@ -44,7 +44,7 @@ typedef struct {
     float *d_wt;                /* W^T packed like U^T (only when in == H): layer-2 operand of the fused two-layer GRU */
     int wt_valid;
     int rr_exact_only;          /* W or U holds a value the bf16 split cannot represent (non-finite, > 3.39e38, denormal): exact kernels only */
-    float *d_rr4;               /* the same weights as images of the four-stream kernels (recurrent_rr4.hip), packed with d_rr */
+    float *d_rr4;               /* the same weights as images of the full-K kernels (recurrent_fk.hip), packed with d_rr */
     float *d_rr;                /* LSTM: weight images of the register-resident split-bf16 kernel (recurrent_rr.hip), made on first use */
     int rr_valid;
     float *d_b4, *d_b4_train;   /* GRU on those kernels: the four-slot bias vector (core_try_gru_rr; the training forward's copy) */
@@ -217,7 +217,10 @@ static int rr_input(rec_core *c, const rr_io *io, int B, const float **xf3) {
      * take the shape (in % 8 != 0); auto: pack once the call is big enough for the pass to pay (measured at the stack's LSTM, 512 x 996
      * x 128: 6.50 -> 6.16 ms including the pack).  The two x forms give the same bits (the split is exact and the kernels sum the same
      * products in the same order -- tests/test_gpu_frag3.py), so this is a speed choice that may depend on the size of the call. */
-    if (f32_ok && (mode == 0 || (mode < 0 && (long)B * c->T < 8192))) return 0;
+    /* a shape the full-K family takes (recurrent_fk.hip) runs on it at EVERY size -- it sums in another order than the split-K family, so
+     * the choice must not depend on the call -- and that family reads frag3 only */
+    const int fk = nntk_shim_fk_image_floats(c->H, c->in) != 0;
+    if (f32_ok && !fk && (mode == 0 || (mode < 0 && (long)B * c->T < 8192))) return 0;
     if (!xf_ok || !io->d_in) return 2;
     float *buf = nntk_devbuf_reserve(&c->d_xf3, nntk_shim_frag3_floats(B, c->T, c->in));
     if (!buf) return -1;
@@ -241,10 +244,10 @@ static int core_try_lstm_rr(rec_core *c, int use_bh, const int *acts, const rr_i
     if (!c->rr_valid) {
         if (!c->d_rr && !(c->d_rr = (float *)nntk_shim_malloc(img * sizeof(float)))) return -1;
         if (nntk_shim_lstm_rr_pack(c->d_ut, c->d_wp, c->d_rr, c->H, c->in)) return -1;
-        const size_t img4 = nntk_shim_rr4_image_floats(c->H, c->in);
+        const size_t img4 = nntk_shim_fk_image_floats(c->H, c->in);
         if (img4) {
             if (!c->d_rr4 && !(c->d_rr4 = (float *)nntk_shim_malloc(img4 * sizeof(float)))) return -1;
-            if (nntk_shim_rr4_pack(c->d_ut, c->d_wp, c->d_rr4, c->H, c->in)) return -1;
+            if (nntk_shim_fk_pack(c->d_ut, c->d_wp, c->d_rr4, c->H, c->in)) return -1;
         }
         c->rr_valid = 1;
     }
@@ -290,10 +293,10 @@ static int gru_rr_build_image(int in, int H, const float *W, const float *U, con
     if (!rc) rc = nntk_shim_upload(d_tmp, tmp, (nW + nU) * sizeof(float));
     if (!rc) rc = nntk_shim_upload(*d_b4, b4, 4 * (size_t)H * sizeof(float));
     if (!rc) rc = nntk_shim_lstm_rr_pack_raw(d_tmp + nW, d_tmp, *d_img, H, in);
-    const size_t img4 = d_img4 ? nntk_shim_rr4_image_floats(H, in) : 0;        /* the four-stream family's images of the same matrices */
+    const size_t img4 = d_img4 ? nntk_shim_fk_image_floats(H, in) : 0;        /* the full-K family's images of the same matrices */
     if (!rc && img4) {
         if (!*d_img4 && !(*d_img4 = (float *)nntk_shim_malloc(img4 * sizeof(float)))) rc = -1;
-        if (!rc) rc = nntk_shim_rr4_pack_raw(d_tmp + nW, d_tmp, *d_img4, H, in);
+        if (!rc) rc = nntk_shim_fk_pack_raw(d_tmp + nW, d_tmp, *d_img4, H, in);
     }
     free(tmp);                                              /* (nntk_shim_upload has copied it) */
     return rc ? -1 : 0;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""ISA checks for the hand-off protocols of recurrent_rr.hip / recurrent_rr4.hip.  Flag protocol: lstm_rr_kernel's COUNTED vmcnt wait (recurrent_rr.hip, `arrive`): the publishing wave waits for its three
+"""ISA checks for the hand-off protocols of recurrent_rr.hip.  Flag protocol: lstm_rr_kernel's COUNTED vmcnt wait (recurrent_rr.hip, `arrive`): the publishing wave waits for its three
 write-through stores with s_waitcnt vmcnt(N), N = the vector-memory instructions it issues between those stores and the wait.
 If the compiler drops or adds one (dead x loads in the last half-steps did), N is wrong: too large and the flag can overtake the
 data.  This script compiles the file and, for every such wait of every instantiation, counts the vector-memory instructions
@@ -7,7 +7,7 @@ between the store group and the wait in the ISA; exit 1 on a mismatch.   usage: 
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRCS = [os.path.join(ROOT, "nntoolkitcore_amd", "csrc", "hip", f) for f in ("recurrent_rr.hip", "recurrent_rr4.hip")]
+SRCS = [os.path.join(ROOT, "nntoolkitcore_amd", "csrc", "hip", f) for f in ("recurrent_rr.hip",)]
 
 
 def main():
@@ -19,7 +19,7 @@ def main():
                                    "--cuda-device-only", "-S", src, "-o", out] + os.environ.get("RR_EXTRA", "").split(), stderr=subprocess.DEVNULL)
             txt += open(out).read() + "\n"
     bad = total = 0
-    for kname in re.findall(r'^(_Z1[345](?:lstm|gru)_rr4?_kernel\w+):', txt, re.M):
+    for kname in re.findall(r'^(_Z1[345](?:lstm|gru)_rr_kernel\w+):', txt, re.M):
         a = txt.index("\n" + kname + ":")
         s = txt[a:txt.index(".Lfunc_end", a)].split("\n")           # (a kernel may hold several s_endpgm and out-of-line blocks behind them)
         b_, t_ = check_counted_waits(kname, s)
@@ -124,7 +124,7 @@ def check_polls(txt):
     that follows it, no instruction names vN as an operand and no branch is taken; and no rr kernel uses scratch (a spill of vN would
     be a hidden read + write)."""
     bad = total = 0
-    for kname in re.findall(r'^(_Z1[345](?:lstm|gru)_rr4?_kernel\w+):', txt, re.M):
+    for kname in re.findall(r'^(_Z1[345](?:lstm|gru)_rr_kernel\w+):', txt, re.M):
         a = txt.index("\n" + kname + ":")
         s = txt[a:txt.index(".Lfunc_end", a)].split("\n")
         m = re.search(r'\.amdhsa_kernel %s\b.*?\.end_amdhsa_kernel' % re.escape(kname), txt, re.S)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostics build only (python tools/build_variant.py build/libs/libstamps.so recurrent_rr.hip,recurrent_rr4.hip -DNNTK_REC_STAMPS; NNTK_LIB=<lib>): run the stack's LSTM on
+"""Diagnostics build only (python tools/build_variant.py build/libs/libstamps.so recurrent_rr.hip -DNNTK_REC_STAMPS; NNTK_LIB=<lib>): run the stack's LSTM on
 lstm_rr_kernel once and print where workgroup 0 / wave 0 spends a half-step (s_memtime cycles).
 usage: NNTK_LIB=<lib built with -DNNTK_REC_STAMPS> python tools/rr_stamps.py [B] [T] [lstm|gru] [in] [H]"""
 import os, sys
@@ -24,8 +24,6 @@ def main():
     lstm.set_weights(u(I, G * H, sc=I ** -0.5), u(H, G * H, sc=H ** -0.5), u(G * H, sc=0.1), u(G * H, sc=0.1))
     capi.set_option("rec_rr", 1)
     capi.set_option("rec_xf", 1)
-    if os.environ.get("RR4"):
-        capi.set_option("rec_rr4", int(os.environ["RR4"]))
     x = torch.randn(B, T, I, device="cuda"); h = torch.empty(B, T, H, device="cuda")
     for _ in range(3):
         lstm.apply_device(x, out=h)
@@ -39,7 +37,7 @@ def main():
     lo, hi = T // 10, T - T // 10
     nst = (4 if H <= 256 else 8) + (1 if I <= 64 else 2 if I <= 128 else 4)
     kname = capi.load().nntk_hip_last_recurrent_kernel().decode()
-    ns = 4 if "rr4" in kname else 2
+    ns = 2
     print("%s in=%d H=%d: %s, %d k steps per half-step, %d streams" % (kind, I, H, kname, nst, ns))
     print("launch %.3f ms incl. stamping = %.2f us/step" % (e0.elapsed_time(e1), e0.elapsed_time(e1) * 1e3 / T))
     for half in range(ns):
