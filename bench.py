@@ -420,20 +420,40 @@ def cpu_baseline(workload, weights, frames, seed):
         nframes = n_utt * fr
         sample = "%d utterances x %d frames x 128" % (n_utt, fr)
     else:
-        n_utt, fr = 3, min(frames, 1000)
+        # best of three passes over 6 utterances on ONE pinned core (a 3-utterance single pass on a shared 256-core host swung
+        # 2.3x between runs); frames/s does not depend on the length of an utterance, so 250 frames each keep the leg at ~10-25 s
+        n_utt, fr = 6, min(frames, 250)
         x = (0.1 * r.standard_normal((n_utt, 240 + 160 * fr))).astype(np.float32)
-        t0 = time.perf_counter()
-        s = O.spectrogram(x, O.window("hann", 400), 512, 240)
-        c = O.activation(O.ACT_RELU, O.batch_norm(O.conv1d(s, w["conv_W"], w["conv_b"], 1), w["bn_gamma"], w["bn_beta"],
-                                                  w["bn_mean"], w["bn_var"], 1e-3))
-        h = O.lstm(c, w["lstm_W"], w["lstm_U"], w["lstm_bi"], w["lstm_bh"], v2=True)
-        O.time_distributed_dense(h, w["tdd_W"], w["tdd_b"])
+        old_aff = None
+        try:
+            old_aff = os.sched_getaffinity(0)
+            os.sched_setaffinity(0, {sorted(old_aff)[len(old_aff) // 2]})
+        except (AttributeError, OSError):
+            pass
+        passes = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            s = O.spectrogram(x, O.window("hann", 400), 512, 240)
+            c = O.activation(O.ACT_RELU, O.batch_norm(O.conv1d(s, w["conv_W"], w["conv_b"], 1), w["bn_gamma"], w["bn_beta"],
+                                                      w["bn_mean"], w["bn_var"], 1e-3))
+            h = O.lstm(c, w["lstm_W"], w["lstm_U"], w["lstm_bi"], w["lstm_bh"], v2=True)
+            O.time_distributed_dense(h, w["tdd_W"], w["tdd_b"])
+            passes.append(time.perf_counter() - t0)
+        if old_aff is not None:
+            try:
+                os.sched_setaffinity(0, old_aff)
+            except OSError:
+                pass
         nframes = n_utt * fr
-        sample = "%d utterances x %d frames of the same stack" % (n_utt, fr)
+        sample = "best of 3 passes over %d utterances x %d frames of the same stack, one pinned core" % (n_utt, fr)
+        t0 = time.perf_counter() - min(passes)
+        spread = [round(nframes / p_, 1) for p_ in sorted(passes, reverse=True)]
     dt = time.perf_counter() - t0
     res = {"value": nframes / dt, "unit": "frames/s", "cores": 1, "kind": "port", "sample": sample,
            "seconds": round(dt, 2), "host_nproc": os.cpu_count()}
     if workload == "stack":
+        res["passes_frames_per_s"] = spread                    # slowest .. fastest of the three passes
+        fr = min(frames, 1000)
         # N independent workers, one utterance each (the reference's Linux build is serial --
         # core/loop.h:23 -- so the 1-thread figure above stays the faithful one; this is its embarrassingly
         # parallel upper bound on this host).  ctypes releases the GIL inside the oracle's C calls.

@@ -92,7 +92,7 @@ extern "C" void nntk_shim_weights_exact_only(const void *d_wp, int on) {
         }
     if (on) { g_exact_only.push_back(d_wp); g_exact_n.store((int)g_exact_only.size(), std::memory_order_relaxed); }
 }
-static bool weights_exact_only(const void *d_wp) {
+bool nntk_weights_exact_only(const void *d_wp) {
     if (g_exact_n.load(std::memory_order_relaxed) == 0) return false;
     std::lock_guard<std::mutex> lk(g_exact_mu);
     for (const void *q : g_exact_only) if (q == d_wp) return true;
@@ -214,7 +214,7 @@ extern "C" int nntk_shim_conv1d(const float *d_in, const float *d_wp, const floa
     bool split = opt.gemm_split_bf16 == 1 || (opt.gemm_split_bf16 < 0 && out_mode == 0) ||
                        (opt.gemm_split_bf16 == 2 && out_mode == 0 && k > 1) ||        // 2 / 3: convolutions only / dense only (A/B)
                        (opt.gemm_split_bf16 == 3 && out_mode == 0 && k == 1);
-    if (split && opt.gemm_split_bf16 < 0 && weights_exact_only(d_wp)) split = false;      // "auto" only: 1 / 2 / 3 force the split (A/B runs)
+    if (split && opt.gemm_split_bf16 < 0 && nntk_weights_exact_only(d_wp)) split = false;      // "auto" only: 1 / 2 / 3 force the split (A/B runs)
     if (wide_window) {
         const bool sp = split && (long)p.Cout_p * k * p.Cin_p * 6 < (long)CONV_OOB;
         return nntk_conv1d_launch_s2(p, a4, sp);

@@ -176,7 +176,11 @@ extern "C" int nntk_shim_conv1d_flatk(const float *d_in, const float *d_wpf, con
     // (256-position tiles -- TM = 4: half the weight stream per output, 229 VGPRs, two workgroups per CU -- measured SLOWER at configs[2]:
     // 0.438 vs 0.388 ms, same box; the kernel lives on waves in flight, not on L2 bytes.  conv_flatk = 4 selects them for A/B.)
     const int KS = (k * Cin + 15) / 16;
+#ifdef NNTK_VARIANT_FLATK      // A/B variant build only (tools/build_variant.py ... conv1d_flatk.hip -DNNTK_VARIANT_FLATK)
     const bool big = opt.conv_flatk == 4 && p.Cout_p % 128 == 0 && (size_t)(255 + k) * 6 * Cin + 16 + 6 * 128 * sizeof(float) <= 72 * 1024;
+#else
+    const bool big = false;
+#endif
     const int BM = big ? 256 : CONV_BM;
     p.tiles_per_seq = (Tout + BM - 1) / BM;
     p.out_mode = 0;
@@ -190,16 +194,24 @@ extern "C" int nntk_shim_conv1d_flatk(const float *d_in, const float *d_wpf, con
     if (p.Cout_p % 64 != 0 || (long)p.Cout_p * KS * 16 * 6 >= (long)CONV_OOB || (long)(p.rows_a + 1) * Cin * 4 >= (long)CONV_OOB) return 1;
     const bool bn128 = p.Cout_p % 128 == 0;
     const int BN = bn128 ? 128 : 64;
-    const bool wdirect = opt.conv_flatk != 2;          // (2: weights through an LDS double buffer with a barrier per k step -- A/B)
+#ifdef NNTK_VARIANT_FLATK
+    const bool wdirect = opt.conv_flatk != 2;          // (2: weights through an LDS double buffer with a barrier per k step: 0.416 vs 0.390 ms)
+#else
+    const bool wdirect = true;
+#endif
     const size_t lds = (size_t)((p.rows_a * 6 * Cin + 15) & ~15) + 16 + (wdirect ? 0 : 2 * (size_t)(BN / 32) * 3 * 1024) + 6 * BN * sizeof(float);
     if (lds > 100 * 1024) return 1;
     p.m_tiles = B * p.tiles_per_seq;
     p.n_tiles = p.Cout_p / BN;
     const long blocks = (long)((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
     if ((long)B * p.tiles_per_seq > 0x7fffffffL / 8 || blocks > 0x7fffffffL) return 1;
+#ifdef NNTK_VARIANT_FLATK
     void (*kern)(ConvParams, int) = big ? conv1d_flatk_bf16x3_kernel<2, true, 4>
                                   : bn128 ? (wdirect ? conv1d_flatk_bf16x3_kernel<2, true> : conv1d_flatk_bf16x3_kernel<2, false>)
                                           : (wdirect ? conv1d_flatk_bf16x3_kernel<1, true> : conv1d_flatk_bf16x3_kernel<1, false>);
+#else
+    void (*kern)(ConvParams, int) = bn128 ? conv1d_flatk_bf16x3_kernel<2, true> : conv1d_flatk_bf16x3_kernel<1, true>;
+#endif
     if (lds > 64 * 1024 && nntk_set_max_dynamic_lds((const void *)kern, lds)) return -1;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, nntk_stream(), p, KS);
     NNTK_LAUNCH_CHECK("conv1d_flatk_bf16x3_kernel");

@@ -39,6 +39,7 @@ __device__ __forceinline__ unsigned f3_cvt_pk(float a, float b) {       // RNE, 
     return __builtin_bit_cast(unsigned, __builtin_convertvector((f3_f32x2){a, b}, f3_bf16x2));
 }
 __device__ __forceinline__ void f3_split_pair(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo) {
+#pragma clang fp contract(off)    // the residuals of the ROUNDED x (an inlined x = a * b must not turn x - hi into fma(a, b, -hi); tools/check_rr_waits.py)
     hi = f3_cvt_pk(x0, x1);
     const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
     mid = f3_cvt_pk(r0, r1);
@@ -282,6 +283,7 @@ __global__ __launch_bounds__(256) void dense_frag3_kernel(DF3Params p) {
     else epilogue(std::integral_constant<int, -1>{});
 }
 
+#ifdef NNTK_VARIANT_DENSE_RING      // A/B variant only (tools/build_variant.py ... frag3.hip -DNNTK_VARIANT_DENSE_RING; option dense_frag3 = 3): measured slower
 // ---- the same GEMM with both operands staged through an LDS ring by LDS-DMA ----------------------------------------
 // First measurement of the register-direct kernel above at the stack's TimeDistributedDense (510 k x 512 x 1000): 3.43 ms against
 // 2.74 ms for the LDS-staged f32-input GEMM it was meant to beat.  Its two wn (wm) waves fetch every A (W) block twice and a wave can
@@ -442,6 +444,8 @@ __global__ __launch_bounds__(256) void dense_frag3_lds_kernel(DF3Params p) {
     else epilogue(std::integral_constant<int, -1>{});
 }
 
+#endif
+
 // (Measured and not kept -- profiles/r04_tdd_three_kernels.log, same box, ms at the stack's shape: register-direct 2.54, this LDS
 // ring 2.63, and a hybrid that took A through a three-stage LDS ring requested TWO k steps ahead (one fetch per workgroup, 12 ds_read
 // per wave and k step under the MFMAs) with W register-direct: 2.60.  Three operand paths, one result: the operand fetch is not what
@@ -456,7 +460,10 @@ extern "C" int nntk_shim_dense_frag3(const void *d_frag, const float *d_wp, cons
     if (act_kind == NNTK_ACT_NONE) act_kind = NNTK_ACT_IDENTITY;
     if (act_kind == NNTK_ACT_SOFTMAX || act_kind == NNTK_ACT_CUSTOM) return 1;
     const NntkOptions &opt = nntk_options();
-    if (opt.gemm_split_bf16 == 0 || opt.dense_frag3 == 0) return 1;
+    if (opt.gemm_split_bf16 == 0 || opt.gemm_split_bf16 == 2 || opt.dense_frag3 == 0) return 1;      // (2: the split contraction for convolutions only)
+    // a weight block the bf16 split cannot hold (non-finite, > 3.39e38, denormal: marked at upload) keeps the exact-f32 GEMM, exactly as
+    // nntk_shim_conv1d decides for the f32 call -- or this route would give NaN where that one stays finite
+    if (opt.gemm_split_bf16 < 0 && nntk_weights_exact_only(d_wp)) return 1;
     int K_p, N_p;
     nntk_shim_conv_pack_sizes(K, N, 1, &K_p, &N_p);
     if ((N % 4) != 0 || (((size_t)d_out) & 15) != 0 || (d_bias && (((size_t)d_bias) & 15) != 0)) return 1;
@@ -473,14 +480,20 @@ extern "C" int nntk_shim_dense_frag3(const void *d_frag, const float *d_wp, cons
     p.act_kind = act_kind; p.relu_a = relu_a;
     p.dbg = opt.conv_dbg;
     const bool wide = N_p % 256 == 0;
-    // default: the register-direct kernel (2.44 vs 2.54 ms at the stack's shape, same box, tools/r04d.sh); dense_frag3 = 3: the LDS ring
+    // the register-direct kernel (2.44 vs 2.54 ms for the LDS-ring variant at the stack's shape, same box: profiles/r04_tdd_three_kernels.log)
+#ifdef NNTK_VARIANT_DENSE_RING
     const bool ring = wide && opt.dense_frag3 == 3;
+#else
+    const bool ring = false;
+#endif
     // ring kernel: a tile is one batch block x 8 timesteps; register-direct kernel: 8 consecutive row blocks (t-major)
     p.m_tiles = ring ? NHT * ((T + 7) / 8) : (int)((p.NRB + 7) / 8);
     if (ring && (size_t)8 * NHT * NKS * 3072 >= (size_t)F3_OOB) return 1;
+    (void)ring;
     p.n_tiles = N_p / (wide ? 256 : 128);
     const long blocks = (long)((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
     if (blocks > 0x7fffffffL) return 1;
+#ifdef NNTK_VARIANT_DENSE_RING
     if (ring) {
         const size_t lds = (size_t)DF3_STAGES * DF3_STAGE_BYTES;
         void (*kern)(DF3Params) = dense_frag3_lds_kernel<0>;
@@ -496,7 +509,9 @@ extern "C" int nntk_shim_dense_frag3(const void *d_frag, const float *d_wp, cons
 #endif
         if (nntk_set_max_dynamic_lds((const void *)kern, lds)) return -1;
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, nntk_stream(), p);
-    } else if (wide) hipLaunchKernelGGL((dense_frag3_kernel<2, 2, 4, 4>), dim3((unsigned)blocks), dim3(256), 0, nntk_stream(), p);
+    } else
+#endif
+    if (wide) hipLaunchKernelGGL((dense_frag3_kernel<2, 2, 4, 4>), dim3((unsigned)blocks), dim3(256), 0, nntk_stream(), p);
     else             hipLaunchKernelGGL((dense_frag3_kernel<4, 1, 2, 4>), dim3((unsigned)blocks), dim3(256), 0, nntk_stream(), p);
     NNTK_LAUNCH_CHECK("dense_frag3_kernel");
     return 0;

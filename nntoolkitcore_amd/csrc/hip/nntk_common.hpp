@@ -29,11 +29,13 @@ struct NntkOptions {
     int train_bptt = -1;         // GRU / LSTM gradient: the whole BPTT loop in one persistent kernel (0: two launches per timestep)
     int spec_ppw = 0;            // frame pairs per wavefront in K1 (0 = auto)
     int spec_variant = -1;       // 1: log-mel as two kernels (K1, then the GEMM) instead of the fused output stage (A/B, tests)
+#ifdef NNTK_VARIANT_SPEC_DMA
     int spec_dma = -1;           // K1 sample images by LDS-DMA (1) or through registers (0); auto = registers (measured faster)
+#endif
     int bn_fast = 0;             // reciprocal-multiply BatchNorm (not the reference's divide)
     int gemm_tm_batch = -1;      // tile time-major GEMM outputs over the batch
     int conv_a4 = 1;             // 16-byte window loads also for channel counts that are not multiples of 4 (0: 4-byte loads there)
-    int conv_flatk = -1;         // flat-K split convolution for Cin % 8 == 0, Cin % 16 != 0 (conv1d_flatk.hip); 0 off
+    int conv_flatk = -1;         // flat-K split convolution for Cin % 8 == 0, Cin % 16 != 0 (conv1d_flatk.hip); 0 off (variant builds: 2, 4)
     int conv_store = -1;         // GEMM epilogue: -1 auto, 0 row form (4-byte stores), 1 quad form (16-byte stores); bit-identical
     int gemm_split_bf16 = -1;    // 3-way split-bf16 contraction: -1 auto (conv / dense / TDD / mel, not the recurrent xW), 0 never, 1 all
     int gemm_wide = -1;          // 128 x 256 tile for wide dense GEMMs on the split path (0 off)
@@ -48,6 +50,7 @@ int nntk_fault_enqueue_copy();                    // async copy of the word to i
 int nntk_persistent_disabled();                   // set after a fault: take the per-timestep kernels
 void nntk_persistent_launch_begin();              // orders persistent launches across the process's streams (holds a mutex)
 void nntk_persistent_launch_end();
+bool nntk_weights_exact_only(const void *d_wp);     // conv1d.hip: the packed weight block holds a value the bf16 split cannot represent
 int nntk_cu_count();                              // cached per device
 void nntk_set_last_rec_kernel(const char *name);  // static string; read back with nntk_hip_last_recurrent_kernel()
 int nntk_set_max_dynamic_lds(const void *kernel, size_t bytes);   // hipFuncSetAttribute once per (kernel, device)

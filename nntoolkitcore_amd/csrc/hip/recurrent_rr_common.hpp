@@ -37,7 +37,9 @@ __device__ __forceinline__ unsigned rr_cvt_pk(float a, float b) {       // RNE, 
 }
 // x = hi + mid + lo exactly (8 + 8 + 8 significand bits), two elements at a time
 __device__ __forceinline__ void rr_split_pair(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo) {
+#ifndef RR_LINT_SELFTEST          // (-DRR_LINT_SELFTEST: what tools/check_rr_waits.py's split check must catch)
 #pragma clang fp contract(off)    // the residuals are those of the ROUNDED x (inlined behind x = a * b, x - hi must not become fma(a, b, -hi))
+#endif
     hi = rr_cvt_pk(x0, x1);
     const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
     mid = rr_cvt_pk(r0, r1);

@@ -51,7 +51,9 @@ static const OptDesc g_opt_table[] = {
     {"train_outer_plain", "NNTK_TRAIN_OUTER_PLAIN", &NntkOptions::train_outer_plain},
     {"spec_ppw", "NNTK_SPEC_PPW", &NntkOptions::spec_ppw},
     {"spec_variant", "NNTK_SPEC_VARIANT", &NntkOptions::spec_variant},
+#ifdef NNTK_VARIANT_SPEC_DMA
     {"spec_dma", "NNTK_SPEC_DMA", &NntkOptions::spec_dma},
+#endif
     {"bn_fast", "NNTK_BN_FAST", &NntkOptions::bn_fast},
     {"gemm_tm_batch", "NNTK_GEMM_TM_BATCH", &NntkOptions::gemm_tm_batch},
     {"gemm_split_bf16", "NNTK_GEMM_SPLIT_BF16", &NntkOptions::gemm_split_bf16},

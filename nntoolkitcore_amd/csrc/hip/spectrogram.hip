@@ -638,10 +638,16 @@ static int spectrogram_launch(const float *d_in, const float *d_window, const fl
         const bool nz7 = window_size > 384 && window_size <= 448;
         const bool ld3 = (step + window_size) * 4 <= 3072;          // 16-byte loads per lane for one pair's samples: 3 or 4
         // LDS-DMA sample images: the BASELINE geometry (3 requests per pair, image <= 576 floats), no fused mel; option spec_dma = 0 / 1 forces
+        // (measured 4-6 % slower, profiles/r03_k1_dma_ab.log: instantiated only in the A/B variant build -DNNTK_VARIANT_SPEC_DMA, tools/build_variant.py)
+#ifdef NNTK_VARIANT_SPEC_DMA
         const bool dma = ld3 && !mel && (step + window_size) <= SPEC_IMG_FLOATS && (nntk_options().spec_dma < 0 ? SPEC_DMA_DEFAULT : nntk_options().spec_dma == 1);
 #define SPEC_KERN2(M, N, Z) (mel ? (ld3 ? spectrogram512_kernel<M, N, Z, 3, true> : spectrogram512_kernel<M, N, Z, 4, true>) \
                                  : dma ? spectrogram512_kernel<M, N, Z, 3, false, true> \
                                  : (ld3 ? spectrogram512_kernel<M, N, Z, 3> : spectrogram512_kernel<M, N, Z, 4>))
+#else
+#define SPEC_KERN2(M, N, Z) (mel ? (ld3 ? spectrogram512_kernel<M, N, Z, 3, true> : spectrogram512_kernel<M, N, Z, 4, true>) \
+                                 : (ld3 ? spectrogram512_kernel<M, N, Z, 3> : spectrogram512_kernel<M, N, Z, 4>))
+#endif
 #define SPEC_KERN(M, N) (nz7 ? SPEC_KERN2(M, N, true) : SPEC_KERN2(M, N, false))
         auto kern = mode == 0 ? (norm ? SPEC_KERN(0, true) : SPEC_KERN(0, false))
                               : (norm ? SPEC_KERN(1, true) : SPEC_KERN(1, false));

@@ -349,22 +349,3 @@ def test_conv1d_stride2_fused_bn_relu_full_size(gpu):
     # timing against the VALU kernel it replaces is in profiles/r03_conv_stride2.log (bench.py --workload conv --conv-stride 2)
     for o in (conv, bn, relu):
         o.destroy()
-
-
-def test_spectrogram_lds_dma_variant_matches_the_default_bit_for_bit(gpu):
-    """K1 with its sample images filled by LDS-DMA (option spec_dma = 1; measured slower than the register-staged default,
-    kept as a recorded experiment): same arithmetic on the same samples, so the same bits -- odd and even frame counts,
-    utterance ends included."""
-    import torch
-    r = rng(5)
-    for B, N in ((3, 16000), (2, 16160), (5, 4000)):
-        x = torch.from_numpy((0.1 * r.standard_normal((B, N))).astype(np.float32)).cuda()
-        spec = NL.Spectrogram(512, 400, 240, N)
-        a = spec.apply_device(x).clone()
-        capi.set_option("spec_dma", 1)
-        b = spec.apply_device(x).clone()
-        capi.set_option("spec_dma", "auto")
-        assert torch.equal(a, b)
-        ref = O.spectrogram(x.cpu().numpy(), O.window("hann", 400), 512, 240)
-        np.testing.assert_allclose(b.cpu().numpy(), ref, rtol=2e-5, atol=1e-6 * float(np.abs(ref).max()))
-        spec.destroy()

@@ -137,9 +137,8 @@ def test_dense_with_a_frag3_input_equals_the_f32_call_bit_for_bit(gpu, B, T, K, 
     kind = {None: O.ACT_NONE, "relu": O.ACT_RELU, "sigmoid": O.ACT_SIGMOID, "tanh": O.ACT_TANH, "softmax": O.ACT_SOFTMAX}[act]
     ref = O.time_distributed_dense(x, W, b, act=kind, **({"softmax_vector_size": 64, "act_size": N // 64} if act == "softmax" else {}))
     np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
-    for mode in (0, 3):         # 0: the fallback route on its own; 3: the LDS-ring kernel (wide shapes; else = auto)
-        capi.set_option("dense_frag3", mode)
-        assert torch.equal(NL.tdd_apply_device_frag3(tdd, NL.frag3_pack_device(xd), B), base), mode
+    capi.set_option("dense_frag3", 0)         # the fallback route on its own
+    assert torch.equal(NL.tdd_apply_device_frag3(tdd, NL.frag3_pack_device(xd), B), base)
     capi.set_option("dense_frag3", "auto")
     tdd.destroy()
     if a:
@@ -188,3 +187,34 @@ def test_kernel_plan_names_the_kernel_family_and_the_reason(gpu):
         ran_rr = L.nntk_hip_last_recurrent_kernel().decode().startswith(cell + "_rr_kernel")
         assert ran_rr == ("_rr_kernel" in plan), (plan, L.nntk_hip_last_recurrent_kernel())
         layer.destroy()
+
+
+@pytest.mark.parametrize("bad", [np.inf, -np.inf, 3.4e38, 1e-40])
+def test_dense_frag3_weights_the_split_cannot_hold_take_the_exact_gemm(gpu, bad):
+    """nntk_shim_dense_frag3 always ran the split-bf16 GEMM, so a Dense weight the split cannot represent (hi = inf, rest =
+    inf - inf) gave NaN through TimeDistributedDenseApplyDeviceFrag3 / LSTMTimeDistributedDenseApplyDevice while the f32 call, which
+    keeps the exact-f32 kernel for such a block, stayed finite.  The frag3 route now makes the same decision: same bits as the f32 call,
+    finite wherever the oracle is."""
+    import torch
+    r = rng(77)
+    B, T, K, N = 70, 4, 128, 256
+    x = u(r, B, T, K)
+    W, b = u(r, K, N, sc=K ** -0.5), u(r, N, sc=0.1)
+    W[5, 9] = bad
+    tdd = NL.TimeDistributedDense(T, K, N)
+    tdd.set_weights(W, b)
+    xd = torch.from_numpy(x).cuda()
+    base = tdd.apply_device(xd).clone()
+    got = NL.tdd_apply_device_frag3(tdd, NL.frag3_pack_device(xd), B)
+    assert torch.equal(got, base)
+    capi.set_option("gemm_split_bf16", 0)
+    exact = tdd.apply_device(xd).clone()
+    capi.set_option("gemm_split_bf16", "auto")
+    assert torch.equal(base, exact)
+    with np.errstate(all="ignore"):
+        ref = O.time_distributed_dense(x, W, b)
+    fin = np.isfinite(ref)
+    g = got.cpu().numpy()
+    assert np.array_equal(np.isfinite(g), fin)
+    np.testing.assert_allclose(g[fin], ref[fin], rtol=1e-5, atol=1e-5)
+    tdd.destroy()

@@ -197,3 +197,39 @@ def test_lstm_rr_wide_input(gpu, B, I, H, T):
     ref = ref[0] if isinstance(ref, tuple) else ref
     np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
     lstm.destroy()
+
+
+@pytest.mark.parametrize("cell,I,H", [("gru", 128, 256), ("gru", 256, 256), ("lstm", 128, 512), ("lstm", 64, 128)])
+def test_rr_stale_hand_off_of_another_input_is_never_taken_for_data(gpu, cell, I, H):
+    """the T-deep hand-off of a launch still holds the VALID-looking fragments of the launch before it, and the repeat / shard
+    tests relaunch the same input into the same scratch, where a stale block equals the right one.  Here two DIFFERENT inputs alternate
+    through one layer (same hand-off scratch, the caller-visible frag3 output included): a consumer that took a stale block for data -- a
+    pending mark that arrived late, a flag that overtook its data -- would mix in the other input's bits.  Both protocols: the pending
+    pattern (H <= 256) and the flag words (H = 512)."""
+    import torch
+    L = capi.load()
+    r = rng(H + I)
+    B, T = 128, 60
+    G = 4 if cell == "lstm" else 3
+    W, U, bi, bh = u(r, I, G * H, sc=I ** -0.5), u(r, H, G * H, sc=H ** -0.5), u(r, G * H, sc=0.1), u(r, G * H, sc=0.1)
+    lay = NL.LSTM(I, H, True, T, v2=True) if cell == "lstm" else NL.GRU(I, H, True, T)
+    lay.set_weights(W, U, bi, bh)
+    xa, xb = u(r, B, T, I), u(r, B, T, I)
+    da, db = torch.from_numpy(xa).cuda(), torch.from_numpy(xb).cuda()
+    f3 = da.new_empty(L.nntk_frag3_floats(B, T, H))
+    first_a, _ = NL.recurrent_apply_device_frag3(lay, x=da, want_f32=True, out_f3=f3)
+    first_a = first_a.clone()
+    assert L.nntk_hip_last_recurrent_kernel().decode().startswith(cell + "_rr_kernel")
+    first_b, _ = NL.recurrent_apply_device_frag3(lay, x=db, want_f32=True, out_f3=f3)
+    first_b = first_b.clone()
+    for _ in range(3):
+        oa, _ = NL.recurrent_apply_device_frag3(lay, x=da, want_f32=True, out_f3=f3)
+        assert torch.equal(oa, first_a) and torch.equal(NL.frag3_unpack_device(f3, B, T, H), first_a)
+        f3.fill_(1.25)                                        # finite, non-pending garbage in EVERY block, marks of the first two steps included
+        ob, _ = NL.recurrent_apply_device_frag3(lay, x=db, want_f32=True, out_f3=f3)
+        assert torch.equal(ob, first_b) and torch.equal(NL.frag3_unpack_device(f3, B, T, H), first_b)
+    ofn = O.lstm if cell == "lstm" else O.gru
+    for xx, got in ((xa, first_a), (xb, first_b)):
+        ref = ofn(xx, W, U, bi, bh, **({"v2": True} if cell == "lstm" else {}))
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    lay.destroy()

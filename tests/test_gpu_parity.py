@@ -484,6 +484,22 @@ def test_spectrogram_default_window_is_ones_and_scale_override(gpu):
     sp.destroy()
 
 
+def test_config2_at_its_real_size_and_specialisation(gpu):
+    """BASELINE configs[1] exactly: B = 256 x 16000 samples, win = 400 (hann), noverlap = 240, nfft = 512, magnitude -- the 7-block
+    instantiation the bench times (the Parseval test below runs the 8-block `ones` / PSD one).  Rows 0 / 128 / 255 against the oracle."""
+    import torch
+    B, N = 256, 16000
+    r = rng(2)
+    x = (0.1 * r.standard_normal((B, N))).astype(np.float32)
+    sp = NL.Spectrogram(512, 400, 240, N)
+    out = sp.apply_device(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert out.shape == (B, 98, 257)
+    rows = [0, 128, 255]
+    ref = O.spectrogram(x[rows], O.window("hann", 400), 512, 240)
+    close(out[rows], ref, atol=1e-6 * float(np.abs(ref).max()), rtol=2e-5)
+    sp.destroy()
+
+
 def test_parseval_property_full_size(gpu):
     """Size-independent property at BASELINE config 2 size (256 x 16000): with a `ones`
     window of nfft samples, sum_k |X_k|^2 over the full spectrum = nfft * sum x^2 per frame."""

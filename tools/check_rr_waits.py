@@ -7,7 +7,7 @@ between the store group and the wait in the ISA; exit 1 on a mismatch.   usage: 
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRCS = [os.path.join(ROOT, "nntoolkitcore_amd", "csrc", "hip", f) for f in ("recurrent_rr.hip",)]
+SRCS = [os.path.join(ROOT, "nntoolkitcore_amd", "csrc", "hip", f) for f in ("recurrent_rr.hip", "recurrent_fk.hip", "frag3.hip")]
 
 
 def main():
@@ -30,7 +30,11 @@ def main():
     print("lstm_rr_kernel / gru_rr_kernel: %d flag polls checked, %d violations" % (ptotal, pbad))
     qbad, qtotal = check_pending(txt)
     print("lstm_rr_kernel / gru_rr_kernel: %d pending-pattern looks checked, %d defects" % (qtotal, qbad))
-    return 1 if bad or total == 0 or pbad or ptotal == 0 or qbad or qtotal == 0 else 0
+    mbad, mtotal = check_marks(txt)
+    print("pending-pattern kernels (rr KH = 4, fk): %d mark groups checked, %d not covered by a vmcnt wait before the second barrier / the next publication" % (mtotal, mbad))
+    fbad, ftotal = check_split_fma(txt)
+    print("bf16 x 3 splits (rr, fk, frag3): %d conversions checked, %d fed by a fused multiply-add of an image" % (ftotal, fbad))
+    return 1 if bad or total == 0 or pbad or ptotal == 0 or qbad or qtotal == 0 or mbad or mtotal == 0 or fbad or ftotal == 0 else 0
 
 
 def is_pub_store(t):
@@ -206,6 +210,126 @@ def check_pending(txt):
         if any("ASMSTART" in s[k - 1] and re.match(r's_waitcnt vmcnt', t) for k, t in enumerate(s)):
             bad += 1
             print("%s: an asm vmcnt wait (the flag protocol) in a pending-pattern kernel" % kname)
+    return bad, total
+
+
+def kernels(txt, pattern):
+    for kname in re.findall(pattern, txt, re.M):
+        a = txt.index("\n" + kname + ":")
+        yield kname, [l.strip() for l in txt[a:txt.index(".Lfunc_end", a)].split("\n")]
+
+
+def check_marks(txt):
+    """Pending-pattern protocol (recurrent_rr.hip KH = 4, recurrent_fk.hip): a block of step t + 2 (fk: t + 1) is MARKED -- stored full of
+    0xffffffff -- long before its data is stored, and the argument why a consumer can never take a stale block of an earlier launch for
+    data needs the mark to have LEFT the wavefront (its vmcnt retired) before the same workgroup stores the data of the step in between.
+    The prose says "the in-order vmcnt waits of the operand loads the wavefront consumes retire the marks"; this checks it in the ISA: a
+    mark group = consecutive write-through stores whose data registers were all set to -1; on EVERY path from it, before the path has
+    crossed two workgroup barriers (rr) or reached the next write-through store of other data (fk: the next publication), there is an
+    `s_waitcnt vmcnt(N)` with N <= the vector-memory instructions issued on that path since the marks (so none of the <= N operations
+    still in flight is a mark)."""
+    bad = total = 0
+    for kname, ins in list(kernels(txt, r'^(_Z1[34](?:lstm|gru)_rr_kernelILi4E\w+):')) + list(kernels(txt, r'^(_Z1[34](?:lstm|gru)_fk_kernel\w+):')):
+        fk = "_fk_kernel" in kname
+        labels = {m.group(1): i for i, t in enumerate(ins) for m in [re.match(r'(\.LBB\w+):', t)] if m}
+        # registers that are ever set to -1 (flow-insensitive: the marks' data registers are constants, set once ahead of the loop or
+        # right before the stores, directly or from an SGPR pair that holds -1)
+        minus1, sminus1 = set(), set()
+        for t in ins:
+            m = re.match(r's_mov_b(?:32|64) (s\d+|s\[\d+:\d+\]), -1$', t)
+            if m:
+                sminus1 |= {("s", r) for r in regs_of(m.group(1).replace("s", "v"))}
+        for t in ins:
+            m = re.match(r'v_mov_b(?:32|64)(?:_e32)? (v\d+|v\[\d+:\d+\]), (-1|s\d+|s\[\d+:\d+\])$', t)
+            if m and (m.group(2) == "-1" or {("s", r) for r in regs_of(m.group(2).replace("s", "v"))} <= sminus1):
+                minus1 |= regs_of(m.group(1))
+        def is_mark(t):
+            m = re.match(r'buffer_store_dwordx[24] (v\[\d+:\d+\]), .* sc1', t)
+            return bool(m) and regs_of(m.group(1)) <= minus1 and len(regs_of(m.group(1))) > 0
+        def is_pub(t):
+            return re.match(r'buffer_store_dwordx[24] ', t) is not None and " sc1" in t and not is_mark(t)
+        for i, t in enumerate(ins):
+            if not (is_mark(t) and not is_mark(ins[i - 1])):
+                continue
+            j = i
+            while is_mark(ins[j]) or ins[j].startswith(";") or not ins[j]:
+                j += 1
+            total += 1
+            ok, seen = True, {}
+            stack = [(j, 0, 0)]                       # (instruction, vector-memory ops since the marks, barriers crossed)
+            while stack and ok:
+                k, cnt, bars = stack.pop()
+                steps = 0
+                while k < len(ins) and steps < 20000:
+                    key = (k, bars)
+                    if seen.get(key, 1 << 30) <= cnt:
+                        break
+                    seen[key] = cnt
+                    u = ins[k]
+                    steps += 1
+                    m = re.match(r's_waitcnt .*vmcnt\((\d+)\)', u)
+                    if m and int(m.group(1)) <= cnt:
+                        break                          # covered on this path
+                    if "s_barrier" in u:
+                        bars += 1
+                        if not fk and bars >= 2:
+                            ok = False
+                            print("%s: marks at +%d: a path crosses two barriers without a vmcnt wait that covers them" % (kname, i))
+                            break
+                    if fk and is_pub(u):
+                        ok = False
+                        print("%s: marks at +%d: a path reaches the next publication (+%d) without a vmcnt wait that covers them" % (kname, i, k))
+                        break
+                    if is_vmem(u):
+                        cnt += 1
+                    m = re.match(r's_branch\s+(\.LBB\w+)', u)
+                    if m:
+                        k = labels[m.group(1)]
+                        continue
+                    m = re.match(r's_cbranch_\w+\s+(\.LBB\w+)', u)
+                    if m:
+                        stack.append((labels[m.group(1)], cnt, bars))
+                    if u.startswith("s_endpgm") or u.startswith("s_setpc"):
+                        break
+                    k += 1
+            bad += not ok
+    return bad, total
+
+
+def check_split_fma(txt):
+    """x = hi + mid + lo must be the split of the ROUNDED x.  Round 4's defect (r04k/t4.log): rr_split_pair inlined behind h = o * tanh(c) and
+    hipcc contracted h - hi into fma(o, tanh c, -hi) -- the residual images then described the unrounded product and 5.7 % of the frag3
+    elements were one ulp off their f32 twins.  Nothing but a full-size route comparison saw it.  Here: in every kernel of the units that
+    split (recurrent_rr.hip, recurrent_fk.hip, frag3.hip), no fused multiply-add (v_fma / v_fmac / v_mad / v_pk_fma) may take as an operand
+    a register that holds a bf16 image widened back to f32 (v_lshlrev_b32 .., 16, <cvt result> or v_and_b32 .., 0xffff0000, <cvt result>):
+    an image may only be SUBTRACTED from the value it was rounded from."""
+    bad = total = 0
+    for kname, ins in kernels(txt, r'^(_Z\w+):'):
+        cvt, img = set(), set()
+        for i, t in enumerate(ins):
+            if re.match(r'\.LBB', t):
+                cvt, img = set(), set()               # (basic-block local: an image lives a few instructions)
+                continue
+            ops = re.split(r'[,\s]+', t)
+            if len(ops) < 2:
+                continue
+            dst = regs_of(ops[1])
+            srcs = set().union(*[regs_of(o) for o in ops[2:]]) if len(ops) > 2 else set()
+            if ops[0].startswith("v_cvt_pk_bf16_f32"):
+                total += 1
+                cvt |= dst
+                img -= dst
+                continue
+            if re.match(r'v_(fma_f32|fmac_f32|mad_f32|pk_fma_f32|fma_mix)', ops[0]) and (srcs & img):
+                bad += 1
+                print("%s: `%s` at +%d multiplies-and-adds a bf16 image (v%s) in one rounding" % (kname, t, i, sorted(srcs & img)))
+            widened = (ops[0].startswith("v_lshlrev_b32") and len(ops) > 3 and ops[2] == "16" and (regs_of(ops[3]) & cvt)) or \
+                      (ops[0].startswith("v_and_b32") and ("0xffff0000" in ops) and (srcs & cvt))
+            if widened:
+                img |= dst
+            else:
+                img -= dst
+            cvt -= dst
     return bad, total
 
 
