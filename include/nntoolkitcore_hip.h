@@ -523,11 +523,16 @@ int bd_merge_sum_device(const float *d_forward, const float *d_backward, float *
  * The default contraction of conv / dense / recurrent layers multiplies every f32 operand as three bf16 terms (x = hi + mid + lo,
  * exactly).  A FRAG3 tensor is a [batch][T][C] f32 tensor stored as those three images in MFMA fragment order:
  * [T][2 ceil(batch / 64)][ceil(C / 16)][3] blocks of 1 KB, block = 32 batch rows x 16 channels, lane 32 kh + n of a wavefront holding
- * channels 16 ks + 8 kh .. + 7 of batch row 32 ht + n as 8 consecutive bf16 (padding rows / channels are zeros).  6 bytes per value
+ * channels 16 ks + 8 kh .. + 7 of batch row 32 ht + n as 8 consecutive bf16.  Padding CHANNELS (past C) are zeros; padding ROWS (past the
+ * batch, up to the next multiple of 64) are unspecified -- nntk_frag3_pack_device writes zeros there, the recurrent kernels write the
+ * state of rows that computed on zero inputs: a consumer must not let them reach a real row (every consumer here masks).  6 bytes per value
  * instead of 4; in exchange a consumer's operand fetch is a run of coalesced 1 KB loads straight into MFMA registers (no LDS
  * staging, no split, no per-row requests).  The register-resident GRU / LSTM kernels produce their output in this form for free
  * (it is their inter-workgroup hand-off) and read their input from it; the dense GEMM reads it as its A operand.
- * The format is exact: unpack(pack(x)) == x for finite x, so every *Frag3 call equals its f32 counterpart BIT FOR BIT.
+ * The format is exact for every value the three bf16 terms can represent -- unpack(pack(x)) == x for finite |x| <= 3.39e38 that are not
+ * denormal (a larger |x| or +-inf gives NaN, a denormal 0: INTEGRATION.md section 6) -- so every *Frag3 call equals its f32 counterpart BIT FOR BIT.
+ * Scratch: a layer on the register-resident kernels keeps its T-deep hand-off (= its output in frag3 form, 6 bytes per batch * T * H value,
+ * 1.5 x the f32 output) in the handle when the caller passes no d_output_frag3 -- also for plain <GRU|LSTM>ApplyDevice calls.
  *   <GRU|LSTM>ApplyDeviceFrag3: input as f32 (d_input) or frag3 (d_input_frag3), one of them NULL; output as f32 (d_output), frag3
  *   (d_output_frag3, needs return_sequences) or both, unused ones NULL.  Zero initial state per sequence.  Shapes the register-resident
  *   kernels do not take run the other kernels through f32 scratch -- the call is valid for every layer.

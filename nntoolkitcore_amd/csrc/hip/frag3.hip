@@ -274,7 +274,11 @@ __global__ __launch_bounds__(256) void dense_frag3_kernel(DF3Params p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         v[e] = ACT == -1 ? nntk_act(p.act_kind, v[e], p.relu_a) : ACT == NNTK_ACT_RELU ? nntk_act(NNTK_ACT_RELU, v[e], p.relu_a) : v[e];
+#ifdef DF3_NT_STORE
+                    __builtin_nontemporal_store((f32x4){v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4 *>(orow + c));
+#else
                     *reinterpret_cast<float4 *>(orow + c) = make_float4(v[0], v[1], v[2], v[3]);
+#endif
                 }
         }
     };

@@ -409,6 +409,8 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
     float z[4][2];
     auto fin_reduce = [&]() __attribute__((always_inline)) {
         RR_BARRIER();                                   // every wave's partial sums are in `red`
+        // (Measured and not kept: a few idle cycles per wave index behind this barrier, so that the four wavefronts do not issue every LDS /
+        // vector-memory burst of the half-step at the same moment: LSTM-512 +0.1 ms, GRU pair +-0: profiles/r05_rr_skew.log)
         rr_v4u s0[4], s1[4];
 #pragma unroll
         for (int src = 0; src < 4; ++src) {

@@ -208,7 +208,9 @@ typedef struct {
 /* decides the x form and provides it: 0 = f32 rows, 1 = frag3 (*xf3 set; packed here when the caller passed f32), 2 = shape not taken */
 static int rr_input(rec_core *c, const rr_io *io, int B, const float **xf3) {
     *xf3 = io->d_in_f3;
-    const int f32_ok = io->d_in && nntk_shim_lstm_rr_image_floats(c->H, c->in) != 0;
+    /* (a misaligned f32 pointer cannot take the 16-byte row requests: it is packed like a shape the f32 form does not take, so the kernel
+     * family -- and the bits -- do not depend on the caller's pointer alignment) */
+    const int f32_ok = io->d_in && (((size_t)io->d_in) & 15) == 0 && nntk_shim_lstm_rr_image_floats(c->H, c->in) != 0;
     const int xf_ok = nntk_shim_rr_image_floats_xf(c->H, c->in) != 0;
     if (io->d_in_f3) return xf_ok ? 1 : 2;
     int mode = -1;

@@ -233,3 +233,27 @@ def test_rr_stale_hand_off_of_another_input_is_never_taken_for_data(gpu, cell, I
         ref = ofn(xx, W, U, bi, bh, **({"v2": True} if cell == "lstm" else {}))
         np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
     lay.destroy()
+
+
+def test_rr_result_does_not_depend_on_the_alignment_of_the_input_pointer(gpu):
+    """a small call with an f32 input that is not 16-byte aligned used to fall to the exact-f32 kernels (another summation
+    order) while the same call with an aligned pointer ran on the register-resident kernel: bits depended on pointer alignment.  A
+    misaligned input is now packed into frag3 form like any shape the f32 row form does not take."""
+    import torch
+    L = capi.load()
+    r = rng(31)
+    B, I, H, T = 40, 128, 256, 7
+    x = u(r, B, T, I)
+    W, U, bi, bh = gru_weights(r, I, H)
+    gru = NL.GRU(I, H, True, T)
+    gru.set_weights(W, U, bi, bh)
+    xa = torch.from_numpy(x).cuda()
+    pad = torch.empty(B * T * I + 1, device="cuda")
+    xm = pad[1:].view(B, T, I)
+    xm.copy_(xa)
+    assert xm.data_ptr() % 16 == 4
+    a = gru.apply_device(xa).clone()
+    b = gru.apply_device(xm).clone()
+    assert L.nntk_hip_last_recurrent_kernel().decode().startswith("gru_rr_kernel")
+    assert torch.equal(a, b)
+    gru.destroy()
