@@ -515,8 +515,19 @@ extern "C" int nntk_shim_dense_frag3(const void *d_frag, const float *d_wp, cons
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, nntk_stream(), p);
     } else
 #endif
+#ifdef DF3_TILE      // A/B: another tile shape, -DDF3_TILE=WM,WN,TM,TN (smaller tiles leave room for a second workgroup per CU)
+    if (wide) {
+        constexpr int sh[4] = {DF3_TILE};
+        p.m_tiles = (int)((p.NRB + sh[0] * sh[2] - 1) / (sh[0] * sh[2]));
+        p.n_tiles = N_p / (sh[1] * sh[3] * 32);
+        const long blocks2 = (long)((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
+        hipLaunchKernelGGL((dense_frag3_kernel<DF3_TILE>), dim3((unsigned)blocks2), dim3(256), 0, nntk_stream(), p);
+    } else
+#else
     if (wide) hipLaunchKernelGGL((dense_frag3_kernel<2, 2, 4, 4>), dim3((unsigned)blocks), dim3(256), 0, nntk_stream(), p);
-    else             hipLaunchKernelGGL((dense_frag3_kernel<4, 1, 2, 4>), dim3((unsigned)blocks), dim3(256), 0, nntk_stream(), p);
+    else
+#endif
+                     hipLaunchKernelGGL((dense_frag3_kernel<4, 1, 2, 4>), dim3((unsigned)blocks), dim3(256), 0, nntk_stream(), p);
     NNTK_LAUNCH_CHECK("dense_frag3_kernel");
     return 0;
 }
