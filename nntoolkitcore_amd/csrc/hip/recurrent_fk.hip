@@ -411,9 +411,9 @@ __device__ __forceinline__ void fk_body(const RRParams &p) {
             const fk_v2u c = {(unsigned)min(sl0, 0xfffffffeu), (unsigned)min(sl1, 0xfffffffeu)};
             // the whole address rides in the VECTOR offset, soffset stays immediate 0 (tools/check_store_hazard.py)
             const __amdgpu_buffer_rsrc_t rs = rs_wr(t);
-            __builtin_amdgcn_raw_buffer_store_b64(a, rs, pub_vo, 0, 16 /* sc1 */);
-            __builtin_amdgcn_raw_buffer_store_b64(b, rs, pub_vo + 1024, 0, 16);
-            __builtin_amdgcn_raw_buffer_store_b64(c, rs, pub_vo + 2048, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b64(a, rs, pub_vo, 0, RR_ST_AUX /* sc1 */);
+            __builtin_amdgcn_raw_buffer_store_b64(b, rs, pub_vo + 1024, 0, RR_ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(c, rs, pub_vo + 2048, 0, RR_ST_AUX);
             RR_BOUND(3, (size_t)t * p.hstep, pub_vo + 2048, 0, hb_bytes, 8);
         }
         olast = (rr_v4u){__float_as_uint(hn[0]), __float_as_uint(hn[1]), __float_as_uint(hn[2]), __float_as_uint(hn[3])};
@@ -433,9 +433,9 @@ __device__ __forceinline__ void fk_body(const RRParams &p) {
         const __amdgpu_buffer_rsrc_t rs2 = rs_wr(t + 1 < T ? t + 1 : t);
         const int vo2 = t + 1 < T ? pub_vo : RR_OOB_F;
         const fk_v2u pend = {RR_PENDING, RR_PENDING};
-        __builtin_amdgcn_raw_buffer_store_b64(pend, rs2, vo2, 0, 16);
-        __builtin_amdgcn_raw_buffer_store_b64(pend, rs2, vo2 + 1024, 0, 16);
-        __builtin_amdgcn_raw_buffer_store_b64(pend, rs2, vo2 + 2048, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b64(pend, rs2, vo2, 0, RR_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(pend, rs2, vo2 + 1024, 0, RR_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(pend, rs2, vo2 + 2048, 0, RR_ST_AUX);
         RR_BOUND(3, (size_t)(t + 1 < T ? t + 1 : t) * p.hstep, vo2 + 2048, 0, hb_bytes, 8);
     };
 

@@ -514,9 +514,9 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
             const int vo = lane16 + (((bt_abs * 2 + half) * NKS + ct) * 3) * 1024;
             if (!RR_DBG(128)) {
                 const __amdgpu_buffer_rsrc_t rs = rs_wr(t);
-                __builtin_amdgcn_raw_buffer_store_b128(a, rs, vo, 0, 16 /* sc1 */);
-                __builtin_amdgcn_raw_buffer_store_b128(b, rs, vo + 1024, 0, 16);
-                __builtin_amdgcn_raw_buffer_store_b128(c, rs, vo + 2048, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(a, rs, vo, 0, RR_ST_AUX /* sc1 */);
+                __builtin_amdgcn_raw_buffer_store_b128(b, rs, vo + 1024, 0, RR_ST_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(c, rs, vo + 2048, 0, RR_ST_AUX);
                 RR_BOUND(3, (size_t)t * p.hstep, vo + 2048, 0, hb_bytes, 16);
             }
         } else if (w == 2 * half + 1) {                 // the output wave: the same row pieces in f32
@@ -551,9 +551,9 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
                 const __amdgpu_buffer_rsrc_t rs2 = rs_wr(t + 2 < T ? t + 2 : t);
                 const int vo2 = t + 2 < T ? vo : RR_OOB_F;
                 const rr_v4u pend = {RR_PENDING, RR_PENDING, RR_PENDING, RR_PENDING};
-                __builtin_amdgcn_raw_buffer_store_b128(pend, rs2, vo2, 0, 16);
-                __builtin_amdgcn_raw_buffer_store_b128(pend, rs2, vo2 + 1024, 0, 16);
-                __builtin_amdgcn_raw_buffer_store_b128(pend, rs2, vo2 + 2048, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(pend, rs2, vo2, 0, RR_ST_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(pend, rs2, vo2 + 1024, 0, RR_ST_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(pend, rs2, vo2 + 2048, 0, RR_ST_AUX);
                 RR_BOUND(3, (size_t)(t + 2 < T ? t + 2 : t) * p.hstep, vo2 + 2048, 0, hb_bytes, 16);
             }
         }

@@ -12,6 +12,9 @@ typedef __bf16 rr_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float rr_f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned rr_v4u __attribute__((ext_vector_type(4)));
 
+#ifndef RR_ST_AUX
+#define RR_ST_AUX 16              // cache policy of the hand-off STORES: 16 = sc1 (write-through, placement-independent)
+#endif
 #define RR_FLAGS 64               // flag words per (batch tile, half): one per column tile (<= 32), padded to one wave-wide load
 #ifndef RR_POLL_LEAD
 #define RR_POLL_LEAD 1           // the flags are requested this many k steps before they are looked at
