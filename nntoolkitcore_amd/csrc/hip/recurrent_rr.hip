@@ -179,7 +179,10 @@ __global__ __launch_bounds__(256) void rr_tile_h0_kernel(const float *__restrict
 // the split, were 0.5 us of a 6.7 us step).  Each half owns an operand set, requested a whole half-step ahead.
 template <int KH, int KX, bool TRAIN, int CELL, bool XF>
 __device__ __forceinline__ void rr_body(const RRParams &p) {
-    constexpr bool ULR = KX > 2;
+#ifndef RR_ULR8
+#define RR_ULR8 0
+#endif
+    constexpr bool ULR = KX > 2 || (RR_ULR8 && KH == 8 && !TRAIN);
     constexpr int NST = KX + KH;                      // k steps one wavefront multiplies per half
 #ifndef RR_S_RED
 #define RR_S_RED 0               // k step of the reduce + gates slice; 1 (KH = 8: the half-step's first 12 MFMAs issue before its barrier) measured
@@ -849,8 +852,9 @@ static bool rr_shape(int H, int in, bool xf, int *KH, int *KX) {
     *KX = in <= 64 ? 1 : in <= 128 ? 2 : (in <= 256 && *KH == 4) ? 4 : 0;
     return *KX != 0;
 }
-static size_t rr_lds_bytes(int KH, int KX) {
-    return (size_t)((KX > 2 ? 0 : 4 * KH * 2) + 4 * KX * 6 + 32) * 1024 + 32 * RR_HX_LD * 4 + 3 * 32 * RR_HS_LD * 4;
+static size_t rr_lds_bytes(int KH, int KX, bool train = false) {
+    const bool ulr = KX > 2 || (RR_ULR8 && KH == 8 && !train);
+    return (size_t)((ulr ? 0 : 4 * KH * 2) + 4 * KX * 6 + 32) * 1024 + 32 * RR_HX_LD * 4 + 3 * 32 * RR_HS_LD * 4;
 }
 // one timestep of the frag3 hand-off / layer output: [NHT = 2 * batch tiles][H / 16 k steps][3 images] blocks of 1 KB
 static size_t rr_step_bytes(int B, int H) { return (size_t)((B + 63) / 64) * 2 * (H / 16) * 3 * 1024; }
@@ -975,7 +979,7 @@ static int rr_launch(const RRIo &io, const float *d_img, const float *d_bi, cons
     else if (KH == 4 && KX == 2) kern = rr_pick<4, 2>(cell, train, xf);
     else if (KH == 4 && KX == 1) kern = rr_pick<4, 1>(cell, train, xf);
     if (!kern) return 1;
-    const size_t lds = rr_lds_bytes(KH, KX);
+    const size_t lds = rr_lds_bytes(KH, KX, train);
     if (lds > 160 * 1024) return 1;
     if (nntk_set_max_dynamic_lds((const void *)kern, lds)) return -1;
     const int resident = nntk_resident_blocks((const void *)kern, 256, lds, 1);
