@@ -404,6 +404,9 @@ static const char *core_plan(rec_core *c, int std_acts, char *buf, size_t n) {
     else if (!xf_ok) why = (c->H % 16) ? "H % 16 != 0" : (c->H < 64 || c->H > 512) ? "H outside 64..512" : "input wider than 128 (256 when H <= 256)";
     if (why)
         snprintf(buf, n, "%s: exact-f32 kernels (projection GEMM + rec_persistent_kernel, per-timestep kernels when that does not fit) -- %s", cell, why);
+    else if (nntk_shim_fk_image_floats(c->H, c->in) != 0)       /* (option rec_fk = 1 and a shape that family takes) */
+        snprintf(buf, n, "%s: %s_fk_kernel<16,%d,%d> (register-resident split-bf16 x 3 without split-K, input projection fused; the input is packed into frag3 form first); the stateful single-sequence call keeps the exact-f32 kernels",
+                 cell, cell, c->in <= 128 ? 8 : 16, c->in <= 128 ? 4 : 2);
     else
         snprintf(buf, n, "%s: %s_rr_kernel<%d,%d> (register-resident split-bf16 x 3, input projection fused)%s; the stateful single-sequence call keeps the exact-f32 kernels",
                  cell, cell, c->H <= 256 ? 4 : 8, c->in <= 64 ? 1 : c->in <= 128 ? 2 : 4,

@@ -121,3 +121,16 @@ def test_fk_fault_is_reported(gpu):
     assert L.nntk_hip_last_recurrent_kernel().decode().startswith("gru_fk_kernel")
     capi.set_option("rec_persistent", "auto")
     lay.destroy()
+
+
+def test_kernel_plan_names_the_full_k_family_when_it_is_switched_on(gpu):
+    L = capi.load()
+    r = np.random.default_rng(1)
+    lay, _ = make("gru", r, 256, 256, True, 4)
+    assert "gru_rr_kernel<4,4>" in L.GRUKernelPlan(lay.h).decode()
+    capi.set_option("rec_fk", 1)
+    assert "gru_fk_kernel<16,16,2>" in L.GRUKernelPlan(lay.h).decode()
+    lay.destroy()
+    lay, _ = make("lstm", r, 128, 512, True, 4)           # a shape the family does not take keeps the split-K kernel
+    assert "lstm_rr_kernel<8,2>" in L.LSTMKernelPlan(lay.h).decode()
+    lay.destroy()
