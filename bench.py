@@ -278,7 +278,7 @@ def pmc_traffic(kernel_prefix, B):
             continue
         if d.get("source_hash") != want or d.get("utterances_per_gpu") != B:
             continue
-        hits = [v.get("hbm_bytes_per_launch") for name, v in d.get("kernels", {}).items() if name.startswith(kernel_prefix)]
+        hits = [v.get("hbm_bytes_per_launch") for name, v in d.get("kernels", {}).items() if name.startswith(kernel_prefix)]   # (str or tuple of str)
         hits = [h for h in hits if h is not None]
         if hits:      # several instantiations of one kernel in a step (the two GRU layers): their average, like ms_per_launch
             return sum(hits) / len(hits), "%s (source_hash %s)" % (os.path.relpath(path, ROOT), want)
@@ -361,10 +361,16 @@ def roofline_for(wl, phase_ms, prof):
         flops = (flops_l1 + flops_l2) / 2
         ach = flops / (ms * 1e-3) / 1e12
         peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
-        fam = "gru_fk_kernel" if last.startswith("gru_fk") else "gru_rr_kernel"
-        traffic, traffic_source = pmc_traffic(fam, B)
-        shapes = ("<16,8,4>", "<16,16,2>") if fam == "gru_fk_kernel" else ("<4,2>", "<4,4>")
-        return {"kernel": "%s%s (layer 1) + %s%s (layer 2)" % (fam, shapes[0], fam, shapes[1]), "bound": "mfma", "achieved": ach, "peak": peak,
+        # which kernel each layer takes is a property of the layer (GRUKernelPlan): by default the split-K kernel for the 128-wide
+        # layer 1 and the full-K one for the 256-wide layer 2
+        import re
+        from nntoolkitcore_amd import capi
+        names = []
+        for g in (wl.g1, wl.g2):
+            m = re.search(r"gru_(?:rr|fk)_kernel<[0-9,]+>", capi.load().GRUKernelPlan(g.h).decode())
+            names.append(m.group(0) if m else last)
+        traffic, traffic_source = pmc_traffic(tuple(sorted(set(n.split("<")[0] for n in names))), B)
+        return {"kernel": "%s (layer 1) + %s (layer 2)" % tuple(names), "bound": "mfma", "achieved": ach, "peak": peak,
                 "peak_note": "dense bf16 MFMA peak / 6 products per f32 product (split-bf16 x 3 contraction); one gate slot in four "
                              "multiplies a zero weight block (the GRU's candidate gate keeps its x and h parts apart), not counted as flops",
                 "unit": "TFLOP/s", "frac": ach / peak, "frac_of_exact_f32_mfma_peak": ach / F32_MFMA_PEAK_TFLOPS,
@@ -655,8 +661,9 @@ def main():
             "gemm": gemm_mode() + " for conv / TDD" + (
                 ("; LSTM: " + prof["rec_kernel"] + " (split-bf16x3 recurrence with the input projection fused into the step)")
                 if prof.get("rec_kernel", "").startswith("lstm_rr") else
-                ("; GRU layers: gru_rr_kernel (split-bf16x3 recurrences with the input projections fused into the step; layer 1 hands h over in frag3 form)")
-                if prof.get("rec_kernel", "").startswith("gru_rr") else
+                ("; GRU layers: register-resident split-bf16x3 recurrences with the input projections fused into the step (gru_rr_kernel: split-K over "
+                 "four wavefronts; gru_fk_kernel: full K per wavefront); layer 1 hands h over in frag3 form")
+                if prof.get("rec_kernel", "").startswith(("gru_rr", "gru_fk")) else
                 ("; exact-f32 for the recurrent input projection and recurrences" if a.workload in ("stack", "gru") else "")),
             "gemm_accuracy": ("f32 results: error vs a float64 contraction <= the exact-f32 MFMA chain's on every BASELINE shape "
                               "(profiles/r02_split_error.log, tools/split_error.py); NNTK_GEMM_SPLIT_BF16=0 selects the exact chain")

@@ -40,17 +40,32 @@
 #include "recurrent_rr_common.hpp"
 
 typedef unsigned fk_v2u __attribute__((ext_vector_type(2)));
-#define FK_RING 4                  // ring slots per wavefront.  A wavefront writes group g + 1's k step (slot of group g - 3) after it has checked its
-                                   // partners' words of group g; each partner wrote that word after ITS check of group g - 1, i.e. after all its reads of
-                                   // group g - 2 had been issued (LDS runs a wavefront's operations in order): three slots would do, four keep the
-                                   // slot index a compile-time constant.  (Two slots with the hand-over at the END of a group -- every read issued first
-                                   // -- were measured slower: the partners then find the word missing and spin, profiles/r05_fk_ring.log)
+// f(integral_constant<int, LO>), .., f(integral_constant<int, HI - 1>): the groups of a step as separate instantiations ("#pragma unroll"
+// gives up on a body this large -- "unrolled size is too large" -- and the staging registers, indexed by the group, then live in scratch)
+template <int LO, int HI, class F>
+__device__ __forceinline__ void fk_for(F &&f) {
+    if constexpr (LO < HI) {
+        f(std::integral_constant<int, LO>{});
+        fk_for<LO + 1, HI>(f);
+    }
+}
+// Ring slots per wavefront.  4 (default): a wavefront writes group g + 1's k step (slot of group g - 3) after it has checked its partners' words of
+// group g; each partner wrote that word after ITS check of group g - 1, i.e. after all its reads of group g - 2 had been issued (LDS runs a
+// wavefront's operations in order): three slots would do, four keep the slot index a compile-time constant, and the ring reads of a group may
+// be spread over the group.  2 (32 units x 256 inputs: W's mid / low images take 128 KB of LDS): every ring read of a group is issued in the
+// group's first block, BEFORE the hand-over of the next group's k step -- the same argument then holds one group shorter.  (Two slots with spread
+// reads and the hand-over at the END of a group were measured slower: the partners find the word missing and spin, profiles/r05_fk_ring.log.)
+__host__ __device__ constexpr int fk_ring(int NKX, int NW) { return NW == 4 && NKX > 8 ? 2 : 4; }
 #ifndef FK_ND_4
 #define FK_ND_4 3                  // staging sets (groups of four k steps requested ahead) of the NW = 4 kernels
 #endif
+#ifndef FK_ND_4W
+#define FK_ND_4W 4                 // ... of the NW = 4 kernels with a 256-wide input (eight groups per step)
+#endif
 #ifndef FK_LEAD_CAP
-#define FK_LEAD_CAP 0              // 1: the head h groups of a step are requested only once the step before has been finished (measured slower: the
-                                   // requests then bunch up behind the finish's stores, profiles/r05_fk_ring.log)
+#define FK_LEAD_CAP 0              // 1: the h groups of a step are requested behind the finish of the step before, and the step's last group waits for the
+                                   // next step's head operand at its END; 0: everything ND groups ahead, the look always in a group's first block.
+                                   // (1 measured slower at in = 128 -- 4.66 vs 4.44 ms -- and equal at in = 256: profiles/r05_fk_ablate.log)
 #endif
 #ifndef FK_FIN_SLICED
 #define FK_FIN_SLICED 0
@@ -153,17 +168,23 @@ template <int NKH, int NKX, int CELL, int NW, int ND>
 __device__ __forceinline__ void fk_body(const RRParams &p) {
     constexpr int NMR = NKH <= 16 ? 3 : 2;            // images of U kept in registers
     constexpr int NMW = NW == 4 && NKX > 8 ? 1 : 0;   // images of W kept in registers
+    constexpr int FK_RING = fk_ring(NKX, NW);
+    constexpr bool BURST = FK_RING == 2;              // every ring read of a group in the group's first block
     constexpr int NGH = NKH / NW, NGX = NKX / NW, NG = NGH + NGX;          // groups of NW k steps per step: h part, x part
     constexpr int NHF = 4 / NW;                       // 32-row halves per workgroup
     static_assert((NW == 2 || NW == 4) && NKH % NW == 0 && NKX % NW == 0 && NGX >= 1, "group schedule");
-    static_assert((2 * NG) % ND == 0 && (2 * NG) % FK_RING == 0 && ND <= NGH, "staging / ring indices repeat every two steps at most");
+    static_assert((2 * NG) % ND == 0 && (2 * NG) % fk_ring(NKX, NW) == 0 && ND <= NGH, "staging / ring indices repeat every two steps at most");
     // REQUEST SCHEDULE: the own k step of group q (of its step) is requested fk_lead(q) groups before the group that multiplies it -- as
     // early as the staging sets allow (ND groups), except the h groups at the head of a step: their data is published by the finish of
     // the step before, so a request issued before the x part of that step can only find the pending pattern (and be repeated).
     constexpr auto fk_lead = [](int q) constexpr {
         if (q >= NGH) return ND;                        // x part: nothing to wait for
-        const int cap = FK_LEAD_CAP ? NGX + q : ND;     // (FK_LEAD_CAP: not before the first x group of the step before)
-        return cap < ND ? cap : ND;
+        if (!FK_LEAD_CAP) return ND;
+        // FK_LEAD_CAP: the h groups of a step are requested in the LAST TWO groups of the step before (2, 3, 3, 4, 4, .. groups ahead) --
+        // behind its finish, when a request reaches memory about as its peers' stores do -- and never before that step's x part
+        const int want = 2 + (q + 1) / 2, cap = NGX + q;
+        const int l = want < cap ? want : cap;
+        return l < ND ? l : ND;
     };
     constexpr int FIN_G = NW == 4 ? 1 : (NGX >= 4 ? 4 : NGX);     // x groups that carry the finish of the previous step (a hidden unit or more each)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -206,7 +227,8 @@ __device__ __forceinline__ void fk_body(const RRParams &p) {
 #pragma unroll
             for (int m = 0; m < NMW; ++m) {
                 wr[pos][m] = __builtin_bit_cast(rr_bf16x8, img[(size_t)NW * NKH * NMR * 64 + (((size_t)ug * NKX + pos) * NMW + m) * 64 + lane]);
-                RR_PIN_A(wr[pos][m]);
+                // (not pinned to the accumulator half: U's 192 registers + these 64 would leave the step's own working set only 256 ordinary
+                // registers, and it spills)
             }
     }
     {
@@ -239,6 +261,9 @@ __device__ __forceinline__ void fk_body(const RRParams &p) {
         return __builtin_amdgcn_make_buffer_rsrc((void *)(p.hseq + (size_t)t * p.hstep), 0, hb_bytes, 0x00020000);
     };
     auto rs_x = [&](int t) __attribute__((always_inline)) {          // x_t as frag3 blocks; t >= T: nothing
+#ifdef FK_X_HOT     // (timing ablation, WRONG results: every step reads x_0 -- an L2-resident x)
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(p.xf3), 0, t < T ? (int)p.xstep : 0, 0x00020000);
+#endif
         return __builtin_amdgcn_make_buffer_rsrc((void *)(p.xf3 + (size_t)(t < T ? t : 0) * p.xstep), 0, t < T ? (int)p.xstep : 0, 0x00020000);
     };
     const int lane16 = lane * 16;
@@ -367,7 +392,8 @@ __device__ __forceinline__ void fk_body(const RRParams &p) {
                 expired = __builtin_amdgcn_s_memrealtime() - t_start > p.spin_ticks;
             }
             if (expired && lane == 0) __hip_atomic_fetch_or(p.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ring_data(1, slot, 0, 3);
+#pragma unroll
+            for (int j = 1; j < (BURST ? NW : 2); ++j) ring_data(j, slot, 0, 3);
         }
     };
     // ---- the finish of step t, straight from the accumulator lanes, in two kinds of pieces: the gate arithmetic of one hidden unit (fin_unit),
@@ -482,8 +508,8 @@ __device__ __forceinline__ void fk_body(const RRParams &p) {
     auto step = [&](auto par_tag, auto hp_tag, int t, f32x16 &acc, f32x16 &accn) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_tag)::value;
         constexpr bool HP = decltype(hp_tag)::value;
-#pragma unroll
-        for (int gs = HP ? 0 : NGH; gs < NG; ++gs) {
+        fk_for<(HP ? 0 : NGH), NG>([&](auto gs_tag) __attribute__((always_inline)) {
+            constexpr int gs = decltype(gs_tag)::value;
             const bool is_h = gs < NGH;
             const int pos0 = NW * (is_h ? gs : gs - NGH);                  // consumption positions of the group in its part: own first
             const int gidx = PAR * NG + gs;                               // global group index modulo 2 NG
@@ -505,7 +531,11 @@ __device__ __forceinline__ void fk_body(const RRParams &p) {
 #define FK_PIN() __builtin_amdgcn_sched_barrier(0)
             // ---- block a: own k step, first half; the partners' k steps of this group requested from their rings; the own k step of
             //      the NEXT group looked at (its words compared in the MFMAs' shadow); ONE branch for both kinds of "not there yet"
-            const bool chk1 = h1 && !RR_DBG(4) && !RR_DBG(1);              // (a run-time t1 > 0 on top: step 0 reads the h_0 slot, written before the launch)
+            // LATE (FK_LEAD_CAP, the step's last group): the next group is the head of the next step -- its operand is in flight from the peers'
+            // finish, and a wait for it here would hold THIS group's MFMAs back behind the hand-off chain; the look, the wait and the
+            // hand-over move to the end of the group
+            const bool LATE = FK_LEAD_CAP && gs == NG - 1;
+            const bool chk1 = h1 && !LATE && !RR_DBG(4) && !RR_DBG(1);     // (a run-time t1 > 0 on top: step 0 reads the h_0 slot, written before the launch)
             unsigned mx0 = 0, mx1 = 0, mx2 = 0;
 #ifdef NNTK_REC_STAMPS
             unsigned long long fine[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -518,9 +548,11 @@ __device__ __forceinline__ void fk_body(const RRParams &p) {
             FK_PIN();
             mult(a, is_h, pos0, 0, S[si], 1, 2); FK_PIN();
             ring_data(1, slot, 0, 3);
+            if (BURST && NW == 4) ring_data(2, slot, 0, 3);
             if (chk1) { const rr_v4u v = S[si1][1]; mx1 = max(mx0, max(max(v.x, v.y), max(v.z, v.w))); asm volatile("" : "+v"(mx1)); }
             FK_PIN();
             mult(a, is_h, pos0, 0, S[si], 2, 3); FK_PIN();
+            if (BURST && NW == 4) ring_data(3, slot, 0, 3);
             if (chk1) { const rr_v4u v = S[si1][2]; mx2 = max(mx1, max(max(v.x, v.y), max(v.z, v.w))); asm volatile("" : "+v"(mx2)); }
             lds_fetch_a(is_h, pos0 + 1, 1); FK_PIN();
             FK_FINE(gs, 1);
@@ -538,17 +570,23 @@ __device__ __forceinline__ void fk_body(const RRParams &p) {
                 }
             }
             FK_FINE(gs, 2);
+#ifdef FK_COARSE_GS
+            if (gs == FK_COARSE_GS) FK_STAMP(t, 40);
+#endif
             // ---- block b: own k step, second half, the next group's own k step handed to the partners between its MFMAs
-            if (!RR_DBG(512)) ring_put(si1, slot1, seq + 1u, 0);
+            if (!RR_DBG(512) && !LATE) ring_put(si1, slot1, seq + 1u, 0);
             FK_PIN();
             mult(a, is_h, pos0, 0, S[si], 3, 4); FK_PIN();
-            if (!RR_DBG(512)) ring_put(si1, slot1, seq + 1u, 1);
+            if (!RR_DBG(512) && !LATE) ring_put(si1, slot1, seq + 1u, 1);
             FK_PIN();
             mult(a, is_h, pos0, 0, S[si], 4, 5); FK_PIN();
-            if (!RR_DBG(512)) ring_put(si1, slot1, seq + 1u, 2);
+            if (!RR_DBG(512) && !LATE) ring_put(si1, slot1, seq + 1u, 2);
             FK_PIN();
             mult(a, is_h, pos0, 0, S[si], 5, 6); FK_PIN();
             if (HP && gs == 0) { mark_next(t); FK_PIN(); }
+#ifdef FK_COARSE_GS
+            if (gs == FK_COARSE_GS) FK_STAMP(t, 41);
+#endif
             FK_FINE(gs, 3);
             // ---- blocks c ..: the partners' k steps multiplied; the own k step of ND groups ahead requested, one fragment per two
             //      MFMAs; the A fragments of the next k step on their way.  The first FIN_G x groups also carry the finish of the step
@@ -558,19 +596,25 @@ __device__ __forceinline__ void fk_body(const RRParams &p) {
 #pragma unroll
             for (int j = 1; j < NW; ++j) {
                 mult(a, is_h, pos0 + j, j & 1, P[j - 1], 0, 2); if (!fin_here) FK_PIN();
-                if (j + 1 < NW) ring_data(j + 1, slot, 0, 1);
+                if (j + 1 < NW && !BURST) ring_data(j + 1, slot, 0, 1);
                 issue_sched(gs, PAR, t, j - 1, 0, 1); if (!fin_here) FK_PIN();
                 if (j + 1 < NW) lds_fetch_a(is_h, pos0 + j + 1, (j + 1) & 1);
                 else lds_fetch_a(h1, NW * (h1 ? q1 : q1 - NGH), 0);
                 if (!fin_here) FK_PIN();
                 mult(a, is_h, pos0 + j, j & 1, P[j - 1], 2, 4); if (!fin_here) FK_PIN();
-                if (j + 1 < NW) ring_data(j + 1, slot, 1, 2);
+                if (j + 1 < NW && !BURST) ring_data(j + 1, slot, 1, 2);
                 issue_sched(gs, PAR, t, j - 1, 1, 2); if (!fin_here) FK_PIN();
                 mult(a, is_h, pos0 + j, j & 1, P[j - 1], 4, 6); if (!fin_here) FK_PIN();
-                if (j + 1 < NW) ring_data(j + 1, slot, 2, 3);
+                if (j + 1 < NW && !BURST) ring_data(j + 1, slot, 2, 3);
                 issue_sched(gs, PAR, t, j - 1, 2, 3); if (!fin_here) FK_PIN();
                 FK_FINE(gs, 3 + j);
+#ifdef FK_COARSE_GS
+                if (gs == FK_COARSE_GS) FK_STAMP(t, 41 + j);
+#endif
             }
+            // (requests of this group-step that found no partner block to ride in: pairs have one block and may be due two or three)
+#pragma unroll
+            for (int k = NW - 1; k < 3; ++k) issue_sched(gs, PAR, t, k, 0, 3);
             if (fin_here) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -584,6 +628,13 @@ __device__ __forceinline__ void fk_body(const RRParams &p) {
                     else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
             }
+            if (LATE) {
+                if (h1 && t1 > 0 && !RR_DBG(4) && !RR_DBG(1)) {
+                    const unsigned long long pend = probe(si1) | inject;
+                    if (__builtin_expect(pend != 0, 0)) settle(q1, si1, t1);
+                }
+                if (!RR_DBG(512)) ring_put(si1, slot1, seq + 1u, -1);
+            }
             __builtin_amdgcn_sched_barrier(0);
             FK_FINE_OUT(gs, t);
             if (!FK_FIN_SLICED && HP && gs == NGH - 1) {
@@ -596,7 +647,7 @@ __device__ __forceinline__ void fk_body(const RRParams &p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (FK_FIN_SLICED && HP && !is_h && gx == FIN_G - 1) FK_STAMP(t, 33);
-        }
+        });
     };
 
     f32x16 accA, accB;
@@ -641,19 +692,26 @@ __global__ __launch_bounds__(256) void gru_fk_kernel(RRParams p) { fk_body<NKH, 
 
 // ---- host side --------------------------------------------------------------------------------------------------
 // NW = 4 (32 rows x 32 units per workgroup, half the operand traffic) when W's images for 32 units fit LDS (in <= 128); else NW = 2
+// rec_fk: 1 every shape the family takes; 0 none; auto: the shapes where it beats the split-K family -- inputs of 129 .. 256 channels (GRU
+// 256 -> 256: 5.60 against 6.13 ms, LSTM 5.83 against 6.33, GRU 200 -> 192: 4.55 against 5.21; at in <= 128 it is 1-4 % behind)
 static bool fk_shape(int H, int in, int *NKH, int *NKX, int *NW) {
     if ((H % 16) != 0 || H <= 128 || H > 256 || in <= 64 || in > 256) return false;
+    const int on = nntk_options().rec_fk;
+    if (on == 0 || (on < 0 && in <= 128)) return false;
     *NKH = 16;
     *NKX = in <= 128 ? 8 : 16;
-    *NW = in <= 128 ? 4 : 2;      // (32 units x 256 inputs: W's images and a four-slot ring do not fit LDS together)
+    *NW = 4;
+#ifdef FK_NW2_WIDE
+    if (in > 128) *NW = 2;        // (A/B: the 256-wide layer on pairs, 64 rows x 16 units)
+#endif
     return true;
 }
 static size_t fk_lds_bytes(int NKH, int NKX, int NW) {
-    return (size_t)(NW * NKH * (3 - fk_nmr(NKH)) + NW * NKX * (3 - fk_nmw(NKX, NW)) + 4 * FK_RING * 3) * 1024 + 4 * FK_RING * 64 * 4;
+    return (size_t)(NW * NKH * (3 - fk_nmr(NKH)) + NW * NKX * (3 - fk_nmw(NKX, NW)) + 4 * fk_ring(NKX, NW) * 3) * 1024 + 4 * fk_ring(NKX, NW) * 64 * 4;
 }
 extern "C" size_t nntk_shim_fk_image_floats(int H, int in) {
     int NKH, NKX, NW;
-    if (nntk_options().rec_fk != 1 || !fk_shape(H, in, &NKH, &NKX, &NW)) return 0;
+    if (!fk_shape(H, in, &NKH, &NKX, &NW)) return 0;
     return (size_t)((H + 8 * NW - 1) / (8 * NW)) * fk_blocks_per_ct(NKH, NKX, NW) * 256;
 }
 static int fk_pack(bool raw, const float *d_u, const float *d_w, float *d_img, int H, int in) {
@@ -680,10 +738,10 @@ extern "C" int nntk_shim_fk_pack_raw(const float *d_U, const float *d_W, float *
 // first two steps preset to the pending pattern, the h_0 slot); d_imgfk: the images of fk_pack.
 int nntk_fk_launch(RRParams q, const float *d_imgfk, int cell, size_t *launches) {
     int NKH, NKX, NW;
-    if (!d_imgfk || !q.xf3 || q.x_tm || q.out_tm || nntk_options().rec_fk != 1 || !fk_shape(q.H, q.in, &NKH, &NKX, &NW)) return 1;
+    if (!d_imgfk || !q.xf3 || q.x_tm || q.out_tm || !fk_shape(q.H, q.in, &NKH, &NKX, &NW)) return 1;
     void (*kern)(RRParams) = nullptr;
-    if (cell == 1) kern = NW == 4 ? gru_fk_kernel<16, 8, 4, FK_ND_4> : gru_fk_kernel<16, 16, 2, FK_ND_2>;
-    else kern = NW == 4 ? lstm_fk_kernel<16, 8, 4, FK_ND_4> : lstm_fk_kernel<16, 16, 2, FK_ND_2>;
+    if (cell == 1) kern = NW == 2 ? gru_fk_kernel<16, 16, 2, FK_ND_2> : NKX == 8 ? gru_fk_kernel<16, 8, 4, FK_ND_4> : gru_fk_kernel<16, 16, 4, FK_ND_4W>;
+    else kern = NW == 2 ? lstm_fk_kernel<16, 16, 2, FK_ND_2> : NKX == 8 ? lstm_fk_kernel<16, 8, 4, FK_ND_4> : lstm_fk_kernel<16, 16, 4, FK_ND_4W>;
     const size_t lds = fk_lds_bytes(NKH, NKX, NW);
     if (lds > 160 * 1024) return 1;
     if (nntk_set_max_dynamic_lds((const void *)kern, lds)) return -1;
@@ -701,7 +759,7 @@ int nntk_fk_launch(RRParams q, const float *d_imgfk, int cell, size_t *launches)
         hipLaunchKernelGGL(kern, dim3((unsigned)(nbt * NCT)), dim3(256), lds, nntk_stream(), q);
     }
     if (launches) *launches = (size_t)((nbt_total + tiles_per_launch - 1) / tiles_per_launch);
-    static const char *const names[2][2] = {{"lstm_fk_kernel<16,8,4>", "lstm_fk_kernel<16,16,2>"}, {"gru_fk_kernel<16,8,4>", "gru_fk_kernel<16,16,2>"}};
-    nntk_set_last_rec_kernel(names[cell == 1][NKX == 16]);
+    static const char *const names[2][3] = {{"lstm_fk_kernel<16,8,4>", "lstm_fk_kernel<16,16,4>", "lstm_fk_kernel<16,16,2>"}, {"gru_fk_kernel<16,8,4>", "gru_fk_kernel<16,16,4>", "gru_fk_kernel<16,16,2>"}};
+    nntk_set_last_rec_kernel(names[cell == 1][NW == 2 ? 2 : NKX == 16]);
     return 0;
 }

@@ -243,6 +243,7 @@ static int core_try_lstm_rr(rec_core *c, int use_bh, const int *acts, const rr_i
     if (xm < 0) return -1;
     if (xm == 2) return 1;
     size_t img = nntk_shim_rr_image_floats_xf(c->H, c->in);
+    if (nntk_shim_fk_image_floats(c->H, c->in) && !c->d_rr4) c->rr_valid = 0;      /* (option rec_fk switched on after the images were packed) */
     if (!c->rr_valid) {
         if (!c->d_rr && !(c->d_rr = (float *)nntk_shim_malloc(img * sizeof(float)))) return -1;
         if (nntk_shim_lstm_rr_pack(c->d_ut, c->d_wp, c->d_rr, c->H, c->in)) return -1;
@@ -315,6 +316,7 @@ static int core_try_gru_rr(rec_core *c, const int *acts, const rr_io *io, int B,
     const int xm = rr_input(c, io, B, &xf3);
     if (xm < 0) return -1;
     if (xm == 2) return 1;
+    if (nntk_shim_fk_image_floats(H, in) && !c->d_rr4) c->rr_valid = 0;            /* (option rec_fk switched on after the images were packed) */
     if (!c->rr_valid) {
         /* from the SHADOW, i.e. the weight version core_upload packed d_wp / d_ut from: the device-pointer calls do not look for
          * host edits (SyncWeights is their contract), and an un-synced edit must not reach this kernel alone */
@@ -406,7 +408,7 @@ static const char *core_plan(rec_core *c, int std_acts, char *buf, size_t n) {
         snprintf(buf, n, "%s: exact-f32 kernels (projection GEMM + rec_persistent_kernel, per-timestep kernels when that does not fit) -- %s", cell, why);
     else if (nntk_shim_fk_image_floats(c->H, c->in) != 0)       /* (option rec_fk = 1 and a shape that family takes) */
         snprintf(buf, n, "%s: %s_fk_kernel<16,%d,%d> (register-resident split-bf16 x 3 without split-K, input projection fused; the input is packed into frag3 form first); the stateful single-sequence call keeps the exact-f32 kernels",
-                 cell, cell, c->in <= 128 ? 8 : 16, c->in <= 128 ? 4 : 2);
+                 cell, cell, c->in <= 128 ? 8 : 16, 4);
     else
         snprintf(buf, n, "%s: %s_rr_kernel<%d,%d> (register-resident split-bf16 x 3, input projection fused)%s; the stateful single-sequence call keeps the exact-f32 kernels",
                  cell, cell, c->H <= 256 ? 4 : 8, c->in <= 64 ? 1 : c->in <= 128 ? 2 : 4,

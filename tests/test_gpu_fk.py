@@ -1,5 +1,6 @@
 """GPU parity of the full-K register-resident recurrent kernels (csrc/hip/recurrent_fk.hip: gru_fk_kernel / lstm_fk_kernel), the round-5
-answer to "a recurrent kernel without split-K" (option rec_fk = 1; not the default: measured 3-8 % behind the split-K family, DESIGN K4d).
+answer to "a recurrent kernel without split-K" (option rec_fk: the default for inputs of 129..256 channels, where it measured 7-13 % ahead
+of the split-K family; rec_fk = 1 also for 65..128 channels, where it measured 1-4 % behind -- DESIGN K4d).
 
 Reference semantics: layers/gru.c:129-187, :246-293; layers/lstm.c:185-239, :426-475.  Checked against the oracle, for repeatability (the
 LDS ring / pending-pattern hand-offs are race detectors in themselves: a stale fragment changes bits), for shards, carried state and the
@@ -29,7 +30,7 @@ def make(cell, r, I, H, seq, T):
 
 @pytest.mark.parametrize("cell,B,I,H,T,seq", [
     ("gru", 64, 128, 256, 20, True),        # configs[3] layer 1: four wavefronts share a 32-row operand
-    ("gru", 64, 256, 256, 20, True),        # configs[3] layer 2: pairs
+    ("gru", 64, 256, 256, 20, True),        # configs[3] layer 2: the default kernel of this shape
     ("lstm", 70, 128, 256, 7, True),        # ragged second row block
     ("gru", 33, 200, 192, 11, True),        # padded input, H = 192
     ("lstm", 70, 256, 160, 3, False),       # last state only; a column tile that is half outside H
@@ -123,13 +124,22 @@ def test_fk_fault_is_reported(gpu):
     lay.destroy()
 
 
-def test_kernel_plan_names_the_full_k_family_when_it_is_switched_on(gpu):
+def test_kernel_plan_names_the_full_k_family_where_it_is_the_default(gpu):
+    """rec_fk: auto = inputs of 129..256 channels (where the family measured ahead of split-K), 1 = every shape it takes, 0 = never."""
     L = capi.load()
     r = np.random.default_rng(1)
+    capi.set_option("rec_fk", "auto")
     lay, _ = make("gru", r, 256, 256, True, 4)
+    assert "gru_fk_kernel<16,16,4>" in L.GRUKernelPlan(lay.h).decode()
+    capi.set_option("rec_fk", 0)
     assert "gru_rr_kernel<4,4>" in L.GRUKernelPlan(lay.h).decode()
+    lay.destroy()
+    lay, _ = make("gru", r, 128, 256, True, 4)
+    assert "gru_rr_kernel<4,2>" in L.GRUKernelPlan(lay.h).decode()
+    capi.set_option("rec_fk", "auto")
+    assert "gru_rr_kernel<4,2>" in L.GRUKernelPlan(lay.h).decode()
     capi.set_option("rec_fk", 1)
-    assert "gru_fk_kernel<16,16,2>" in L.GRUKernelPlan(lay.h).decode()
+    assert "gru_fk_kernel<16,8,4>" in L.GRUKernelPlan(lay.h).decode()
     lay.destroy()
     lay, _ = make("lstm", r, 128, 512, True, 4)           # a shape the family does not take keeps the split-K kernel
     assert "lstm_rr_kernel<8,2>" in L.LSTMKernelPlan(lay.h).decode()

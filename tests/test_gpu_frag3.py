@@ -57,7 +57,7 @@ def test_frag3_pack_layout_and_exact_round_trip(gpu, B, T, C):
     (64, 128, 512, 12),      # the stack's LSTM shape, KH = 8 / KX = 2
     (33, 40, 128, 9),        # ragged second half-tile; in padded to 48 of 64
     (130, 100, 256, 7),      # in % 8 != 0: only the frag3 input form can feed the register-resident kernels
-    (65, 256, 256, 6),       # KX = 4 (x requests behind the poll)
+    (65, 256, 256, 6),       # 256-wide input: the full-K kernel (gru_fk / lstm_fk <16,16,4>), which reads frag3 only
     (96, 72, 320, 5),        # H between the compiled depths: k steps past H / 16 read as zeros
     (5, 8, 64, 11),          # fewer rows than one half-tile
 ])
@@ -76,7 +76,7 @@ def test_recurrent_frag3_routes_equal_the_f32_route_bit_for_bit(gpu, cell, B, I,
     base = layer.apply_device(xd).clone()                               # the f32 route (oracle-checked below)
     x3 = NL.frag3_pack_device(xd)
     o_a, f_a = NL.recurrent_apply_device_frag3(layer, x=xd, want_f32=True, want_f3=True)
-    assert L.nntk_hip_last_recurrent_kernel().decode().startswith(cell + "_rr_kernel")
+    assert L.nntk_hip_last_recurrent_kernel().decode().startswith(cell + ("_fk_kernel" if (I, H) == (256, 256) else "_rr_kernel"))
     o_b, f_b = NL.recurrent_apply_device_frag3(layer, x_f3=x3, batch=B, want_f32=True, want_f3=True)
     _, f_c = NL.recurrent_apply_device_frag3(layer, x_f3=x3, batch=B, want_f32=False, want_f3=True)
     assert torch.equal(o_a, base) and torch.equal(o_b, base)
@@ -175,7 +175,7 @@ def test_kernel_plan_names_the_kernel_family_and_the_reason(gpu):
     import torch
     L = capi.load()
     r = rng(3)
-    cases = [("lstm", 128, 512, "lstm_rr_kernel<8,2>"), ("gru", 256, 256, "gru_rr_kernel<4,4>"), ("lstm", 100, 128, "frag3"),
+    cases = [("lstm", 128, 512, "lstm_rr_kernel<8,2>"), ("gru", 256, 256, "gru_fk_kernel<16,16,4>"), ("gru", 128, 256, "gru_rr_kernel<4,2>"), ("lstm", 100, 128, "frag3"),
              ("lstm", 24, 40, "H % 16"), ("gru", 300, 512, "wider"), ("lstm", 8, 640, "outside")]
     for cell, I, H, want in cases:
         layer = NL.LSTM(I, H, True, 4, v2=True) if cell == "lstm" else NL.GRU(I, H, True, 4)
@@ -184,8 +184,10 @@ def test_kernel_plan_names_the_kernel_family_and_the_reason(gpu):
         plan = (L.LSTMKernelPlan if cell == "lstm" else L.GRUKernelPlan)(layer.h).decode()
         assert want in plan, plan
         layer.apply_device(torch.from_numpy(u(r, 3, 4, I)).cuda())
-        ran_rr = L.nntk_hip_last_recurrent_kernel().decode().startswith(cell + "_rr_kernel")
-        assert ran_rr == ("_rr_kernel" in plan), (plan, L.nntk_hip_last_recurrent_kernel())
+        ran = L.nntk_hip_last_recurrent_kernel().decode()
+        assert ran.startswith((cell + "_rr_kernel", cell + "_fk_kernel")) == ("_rr_kernel" in plan or "_fk_kernel" in plan), (plan, ran)
+        if "_kernel<" in want:
+            assert ran == want, (ran, want)
         layer.destroy()
 
 

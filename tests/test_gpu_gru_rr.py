@@ -52,6 +52,7 @@ def _both(layer, xd):
 def test_gru_rr_matches_oracle(gpu, B, I, H, T, seq):
     import torch
     L = capi.load()
+    capi.set_option("rec_fk", 0)      # this file covers the split-K family on all its shapes (tests/test_gpu_fk.py: the full-K one)
     r = rng(B * 17 + H + T + I)
     x = u(r, B, T, I)
     W, U, bi, bh = gru_weights(r, I, H)
@@ -130,8 +131,9 @@ def test_gru_rr_weight_edits_repack_the_image(gpu):
 
 
 def test_gru_stack2_takes_the_rr_pair_and_equals_two_calls(gpu):
-    """GRUStack2ApplyDevice on shapes both layers' rr kernels take: two launches (layer 1, layer 2), bit-identical to the two
-    layer calls; rec_fused2 = 1 brings the fused exact-f32 kernel back (same tolerance, other bits)."""
+    """GRUStack2ApplyDevice on shapes both layers' register-resident kernels take: two launches (layer 1 on the split-K kernel, the
+    256-wide layer 2 on the full-K one since round 5; rec_fk = 0 keeps both on split-K), bit-identical to the two layer calls;
+    rec_fused2 = 1 brings the fused exact-f32 kernel back (same tolerance, other bits)."""
     import torch
     L = capi.load()
     r = rng(31)
@@ -142,11 +144,17 @@ def test_gru_stack2_takes_the_rr_pair_and_equals_two_calls(gpu):
     g1.set_weights(*w1); g2.set_weights(*w2)
     xd = torch.from_numpy(x).cuda()
     got = NL.gru_stack2_apply_device(g1, g2, xd).clone()
-    assert L.nntk_hip_last_recurrent_kernel().decode() == "gru_rr_kernel<4,4>"
+    assert L.nntk_hip_last_recurrent_kernel().decode() == "gru_fk_kernel<16,16,4>"
     two = g2.apply_device(g1.apply_device(xd).clone()).clone()
     assert torch.equal(got, two)
     ref = O.gru(O.gru(x, *w1), *w2)
     np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    capi.set_option("rec_fk", 0)
+    old = NL.gru_stack2_apply_device(g1, g2, xd).clone()
+    assert L.nntk_hip_last_recurrent_kernel().decode() == "gru_rr_kernel<4,4>"
+    assert torch.equal(old, g2.apply_device(g1.apply_device(xd).clone()))
+    capi.set_option("rec_fk", "auto")
+    np.testing.assert_allclose(old.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
     capi.set_option("rec_fused2", 1)
     fused = NL.gru_stack2_apply_device(g1, g2, xd).clone()
     assert L.nntk_hip_last_recurrent_kernel().decode().startswith("gru2_persistent_kernel")
@@ -182,7 +190,7 @@ def test_gru_rr_long_recurrence_error_at_config4_shape(gpu):
 @pytest.mark.parametrize("B,I,H,T", [(64, 256, 256, 15), (40, 160, 128, 9)])
 def test_lstm_rr_wide_input(gpu, B, I, H, T):
     """lstm_rr_kernel<4, 4>: inputs of 129..256 channels at H <= 256 (the W images take 96 KB of LDS, U's low image moves to
-    registers)."""
+    registers).  Since round 5 the default for 128 < H <= 256 is the full-K kernel; rec_fk = 0 pins this one."""
     import torch
     L = capi.load()
     r = rng(B + I + H)
@@ -191,7 +199,9 @@ def test_lstm_rr_wide_input(gpu, B, I, H, T):
     lstm = NL.LSTM(I, H, True, T, v2=True)
     lstm.set_weights(W, U, bi, bh)
     xd = torch.from_numpy(x).cuda()
+    capi.set_option("rec_fk", 0)
     got = lstm.apply_device(xd).cpu().numpy()
+    capi.set_option("rec_fk", "auto")
     assert L.nntk_hip_last_recurrent_kernel().decode() == "lstm_rr_kernel<4,4>"
     ref = O.lstm(x, W, U, bi, bh, v2=True)
     ref = ref[0] if isinstance(ref, tuple) else ref
@@ -199,15 +209,17 @@ def test_lstm_rr_wide_input(gpu, B, I, H, T):
     lstm.destroy()
 
 
-@pytest.mark.parametrize("cell,I,H", [("gru", 128, 256), ("gru", 256, 256), ("lstm", 128, 512), ("lstm", 64, 128)])
-def test_rr_stale_hand_off_of_another_input_is_never_taken_for_data(gpu, cell, I, H):
+@pytest.mark.parametrize("cell,I,H,fam", [("gru", 128, 256, "rr"), ("gru", 256, 256, "rr"), ("gru", 256, 256, "fk"), ("lstm", 256, 256, "fk"),
+                                          ("lstm", 128, 512, "rr"), ("lstm", 64, 128, "rr")])
+def test_rr_stale_hand_off_of_another_input_is_never_taken_for_data(gpu, cell, I, H, fam):
     """the T-deep hand-off of a launch still holds the VALID-looking fragments of the launch before it, and the repeat / shard
     tests relaunch the same input into the same scratch, where a stale block equals the right one.  Here two DIFFERENT inputs alternate
     through one layer (same hand-off scratch, the caller-visible frag3 output included): a consumer that took a stale block for data -- a
     pending mark that arrived late, a flag that overtook its data -- would mix in the other input's bits.  Both protocols: the pending
-    pattern (H <= 256) and the flag words (H = 512)."""
+    pattern (H <= 256) and the flag words (H = 512); both families on the 256-wide shapes (the full-K one is their default)."""
     import torch
     L = capi.load()
+    capi.set_option("rec_fk", "auto" if fam == "fk" else 0)
     r = rng(H + I)
     B, T = 128, 60
     G = 4 if cell == "lstm" else 3
@@ -219,7 +231,7 @@ def test_rr_stale_hand_off_of_another_input_is_never_taken_for_data(gpu, cell, I
     f3 = da.new_empty(L.nntk_frag3_floats(B, T, H))
     first_a, _ = NL.recurrent_apply_device_frag3(lay, x=da, want_f32=True, out_f3=f3)
     first_a = first_a.clone()
-    assert L.nntk_hip_last_recurrent_kernel().decode().startswith(cell + "_rr_kernel")
+    assert L.nntk_hip_last_recurrent_kernel().decode().startswith(cell + "_" + fam + "_kernel")
     first_b, _ = NL.recurrent_apply_device_frag3(lay, x=db, want_f32=True, out_f3=f3)
     first_b = first_b.clone()
     for _ in range(3):
@@ -232,6 +244,7 @@ def test_rr_stale_hand_off_of_another_input_is_never_taken_for_data(gpu, cell, I
     for xx, got in ((xa, first_a), (xb, first_b)):
         ref = ofn(xx, W, U, bi, bh, **({"v2": True} if cell == "lstm" else {}))
         np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    capi.set_option("rec_fk", "auto")
     lay.destroy()
 
 

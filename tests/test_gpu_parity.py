@@ -604,10 +604,11 @@ def test_full_size_config4_two_layer_gru(gpu):
     assert y.shape == (B, T, H)
     # the kernel behind bench.py's config-4 line: both layers in ONE persistent launch (gru2_persistent_kernel), at the
     # benchmark's own size -- 16 batch tiles x 16 column tiles = all 256 CUs, 1000 steps
-    # ... and the stack call's default since round 3: two launches of gru_rr_kernel (the bench's config-4 kernels)
+    # ... and the stack call's default since round 3: two register-resident launches (the bench's config-4 kernels: gru_rr_kernel<4,2>
+    # for the 128-wide layer 1, and since round 5 the full-K gru_fk_kernel<16,16,4> for the 256-wide layer 2)
     L = capi.load()
     yr = NL.gru_stack2_apply_device(g1, g2, x).clone()
-    assert L.nntk_hip_last_recurrent_kernel().decode() == "gru_rr_kernel<4,4>" and torch.equal(yr, y)
+    assert L.nntk_hip_last_recurrent_kernel().decode() == "gru_fk_kernel<16,16,4>" and torch.equal(yr, y)
     # race detector for the hand-off without flags (pending pattern, H <= 256) at the full grid of 256 workgroups: a second run and a
     # 512-row shard (another set of batch tiles, half the workgroups) equal the first run bit for bit over the whole batch
     assert torch.equal(NL.gru_stack2_apply_device(g1, g2, x), yr)

@@ -24,7 +24,9 @@ NNTK_REC_FUSED2=1 timeout -k 10 300 python bench.py --workload gru --no-cpu-base
 timeout -k 10 300 python bench.py --batch-per-gpu 4096 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_stack_b4096.json 2> $O/bench_stack_b4096.err; tail -c 300 $O/bench_stack_b4096.json; echo
 NNTK_BENCH_STACK_F32=1 NNTK_REC_XF=0 timeout -k 10 300 python bench.py --no-cpu-baseline > $O/bench_stack_f32route.json 2> /dev/null; tail -c 200 $O/bench_stack_f32route.json; echo
 NNTK_CONV_FLATK=0 timeout -k 10 300 python bench.py --workload conv --no-cpu-baseline > $O/bench_conv_chunked.json 2> /dev/null; tail -c 200 $O/bench_conv_chunked.json; echo
-NNTK_REC_FK=1 timeout -k 10 300 python bench.py --workload gru --no-cpu-baseline > $O/bench_gru_fk.json 2> /dev/null; tail -c 200 $O/bench_gru_fk.json; echo
+# the GRU pair with the full-K family off (both layers split-K: the round-4 default) and on for every shape it takes (layer 1 too)
+NNTK_REC_FK=0 timeout -k 10 300 python bench.py --workload gru --no-cpu-baseline > $O/bench_gru_fk0.json 2> /dev/null; tail -c 200 $O/bench_gru_fk0.json; echo
+NNTK_REC_FK=1 timeout -k 10 300 python bench.py --workload gru --no-cpu-baseline > $O/bench_gru_fk1.json 2> /dev/null; tail -c 200 $O/bench_gru_fk1.json; echo
 fi
 [ "$PART" = bench ] && { ls $O; exit 0; }
 cd /tmp && export TMPDIR=/tmp

@@ -12,8 +12,7 @@ def main():
     import oracle as O
     from nntoolkitcore_amd import capi, layers as NL
     torch.cuda.set_device(0); L = capi.load(); NL.use_torch_stream()
-    if os.environ.get("NNTK_REC_FK", "1") != "0":
-        capi.set_option("rec_fk", 1)
+    capi.set_option("rec_fk", int(os.environ.get("NNTK_REC_FK", "1")))
     r = np.random.default_rng(11)
     u = lambda *sh, sc=1.0: r.uniform(-sc, sc, sh).astype(np.float32)
     bad = 0

@@ -12,8 +12,7 @@ def main():
     import torch
     from nntoolkitcore_amd import capi, layers as NL
     torch.cuda.set_device(0); capi.load(); NL.use_torch_stream()
-    if os.environ.get("NNTK_REC_FK", "1") != "0":
-        capi.set_option("rec_fk", 1)
+    capi.set_option("rec_fk", int(os.environ.get("NNTK_REC_FK", "1")))
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     T = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     kind = sys.argv[3] if len(sys.argv) > 3 else "gru"
@@ -51,6 +50,11 @@ def main():
     lab = ["own0-2+ring_get+look", "branch", "own3-5+ring_put"] + ["partner%d" % j for j in range(1, nw)]
     f = d[:, 48:48 + len(lab) + 1]
     print("inside group 2 (s_memtime, no waits): " + "  ".join("%s %.0f" % (lab[i], (f[:, i + 1] - f[:, i]).mean()) for i in range(len(lab))))
+    if os.environ.get("FK_COARSE_GS"):
+        g = int(os.environ["FK_COARSE_GS"])
+        pts = [g, 40, 41] + [41 + j for j in range(1, nw)]
+        lab = ["block a + branch", "block b"] + ["partner%d" % j for j in range(1, nw)]
+        print("inside group %d (stamps with a store each, ~70 cycles apiece): " % g + "  ".join("%s %.0f" % (lab[i], (d[:, pts[i + 1]] - d[:, pts[i]]).mean()) for i in range(len(lab))))
     lay.destroy()
 
 

@@ -11,8 +11,7 @@ def main():
     import torch
     from nntoolkitcore_amd import capi, layers as NL
     torch.cuda.set_device(0); L = capi.load(); NL.use_torch_stream()
-    if os.environ.get("NNTK_REC_FK", "1") != "0":
-        capi.set_option("rec_fk", 1)
+    capi.set_option("rec_fk", int(os.environ.get("NNTK_REC_FK", "1")))
     reps = 7
     args = sys.argv[1:]
     if args and args[0] == "--reps":

@@ -16,7 +16,7 @@ def main():
     for path in glob.glob(d + "/*/*counter_collection.csv"):
         for row in csv.DictReader(open(path)):
             name = row["Kernel_Name"].split("(")[0].replace("void ", "")
-            if not any(t in name for t in ("rec_", "gru2_", "lstm_rr", "gru_rr", "conv1d", "spectrogram", "bptt_", "outer_mfma", "dense_frag3", "frag3_pack")):
+            if not any(t in name for t in ("rec_", "gru2_", "lstm_rr", "gru_rr", "lstm_fk", "gru_fk", "conv1d", "spectrogram", "bptt_", "outer_mfma", "dense_frag3", "frag3_pack")):
                 continue
             key = "%s grid=%d" % (name, int(row["Grid_Size"]))
             vals[key][row["Counter_Name"]].append(float(row["Counter_Value"]))

@@ -38,7 +38,7 @@ def main():
                    "for narrower reads it is an upper bound on the read side.",
            "workload": workload, "utterances_per_gpu": B, "source_hash": source_hash(), "kernels": {}}
     for k, v in f.items():
-        if not any(t in k for t in ("rec_", "gru2_", "lstm_rr", "gru_rr", "conv1d", "spectrogram", "bptt_", "outer_mfma", "dense_frag3", "frag3_pack")) or k not in w:
+        if not any(t in k for t in ("rec_", "gru2_", "lstm_rr", "gru_rr", "lstm_fk", "gru_fk", "conv1d", "spectrogram", "bptt_", "outer_mfma", "dense_frag3", "frag3_pack")) or k not in w:
             continue
         fv, wv = sum(v) / len(v), sum(w[k]) / len(w[k])
         out["kernels"][k] = {"FETCH_SIZE_KiB": round(fv, 1), "WRITE_SIZE_KiB": round(wv, 1),

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Do the register-resident recurrent kernels ever ask for a byte outside the tensors they were given?
 
-Builds a diagnostics copy of the library with recurrent_rr.hip compiled -DNNTK_RR_BOUNDS (every request towards a caller-visible
+Builds a diagnostics copy of the library with recurrent_rr.hip and recurrent_fk.hip compiled -DNNTK_RR_BOUNDS (every request towards a caller-visible
 tensor records the last byte it really touches; lanes the buffer range check drops are skipped, as the hardware skips them), runs
 GRU / LSTM layers whose last batch tile is ragged (B = 33, 65, 130: a tile with one row in its second half, one row in its first
 half, a half-empty tile) through every input / output form, and compares the recorded extents with the tensors' sizes.
@@ -23,12 +23,15 @@ def build():
     sys.path.insert(0, ROOT)
     from nntoolkitcore_amd import _build
     _build.build()                                                   # the product objects (up to date on the GPU box: they travel)
-    obj = os.path.join(OUT, "recurrent_rr_bounds.o")
-    src = os.path.join(_build.CSRC, "hip", "recurrent_rr.hip")
-    subprocess.check_call([_build.HIPCC, "-O3", "--offload-arch=" + _build.ARCH, "-fPIC", "-std=c++17", "-Wno-unused-function",
-                           "-DNNTK_RR_BOUNDS", "-c", src, "-o", obj])
-    others = [o for o in glob.glob(os.path.join(_build.OBJ, "*.o")) if not o.endswith("recurrent_rr.hip.o")]
-    subprocess.check_call([_build.HIPCC, "--offload-arch=" + _build.ARCH, "-shared", "-fPIC", "-o", LIB, obj] + others)
+    objs, procs = [], []
+    for unit in ("recurrent_rr.hip", "recurrent_fk.hip"):            # both register-resident families record their requests
+        obj = os.path.join(OUT, unit[:-4] + "_bounds.o")
+        objs.append(obj)
+        procs.append(subprocess.Popen([_build.HIPCC, "-O3", "--offload-arch=" + _build.ARCH, "-fPIC", "-std=c++17", "-Wno-unused-function",
+                                       "-DNNTK_RR_BOUNDS", "-c", os.path.join(_build.CSRC, "hip", unit), "-o", obj]))
+    assert all(p.wait() == 0 for p in procs)
+    others = [o for o in glob.glob(os.path.join(_build.OBJ, "*.o")) if not o.endswith(("recurrent_rr.hip.o", "recurrent_fk.hip.o"))]
+    subprocess.check_call([_build.HIPCC, "--offload-arch=" + _build.ARCH, "-shared", "-fPIC", "-o", LIB] + objs + others)
 
 
 def run():
@@ -62,15 +65,17 @@ def run():
                 src, dst = route.split("->")
                 NL.recurrent_apply_device_frag3(layer, x=x if src == "f32" else None, x_f3=x3 if src == "frag3" else None, batch=B,
                                                 want_f32=dst == "f32", want_f3=dst == "frag3")
-                assert L.nntk_hip_last_recurrent_kernel().decode().startswith(cell + "_rr_kernel")
+                kern = L.nntk_hip_last_recurrent_kernel().decode()
+                assert kern.startswith((cell + "_rr_kernel", cell + "_fk_kernel")), kern
+                fk = "_fk_kernel" in kern                              # (the full-K family reads frag3 only: an f32 input is packed first)
                 got = (C.c_ulonglong * 8)()
                 assert fetch(got) == 0
                 got = list(got)[:5]
                 ok = all(g <= lim for g, lim in zip(got, limits))
                 # the instrument is alive: the forms in use reach exactly the end of their tensors (the last row's last bytes)
-                live = (got[0] == limits[0]) if src == "f32" else (got[1] > 0 and got[0] == 0)
+                live = (got[0] == limits[0]) if (src == "f32" and not fk) else (got[1] > 0 and got[0] == 0)
                 live = live and ((got[2] == limits[2]) if dst == "f32" else got[2] == 0) and got[3] > 0 and got[4] > 0
-                print("%s B=%d in=%d H=%d T=%d %-12s %s%s" % (cell, B, I, H, T, route,
+                print("%s B=%d in=%d H=%d T=%d %-12s %-22s %s%s" % (cell, B, I, H, T, route, kern,
                       "  ".join("%s %d/%d" % (n, g, lim) for n, g, lim in zip(names, got, limits)),
                       "" if ok and live else "   <-- %s" % ("OUT OF BOUNDS" if not ok else "instrument silent")))
                 bad += (not ok) or (not live)
