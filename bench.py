@@ -203,6 +203,11 @@ class Workload:
                 self.lstm_out = torch.empty((B, Tc, 512), device=dev)
             else:
                 self.lstm_f3 = torch.empty(capi_lib().nntk_frag3_floats(B, Tc, 512), device=dev)
+            # ... and the conv layer hands ITS output to the LSTM in frag3 form too, written by the conv kernel's epilogue
+            # (Conv1dBatchNormActivationApplyDeviceFrag3); NNTK_BENCH_CONV_F32=1: f32 tensor + the LSTM call's pack pass, as round 4 did
+            self.conv_f3_route = not self.f32_route and not bool(int(os.environ.get("NNTK_BENCH_CONV_F32", "0")))
+            if self.conv_f3_route:
+                self.conv_f3 = torch.empty(capi_lib().nntk_frag3_floats(B, Tc, 128), device=dev)
         if name == "gru":
             self.g1 = NL.GRU(128, 256, True, frames)
             self.g2 = NL.GRU(256, 256, True, frames)
@@ -230,14 +235,20 @@ class Workload:
             self.spec.apply_device(self.x, out=self.spec_out)
             mark("spectrogram")
         if self.name == "stack":
-            self.conv.apply_device(self.spec_out, out=self.conv_out, bn=self.bn, act=self.relu)
+            if self.conv_f3_route:
+                self.conv.apply_device_frag3(self.spec_out, out_f3=self.conv_f3, bn=self.bn, act=self.relu)
+            else:
+                self.conv.apply_device(self.spec_out, out=self.conv_out, bn=self.bn, act=self.relu)
             mark("conv_bn_relu")
             if self.f32_route:
                 self.lstm.apply_device(self.conv_out, out=self.lstm_out)
                 mark("lstm")
                 self.tdd.apply_device(self.lstm_out, out=self.tdd_out)
             else:       # = LSTMTimeDistributedDenseApplyDevice, as its two halves so that each gets its own HIP-event phase
-                self.NL.recurrent_apply_device_frag3(self.lstm, x=self.conv_out, want_f32=False, out_f3=self.lstm_f3)
+                if self.conv_f3_route:
+                    self.NL.recurrent_apply_device_frag3(self.lstm, x_f3=self.conv_f3, batch=self.B, want_f32=False, out_f3=self.lstm_f3)
+                else:
+                    self.NL.recurrent_apply_device_frag3(self.lstm, x=self.conv_out, want_f32=False, out_f3=self.lstm_f3)
                 mark("lstm")
                 self.NL.tdd_apply_device_frag3(self.tdd, self.lstm_f3, self.B, out=self.tdd_out)
             mark("tdd")
@@ -655,6 +666,9 @@ def main():
             "parallelism": "utterance shards, dp%d, no data-path collective" % world,
             "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
             "ranks_seen": ranks_seen,
+            "conv_to_lstm": ("frag3 tensor written by the conv kernel's epilogue (Conv1dBatchNormActivationApplyDeviceFrag3; no pack pass); "
+                             "bit-identical to the f32 route" if getattr(wl, "conv_f3_route", False) else
+                             "f32 tensor, packed into frag3 form inside the LSTM call") if a.workload == "stack" else None,
             "lstm_to_tdd": ("f32 tensor" if getattr(wl, "f32_route", True) else
                             "frag3 tensor: the LSTM kernel's T-deep hand-off buffer (h already split into three bf16 images, MFMA fragment order) "
                             "is the dense GEMM's A operand; bit-identical to the f32 route") if a.workload == "stack" else None,

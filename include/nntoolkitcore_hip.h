@@ -425,6 +425,10 @@ int         nntk_hip_device_status(void);
  * resident split-bf16 LSTM with the fused input projection), "rec_persistent_kernel<4,LSTM>", "gru2_persistent_kernel<8>",
  * "rec_step_kernel<3,GRU>", ...  Diagnostics: which of the paths described under "rec_rr" / "rec_persistent" a call took. */
 const char *nntk_hip_last_recurrent_kernel(void);
+/* The same for the Conv1d / Dense / TimeDistributedDense GEMM kernels: "conv1d_mfma_bf16x3_kernel", "conv1d_mfma_bf16x3_kernel<frag3>"
+ * (the frag3 epilogue of Conv1dBatchNormActivationApplyDeviceFrag3), "conv1d_flatk_bf16x3_kernel", "conv1d_mfma_kernel" (exact f32),
+ * "conv1d_valu_kernel". */
+const char *nntk_hip_last_conv_kernel(void);
 /* Optional HIP-event spans around the recurrent kernel launches (name "rec_step"): enable,
  * run, then read the summed milliseconds, the number of kernel launches and the timesteps they
  * covered (a persistent launch covers all T of a sequence).  Reading clears the spans. */
@@ -548,6 +552,13 @@ const char *LSTMKernelPlan(LSTM filter);
 int GRUApplyDeviceFrag3(GRU filter, const float *d_input, const float *d_input_frag3, float *d_output, float *d_output_frag3, int batch);
 int LSTMApplyDeviceFrag3(LSTM filter, const float *d_input, const float *d_input_frag3, float *d_output, float *d_output_frag3, int batch);
 int TimeDistributedDenseApplyDeviceFrag3(TimeDistributedDense filter, const float *d_input_frag3 /*[batch,ts,in]*/, float *d_output, int batch);
+/* Conv1d -> BatchNorm -> activation (bn / act may be NULL) with the output as a frag3 tensor [batch][Tout][Cout]
+ * (nntk_frag3_floats(batch, Tout, Cout) floats), written by the conv kernel's epilogue: the layer in front of a recurrent layer
+ * hands over the operand form directly (reference seam: layers/conv_1d.c:122-147 -> layers/lstm.c:201).  Equals
+ * Conv1dBatchNormActivationApplyDevice -> nntk_frag3_pack_device bit for bit; valid for every layer (shapes the epilogue does not take
+ * -- stride != 1, kernel_size > 9 -- run those two calls through scratch in the handle). */
+int Conv1dBatchNormActivationApplyDeviceFrag3(Conv1d filter, BatchNorm bn, ActivationFunction act,
+                                              const float *d_input /*[batch,T,Cin]*/, float *d_output_frag3, int batch);
 int LSTMTimeDistributedDenseApplyDevice(LSTM lstm, TimeDistributedDense tdd, const float *d_input /*[batch,T,in]*/,
                                         float *d_output /*[batch,T,out]*/, int batch);
 int DenseApplyDevice(Dense filter, const float *d_input /*[rows,in]*/, float *d_output /*[rows,out]*/, int rows);

@@ -288,6 +288,7 @@ SIGNATURES = {
     "nntk_hip_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "nntk_hip_device_status": (C.c_int, []),
     "nntk_hip_last_recurrent_kernel": (C.c_char_p, []),
+    "nntk_hip_last_conv_kernel": (C.c_char_p, []),
     "nntk_hip_profile_enable": (None, [C.c_int]),
     "nntk_hip_profile_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "nntk_device_alloc": (vp, [C.c_size_t]),
@@ -330,6 +331,7 @@ SIGNATURES = {
     "SpectrogramApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
     "Conv1dApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
     "Conv1dBatchNormActivationApplyDevice": (C.c_int, [vp, vp, vp, vp, vp, C.c_int]),
+    "Conv1dBatchNormActivationApplyDeviceFrag3": (C.c_int, [vp, vp, vp, vp, vp, C.c_int]),
     "BatchNormApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
     "ActivationFunctionApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),
     "GRUApplyDevice": (C.c_int, [vp, vp, vp, C.c_int]),

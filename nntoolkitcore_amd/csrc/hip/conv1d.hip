@@ -188,6 +188,7 @@ extern "C" int nntk_shim_conv1d(const float *d_in, const float *d_wp, const floa
         if (g > 4096) g = 4096;
         hipLaunchKernelGGL(conv1d_valu_kernel, dim3((unsigned)g), dim3(256), 0, nntk_stream(), p);
         NNTK_LAUNCH_CHECK("conv1d_valu_kernel");
+        nntk_set_last_conv_kernel("conv1d_valu_kernel");
         return 0;
     }
     // 16-byte window loads need only 4-byte alignment (MUBUF dwordx4), so odd channel counts take them too; the pieces
@@ -230,4 +231,47 @@ extern "C" int nntk_shim_conv1d(const float *d_in, const float *d_wp, const floa
     if (p.Cout_p % 128 == 0) return a4 ? launch_mfma<2, 2, 2, 2, true>(p) : launch_mfma<2, 2, 2, 2, false>(p);
     if (p.Cout_p % 64 == 0)  return a4 ? launch_mfma<4, 1, 1, 2, true>(p) : launch_mfma<4, 1, 1, 2, false>(p);
     return a4 ? launch_mfma<4, 1, 1, 1, true>(p) : launch_mfma<4, 1, 1, 1, false>(p);
+}
+
+// Conv1d (+ BatchNorm + activation) whose output leaves as a frag3 tensor [Tout][2 ceil(B / 64)][ceil(Cout / 16)][3][1 KB] -- the operand
+// form of the register-resident recurrent kernels and of dense_frag3_kernel -- instead of f32 [B][Tout][Cout] (conv_epilogue_frag3).
+// Returns 1 when this form does not take the call (the caller then runs conv -> f32 scratch -> nntk_shim_frag3_pack: same bits):
+// stride != 1, a window of 8 x (15 + k) rows past the staging budget (k > 9), the exact-f32 contraction (option or weights the split
+// cannot hold), fewer than 32 output channels.
+extern "C" int nntk_shim_conv1d_frag3(const float *d_in, const float *d_wp, const float *d_bias, const float *d_bn,
+                                      float bn_eps, int act_kind, float relu_a, float *d_out_f3,
+                                      int B, int T, int Cin, int Cout, int k, int stride, int Tout) {
+    if (B <= 0 || Tout <= 0) return 0;
+    if (act_kind == NNTK_ACT_SOFTMAX || act_kind == NNTK_ACT_CUSTOM)
+        return nntk_fail_msg("conv1d epilogue: softmax/custom activations are not fusable");
+    if (act_kind == NNTK_ACT_NONE) act_kind = NNTK_ACT_IDENTITY;
+    const NntkOptions &opt = nntk_options();
+    if (opt.conv_frag3_out == 0) return 1;
+    ConvParams p;
+    p.in = d_in; p.wp = d_wp; p.bias = d_bias; p.bn = d_bn; p.out = d_out_f3;
+    p.bn_eps = bn_eps; p.relu_a = relu_a; p.act_kind = act_kind;
+    p.B = B; p.T = T; p.Cin = Cin; p.Cout = Cout; p.k = k; p.stride = stride; p.Tout = Tout;
+    p.in_seq = (long)T * Cin; p.in_row = Cin;
+    nntk_shim_conv_pack_sizes(Cin, Cout, k, &p.Cin_p, &p.Cout_p);
+    p.tiles_per_seq = (Tout + CONV_F3_TT - 1) / CONV_F3_TT;
+    p.out_mode = 0;
+    p.rows_a = CONV_F3_BB * (CONV_F3_TT + k - 1);
+    p.bn_fast = opt.bn_fast == 1 ? 1 : 0;
+    p.store16 = 1; p.quad = 1;
+    p.f3_nht = (B + 63) / 64 * 2; p.f3_nks = (Cout + 15) / 16;
+#ifdef NNTK_CONV_DBG
+    p.dbg = opt.conv_dbg;
+#endif
+    const long Kdim = (long)Cin * k;
+    const bool split = (opt.gemm_split_bf16 < 0 && !nntk_weights_exact_only(d_wp)) || opt.gemm_split_bf16 == 1 ||
+                       (opt.gemm_split_bf16 == 2 && k > 1) || (opt.gemm_split_bf16 == 3 && k == 1);
+    if (!split || stride != 1 || p.rows_a > 192 || Kdim < 16 || Cout < 32) return 1;
+    if ((long)p.Cout_p * k * p.Cin_p * 6 >= (long)CONV_OOB) return 1;
+    if ((double)Tout * p.f3_nht * p.f3_nks * 3 * 1024 >= (double)CONV_OOB) return 1;            // 32-bit offsets into the frag3 tensor
+    if (((long)(CONV_F3_BB - 1) * T + CONV_F3_TT + k) * Cin * 4 >= (long)CONV_OOB) return 1;    // ... and into the tile's eight windows
+    const bool a4 = ((Cin % 4 == 0) && ((size_t)d_in % 16 == 0)) || opt.conv_a4 != 0;
+    // (same instantiation per Cout as the f32 form: same products in the same order)
+    if (p.Cout_p % 128 == 0) return a4 ? launch_mfma_f3<2, 2, 2, 2, true>(p) : launch_mfma_f3<2, 2, 2, 2, false>(p);
+    if (p.Cout_p % 64 == 0)  return a4 ? launch_mfma_f3<4, 1, 1, 2, true>(p) : launch_mfma_f3<4, 1, 1, 2, false>(p);
+    return a4 ? launch_mfma_f3<4, 1, 1, 1, true>(p) : launch_mfma_f3<4, 1, 1, 1, false>(p);
 }

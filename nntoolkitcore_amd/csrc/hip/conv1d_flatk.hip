@@ -215,5 +215,6 @@ extern "C" int nntk_shim_conv1d_flatk(const float *d_in, const float *d_wpf, con
     if (lds > 64 * 1024 && nntk_set_max_dynamic_lds((const void *)kern, lds)) return -1;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, nntk_stream(), p, KS);
     NNTK_LAUNCH_CHECK("conv1d_flatk_bf16x3_kernel");
+    nntk_set_last_conv_kernel("conv1d_flatk_bf16x3_kernel");
     return 0;
 }

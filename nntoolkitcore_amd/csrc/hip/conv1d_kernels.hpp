@@ -28,6 +28,7 @@ struct ConvParams {
     int bn_fast;         // A/B: multiply by 1/sd instead of the reference's divide
     int store16;         // Cout % 4 == 0 and out 16-byte aligned: 16-byte stores of channel quads
     int quad;            // which accumulator orientation / epilogue (host choice, see conv_epilogue_rows)
+    int f3_nht, f3_nks;  // frag3 output (conv1d_mfma_bf16x3_kernel<.., F3OUT>): row blocks 2 ceil(B / 64), k steps ceil(Cout / 16)
 #ifdef NNTK_CONV_DBG
     int dbg;             // timing experiments only: 1 no stores, 2 no MFMAs, 4 no global loads in the loop
 #endif
@@ -274,6 +275,127 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvParams &p, f32x16 (
     }
 }
 
+// ---- frag3 epilogue (F3OUT): the layer output leaves as the NEXT layer's MFMA operand ---------------------------------------------
+// out = frag3 tensor [Tout][2 ceil(B / 64)][ceil(Cout / 16)][3] blocks of 1 KB (frag3.hip): block = 32 batch rows x 16 channels, lane
+// 32 kh' + n = 8 consecutive bf16 channels of batch row n.  A row block needs 32 UTTERANCES of one timestep, so the tile of this mode is
+// 8 utterances x 16 timesteps (tile row m = 16 bl + tl) instead of 128 timesteps of one utterance: eight rows of one block are then 128
+// contiguous bytes = one cache line, filled by this workgroup alone.  Quad orientation: a lane owns position (bl, tl) and, per 16-channel
+// k step, channels 4 kh .. 4 kh + 3 of BOTH 8-channel slots; v_permlane32_swap (gfx950) trades the half it does not store against the
+// half it lacks -- upper lanes' slot-0 registers <-> lower lanes' slot-1 registers -- after which lane 32 kh' + l31 holds exactly the 16
+// bytes of fragment lane (kh', row): one 16-byte store per k step and image, no LDS.  Values are bias + BatchNorm + activation as in
+// conv_epilogue, split as frag3_pack_kernel splits them (same instructions, fp contract off): the tensor equals
+// conv -> nntk_frag3_pack_device BIT FOR BIT (tests/test_gpu_conv_frag3.py).  Padding channels are zeros; padding rows are not written.
+typedef __bf16 cf3_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float cf3_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cf3_cvt_pk(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((cf3_f32x2){a, b}, cf3_bf16x2));
+}
+__device__ __forceinline__ void cf3_split_pair(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo) {
+#pragma clang fp contract(off)    // residuals of the ROUNDED value (frag3.hip f3_split_pair)
+    hi = cf3_cvt_pk(x0, x1);
+    const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+    mid = cf3_cvt_pk(r0, r1);
+    const float s0 = r0 - __uint_as_float(mid << 16), s1 = r1 - __uint_as_float(mid & 0xffff0000u);
+    lo = cf3_cvt_pk(s0, s1);
+}
+
+#define CONV_F3_BB 8              // utterances per tile
+#define CONV_F3_TT 16             // timesteps per tile
+
+template <int TM, int TN, int WN>
+__device__ __forceinline__ void conv_epilogue_frag3(const ConvParams &p, f32x16 (&acc)[TM][TN], int b0, int x0, int n0,
+                                                    int wm, int wn, int l31, int kh, const float *cst) {
+    constexpr int BN = WN * TN * 32;
+    const size_t total = (size_t)p.Tout * p.f3_nht * p.f3_nks * 3 * 1024;          // host: < CONV_OOB
+    const __amdgpu_buffer_rsrc_t rs_out = conv_rsrc(p.out, total);
+    auto epilogue = [&](auto bn_tag, auto act_tag) {
+        constexpr bool HAS_BN = decltype(bn_tag)::value;
+        constexpr int ACT = decltype(act_tag)::value;
+        int row_voff[TM];                        // byte offset of this lane's 16-byte slot inside block (t, row block, k step 0, image 0)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = (wm * TM + i) * 32 + l31;
+            const int b = b0 + (m >> 4), x = x0 + (m & 15);
+            row_voff[i] = (b < p.B && x < p.Tout) ? (int)((((size_t)x * p.f3_nht + (b >> 5)) * p.f3_nks * 3) * 1024) + (32 * kh + (b & 31)) * 16
+                                                  : CONV_OOB;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {                                     // 16-channel k step of the 32-channel tile
+                const int cu = n0 + (wn * TN + j) * 32 + 16 * gp;                // wave-uniform first channel of the k step
+                const bool ks_ok = cu < p.Cout;                                  // (k steps past ceil(Cout / 16) are not in the tensor)
+                const int ks_off = (cu >> 4) * 3 * 1024;
+                unsigned img[TM][2][3][2];                                       // [tile][slot][image][channel pair]
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int g = 2 * gp + s;
+                    const int cb = cu + 8 * s + 4 * kh;
+                    const int cl = (wn * TN + j) * 32 + 8 * g + 4 * kh;
+                    const float4 bias4 = *reinterpret_cast<const float4 *>(cst + cl);
+                    const float bias[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
+                    float ga[4] = {1.f, 1.f, 1.f, 1.f}, be[4] = {0.f, 0.f, 0.f, 0.f}, mu[4] = {0.f, 0.f, 0.f, 0.f},
+                          sd[4] = {1.f, 1.f, 1.f, 1.f}, rsd[4] = {1.f, 1.f, 1.f, 1.f};
+                    if (HAS_BN) {
+                        const float4 t1 = *reinterpret_cast<const float4 *>(cst + BN + cl);
+                        const float4 t2 = *reinterpret_cast<const float4 *>(cst + 2 * BN + cl);
+                        const float4 t3 = *reinterpret_cast<const float4 *>(cst + 3 * BN + cl);
+                        const float4 t4 = *reinterpret_cast<const float4 *>(cst + 4 * BN + cl);
+                        const float4 t5 = *reinterpret_cast<const float4 *>(cst + 5 * BN + cl);
+                        ga[0] = t1.x; ga[1] = t1.y; ga[2] = t1.z; ga[3] = t1.w;
+                        be[0] = t2.x; be[1] = t2.y; be[2] = t2.z; be[3] = t2.w;
+                        mu[0] = t3.x; mu[1] = t3.y; mu[2] = t3.z; mu[3] = t3.w;
+                        sd[0] = t4.x; sd[1] = t4.y; sd[2] = t4.z; sd[3] = t4.w;
+                        rsd[0] = t5.x; rsd[1] = t5.y; rsd[2] = t5.z; rsd[3] = t5.w;
+                    }
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = acc[i][j][4 * g + e] + bias[e];
+                            if (HAS_BN) {                                        // (same expressions as conv_epilogue)
+                                const float d = v[e] - mu[e];
+                                float qn = d * rsd[e];
+                                qn = fmaf(fmaf(-qn, sd[e], d), rsd[e], qn);
+                                v[e] = p.bn_fast ? (d * rsd[e]) * ga[e] + be[e] : nofma_muladd(qn, ga[e], be[e]);
+                            }
+                            v[e] = ACT == -1 ? nntk_act(p.act_kind, v[e], p.relu_a)
+                                 : ACT == NNTK_ACT_RELU ? nntk_act(NNTK_ACT_RELU, v[e], p.relu_a)
+                                 : v[e];
+                            if (cb + e >= p.Cout) v[e] = 0.0f;                   // padding channels of the last k step
+                        }
+                        cf3_split_pair(v[0], v[1], img[i][s][0][0], img[i][s][1][0], img[i][s][2][0]);
+                        cf3_split_pair(v[2], v[3], img[i][s][0][1], img[i][s][1][1], img[i][s][2][1]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int im = 0; im < 3; ++im) {
+                        // upper lanes' slot-0 halves <-> lower lanes' slot-1 halves: lane 32 kh' + l31 then holds slot kh' whole
+                        const auto s01 = __builtin_amdgcn_permlane32_swap(img[i][0][im][0], img[i][1][im][0], false, false);
+                        const auto s23 = __builtin_amdgcn_permlane32_swap(img[i][0][im][1], img[i][1][im][1], false, false);
+                        const v4u32_t pk = {s01[0], s23[0], s01[1], s23[1]};
+                        // (offsets ride in the VECTOR offset: the immediate field is too short and an SGPR soffset trips the
+                        // store hazard of conv_epilogue's note)
+                        const int vo = (ks_ok && row_voff[i] != CONV_OOB) ? row_voff[i] + ks_off + im * 1024 : CONV_OOB;
+                        __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, vo, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+    using T_ = std::true_type; using F_ = std::false_type;
+    using AId = std::integral_constant<int, NNTK_ACT_IDENTITY>;
+    using ARelu = std::integral_constant<int, NNTK_ACT_RELU>;
+    using AAny = std::integral_constant<int, -1>;
+    if (!p.bn && p.act_kind == NNTK_ACT_IDENTITY) epilogue(F_{}, AId{});
+    else if (p.bn && p.act_kind == NNTK_ACT_RELU) epilogue(T_{}, ARelu{});
+    else if (p.bn)                                epilogue(T_{}, AAny{});
+    else                                          epilogue(F_{}, AAny{});
+}
+
 // WM x WN wavefronts, each computing TM x TN MFMA tiles of 32x32.
 // A4 = the window is fetched with 16-byte loads (always, unless option conv_a4 = 0 and the rows are not 16-byte multiples).
 // QUAD: weights as the MFMA's A operand and the 16-byte quad epilogue; else window as A and the row epilogue.
@@ -507,11 +629,14 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned &hi, un
 
 #define SPLIT_ROW 96              // LDS bytes per window row: 3 images x 16 bf16
 
-template <int WM, int WN, int TM, int TN, bool A4, bool QUAD, int AMAX = 192>
+// F3OUT: the tile is 8 utterances x 16 timesteps (stride 1; the window = 8 runs of 16 + k - 1 rows) and the epilogue writes a frag3 tensor
+// (conv_epilogue_frag3); everything between staging and epilogue is the same instruction stream.
+template <int WM, int WN, int TM, int TN, bool A4, bool QUAD, int AMAX = 192, bool F3OUT = false>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16x3_kernel(ConvParams p) {
     constexpr int BN = WN * TN * 32;
     constexpr int KC = CONV_KC;
     static_assert(WM * WN == 4 && WM * TM * 32 == CONV_BM, "4 wavefronts, BM = 128");
+    static_assert(!F3OUT || QUAD, "the frag3 epilogue is written for the quad orientation");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char *lds = reinterpret_cast<char *>(smem);
     // LDS carve (bytes): window [2][rows_a][96] | weights [2][BN / 32 column tiles][3 images][1 KB fragment block]
@@ -526,13 +651,21 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16x3_kernel(ConvParams p
     const int l31 = lane & 31, kh = lane >> 5;
 
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;          // same XCD-aware tile order as the f32 kernel
+#ifndef CONV_F3_INTERLEAVED
+    // F3OUT: an XCD walks a CONTIGUOUS run of tiles -- neighbours in time are neighbouring 16-timestep blocks of the same eight utterances,
+    // whose windows share k - 1 of 15 + k rows (a quarter of the input at k = 5): those re-reads hit the XCD's own L2
+    const int tile = F3OUT ? xcd * ((p.m_tiles + 7) >> 3) + local / p.n_tiles : (local / p.n_tiles) * 8 + xcd;
+#else
     const int tile = (local / p.n_tiles) * 8 + xcd;
+#endif
     if (tile >= p.m_tiles) return;
-    const int b = tile / p.tiles_per_seq;
-    const int x0 = (tile % p.tiles_per_seq) * CONV_BM;
+    // F3OUT: b = first utterance of the tile's eight, x0 = first of its 16 timesteps
+    const int b = F3OUT ? (tile / p.tiles_per_seq) * CONV_F3_BB : tile / p.tiles_per_seq;
+    const int x0 = (tile % p.tiles_per_seq) * (F3OUT ? CONV_F3_TT : CONV_BM);
     const int n0 = (local % p.n_tiles) * BN;
     const int Ktot = p.k * p.Cin_p;
     const int ksteps = Ktot >> 4, cin_steps = p.Cin_p >> 4;
+    const int wrows = CONV_F3_TT + p.k - 1;               // F3OUT: window rows per utterance
 
     f32x16 acc[TM][TN];
 
@@ -547,7 +680,15 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16x3_kernel(ConvParams p
     v4u32_t wreg[W_CT][3];
     int a_voff[A_PT];
 #pragma unroll
-    for (int q = 0; q < A_PT; ++q) a_voff[q] = (int)(((long)(ar + q * AR_STEP) * p.in_row + ac) * 4);
+    for (int q = 0; q < A_PT; ++q) {
+        const int r = ar + q * AR_STEP;
+        if (F3OUT) {      // window row r = utterance r / wrows, its row r % wrows (rows past the utterance's end feed unstored positions only)
+            const int bl = r / wrows, tr = r - bl * wrows;
+            a_voff[q] = (r < p.rows_a && b + bl < p.B) ? (int)(((long)bl * p.in_seq + (long)tr * p.in_row + ac) * 4) : CONV_OOB;
+        } else {
+            a_voff[q] = (int)(((long)r * p.in_row + ac) * 4);
+        }
+    }
     const bool cin_ragged = (p.Cin % KC) != 0;
     const int n_cchunks = p.Cin_p / KC;
     const int n_chunks = n_cchunks * p.k;
@@ -614,6 +755,12 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16x3_kernel(ConvParams p
     };
 
     const int a_row0 = (wm * TM * 32 + l31) * p.stride;       // window row of tile i at tap kk: a_row0 + i * 32 * stride + kk
+    int a_row_f3[TM];                                         // F3OUT: tile row m = 16 bl + tl sits at window row bl * wrows + tl (+ kk)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = (wm * TM + i) * 32 + l31;
+        a_row_f3[i] = (m >> 4) * wrows + (m & 15);
+    }
     const int w_rd = w_base + (wn * TN * 3) * 1024 + lane * 16;     // this wave's first column tile, image 0
     const int w_wr = w_base + (wave * 3) * 1024 + lane * 16;
 
@@ -656,7 +803,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16x3_kernel(ConvParams p
         bf16x8_t a[3][TM], w[3][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int row = a_row0 + i * 32 * p.stride + kk;
+            const int row = F3OUT ? a_row_f3[i] + kk : a_row0 + i * 32 * p.stride + kk;
             const char *src = Ab + row * SPLIT_ROW + 16 * (kh ^ ((row >> 3) & 1));
 #pragma unroll
             for (int m = 0; m < 3; ++m)
@@ -693,10 +840,31 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16x3_kernel(ConvParams p
         cc = ncc; kk = nkk;
     }
     if (CONV_DBG(1) && acc[0][0][0] != 12345.678f) return;
-    if constexpr (QUAD) conv_epilogue<TM, TN, WN>(p, acc, b, x0, n0, wm, wn, l31, kh, cst);
+    if constexpr (F3OUT) conv_epilogue_frag3<TM, TN, WN>(p, acc, b, x0, n0, wm, wn, l31, kh, cst);
+    else if constexpr (QUAD) conv_epilogue<TM, TN, WN>(p, acc, b, x0, n0, wm, wn, l31, kh, cst);
     else conv_epilogue_rows<TM, TN, WN>(p, acc, b, x0, n0, wm, wn, l31, kh, cst);
 }
 
+// frag3 output: m_tiles = groups of eight utterances x blocks of 16 timesteps (p.tiles_per_seq = ceil(Tout / 16), set by the caller)
+template <int WM, int WN, int TM, int TN, bool A4>
+static int launch_mfma_f3(const ConvParams &p) {
+    constexpr int BN = WN * TN * 32;
+    size_t lds = (size_t)2 * (p.rows_a * SPLIT_ROW + (BN / 32) * 3 * 1024) + 6 * BN * sizeof(float);
+    ConvParams q = p;
+    q.m_tiles = ((p.B + CONV_F3_BB - 1) / CONV_F3_BB) * p.tiles_per_seq;
+    q.n_tiles = p.Cout_p / BN;
+    const long blocks = (long)((q.m_tiles + 7) / 8) * 8 * q.n_tiles;
+    if ((long)((p.B + CONV_F3_BB - 1) / CONV_F3_BB) * p.tiles_per_seq > 0x7fffffffL / 8 || blocks > 0x7fffffffL)
+        return nntk_fail_msg("conv1d: too many tiles for one launch");
+    auto kern = conv1d_mfma_bf16x3_kernel<WM, WN, TM, TN, A4, true, 192, true>;
+    if (lds > 64 * 1024) {
+        if (nntk_set_max_dynamic_lds((const void *)kern, lds)) return -1;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, nntk_stream(), q);
+    NNTK_LAUNCH_CHECK("conv1d_mfma_bf16x3_kernel<frag3>");
+    nntk_set_last_conv_kernel("conv1d_mfma_bf16x3_kernel<frag3>");
+    return 0;
+}
 
 template <int WM, int WN, int TM, int TN, bool A4, bool SPLIT, bool QUAD, int AMAX = 192>
 static int launch_mfma_o(const ConvParams &p) {
@@ -718,6 +886,7 @@ static int launch_mfma_o(const ConvParams &p) {
     dim3 grid((unsigned)blocks);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, nntk_stream(), q);
     NNTK_LAUNCH_CHECK("conv1d_mfma_kernel");
+    nntk_set_last_conv_kernel(SPLIT ? "conv1d_mfma_bf16x3_kernel" : "conv1d_mfma_kernel");
     return 0;
 }
 

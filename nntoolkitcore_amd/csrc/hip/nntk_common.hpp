@@ -23,7 +23,7 @@ struct NntkOptions {
     int rec_fused2 = -1;         // fused two-layer GRU kernel (0 off)
     int rec_rr = -1;             // register-resident split-bf16 LSTM kernel with the fused input projection (0 off, 1 also for small batches)
     int rec_xf = -1;             // register-resident kernels: f32 input packed into frag3 form first (1 always, 0 only when the f32 path cannot take the shape; auto: see recurrent.c)
-    int rec_fk = -1;             // 1: full-K register-resident kernels (recurrent_fk.hip) for the shapes they take; auto = off while they do not beat the split-K family
+    int rec_fk = -1;             // full-K register-resident kernels (recurrent_fk.hip): 1 every shape they take, 0 none; auto: 256-wide inputs (where they beat the split-K family)
     int dense_frag3 = -1;        // dense GEMM with a frag3 A operand (0: consumers unpack to f32 and run the LDS-staged GEMM)
     int train_outer_plain = -1;  // weight-gradient products of plain matrices on the VALU-free MFMA kernel (0: the general one; A/B)
     int train_bptt = -1;         // GRU / LSTM gradient: the whole BPTT loop in one persistent kernel (0: two launches per timestep)
@@ -36,6 +36,7 @@ struct NntkOptions {
     int gemm_tm_batch = -1;      // tile time-major GEMM outputs over the batch
     int conv_a4 = 1;             // 16-byte window loads also for channel counts that are not multiples of 4 (0: 4-byte loads there)
     int conv_flatk = -1;         // flat-K split convolution for Cin % 8 == 0, Cin % 16 != 0 (conv1d_flatk.hip); 0 off (variant builds: 2, 4)
+    int conv_frag3_out = -1;     // Conv1d...ApplyDeviceFrag3: -1 / 1 the frag3 epilogue where it applies, 0 always conv -> f32 scratch -> pack (same bits)
     int conv_store = -1;         // GEMM epilogue: -1 auto, 0 row form (4-byte stores), 1 quad form (16-byte stores); bit-identical
     int gemm_split_bf16 = -1;    // 3-way split-bf16 contraction: -1 auto (conv / dense / TDD / mel, not the recurrent xW), 0 never, 1 all
     int gemm_wide = -1;          // 128 x 256 tile for wide dense GEMMs on the split path (0 off)
@@ -52,6 +53,7 @@ void nntk_persistent_launch_begin();              // orders persistent launches 
 void nntk_persistent_launch_end();
 bool nntk_weights_exact_only(const void *d_wp);     // conv1d.hip: the packed weight block holds a value the bf16 split cannot represent
 int nntk_cu_count();                              // cached per device
+void nntk_set_last_conv_kernel(const char *name); // static string; read back with nntk_hip_last_conv_kernel()
 void nntk_set_last_rec_kernel(const char *name);  // static string; read back with nntk_hip_last_recurrent_kernel()
 int nntk_set_max_dynamic_lds(const void *kernel, size_t bytes);   // hipFuncSetAttribute once per (kernel, device)
 // train.hip: C^T-sliced weight-gradient product on the f32 MFMA (outer_mfma_kernel); 0 = shape not taken, else slices written

@@ -44,6 +44,7 @@ int nntk_shim_get_option(const char *name, int *value);
 /* sticky fault word of the persistent recurrent kernel (see runtime.hip) */
 int nntk_shim_take_fault(void);            /* after a stream sync: 1 = a launch faulted (cleared, per-step kernels from now on) */
 int nntk_shim_persistent_disabled(void);
+const char *nntk_shim_last_conv_kernel(void);  /* ... of the Conv1d / dense GEMM kernel ("conv1d_mfma_bf16x3_kernel<frag3>", ...) */
 const char *nntk_shim_last_rec_kernel(void);   /* name of the recurrent kernel this thread launched last ("" before the first) */
 int nntk_shim_device_status(void);         /* non-blocking: 1 = a completed recurrent launch has faulted */
 
@@ -88,6 +89,10 @@ int  nntk_shim_conv1d(const float *d_in, const float *d_wp, const float *d_bias,
                       int B, int T, int Cin, int Cout, int k, int stride, int Tout, int out_mode);
 
 /* ---- training, first slice: Conv1dCalculateGradient (conv_1d.c:185-245); untuned VALU kernels, deterministic ---- */
+/* Conv1d (+ BatchNorm + activation) with a frag3 tensor as output (conv1d.hip conv_epilogue_frag3); 1 = this form does not take the call */
+int  nntk_shim_conv1d_frag3(const float *d_in, const float *d_wp, const float *d_bias, const float *d_bn,
+                            float bn_eps, int act_kind, float relu_a, float *d_out_f3,
+                            int B, int T, int Cin, int Cout, int k, int stride, int Tout);
 /* flat-K split convolution (conv1d_flatk.hip; stride 1, Cin % 8 == 0, Cin % 16 != 0): d_wpf = [Cout_p][Kf_p] with K = tap * Cin + channel,
  * Kf_p = k * Cin rounded up to 16, followed by its split images (nntk_upload_packed_weights).  Returns 1 when not taken. */
 int nntk_shim_conv1d_flatk(const float *d_in, const float *d_wpf, const float *d_bias, const float *d_bn,

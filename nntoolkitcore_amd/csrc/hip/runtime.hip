@@ -58,6 +58,7 @@ static const OptDesc g_opt_table[] = {
     {"gemm_tm_batch", "NNTK_GEMM_TM_BATCH", &NntkOptions::gemm_tm_batch},
     {"gemm_split_bf16", "NNTK_GEMM_SPLIT_BF16", &NntkOptions::gemm_split_bf16},
     {"conv_store", "NNTK_CONV_STORE", &NntkOptions::conv_store},
+    {"conv_frag3_out", "NNTK_CONV_FRAG3_OUT", &NntkOptions::conv_frag3_out},
     {"conv_flatk", "NNTK_CONV_FLATK", &NntkOptions::conv_flatk},
     {"conv_a4", "NNTK_CONV_A4", &NntkOptions::conv_a4},
     {"gemm_wide", "NNTK_GEMM_WIDE", &NntkOptions::gemm_wide},
@@ -233,6 +234,8 @@ int nntk_resident_blocks(const void *kernel, int threads, size_t lds, int max_pe
 // name of the recurrent kernel the calling thread launched last (bench.py labels its roofline line with it)
 static thread_local const char *t_last_rec_kernel = "";
 void nntk_set_last_rec_kernel(const char *name) { t_last_rec_kernel = name; }
+static thread_local const char *t_last_conv_kernel = "";
+void nntk_set_last_conv_kernel(const char *name) { t_last_conv_kernel = name; }
 
 extern "C" {
 
@@ -296,6 +299,7 @@ int nntk_shim_set_device(int device) {
     return 0;
 }
 const char *nntk_shim_last_rec_kernel(void) { return t_last_rec_kernel; }
+const char *nntk_shim_last_conv_kernel(void) { return t_last_conv_kernel; }
 int nntk_shim_get_device(void) {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return -1; }

@@ -186,6 +186,42 @@ int Conv1dBatchNormActivationApplyDevice(Conv1d filter, BatchNorm bn, Activation
     return conv_launch(filter, d_bn, eps, kind, a, d_input, d_output, batch);
 }
 
+/* additive: the fused layer's output as a frag3 tensor [batch][Tout][Cout] (include/nntoolkitcore_hip.h "frag3 tensors") -- what a
+ * register-resident GRU / LSTM layer or TimeDistributedDenseApplyDeviceFrag3 reads -- written by the conv kernel's own epilogue
+ * (conv_1d.c:122-147 feeding lstm.c:201 without the f32 tensor and the pack pass in between).  Bit-identical to
+ * Conv1dBatchNormActivationApplyDevice -> nntk_frag3_pack_device; shapes the frag3 epilogue does not take (stride != 1, k > 9, the
+ * flat-K and exact-f32 kernels) run exactly those two calls through scratch in the handle: valid for every layer. */
+int Conv1dBatchNormActivationApplyDeviceFrag3(Conv1d filter, BatchNorm bn, ActivationFunction act,
+                                              const float *d_input, float *d_output_frag3, int batch) {
+    nntk_shim_clear_error();
+    if (!filter) NNTK_FAIL("Conv1dBatchNormActivationApplyDeviceFrag3: NULL conv handle");
+    if (!d_input || !d_output_frag3) NNTK_FAIL("Conv1dBatchNormActivationApplyDeviceFrag3: NULL tensor");
+    if (batch <= 0) return 0;
+    if (conv_ensure(filter, 0)) return -1;
+    const Conv1dConfig *c = &filter->config;
+    const float *d_bn = NULL;
+    float eps = 0.f;
+    if (bn) {
+        if (nntk_batch_norm_channels(bn) != c->output_feature_channels)
+            NNTK_FAIL("fused conv+bn: BatchNorm feature_channels must equal conv output channels");
+        d_bn = nntk_batch_norm_device_block(bn, 0);
+        if (!d_bn) return -1;
+        eps = nntk_batch_norm_epsilon(bn);
+    }
+    if (!nntk_act_fusable(act)) NNTK_FAIL("fused conv+bn+act: activation must be identity/sigmoid/tanh/relu");
+    int kind = act ? act->kind : NNTK_ACT_IDENTITY;
+    float a = act ? act->relu_a : 1.0f;
+    if (!filter->flatk_ok) {        /* (the flat-K kernel sums in another order: a layer that takes it keeps it, through scratch) */
+        int rc = nntk_shim_conv1d_frag3(d_input, filter->d_wp, filter->d_bias, d_bn, eps, kind, a, d_output_frag3, batch, c->input_size,
+                                        c->input_feature_channels, c->output_feature_channels, c->kernel_size, c->stride, c->output_size);
+        if (rc <= 0) return rc;
+    }
+    float *d_out = nntk_devbuf_reserve(&filter->d_out, (size_t)batch * c->output_size * c->output_feature_channels);
+    if (!d_out) return -1;
+    if (conv_launch(filter, d_bn, eps, kind, a, d_input, d_out, batch)) return -1;
+    return nntk_shim_frag3_pack(d_out, d_output_frag3, batch, c->output_size, c->output_feature_channels);
+}
+
 int Conv1dApplyInferenceBatch(Conv1d filter, const float *input, float *output, int batch) {
     nntk_shim_clear_error();
     if (!filter) NNTK_FAIL("Conv1dApplyInferenceBatch: NULL handle");

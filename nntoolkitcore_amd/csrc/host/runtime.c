@@ -24,6 +24,7 @@ int nntk_hip_set_option(const char *name, const char *value) { nntk_shim_clear_e
 int nntk_hip_get_option(const char *name, int *value) { nntk_shim_clear_error(); return nntk_shim_get_option(name, value); }
 int nntk_hip_device_status(void) { return nntk_shim_device_status(); }
 const char *nntk_hip_last_recurrent_kernel(void) { return nntk_shim_last_rec_kernel(); }
+const char *nntk_hip_last_conv_kernel(void) { return nntk_shim_last_conv_kernel(); }
 
 /* ---- multi-GPU (dist.hip) ---- */
 int nntk_dist_get_unique_id(unsigned char id[NNTK_DIST_ID_BYTES]) { nntk_shim_clear_error(); return nntk_shim_dist_unique_id(id); }

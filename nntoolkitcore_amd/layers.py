@@ -120,6 +120,16 @@ class Conv1d:
                                                          _dp(x), _dp(out), B), "Conv1dBatchNormActivationApplyDevice")
         return out
 
+    def apply_device_frag3(self, x, out_f3=None, bn=None, act=None):
+        """Conv1dBatchNormActivationApplyDeviceFrag3: the (fused) layer output [B, Tout, Cout] as a frag3 buffer."""
+        B = x.shape[0]
+        L = capi.load()
+        if out_f3 is None:
+            out_f3 = x.new_empty(L.nntk_frag3_floats(B, *self.out_shape))
+        check(L.Conv1dBatchNormActivationApplyDeviceFrag3(self.h, bn.h if bn else None, act.h if act else None,
+                                                          _dp(x), _dp(out_f3), B), "Conv1dBatchNormActivationApplyDeviceFrag3")
+        return out_f3
+
     def sync_weights(self):
         check(capi.load().Conv1dSyncWeights(self.h), "Conv1dSyncWeights")
 
