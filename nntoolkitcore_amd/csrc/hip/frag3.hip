@@ -261,20 +261,35 @@ __global__ __launch_bounds__(256) void dense_frag3_kernel(DF3Params p) {
             if (rb >= p.NRB) continue;                    // wave-uniform
             const int t = (int)(rb / p.NHT), ht = (int)(rb % p.NHT);
             const int b = ht * 32 + l31;
+#if defined(DF3_DBG_STORES) && DF3_DBG_STORES == 2      // timing experiment (WRONG results): every store lands in a 4 MB window that stays in L2
+            float *orow = p.out + ((size_t)(b & 31) * p.T + (t & 31)) * p.N;
+#elif defined(DF3_DBG_STORES) && DF3_DBG_STORES == 3    // ... the same 4 MB, but contiguous: a store instruction's 32 rows share a page
+            float *orow = p.out + ((size_t)(b & 31) * 32 + (t & 31)) * p.N;
+#else
             float *orow = p.out + ((size_t)b * p.T + t) * p.N;
+#endif
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int c = n0 + (wn * TN + j) * 32 + 8 * g + 4 * kh;
                     if (b >= p.B || c >= p.N) continue;   // N % 4 == 0 (host): a quad is whole or absent
+#if defined(DF3_DBG_STORES) && DF3_DBG_STORES == 1      // timing experiment (WRONG results): the epilogue's arithmetic without its stores
+                    if (acc[i][j][4 * g] != 12345.678f) continue;
+#endif
                     float4 bi = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (p.bias) bi = *reinterpret_cast<const float4 *>(p.bias + c);
                     float v[4] = {acc[i][j][4 * g + 0] + bi.x, acc[i][j][4 * g + 1] + bi.y, acc[i][j][4 * g + 2] + bi.z, acc[i][j][4 * g + 3] + bi.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         v[e] = ACT == -1 ? nntk_act(p.act_kind, v[e], p.relu_a) : ACT == NNTK_ACT_RELU ? nntk_act(NNTK_ACT_RELU, v[e], p.relu_a) : v[e];
-#ifdef DF3_NT_STORE
+#if defined(DF3_DBG_STORES) && DF3_DBG_STORES == 4      // timing experiment (PERMUTED results): what the stores cost when an instruction writes 8 whole
+                    {                                           // 128-byte lines (rows 8 g .. 8 g + 7 of the block) instead of 32 bytes of 32 lines
+                        const int b4 = ht * 32 + 8 * g + (lane >> 3);
+                        float *d4 = p.out + ((size_t)b4 * p.T + t) * p.N + n0 + (wn * TN + j) * 32 + 4 * (lane & 7);
+                        if (b4 < p.B && n0 + (wn * TN + j) * 32 + 4 * (lane & 7) < p.N) *reinterpret_cast<float4 *>(d4) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+#elif defined(DF3_NT_STORE)
                     __builtin_nontemporal_store((f32x4){v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4 *>(orow + c));
 #else
                     *reinterpret_cast<float4 *>(orow + c) = make_float4(v[0], v[1], v[2], v[3]);
