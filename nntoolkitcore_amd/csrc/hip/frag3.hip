@@ -33,7 +33,23 @@ typedef float f3_f32x2 __attribute__((ext_vector_type(2)));
 #ifndef DF3_MFMA_PER_LOAD
 #define DF3_MFMA_PER_LOAD 2
 #endif
+#ifndef DF3_LDS_EPI
+#define DF3_LDS_EPI 1             // dense_frag3_kernel: whole-line stores through an LDS transposition (0: a lane stores its own quads)
+#endif
+#ifndef DF3_STAGGER
+#define DF3_STAGGER 0             // ... first round of workgroups delayed by (CU index) x DF3_STAGGER x 10 ns (s_memrealtime ticks)
+#endif
 #define F3_OOB 0x70000000          // out-of-range vector offset (every descriptor here is shorter; + a few KB of immediates does not wrap)
+
+// compile-time loop: '#pragma unroll' gives up silently on large bodies ("unrolled size is too large"), and a loop that survives indexes the
+// accumulator array dynamically -- hipcc then keeps all 256 accumulators in scratch (1 088 bytes in the first build of the LDS epilogue)
+template <int LO, int HI, class F>
+__device__ __forceinline__ void f3_for(F &&f) {
+    if constexpr (LO < HI) {
+        f(std::integral_constant<int, LO>{});
+        f3_for<LO + 1, HI>(f);
+    }
+}
 
 __device__ __forceinline__ unsigned f3_cvt_pk(float a, float b) {       // RNE, a in the low half
     return __builtin_bit_cast(unsigned, __builtin_convertvector((f3_f32x2){a, b}, f3_bf16x2));
@@ -168,6 +184,20 @@ __global__ __launch_bounds__(256) void dense_frag3_kernel(DF3Params p) {
     // stores in a burst while every MFMA pipe idles -- fall into each other's main loops: 2.60 ms with and without, tools/r04j.sh.)
     const int n0 = (local % p.n_tiles) * BN;
     const long rb0 = (long)tile * BM_RB + wm * TM;    // this wave's first row block
+#if DF3_LDS_EPI
+    // the tile's bias values wait in LDS: fetched from global memory inside the epilogue they are sixteen load -> use round trips per
+    // wavefront at the moment the MFMA pipe has just gone idle
+    __shared__ __attribute__((aligned(16))) float epi_bias[BN];
+    for (int c = threadIdx.x; c < BN; c += 256) epi_bias[c] = (p.bias && n0 + c < p.N) ? p.bias[n0 + c] : 0.0f;
+    __syncthreads();
+#endif
+#if DF3_STAGGER
+    if (blockIdx.x < 256) {                           // the first round (one workgroup per CU): spread the CUs' epilogues over one tile period
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long wait = (unsigned long long)(blockIdx.x & 255) * DF3_STAGGER;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     const int NKS = p.NKS;
 
     // A: one descriptor at the wave's first row block; row blocks past the tensor read zeros (range-checked VECTOR offset)
@@ -283,13 +313,7 @@ __global__ __launch_bounds__(256) void dense_frag3_kernel(DF3Params p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         v[e] = ACT == -1 ? nntk_act(p.act_kind, v[e], p.relu_a) : ACT == NNTK_ACT_RELU ? nntk_act(NNTK_ACT_RELU, v[e], p.relu_a) : v[e];
-#if defined(DF3_DBG_STORES) && DF3_DBG_STORES == 4      // timing experiment (PERMUTED results): what the stores cost when an instruction writes 8 whole
-                    {                                           // 128-byte lines (rows 8 g .. 8 g + 7 of the block) instead of 32 bytes of 32 lines
-                        const int b4 = ht * 32 + 8 * g + (lane >> 3);
-                        float *d4 = p.out + ((size_t)b4 * p.T + t) * p.N + n0 + (wn * TN + j) * 32 + 4 * (lane & 7);
-                        if (b4 < p.B && n0 + (wn * TN + j) * 32 + 4 * (lane & 7) < p.N) *reinterpret_cast<float4 *>(d4) = make_float4(v[0], v[1], v[2], v[3]);
-                    }
-#elif defined(DF3_NT_STORE)
+#if defined(DF3_NT_STORE)
                     __builtin_nontemporal_store((f32x4){v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4 *>(orow + c));
 #else
                     *reinterpret_cast<float4 *>(orow + c) = make_float4(v[0], v[1], v[2], v[3]);
@@ -297,9 +321,60 @@ __global__ __launch_bounds__(256) void dense_frag3_kernel(DF3Params p) {
                 }
         }
     };
+#if DF3_LDS_EPI
+    // ---- the same epilogue with WHOLE-LINE stores: a lane owns 16 channels of ONE row (an utterance; rows lie T * N * 4 bytes apart), so the
+    // direct form's instructions write 32 bytes of 32 different lines -- 12.5 B/clk and CU (tools/micro/tdd_store_pattern.hip: 8 CUs reach
+    // 0.21 TB/s that way and 0.69 TB/s when an instruction writes 8 whole lines): ~10 us per tile and CU that no other CU's work can hide.
+    // Each 32 x 32 tile goes through 4 KB of the wavefront's own LDS (row-major, the 16-byte quad index XORed with (row >> 1) & 7: writes
+    // and reads conflict-free), comes back as lane -> (row 8 s + lane / 8, quad lane % 8) and leaves as four instructions of 8 x 128
+    // bytes.  No barrier: a wavefront's LDS operations execute in order.  Same values (bias and activation applied before the trip).
+    __shared__ f3_v4u epi_lds[4][2][256];                // [wavefront][parity][32 rows x 8 quads]
+    auto epilogue_lds = [&](auto act_tag) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(act_tag)::value;
+        // (the kernel sits at 512 registers: whatever the epilogue derives from the lane id must not be hoisted above the K loop, or the
+        // loop spills -- 1 088 bytes of scratch in the first build; the empty asm pins the derivation down here)
+        int le = lane;
+        asm volatile("" : "+v"(le));
+        const int wr_row = (le & 31) * 8, wr_sw = ((le & 31) >> 1) & 7;
+        const int rd_r = le >> 3, rd_q = le & 7;
+        f3_for<0, TM>([&](auto i_tag) __attribute__((always_inline)) {
+            constexpr int i = decltype(i_tag)::value;
+            const long rb = rb0 + i;
+            if (rb >= p.NRB) return;                      // wave-uniform
+            const int t = (int)(rb / p.NHT), ht = (int)(rb % p.NHT);
+            f3_for<0, TN>([&](auto j_tag) __attribute__((always_inline)) {
+                constexpr int j = decltype(j_tag)::value;
+                f3_v4u *buf = epi_lds[wave][(i * TN + j) & 1];
+                const int cw = n0 + (wn * TN + j) * 32;
+                f32x16 tile = acc[i][j];
+                asm volatile("" : "+v"(tile));            // one accumulator tile at a time out of the accumulator half (else hipcc dumps all 256 to scratch at the loop's exit)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bi = *reinterpret_cast<const float4 *>(epi_bias + (wn * TN + j) * 32 + 8 * g + 4 * (le >> 5));
+                    float v[4] = {tile[4 * g + 0] + bi.x, tile[4 * g + 1] + bi.y, tile[4 * g + 2] + bi.z, tile[4 * g + 3] + bi.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = ACT == -1 ? nntk_act(p.act_kind, v[e], p.relu_a) : ACT == NNTK_ACT_RELU ? nntk_act(NNTK_ACT_RELU, v[e], p.relu_a) : v[e];
+                    buf[wr_row + ((2 * g + (le >> 5)) ^ wr_sw)] = (f3_v4u){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int row = 8 * s + rd_r;
+                    const f3_v4u x = buf[row * 8 + (rd_q ^ ((row >> 1) & 7))];
+                    const int b = ht * 32 + row, c = cw + 4 * rd_q;
+                    if (b < p.B && c < p.N) *reinterpret_cast<f3_v4u *>(p.out + ((size_t)b * p.T + t) * p.N + c) = x;
+                }
+            });
+        });
+    };
+    if (p.act_kind == NNTK_ACT_IDENTITY) epilogue_lds(std::integral_constant<int, NNTK_ACT_IDENTITY>{});
+    else if (p.act_kind == NNTK_ACT_RELU) epilogue_lds(std::integral_constant<int, NNTK_ACT_RELU>{});
+    else epilogue_lds(std::integral_constant<int, -1>{});
+#else
     if (p.act_kind == NNTK_ACT_IDENTITY) epilogue(std::integral_constant<int, NNTK_ACT_IDENTITY>{});
     else if (p.act_kind == NNTK_ACT_RELU) epilogue(std::integral_constant<int, NNTK_ACT_RELU>{});
     else epilogue(std::integral_constant<int, -1>{});
+#endif
 }
 
 #ifdef NNTK_VARIANT_DENSE_RING      // A/B variant only (tools/build_variant.py ... frag3.hip -DNNTK_VARIANT_DENSE_RING; option dense_frag3 = 3): measured slower

@@ -40,3 +40,5 @@ def test_lstm_rr_counted_waits_match_the_isa():
     # ... and the KH = 4 instantiations, which hand over without flags (pending pattern): every look covers all twelve words of a
     # k step's three fragments, no flag-protocol drain is left in them, no scratch
     assert "0 defects" in r.stdout and " 0 pending-pattern looks" not in r.stdout
+    # ... and no kernel of these units (rr, fk, dense_frag3, conv1d) has a private segment: a spill still passes every test
+    assert "0 with a private segment" in r.stdout

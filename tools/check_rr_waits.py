@@ -7,16 +7,21 @@ between the store group and the wait in the ISA; exit 1 on a mismatch.   usage: 
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRCS = [os.path.join(ROOT, "nntoolkitcore_amd", "csrc", "hip", f) for f in ("recurrent_rr.hip", "recurrent_fk.hip", "frag3.hip")]
+SRCS = [os.path.join(ROOT, "nntoolkitcore_amd", "csrc", "hip", f) for f in ("recurrent_rr.hip", "recurrent_fk.hip", "frag3.hip", "conv1d.hip")]
 
 
 def main():
     txt = ""
     with tempfile.TemporaryDirectory() as td:
-        for k, src in enumerate(SRCS):
+        procs = []
+        for k, src in enumerate(SRCS):                  # (the four units compile side by side)
             out = os.path.join(td, "rr%d.s" % k)
-            subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-Wno-unused-function",
-                                   "--cuda-device-only", "-S", src, "-o", out] + os.environ.get("RR_EXTRA", "").split(), stderr=subprocess.DEVNULL)
+            procs.append((out, subprocess.Popen(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-Wno-unused-function",
+                                                 "--cuda-device-only", "-S", src, "-o", out] + os.environ.get("RR_EXTRA", "").split(),
+                                                stderr=subprocess.DEVNULL)))
+        for out, pr in procs:
+            if pr.wait() != 0:
+                raise SystemExit("hipcc failed on " + out)
             txt += open(out).read() + "\n"
     bad = total = 0
     for kname in re.findall(r'^(_Z1[345](?:lstm|gru)_rr_kernel\w+):', txt, re.M):
@@ -33,8 +38,25 @@ def main():
     mbad, mtotal = check_marks(txt)
     print("pending-pattern kernels (rr KH = 4, fk): %d mark groups checked, %d not covered by a vmcnt wait before the second barrier / the next publication" % (mtotal, mbad))
     fbad, ftotal = check_split_fma(txt)
-    print("bf16 x 3 splits (rr, fk, frag3): %d conversions checked, %d fed by a fused multiply-add of an image" % (ftotal, fbad))
-    return 1 if bad or total == 0 or pbad or ptotal == 0 or qbad or qtotal == 0 or mbad or mtotal == 0 or fbad or ftotal == 0 else 0
+    print("bf16 x 3 splits (rr, fk, frag3, conv): %d conversions checked, %d fed by a fused multiply-add of an image" % (ftotal, fbad))
+    sbad, stotal = check_scratch(txt)
+    print("register-resident / MFMA kernels (rr, fk, dense_frag3, conv1d): %d kernels checked, %d with a private segment (spills)" % (stotal, sbad))
+    return 1 if (bad or total == 0 or pbad or ptotal == 0 or qbad or qtotal == 0 or mbad or mtotal == 0 or fbad or ftotal == 0
+                 or sbad or stotal == 0) else 0
+
+
+def check_scratch(txt):
+    """No kernel of these units may spill: the register-resident kernels and dense_frag3_kernel sit at the 512-register limit on purpose, and a
+    change that tips them over still compiles, still passes every test -- and runs 1.1 to 10 x slower (the '#pragma unroll' that gives up
+    silently and leaves a loop indexing the accumulators dynamically is the usual cause: recurrent_fk.hip fk_for, frag3.hip f3_for)."""
+    bad = total = 0
+    for m in re.finditer(r'\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel', txt, re.S):
+        ps = re.search(r'\.amdhsa_private_segment_fixed_size (\d+)', m.group(2))
+        total += 1
+        if ps and ps.group(1) != "0":
+            bad += 1
+            print("%s: private_segment_fixed_size %s" % (m.group(1), ps.group(1)))
+    return bad, total
 
 
 def is_pub_store(t):
