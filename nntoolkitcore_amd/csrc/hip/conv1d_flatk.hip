@@ -150,7 +150,15 @@ __global__ __launch_bounds__(256, 2) void conv1d_flatk_bf16x3_kernel(ConvParams 
         c0 += 16;
         while (c0 >= Cin) { c0 -= Cin; ++kk0; }
     }
-    conv_epilogue<TM, TN, WN>(p, acc, b, x0, n0, wm, wn, l31, kh, cst);
+    // whole-line stores through the window buffer (dead once every wavefront has left the K loop: barrier); the constants sit behind it
+    v4u32_t *epi = nullptr;
+#ifndef CONV_EPI_DIRECT
+    if (w_base + 2 * w_bytes >= CONV_EPI_LDS_BYTES) {
+        __syncthreads();
+        epi = reinterpret_cast<v4u32_t *>(lds);
+    }
+#endif
+    conv_epilogue<TM, TN, WN>(p, acc, b, x0, n0, wm, wn, l31, kh, cst, epi);
 }
 
 // 0 = launched; 1 = shape / configuration not taken (the caller runs nntk_shim_conv1d); -1 = error.

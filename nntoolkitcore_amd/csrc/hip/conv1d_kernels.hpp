@@ -41,6 +41,16 @@ struct ConvParams {
 
 typedef unsigned v4u32_t __attribute__((ext_vector_type(4)));
 
+// compile-time loop ('#pragma unroll' gives up silently on large bodies; a loop that survives indexes the accumulators dynamically)
+template <int LO, int HI, class F>
+__device__ __forceinline__ void conv_for(F &&f) {
+    if constexpr (LO < HI) {
+        f(std::integral_constant<int, LO>{});
+        conv_for<LO + 1, HI>(f);
+    }
+}
+#define CONV_EPI_LDS_BYTES 16384      // four wavefronts x 4 KB: the LDS the whole-line epilogue borrows from the (dead) window buffer
+
 // Out-of-range sentinel for a lane's VECTOR offset (the only part of a buffer address the hardware range-checks).
 // Every descriptor here is clamped to at most CONV_OOB bytes, so the sentinel is out of range whatever the
 // tensor's size: a load returns 0, a store is dropped.  Legitimate vector offsets stay far below it: descriptors
@@ -102,9 +112,15 @@ __device__ __forceinline__ void conv_stage_constants(float *cst, int tid, const 
     }
 }
 
+// epi != NULL (16 KB of LDS nobody reads any more; the caller has passed a barrier): WHOLE-LINE stores.  A lane owns 16 channels of one
+// position, so the direct form's instructions write 32 bytes of 32 different lines -- 12.5 B/clk and CU on this chip against 41 when an
+// instruction writes 8 whole lines (tools/micro/tdd_store_pattern.hip); at configs[2] the stores were a third of the kernel
+// (profiles/r05_conv_store_ablation.log).  Each 32 x 32 tile takes a trip through 4 KB of the wavefront's own LDS region (row-major, the
+// 16-byte quad index XORed with (row >> 1) & 7: writes and reads conflict-free; a wavefront's LDS operations execute in order, no barrier)
+// and comes back as lane -> (row 8 s + lane / 8, quad lane % 8).  Same values, same bits.
 template <int TM, int TN, int WN>
 __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)[TM][TN], int b, int x0, int n0,
-                                              int wm, int wn, int l31, int kh, const float *cst) {
+                                              int wm, int wn, int l31, int kh, const float *cst, v4u32_t *epi = nullptr) {
     constexpr int BN = WN * TN * 32;
     const size_t row_elems = (size_t)(p.out_mode ? p.B : 1) * p.Cout;           // distance between output rows x, x+1
     const size_t row_bytes = row_elems * 4;
@@ -175,6 +191,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
                         // soffset stays IMMEDIATE on purpose: with an SGPR soffset the compiler inserts no wait state
                         // before the next VALU write of these data registers (it believes that form has no hazard) and
                         // MI355X then stores the overwritten value in some lanes (tools/check_store_hazard.py)
+#ifdef CONV_EPI_NOSTORE      // timing experiment (WRONG results): the epilogue's arithmetic without its stores
+                        if (v[0] == 12345.678f)
+#endif
                         __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, col_ok ? row_voff[i] + cu * 4 : CONV_OOB, 0, 0);
                     } else if (row_ok[i]) {
                         const int x = x0 + wm * TM * 32 + i * 32 + l31;
@@ -187,11 +206,74 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
             }
         }
     };
+    auto epilogue_lds = [&](auto bn_tag, auto act_tag) {
+        constexpr bool HAS_BN = decltype(bn_tag)::value;
+        constexpr int ACT = decltype(act_tag)::value;
+        int le = kh * 32 + l31;
+        asm volatile("" : "+v"(le));                             // (lane-derived values are derived HERE, not above the K loop)
+        v4u32_t *buf = epi + (wm * WN + wn) * 256;
+        const int wr = (le & 31) * 8, wr_sw = ((le & 31) >> 1) & 7, khe = le >> 5;
+        const int rd_r = le >> 3, rd_q = le & 7;
+        conv_for<0, TM>([&](auto i_tag) {
+            constexpr int i = decltype(i_tag)::value;
+            conv_for<0, TN>([&](auto j_tag) {
+                constexpr int j = decltype(j_tag)::value;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cl = (wn * TN + j) * 32 + 8 * g + 4 * khe;
+                    const float4 bias4 = *reinterpret_cast<const float4 *>(cst + cl);
+                    const float bias[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
+                    float ga[4] = {1.f, 1.f, 1.f, 1.f}, be[4] = {0.f, 0.f, 0.f, 0.f}, mu[4] = {0.f, 0.f, 0.f, 0.f},
+                          sd[4] = {1.f, 1.f, 1.f, 1.f}, rsd[4] = {1.f, 1.f, 1.f, 1.f};
+                    if (HAS_BN) {
+                        const float4 t1 = *reinterpret_cast<const float4 *>(cst + BN + cl);
+                        const float4 t2 = *reinterpret_cast<const float4 *>(cst + 2 * BN + cl);
+                        const float4 t3 = *reinterpret_cast<const float4 *>(cst + 3 * BN + cl);
+                        const float4 t4 = *reinterpret_cast<const float4 *>(cst + 4 * BN + cl);
+                        const float4 t5 = *reinterpret_cast<const float4 *>(cst + 5 * BN + cl);
+                        ga[0] = t1.x; ga[1] = t1.y; ga[2] = t1.z; ga[3] = t1.w;
+                        be[0] = t2.x; be[1] = t2.y; be[2] = t2.z; be[3] = t2.w;
+                        mu[0] = t3.x; mu[1] = t3.y; mu[2] = t3.z; mu[3] = t3.w;
+                        sd[0] = t4.x; sd[1] = t4.y; sd[2] = t4.z; sd[3] = t4.w;
+                        rsd[0] = t5.x; rsd[1] = t5.y; rsd[2] = t5.z; rsd[3] = t5.w;
+                    }
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[i][j][4 * g + e] + bias[e];
+                        if (HAS_BN) {                            // (the expressions of the direct form)
+                            const float d = v[e] - mu[e];
+                            float qn = d * rsd[e];
+                            qn = fmaf(fmaf(-qn, sd[e], d), rsd[e], qn);
+                            v[e] = p.bn_fast ? (d * rsd[e]) * ga[e] + be[e] : nofma_muladd(qn, ga[e], be[e]);
+                        }
+                        v[e] = ACT == -1 ? nntk_act(p.act_kind, v[e], p.relu_a)
+                             : ACT == NNTK_ACT_RELU ? nntk_act(NNTK_ACT_RELU, v[e], p.relu_a)
+                             : v[e];
+                    }
+                    buf[wr + ((2 * g + khe) ^ wr_sw)] = (v4u32_t){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int row = 8 * s + rd_r;
+                    const v4u32_t x = buf[row * 8 + (rd_q ^ ((row >> 1) & 7))];
+                    const int xr = wm * TM * 32 + i * 32 + row;
+                    const int c = n0 + (wn * TN + j) * 32 + 4 * rd_q;
+                    __builtin_amdgcn_raw_buffer_store_b128(x, rs_out, (x0 + xr < p.Tout && c < p.Cout) ? xr * rb + c * 4 : CONV_OOB, 0, 0);
+                }
+            });
+        });
+    };
     using T_ = std::true_type; using F_ = std::false_type;
     using AId = std::integral_constant<int, NNTK_ACT_IDENTITY>;
     using ARelu = std::integral_constant<int, NNTK_ACT_RELU>;
     using AAny = std::integral_constant<int, -1>;
-    if (vec_store) {
+    if (vec_store && epi) {
+        if (!p.bn && p.act_kind == NNTK_ACT_IDENTITY) epilogue_lds(F_{}, AId{});
+        else if (p.bn && p.act_kind == NNTK_ACT_RELU) epilogue_lds(T_{}, ARelu{});
+        else if (p.bn)                                epilogue_lds(T_{}, AAny{});
+        else                                          epilogue_lds(F_{}, AAny{});
+    } else if (vec_store) {
         if (!p.bn && p.act_kind == NNTK_ACT_IDENTITY) epilogue(F_{}, AId{}, T_{});
         else if (p.bn && p.act_kind == NNTK_ACT_RELU) epilogue(T_{}, ARelu{}, T_{});
         else if (p.bn)                                epilogue(T_{}, AAny{}, T_{});
@@ -841,7 +923,18 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16x3_kernel(ConvParams p
     }
     if (CONV_DBG(1) && acc[0][0][0] != 12345.678f) return;
     if constexpr (F3OUT) conv_epilogue_frag3<TM, TN, WN>(p, acc, b, x0, n0, wm, wn, l31, kh, cst);
-    else if constexpr (QUAD) conv_epilogue<TM, TN, WN>(p, acc, b, x0, n0, wm, wn, l31, kh, cst);
+    else if constexpr (QUAD) {
+        // whole-line stores through the window buffer, which nobody reads once every wavefront has left the K loop (barrier); the
+        // epilogue constants sit behind it
+        v4u32_t *epi = nullptr;
+#ifndef CONV_EPI_DIRECT
+        if (2 * a_bytes + 2 * w_bytes >= CONV_EPI_LDS_BYTES && p.out_mode == 0) {
+            __syncthreads();
+            epi = reinterpret_cast<v4u32_t *>(lds);
+        }
+#endif
+        conv_epilogue<TM, TN, WN>(p, acc, b, x0, n0, wm, wn, l31, kh, cst, epi);
+    }
     else conv_epilogue_rows<TM, TN, WN>(p, acc, b, x0, n0, wm, wn, l31, kh, cst);
 }
 
