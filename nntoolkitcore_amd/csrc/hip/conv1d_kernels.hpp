@@ -360,7 +360,7 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvParams &p, f32x16 (
 // ---- frag3 epilogue (F3OUT): the layer output leaves as the NEXT layer's MFMA operand ---------------------------------------------
 // out = frag3 tensor [Tout][2 ceil(B / 64)][ceil(Cout / 16)][3] blocks of 1 KB (frag3.hip): block = 32 batch rows x 16 channels, lane
 // 32 kh' + n = 8 consecutive bf16 channels of batch row n.  A row block needs 32 UTTERANCES of one timestep, so the tile of this mode is
-// 8 utterances x 16 timesteps (tile row m = 16 bl + tl) instead of 128 timesteps of one utterance: eight rows of one block are then 128
+// 8 utterances x 16 timesteps (tile row m = 8 tl + bl) instead of 128 timesteps of one utterance: eight rows of one block are then 128
 // contiguous bytes = one cache line, filled by this workgroup alone.  Quad orientation: a lane owns position (bl, tl) and, per 16-channel
 // k step, channels 4 kh .. 4 kh + 3 of BOTH 8-channel slots; v_permlane32_swap (gfx950) trades the half it does not store against the
 // half it lacks -- upper lanes' slot-0 registers <-> lower lanes' slot-1 registers -- after which lane 32 kh' + l31 holds exactly the 16
@@ -383,6 +383,15 @@ __device__ __forceinline__ void cf3_split_pair(float x0, float x1, unsigned &hi,
 
 #define CONV_F3_BB 8              // utterances per tile
 #define CONV_F3_TT 16             // timesteps per tile
+// tile row m -> (utterance, timestep): the utterance is the FAST index, so the 64 lanes of a store instruction (after the half-slot swap:
+// 2 slots x 4 timesteps x 8 utterances x 16 bytes) write 8 WHOLE 128-byte lines of the frag3 tensor instead of 32 bytes of 32 lines
+#ifndef CONV_F3_TMAJOR
+#define CONV_F3_BL(m) ((m) & 7)
+#define CONV_F3_TL(m) ((m) >> 3)
+#else                             // A/B: the first version (16 timesteps of one utterance per half wavefront)
+#define CONV_F3_BL(m) ((m) >> 4)
+#define CONV_F3_TL(m) ((m) & 15)
+#endif
 
 template <int TM, int TN, int WN>
 __device__ __forceinline__ void conv_epilogue_frag3(const ConvParams &p, f32x16 (&acc)[TM][TN], int b0, int x0, int n0,
@@ -397,7 +406,7 @@ __device__ __forceinline__ void conv_epilogue_frag3(const ConvParams &p, f32x16 
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = (wm * TM + i) * 32 + l31;
-            const int b = b0 + (m >> 4), x = x0 + (m & 15);
+            const int b = b0 + CONV_F3_BL(m), x = x0 + CONV_F3_TL(m);
             row_voff[i] = (b < p.B && x < p.Tout) ? (int)((((size_t)x * p.f3_nht + (b >> 5)) * p.f3_nks * 3) * 1024) + (32 * kh + (b & 31)) * 16
                                                   : CONV_OOB;
         }
@@ -841,7 +850,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16x3_kernel(ConvParams p
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = (wm * TM + i) * 32 + l31;
-        a_row_f3[i] = (m >> 4) * wrows + (m & 15);
+        a_row_f3[i] = CONV_F3_BL(m) * wrows + CONV_F3_TL(m);
     }
     const int w_rd = w_base + (wn * TN * 3) * 1024 + lane * 16;     // this wave's first column tile, image 0
     const int w_wr = w_base + (wave * 3) * 1024 + lane * 16;
