@@ -634,8 +634,8 @@ def test_full_size_config4_two_layer_gru(gpu):
 
 
 def test_full_size_config5_stack_one_gpu_shard(gpu):
-    """The bench workload itself: 512 utterances x 1000 frames through the whole stack (the LSTM hands its output to the dense layer
-    in frag3 form).  Every stage of rows 0 and 511 against the oracle; and over the WHOLE batch: the f32 route (LSTMApplyDevice then
+    """The bench workload itself: 512 utterances x 1000 frames through the whole stack (the conv layer hands its output to the LSTM, and the
+    LSTM its output to the dense layer, in frag3 form).  Every stage of rows 0 and 511 against the oracle; and over the WHOLE batch: the f32 route (LSTMApplyDevice then
     TimeDistributedDenseApplyDevice) equal to the frag3 route bit for bit, and the exact kernels (rec_rr = 0, gemm_split_bf16 = 0)
     within the summation-order bound -- the race detector VERDICT r03 asked for."""
     import torch
@@ -644,8 +644,12 @@ def test_full_size_config5_stack_one_gpu_shard(gpu):
     wl = bench.Workload("stack", 512, 1000, w, torch, NL)
     wl.step()
     torch.cuda.synchronize()
-    assert wl.tdd_out.shape == (512, 996, 1000) and not wl.f32_route
+    assert wl.tdd_out.shape == (512, 996, 1000) and not wl.f32_route and wl.conv_f3_route
+    assert capi.load().nntk_hip_last_conv_kernel().decode() == "conv1d_mfma_bf16x3_kernel<frag3>"
     lstm_out = NL.frag3_unpack_device(wl.lstm_f3, 512, 996, 512)
+    # the conv layer's output exists in frag3 form only (its epilogue wrote it): the f32 route of the same layer, same bits over the whole batch
+    conv_out = wl.conv.apply_device(wl.spec_out, out=wl.conv_out, bn=wl.bn, act=wl.relu)
+    assert torch.equal(NL.frag3_unpack_device(wl.conv_f3, 512, 996, 128), conv_out)
     win = O.window("hann", 400)
     for i in (0, 511):
         a = wl.x[i].cpu().numpy()
