@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Random-shape soak of the conv / dense / recurrent kernels against the oracle (~580 cases incl. spectrogram geometries, the RNN, and round 2's streaming / fused-GRU / mixed-radix / log-mel paths and the training path, ~1.5 min on the GPU):
+"""Random-shape soak of the conv / dense / recurrent kernels against the oracle (~835 cases incl. round 5's conv -> frag3 epilogue, dense-on-frag3 and full-K shapes, spectrogram geometries, the RNN, and round 2's streaming / fused-GRU / mixed-radix / log-mel paths and the training path, ~1.5 min on the GPU):
 python tools/soak.py [seed]"""
 import os, sys
 import numpy as np
@@ -182,4 +182,48 @@ for _ in range(20):
     for ptr, rf in zip((g.contents.d_beta, g.contents.d_gamma, g.contents.d_x), O.batch_norm_gradient(x, dout, gam, om, ov, 1e-3)):
         assert rel(np.ctypeslib.as_array(ptr, shape=rf.shape), rf) < 1e-4, (count, mb, F)
     L.BatchNormGradientDestroy(g); L.BatchNormDestroy(h); n += 1
+# ---- round 5: the conv epilogue that writes frag3 (random shapes, bit-identity with conv -> pack; ragged utterance groups and timestep blocks,
+#      padding channels, every activation), the dense GEMM's LDS epilogue on frag3 inputs, and the full-K recurrent family on wide inputs ----
+for _ in range(60):
+    cin, cout = int(r.integers(4, 300)), int(r.integers(32, 300))
+    k, stride = int(r.integers(1, 12)), (1 if r.random() < 0.8 else 2)
+    T = int(r.integers(k + 1, 120)); B = int(r.integers(1, 80))
+    conv = NL.Conv1d(cin, cout, k, stride, T); conv.set_weights(u(cout, cin, k, sc=(cin * k) ** -0.5), u(cout, sc=0.2))
+    Tc = conv.out_shape[0]
+    bn = act = None
+    if r.random() < 0.6:
+        bn = NL.BatchNorm(cout, 1e-3, B * Tc); bn.set_weights(1 + u(cout, sc=0.4), u(cout, sc=0.5), u(cout, sc=0.2), 1 + u(cout, sc=0.4))
+    kind = ["relu", "sigmoid", "tanh", "identity", None][int(r.integers(0, 5))]
+    if kind: act = NL.Activation(kind, B * Tc * cout, 0.5)
+    xd = torch.from_numpy(u(B, T, cin)).cuda()
+    y = conv.apply_device(xd, bn=bn, act=act)
+    ref3 = NL.frag3_pack_device(y)
+    out3 = torch.zeros_like(ref3)
+    conv.apply_device_frag3(xd, out_f3=out3, bn=bn, act=act)
+    assert torch.equal(out3.view(torch.int32), ref3.view(torch.int32)), (B, T, cin, cout, k, stride, kind)
+    for h in (conv, bn, act):
+        if h is not None: h.destroy()
+    n += 1
+for _ in range(40):
+    ts, I, Ov = int(r.integers(1, 60)), int(r.integers(1, 40)) * 16, int(r.integers(1, 280)) * 4
+    Bb = int(r.integers(1, 150))
+    W, b, x = u(I, Ov, sc=I ** -0.5), u(Ov, sc=0.2), u(Bb, ts, I)
+    tdd = NL.TimeDistributedDense(ts, I, Ov); tdd.set_weights(W, b)
+    xd = torch.from_numpy(x).cuda()
+    a = tdd.apply_device(xd)
+    b3 = NL.tdd_apply_device_frag3(tdd, NL.frag3_pack_device(xd), Bb)
+    assert torch.equal(a, b3), (Bb, ts, I, Ov)
+    close(a.cpu().numpy(), O.time_distributed_dense(x, W, b)); tdd.destroy(); n += 1
+for _ in range(30):
+    I, H = int(r.integers(129, 257)), int(r.integers(9, 17)) * 16
+    T, B = int(r.integers(1, 12)), int(r.integers(1, 150))
+    x = u(B, T, I)
+    W, U, bi, bh = u(I, 3 * H, sc=I ** -0.5), u(H, 3 * H, sc=H ** -0.5), u(3 * H, sc=0.1), u(3 * H, sc=0.1)
+    g = NL.GRU(I, H, True, T); g.set_weights(W, U, bi, bh)
+    close(g.apply(x), O.gru(x, W, U, bi, bh), 1e-4)
+    assert capi.load().nntk_hip_last_recurrent_kernel().decode().startswith("gru_fk_kernel"), (I, H)
+    g.destroy()
+    W, U, bi, bh = u(I, 4 * H, sc=I ** -0.5), u(H, 4 * H, sc=H ** -0.5), u(4 * H, sc=0.1), u(4 * H, sc=0.1)
+    l = NL.LSTM(I, H, False, T); l.set_weights(W, U, bi, bh)
+    close(l.apply(x), O.lstm(x, W, U, bi, bh, return_sequences=False), 1e-4); l.destroy(); n += 2
 print("soak ok:", n, "cases")
