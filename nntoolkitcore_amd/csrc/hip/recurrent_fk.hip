@@ -740,8 +740,11 @@ int nntk_fk_launch(RRParams q, const float *d_imgfk, int cell, size_t *launches)
     int NKH, NKX, NW;
     if (!d_imgfk || !q.xf3 || q.x_tm || q.out_tm || !fk_shape(q.H, q.in, &NKH, &NKX, &NW)) return 1;
     void (*kern)(RRParams) = nullptr;
-    if (cell == 1) kern = NW == 2 ? gru_fk_kernel<16, 16, 2, FK_ND_2> : NKX == 8 ? gru_fk_kernel<16, 8, 4, FK_ND_4> : gru_fk_kernel<16, 16, 4, FK_ND_4W>;
-    else kern = NW == 2 ? lstm_fk_kernel<16, 16, 2, FK_ND_2> : NKX == 8 ? lstm_fk_kernel<16, 8, 4, FK_ND_4> : lstm_fk_kernel<16, 16, 4, FK_ND_4W>;
+    if (cell == 1) kern = NKX == 8 ? gru_fk_kernel<16, 8, 4, FK_ND_4> : gru_fk_kernel<16, 16, 4, FK_ND_4W>;
+    else kern = NKX == 8 ? lstm_fk_kernel<16, 8, 4, FK_ND_4> : lstm_fk_kernel<16, 16, 4, FK_ND_4W>;
+#ifdef FK_NW2_WIDE      // A/B build only: the 256-wide layer on pairs of wavefronts (64 rows x 16 units), measured 8 % behind split-K
+    if (NW == 2) kern = cell == 1 ? gru_fk_kernel<16, 16, 2, FK_ND_2> : lstm_fk_kernel<16, 16, 2, FK_ND_2>;
+#endif
     const size_t lds = fk_lds_bytes(NKH, NKX, NW);
     if (lds > 160 * 1024) return 1;
     if (nntk_set_max_dynamic_lds((const void *)kern, lds)) return -1;
