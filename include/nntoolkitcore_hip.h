@@ -529,7 +529,8 @@ int bd_merge_sum_device(const float *d_forward, const float *d_backward, float *
  * [T][2 ceil(batch / 64)][ceil(C / 16)][3] blocks of 1 KB, block = 32 batch rows x 16 channels, lane 32 kh + n of a wavefront holding
  * channels 16 ks + 8 kh .. + 7 of batch row 32 ht + n as 8 consecutive bf16.  Padding CHANNELS (past C) are zeros; padding ROWS (past the
  * batch, up to the next multiple of 64) are unspecified -- nntk_frag3_pack_device writes zeros there, the recurrent kernels write the
- * state of rows that computed on zero inputs: a consumer must not let them reach a real row (every consumer here masks).  6 bytes per value
+ * state of rows that computed on zero inputs, the conv epilogue (Conv1dBatchNormActivationApplyDeviceFrag3) does not write them at all:
+ * a consumer must not let them reach a real row (every consumer here masks).  6 bytes per value
  * instead of 4; in exchange a consumer's operand fetch is a run of coalesced 1 KB loads straight into MFMA registers (no LDS
  * staging, no split, no per-row requests).  The register-resident GRU / LSTM kernels produce their output in this form for free
  * (it is their inter-workgroup hand-off) and read their input from it; the dense GEMM reads it as its A operand.
