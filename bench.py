@@ -203,6 +203,12 @@ class Workload:
                 self.lstm_out = torch.empty((B, Tc, 512), device=dev)
             else:
                 self.lstm_f3 = torch.empty(capi_lib().nntk_frag3_floats(B, Tc, 512), device=dev)
+            # ... by default in FRAG2H form (two f16 images of h * 2^15 written by the LSTM kernel's output wave; the dense GEMM sums three
+            # products per k step instead of six -- what LSTMTimeDistributedDenseApplyDevice does); NNTK_DENSE_F16X2=0: the frag3 route
+            from nntoolkitcore_amd import capi as _capi
+            self.h2_route = not self.f32_route and _capi.get_option("dense_f16x2") != 0
+            if self.h2_route:
+                self.lstm_h2 = torch.empty(capi_lib().nntk_frag2h_floats(B, Tc, 512), device=dev)
             # ... and the conv layer hands ITS output to the LSTM in frag3 form too, written by the conv kernel's epilogue
             # (Conv1dBatchNormActivationApplyDeviceFrag3); NNTK_BENCH_CONV_F32=1: f32 tensor + the LSTM call's pack pass, as round 4 did
             self.conv_f3_route = not self.f32_route and not bool(int(os.environ.get("NNTK_BENCH_CONV_F32", "0")))
@@ -244,7 +250,14 @@ class Workload:
                 self.lstm.apply_device(self.conv_out, out=self.lstm_out)
                 mark("lstm")
                 self.tdd.apply_device(self.lstm_out, out=self.tdd_out)
-            else:       # = LSTMTimeDistributedDenseApplyDevice, as its two halves so that each gets its own HIP-event phase
+            elif self.h2_route:       # = LSTMTimeDistributedDenseApplyDevice, as its two halves so that each gets its own HIP-event phase
+                if self.conv_f3_route:
+                    self.NL.lstm_apply_device_frag2h(self.lstm, x_f3=self.conv_f3, batch=self.B, out_h2=self.lstm_h2)
+                else:
+                    self.NL.lstm_apply_device_frag2h(self.lstm, x=self.conv_out, out_h2=self.lstm_h2)
+                mark("lstm")
+                self.NL.tdd_apply_device_frag2h(self.tdd, self.lstm_h2, self.B, out=self.tdd_out)
+            else:       # ... on the frag3 form (option dense_f16x2 = 0)
                 if self.conv_f3_route:
                     self.NL.recurrent_apply_device_frag3(self.lstm, x_f3=self.conv_f3, batch=self.B, want_f32=False, out_f3=self.lstm_f3)
                 else:
@@ -670,6 +683,10 @@ def main():
                              "bit-identical to the f32 route" if getattr(wl, "conv_f3_route", False) else
                              "f32 tensor, packed into frag3 form inside the LSTM call") if a.workload == "stack" else None,
             "lstm_to_tdd": ("f32 tensor" if getattr(wl, "f32_route", True) else
+                            "frag2h tensor: h as two f16 images of h * 2^15 (|h| < 1; operands to 2^-23 relative at worst) written by the LSTM kernel's output wave, "
+                            "W as two f16 images of W * 2^q; the dense GEMM sums three products per k step (f32 accumulation); error vs f64 below the "
+                            "frag3 route's (tests/test_gpu_frag2h.py, profiles/r05_gemm_f16x2_micro.log); NNTK_DENSE_F16X2=0 selects the frag3 route"
+                            if getattr(wl, "h2_route", False) else
                             "frag3 tensor: the LSTM kernel's T-deep hand-off buffer (h already split into three bf16 images, MFMA fragment order) "
                             "is the dense GEMM's A operand; bit-identical to the f32 route") if a.workload == "stack" else None,
             "gemm": gemm_mode() + " for conv / TDD" + (

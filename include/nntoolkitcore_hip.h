@@ -541,7 +541,8 @@ int bd_merge_sum_device(const float *d_forward, const float *d_backward, float *
  *   <GRU|LSTM>ApplyDeviceFrag3: input as f32 (d_input) or frag3 (d_input_frag3), one of them NULL; output as f32 (d_output), frag3
  *   (d_output_frag3, needs return_sequences) or both, unused ones NULL.  Zero initial state per sequence.  Shapes the register-resident
  *   kernels do not take run the other kernels through f32 scratch -- the call is valid for every layer.
- *   LSTMTimeDistributedDenseApplyDevice = LSTMApplyDevice then TimeDistributedDenseApplyDevice without the f32 tensor in between. */
+ *   LSTMTimeDistributedDenseApplyDevice = LSTMApplyDevice then TimeDistributedDenseApplyDevice without the f32 tensor in between
+ *   (on the FRAG2H form below by default; option dense_f16x2 = 0: on frag3, bit for bit the two f32 calls). */
 size_t nntk_frag3_floats(int batch, int T, int C);                       /* size of a frag3 tensor, in floats */
 int nntk_frag3_pack_device(const float *d_x /*[batch,T,C]*/, float *d_frag3, int batch, int T, int C);
 int nntk_frag3_unpack_device(const float *d_frag3, float *d_x /*[batch,T,C]*/, int batch, int T, int C);
@@ -560,6 +561,23 @@ int TimeDistributedDenseApplyDeviceFrag3(TimeDistributedDense filter, const floa
  * -- stride != 1, kernel_size > 9 -- run those two calls through scratch in the handle). */
 int Conv1dBatchNormActivationApplyDeviceFrag3(Conv1d filter, BatchNorm bn, ActivationFunction act,
                                               const float *d_input /*[batch,T,Cin]*/, float *d_output_frag3, int batch);
+/* ---- FRAG2H tensors: a bounded activation tensor as two f16 images, for a three-product contraction ----------------------------
+ * The same block structure as frag3 -- [T][2 ceil(batch / 64)][ceil(C / 16)][2] blocks of 1 KB, same lane order -- holding hi = f16(x 2^15)
+ * and lo = f16(x 2^15 - hi): |x - (hi + lo) 2^-15| <= 2^-23 |x| (at worst one f32 ulp, 0.3 ulp rms; absolute 2^-40 below |x| ~ 2^-17), 4 bytes
+ * per value.  f16 ends at 65 504, so the form is DEFINED FOR |x| < 2 ONLY (a larger value becomes inf): it is what a GRU / LSTM layer with
+ * the standard activations produces (|h| < 1).  The dense GEMM on it (weights as two f16 images of W 2^q, q chosen at upload so that
+ * max |W| 2^q <= 32 768; weights must be finite) sums three products hi.hi + hi.lo + lo.hi per k step instead of frag3's six at the same MFMA
+ * rate, f32 accumulation, one exact multiplication by 2^-(15 + q) in the epilogue.  Measured against an f64 dot product of the same f32
+ * operands the error is below the frag3 / f32-input GEMM's and below that of the reference's own f32 accumulation order
+ * (profiles/r05_gemm_f16x2_micro.log; tests/test_gpu_frag2h.py) -- but the results are NOT bit-identical to those routes.
+ *   LSTMApplyDeviceFrag2h: the layer's sequence output in this form; -1 for non-standard activations / return_sequences == false.
+ *   TimeDistributedDenseApplyDeviceFrag2h: valid for every layer (shapes / weights the f16 kernel does not take unpack to f32).
+ *   LSTMTimeDistributedDenseApplyDevice takes this route by default when it applies (option dense_f16x2 = 0: the frag3 route). */
+size_t nntk_frag2h_floats(int batch, int T, int C);
+int nntk_frag2h_pack_device(const float *d_x /*[batch,T,C], |x| < 2*/, float *d_frag2h, int batch, int T, int C);
+int nntk_frag2h_unpack_device(const float *d_frag2h, float *d_x /*[batch,T,C]*/, int batch, int T, int C);
+int LSTMApplyDeviceFrag2h(LSTM filter, const float *d_input, const float *d_input_frag3, float *d_output_frag2h, int batch);
+int TimeDistributedDenseApplyDeviceFrag2h(TimeDistributedDense filter, const float *d_input_frag2h /*[batch,ts,in]*/, float *d_output, int batch);
 int LSTMTimeDistributedDenseApplyDevice(LSTM lstm, TimeDistributedDense tdd, const float *d_input /*[batch,T,in]*/,
                                         float *d_output /*[batch,T,out]*/, int batch);
 int DenseApplyDevice(Dense filter, const float *d_input /*[rows,in]*/, float *d_output /*[rows,out]*/, int rows);

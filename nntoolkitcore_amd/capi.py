@@ -342,6 +342,11 @@ SIGNATURES = {
     "nntk_frag3_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "nntk_frag3_pack_device": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int]),
     "nntk_frag3_unpack_device": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int]),
+    "nntk_frag2h_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "nntk_frag2h_pack_device": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int]),
+    "nntk_frag2h_unpack_device": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int]),
+    "LSTMApplyDeviceFrag2h": (C.c_int, [vp, vp, vp, vp, C.c_int]),
+    "TimeDistributedDenseApplyDeviceFrag2h": (C.c_int, [vp, vp, vp, C.c_int]),
     "GRUKernelPlan": (C.c_char_p, [vp]),
     "LSTMKernelPlan": (C.c_char_p, [vp]),
     "GRUApplyDeviceFrag3": (C.c_int, [vp, vp, vp, vp, vp, C.c_int]),

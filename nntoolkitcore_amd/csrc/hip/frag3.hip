@@ -22,6 +22,19 @@
 // (16 accumulator tiles = 256 registers) of a 256 x 256 workgroup tile and stream 24 coalesced 1 KB loads per 16-deep k step
 // against 96 MFMAs.  Same products in the same order as conv1d_mfma_bf16x3_kernel: bit-identical to TimeDistributedDenseApplyDevice
 // on the f32 tensor the frag3 tensor was split from.
+//
+// FRAG2H (round 5, late): the same tensor as TWO f16 images of a power-of-two multiple, x * 2^15 = hi + lo with hi = f16(x 2^15), lo = f16(x 2^15 - hi):
+//   [T][NHT][NKS][2 images hi, lo] blocks of 1 KB in the same lane order (the B fragment of v_mfma_f32_32x32x16_f16 is that of the bf16 form).
+//   11 + 11 significand bits plus the residual's sign: |x - (hi + lo) 2^-15| <= 2^-23 |x| -- at worst ONE f32 ulp (just above a power of two),
+//   0.3 ulp rms -- instead of exact; and the contraction needs THREE products (lo.hi, hi.lo, hi.hi; dropped: lo.lo at 2^-24, where the bf16 form drops mid.lo, lo.mid,
+//   lo.lo) instead of six at the same MFMA rate.  The step is power-limited (DESIGN status, round 5): MFMA work is the currency.
+//   Range: f16 ends at 65 504, so the form is for tensors of magnitude < 2 -- the outputs of the recurrent layers with their standard
+//   activations (|h| <= 1), which is who produces it (lstm_rr_kernel / gru_rr_kernel's output wave, recurrent_rr.hip) -- and the scale keeps
+//   the low image out of f16's subnormals down to |x| ~ 2^-17.  The weights get their own scale 2^q, the largest power of two with
+//   max |W| 2^q <= 32 768 (nntk_shim_split_f16x2 at upload); the epilogue multiplies the sums by 2^-(15 + q), exactly.
+//   Measured at the stack's TimeDistributedDense (tools/micro/gemm_f16x2.hip, profiles/r05_gemm_f16x2_micro.log): 1.51 ms against 2.36, error
+//   against an f64 dot product of the same f32 operands rms 5.6e-8 / max 4.8e-7 -- below the six-product kernel's (7.6e-8 / 7.7e-7) and
+//   below the reference's own left-to-right f32 accumulation (8.8e-8 / 8.4e-7, core/default_ops.cc:224-231).
 #include "nntk_common.hpp"
 #include <type_traits>
 
@@ -29,6 +42,8 @@ typedef unsigned f3_v4u __attribute__((ext_vector_type(4)));
 typedef __bf16 f3_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 f3_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f3_f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f3_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f3_f16x2 __attribute__((ext_vector_type(2)));
 
 #ifndef DF3_MFMA_PER_LOAD
 #define DF3_MFMA_PER_LOAD 2
@@ -159,6 +174,7 @@ struct DF3Params {
     float relu_a;
     int m_tiles, n_tiles;
     int dbg;              // unused by the product kernels (the probes are compile-time instantiations)
+    float out_scale;      // FMT 1: 2^-(15 + q), the operands' power-of-two scales taken back out of the sums
 };
 
 // WM x WN wavefronts, each TM row blocks x TN column tiles of 32 x 32.  D = W x h^T, so a lane owns ONE output row (batch row n of
@@ -166,9 +182,12 @@ struct DF3Params {
 // one 16-byte store (the orientation of conv_epilogue).
 // (Tried: the A fragments requested TWO k steps ahead through a ring of three register sets -- 240 operand registers next to the 256
 // accumulators: 2 784 bytes of scratch, not measured.  The deeper A prefetch lives in dense_frag3_hybrid_kernel below instead.)
-template <int WM, int WN, int TM, int TN>
+// FMT 1: the FRAG2H form of both operands (see below) -- two f16 images, three products, v_mfma_f32_32x32x16_f16; p.a / p.w / p.img_bytes
+// describe that form's blocks, everything else is the same kernel.
+template <int WM, int WN, int TM, int TN, int FMT = 0>
 __global__ __launch_bounds__(256) void dense_frag3_kernel(DF3Params p) {
     static_assert(WM * WN == 4, "4 wavefronts");
+    constexpr int NIMG = FMT == 0 ? 3 : 2, NPROD = FMT == 0 ? 6 : 3;
     constexpr int BM_RB = WM * TM;                   // row blocks per workgroup tile
     constexpr int BN = WN * TN * 32;
     const int lane = threadIdx.x & 63;
@@ -201,9 +220,9 @@ __global__ __launch_bounds__(256) void dense_frag3_kernel(DF3Params p) {
     const int NKS = p.NKS;
 
     // A: one descriptor at the wave's first row block; row blocks past the tensor read zeros (range-checked VECTOR offset)
-    const size_t rb_bytes = (size_t)NKS * 3072;
+    const size_t rb_bytes = (size_t)NKS * NIMG * 1024;
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void *)(p.a + (size_t)rb0 * rb_bytes), 0, (int)(TM * rb_bytes), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)(3 * p.img_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)(NIMG * p.img_bytes), 0x00020000);
     const int lane16 = lane * 16;
     int a_vo[TM];
 #pragma unroll
@@ -213,16 +232,16 @@ __global__ __launch_bounds__(256) void dense_frag3_kernel(DF3Params p) {
     for (int j = 0; j < TN; ++j) w_vo[j] = lane16 + (((n0 >> 5) + wn * TN + j) * NKS) * 1024;
     const int img = (int)p.img_bytes;
 
-    f3_v4u av[2][TM][3], wv[2][TN][3];
+    f3_v4u av[2][TM][NIMG], wv[2][TN][NIMG];
     // requested in the order the products need them (lo of A and hi of W first, see PA / PW below), so the consumer's counted waits
     // release its first MFMAs before the whole set has landed
-    constexpr int MA[3] = {2, 0, 1}, MW[3] = {0, 2, 1};
+    constexpr int MA[3] = {NIMG - 1, 0, 1}, MW[3] = {0, NIMG - 1, 1};
     auto load = [&](auto buf_tag, int ks) __attribute__((always_inline)) {
         constexpr int buf = decltype(buf_tag)::value;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < NIMG; ++q) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) av[buf][i][MA[q]] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_vo[i] + MA[q] * 1024, ks * 3072, 0);
+            for (int i = 0; i < TM; ++i) av[buf][i][MA[q]] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_vo[i] + MA[q] * 1024, ks * NIMG * 1024, 0);
 #pragma unroll
             for (int j = 0; j < TN; ++j) wv[buf][j][MW[q]] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_vo[j], ks * 1024 + MW[q] * img, 0);
         }
@@ -240,18 +259,23 @@ __global__ __launch_bounds__(256) void dense_frag3_kernel(DF3Params p) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("" : "+a"(acc[i][j]));
-    // smallest terms first, the order of conv1d_mfma_bf16x3_kernel (bit-identical sums): (A image, W image)
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PW[6] = {0, 2, 1, 0, 1, 0};
+    // smallest terms first, the order of conv1d_mfma_bf16x3_kernel (bit-identical sums): (A image, W image); FRAG2H: lo.hi, hi.lo, hi.hi
+    constexpr int PA[6] = {NIMG - 1, 0, FMT == 0 ? 1 : 0, 1, 0, 0}, PW[6] = {0, NIMG - 1, FMT == 0 ? 1 : 0, 0, 1, 0};
     auto mma2 = [&](auto abuf_tag, auto wbuf_tag) __attribute__((always_inline)) {
         constexpr int ab = decltype(abuf_tag)::value, wb = decltype(wbuf_tag)::value;
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+        for (int t = 0; t < NPROD; ++t)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(f3_bf16x8, wv[wb][j][PW[t]]),
-                                                                        __builtin_bit_cast(f3_bf16x8, av[ab][i][PA[t]]), acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (FMT == 0)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(f3_bf16x8, wv[wb][j][PW[t]]),
+                                                                            __builtin_bit_cast(f3_bf16x8, av[ab][i][PA[t]]), acc[i][j], 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f3_f16x8, wv[wb][j][PW[t]]),
+                                                                           __builtin_bit_cast(f3_f16x8, av[ab][i][PA[t]]), acc[i][j], 0, 0, 0);
+                }
     };
     auto mma = [&](auto buf_tag) __attribute__((always_inline)) { mma2(buf_tag, buf_tag); };
     using I0 = std::integral_constant<int, 0>;
@@ -265,7 +289,7 @@ __global__ __launch_bounds__(256) void dense_frag3_kernel(DF3Params p) {
     // 24 stalls the issuing wave and its MFMAs), the second half is the cover for the requests' latency
     auto interleave = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < 3 * (TM + TN); ++q) {
+        for (int q = 0; q < NIMG * (TM + TN); ++q) {
             __builtin_amdgcn_sched_group_barrier(0x008, DF3_MFMA_PER_LOAD, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
@@ -310,6 +334,10 @@ __global__ __launch_bounds__(256) void dense_frag3_kernel(DF3Params p) {
                     float4 bi = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (p.bias) bi = *reinterpret_cast<const float4 *>(p.bias + c);
                     float v[4] = {acc[i][j][4 * g + 0] + bi.x, acc[i][j][4 * g + 1] + bi.y, acc[i][j][4 * g + 2] + bi.z, acc[i][j][4 * g + 3] + bi.w};
+                    if constexpr (FMT != 0) {
+                        v[0] = fmaf(acc[i][j][4 * g + 0], p.out_scale, bi.x); v[1] = fmaf(acc[i][j][4 * g + 1], p.out_scale, bi.y);
+                        v[2] = fmaf(acc[i][j][4 * g + 2], p.out_scale, bi.z); v[3] = fmaf(acc[i][j][4 * g + 3], p.out_scale, bi.w);
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         v[e] = ACT == -1 ? nntk_act(p.act_kind, v[e], p.relu_a) : ACT == NNTK_ACT_RELU ? nntk_act(NNTK_ACT_RELU, v[e], p.relu_a) : v[e];
@@ -337,6 +365,8 @@ __global__ __launch_bounds__(256) void dense_frag3_kernel(DF3Params p) {
         asm volatile("" : "+v"(le));
         const int wr_row = (le & 31) * 8, wr_sw = ((le & 31) >> 1) & 7;
         const int rd_r = le >> 3, rd_q = le & 7;
+        const float osc = p.out_scale;
+        (void)osc;
         f3_for<0, TM>([&](auto i_tag) __attribute__((always_inline)) {
             constexpr int i = decltype(i_tag)::value;
             const long rb = rb0 + i;
@@ -352,6 +382,10 @@ __global__ __launch_bounds__(256) void dense_frag3_kernel(DF3Params p) {
                 for (int g = 0; g < 4; ++g) {
                     const float4 bi = *reinterpret_cast<const float4 *>(epi_bias + (wn * TN + j) * 32 + 8 * g + 4 * (le >> 5));
                     float v[4] = {tile[4 * g + 0] + bi.x, tile[4 * g + 1] + bi.y, tile[4 * g + 2] + bi.z, tile[4 * g + 3] + bi.w};
+                    if constexpr (FMT != 0) {      // the sums carry the operands' scales 2^15 (h) and 2^q (W): one exact multiplication, fused with the bias
+                        v[0] = fmaf(tile[4 * g + 0], osc, bi.x); v[1] = fmaf(tile[4 * g + 1], osc, bi.y);
+                        v[2] = fmaf(tile[4 * g + 2], osc, bi.z); v[3] = fmaf(tile[4 * g + 3], osc, bi.w);
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         v[e] = ACT == -1 ? nntk_act(p.act_kind, v[e], p.relu_a) : ACT == NNTK_ACT_RELU ? nntk_act(NNTK_ACT_RELU, v[e], p.relu_a) : v[e];
@@ -546,6 +580,145 @@ __global__ __launch_bounds__(256) void dense_frag3_lds_kernel(DF3Params p) {
 // holds the kernels at 0.61 MFMA-busy; the exposed epilogue (0.35-0.4 ms: one workgroup owns the CU) and the clock the bf16 pipe is
 // allowed (1.89 GHz here) are.  The hybrid kernel was removed again; this ring kernel stays as the probe harness, tools/tdd_probe.py.)
 
+
+// ---- FRAG2H: pack / unpack (tests, fallbacks) and the weights' two f16 images -----------------------------------------
+#define F3_H2_SCALE 32768.0f
+__device__ __forceinline__ void f3_split_pair_h2(float x0, float x1, float scale, unsigned &hi, unsigned &lo) {
+#pragma clang fp contract(off)    // the residual is that of the ROUNDED product
+    const float y0 = x0 * scale, y1 = x1 * scale;                         // power of two: exact
+    const f3_f16x2 hh = __builtin_convertvector((f3_f32x2){y0, y1}, f3_f16x2);
+    const f3_f16x2 ll = __builtin_convertvector((f3_f32x2){y0 - (float)hh[0], y1 - (float)hh[1]}, f3_f16x2);
+    hi = __builtin_bit_cast(unsigned, hh);
+    lo = __builtin_bit_cast(unsigned, ll);
+}
+extern "C" size_t nntk_shim_frag2h_floats(int B, int T, int C) {
+    if (B <= 0 || T <= 0 || C <= 0) return 0;
+    return (size_t)T * ((size_t)(B + 63) / 64 * 2) * (size_t)((C + 15) / 16) * 2 * 256;
+}
+// f32 [B][T][C] (|x| < 2) -> frag2h; the recurrent kernels write the same bits for the same values (rr_split8_h2)
+__global__ __launch_bounds__(256) void frag2h_pack_kernel(const float *__restrict__ x, f3_v4u *__restrict__ dst, int B, int T, int C, int NHT, int NKS) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n = lane & 31, kh = lane >> 5;
+    const long rb = blockIdx.x;
+    const int t = (int)(rb / NHT), ht = (int)(rb % NHT);
+    const int b = ht * 32 + n;
+    const float *row = x + ((size_t)b * T + t) * C;
+    for (int ks = w; ks < NKS; ks += 4) {
+        const int c0 = 16 * ks + 8 * kh;
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (b < B && c0 + q < C) ? row[c0 + q] : 0.0f;
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f3_split_pair_h2(v[2 * i], v[2 * i + 1], F3_H2_SCALE, h[i], l[i]);
+        f3_v4u *d = dst + (((size_t)rb * NKS + ks) * 2) * 64 + lane;
+        d[0] = (f3_v4u){h[0], h[1], h[2], h[3]};
+        d[64] = (f3_v4u){l[0], l[1], l[2], l[3]};
+    }
+}
+extern "C" int nntk_shim_frag2h_pack(const float *d_x, void *d_frag, int B, int T, int C) {
+    if (B <= 0 || T <= 0 || C <= 0) return 0;
+    const int NHT = (B + 63) / 64 * 2, NKS = (C + 15) / 16;
+    const long blocks = (long)T * NHT;
+    if (blocks > 0x7fffffffL) return nntk_fail_msg("frag2h_pack: too many row blocks");
+    hipLaunchKernelGGL(frag2h_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, nntk_stream(), d_x, (f3_v4u *)d_frag, B, T, C, NHT, NKS);
+    NNTK_LAUNCH_CHECK("frag2h_pack_kernel");
+    return 0;
+}
+// frag2h -> f32: x = (hi + lo) 2^-15 (the sum is exact in f32: lo lies within half an ulp of hi's 11 bits and has 11 bits itself)
+__global__ __launch_bounds__(256) void frag2h_unpack_kernel(const f3_v4u *__restrict__ src, float *__restrict__ x, int B, int T, int C, int NHT, int NKS) {
+    const long total = (long)T * NHT * NKS * 64;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(e & 63);
+        long r = e >> 6;
+        const int ks = (int)(r % NKS); r /= NKS;
+        const int ht = (int)(r % NHT);
+        const int t = (int)(r / NHT);
+        const int b = ht * 32 + (lane & 31);
+        if (b >= B) continue;
+        const f3_v4u *s = src + ((((size_t)t * NHT + ht) * NKS + ks) * 2) * 64 + lane;
+        const f3_v4u hi = s[0], lo = s[64];
+        const unsigned hh[4] = {hi.x, hi.y, hi.z, hi.w}, ll[4] = {lo.x, lo.y, lo.z, lo.w};
+        const int c0 = 16 * ks + 8 * (lane >> 5);
+        float *row = x + ((size_t)b * T + t) * C;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f3_f16x2 h2 = __builtin_bit_cast(f3_f16x2, hh[i]), l2 = __builtin_bit_cast(f3_f16x2, ll[i]);
+            if (c0 + 2 * i < C) row[c0 + 2 * i] = ((float)h2[0] + (float)l2[0]) * (1.0f / F3_H2_SCALE);
+            if (c0 + 2 * i + 1 < C) row[c0 + 2 * i + 1] = ((float)h2[1] + (float)l2[1]) * (1.0f / F3_H2_SCALE);
+        }
+    }
+}
+extern "C" int nntk_shim_frag2h_unpack(const void *d_frag, float *d_x, int B, int T, int C) {
+    if (B <= 0 || T <= 0 || C <= 0) return 0;
+    const int NHT = (B + 63) / 64 * 2, NKS = (C + 15) / 16;
+    long g = ((long)T * NHT * NKS * 64 + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(frag2h_unpack_kernel, dim3((unsigned)g), dim3(256), 0, nntk_stream(), (const f3_v4u *)d_frag, d_x, B, T, C, NHT, NKS);
+    NNTK_LAUNCH_CHECK("frag2h_unpack_kernel");
+    return 0;
+}
+// packed weights src [rows][ktot] f32 (rows % 32 == 0, ktot % 16 == 0: nntk_upload_gemm_weights) -> dst [2 images][rows / 32][ktot / 16][2][32][8] f16
+// of src * scale -- the order of split_bf16x3_kernel (conv1d.hip), i.e. the A fragment of column tile rows / 32, k step ktot / 16
+__global__ __launch_bounds__(256) void split_f16x2_kernel(const float *__restrict__ src, unsigned *__restrict__ dst, int rows, int ktot, float scale) {
+    const size_t n_pairs = (size_t)rows * ktot / 2;
+    const int ksteps = ktot >> 4;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n_pairs; e += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(e / (ktot / 2)), kt = (int)(e % (ktot / 2)) * 2;
+        unsigned h, l;
+        f3_split_pair_h2(src[2 * e], src[2 * e + 1], scale, h, l);
+        const size_t d = ((((size_t)(row >> 5) * ksteps + (kt >> 4)) * 2 + ((kt >> 3) & 1)) * 32 + (row & 31)) * 4 + ((kt & 7) >> 1);
+        dst[d] = h; dst[n_pairs + d] = l;
+    }
+}
+extern "C" int nntk_shim_split_f16x2(const float *d_src, void *d_dst, int rows, int ktot, float scale) {
+    if (rows <= 0 || ktot <= 0) return 0;
+    if ((rows & 31) || (ktot & 15)) return nntk_fail_msg("split_f16x2: rows must be a multiple of 32 and ktot of 16");
+    size_t g = ((size_t)rows * ktot / 2 + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(split_f16x2_kernel, dim3((unsigned)g), dim3(256), 0, nntk_stream(), d_src, (unsigned *)d_dst, rows, ktot, scale);
+    NNTK_LAUNCH_CHECK("split_f16x2_kernel");
+    return 0;
+}
+
+// The GEMM on FRAG2H operands.  d_wh2: the weights' two f16 images of W * w_scale (nntk_shim_split_f16x2 over the packed f32 matrix, N_p * K_p
+// pairs each); w_scale a power of two.  0 = launched; 1 = shape not taken (probe = 1: nothing is launched, the answer only); -1 = error.
+extern "C" int nntk_shim_dense_frag2h(const void *d_frag, const void *d_wh2, float w_scale, const float *d_bias, int act_kind, float relu_a,
+                                      float *d_out, int B, int T, int K, int N, int probe) {
+    if (B <= 0 || T <= 0) return 0;
+    if (act_kind == NNTK_ACT_NONE) act_kind = NNTK_ACT_IDENTITY;
+    if (act_kind == NNTK_ACT_SOFTMAX || act_kind == NNTK_ACT_CUSTOM) return 1;
+    const NntkOptions &opt = nntk_options();
+    if (opt.gemm_split_bf16 == 0 || opt.gemm_split_bf16 == 2 || opt.dense_frag3 == 0 || opt.dense_f16x2 == 0) return 1;
+    if (!d_wh2 || !(w_scale > 0.0f)) return 1;
+    int K_p, N_p;
+    nntk_shim_conv_pack_sizes(K, N, 1, &K_p, &N_p);
+    if ((N % 4) != 0 || (((size_t)d_out) & 15) != 0 || (d_bias && (((size_t)d_bias) & 15) != 0)) return 1;
+    if (N_p % 128 != 0 || K_p != ((K + 15) / 16) * 16) return 1;
+    const int NHT = (B + 63) / 64 * 2, NKS = K_p / 16;
+    const size_t n_w = (size_t)N_p * K_p;
+    if (n_w * 4 >= (size_t)F3_OOB || (size_t)8 * NKS * 2048 >= (size_t)F3_OOB) return 1;
+    DF3Params p;
+    p.a = (const char *)d_frag;
+    p.w = (const char *)d_wh2;
+    p.img_bytes = n_w * 2;
+    p.bias = d_bias; p.out = d_out;
+    p.NRB = (long)T * NHT; p.NHT = NHT; p.NKS = NKS; p.B = B; p.T = T; p.N = N;
+    p.act_kind = act_kind; p.relu_a = relu_a;
+    p.dbg = 0;
+    p.out_scale = 1.0f / (F3_H2_SCALE * w_scale);           // powers of two: exact
+    const bool wide = N_p % 256 == 0;
+    p.m_tiles = (int)((p.NRB + 7) / 8);
+    p.n_tiles = N_p / (wide ? 256 : 128);
+    const long blocks = (long)((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
+    if (blocks > 0x7fffffffL) return 1;
+    if (probe) return 0;
+    if (wide) hipLaunchKernelGGL((dense_frag3_kernel<2, 2, 4, 4, 1>), dim3((unsigned)blocks), dim3(256), 0, nntk_stream(), p);
+    else hipLaunchKernelGGL((dense_frag3_kernel<4, 1, 2, 4, 1>), dim3((unsigned)blocks), dim3(256), 0, nntk_stream(), p);
+    NNTK_LAUNCH_CHECK("dense_frag3_kernel<f16x2>");
+    return 0;
+}
+
 // 0 = launched; 1 = shape not taken (the caller unpacks and runs the f32 GEMM); -1 = error.
 // d_wp: the packed weights of nntk_upload_gemm_weights ([N_p][K_p] f32 followed by the three split images); K = the frag3 tensor's C.
 extern "C" int nntk_shim_dense_frag3(const void *d_frag, const float *d_wp, const float *d_bias, int act_kind, float relu_a,
@@ -573,6 +746,7 @@ extern "C" int nntk_shim_dense_frag3(const void *d_frag, const float *d_wp, cons
     p.NRB = (long)T * NHT; p.NHT = NHT; p.NKS = NKS; p.B = B; p.T = T; p.N = N;
     p.act_kind = act_kind; p.relu_a = relu_a;
     p.dbg = opt.conv_dbg;
+    p.out_scale = 1.0f;
     const bool wide = N_p % 256 == 0;
     // the register-direct kernel (2.44 vs 2.54 ms for the LDS-ring variant at the stack's shape, same box: profiles/r04_tdd_three_kernels.log)
 #ifdef NNTK_VARIANT_DENSE_RING

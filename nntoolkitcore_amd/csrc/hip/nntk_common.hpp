@@ -25,6 +25,7 @@ struct NntkOptions {
     int rec_xf = -1;             // register-resident kernels: f32 input packed into frag3 form first (1 always, 0 only when the f32 path cannot take the shape; auto: see recurrent.c)
     int rec_fk = -1;             // full-K register-resident kernels (recurrent_fk.hip): 1 every shape they take, 0 none; auto: 256-wide inputs (where they beat the split-K family)
     int dense_frag3 = -1;        // dense GEMM with a frag3 A operand (0: consumers unpack to f32 and run the LDS-staged GEMM)
+    int dense_f16x2 = -1;        // LSTM -> TimeDistributedDense: the tensor in between as two f16 images, three products (frag3.hip FRAG2H); 0: the frag3 route
     int train_outer_plain = -1;  // weight-gradient products of plain matrices on the VALU-free MFMA kernel (0: the general one; A/B)
     int train_bptt = -1;         // GRU / LSTM gradient: the whole BPTT loop in one persistent kernel (0: two launches per timestep)
     int spec_ppw = 0;            // frame pairs per wavefront in K1 (0 = auto)

@@ -210,8 +210,8 @@ int nntk_shim_gru_rr_train_forward(const float *d_x, const float *d_img, const f
 int nntk_shim_lstm_rr_train_forward(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,
                                     float *d_h, float *d_c, float *d_zifgo, float *d_hseq, float *d_work, int B, int T, int in, int H);
 int nntk_shim_lstm_rr(const float *d_x, const void *d_xf3, const float *d_img, const float *d_img4, const float *d_bi, const float *d_bh,
-                      const float *d_h0, const float *d_c0, float *d_out, float *d_hseq, float *d_hT, float *d_cT,
-                      float *d_work, int B, int T, int in, int H, int return_sequences);
+                      const float *d_h0, const float *d_c0, float *d_out, float *d_out_h2 /* frag2h form of the sequence output, or NULL; needs d_out == NULL */,
+                      float *d_hseq, float *d_hT, float *d_cT, float *d_work, int B, int T, int in, int H, int return_sequences);
 
 /* ---- frag3 tensors (frag3.hip): a [B][T][C] f32 tensor as three bf16 images (x = hi + mid + lo exactly) in MFMA fragment order,
  * [T][2 ceil(B / 64)][ceil(C / 16)][3] blocks of 1 KB.  nntk_shim_dense_frag3: out [B][T][N] = act(h . W + b) with h in frag3 form and
@@ -219,6 +219,16 @@ int nntk_shim_lstm_rr(const float *d_x, const void *d_xf3, const float *d_img, c
 size_t nntk_shim_frag3_floats(int B, int T, int C);
 int nntk_shim_frag3_pack(const float *d_x, void *d_frag, int B, int T, int C);
 int nntk_shim_frag3_unpack(const void *d_frag, float *d_x, int B, int T, int C);
+/* FRAG2H (frag3.hip): the same tensor as two f16 images of x * 2^15 (|x| < 2), [T][2 ceil(B / 64)][ceil(C / 16)][2] blocks of 1 KB; the
+ * dense GEMM on that form sums three products per k step.  d_wh2: the two f16 images of W * w_scale made by nntk_shim_split_f16x2 from the
+ * packed f32 matrix ([N_p][K_p], nntk_shim_conv_pack_sizes; 2 * N_p * K_p halves), w_scale a power of two with max |W| w_scale <= 32768.
+ * nntk_shim_dense_frag2h returns 1 when the shape / configuration is not taken (probe = 1: asks only, launches nothing). */
+size_t nntk_shim_frag2h_floats(int B, int T, int C);
+int nntk_shim_frag2h_pack(const float *d_x, void *d_frag, int B, int T, int C);
+int nntk_shim_frag2h_unpack(const void *d_frag, float *d_x, int B, int T, int C);
+int nntk_shim_split_f16x2(const float *d_src, void *d_dst, int rows, int ktot, float scale);
+int nntk_shim_dense_frag2h(const void *d_frag, const void *d_wh2, float w_scale, const float *d_bias, int act_kind, float relu_a,
+                           float *d_out, int B, int T, int K, int N, int probe);
 int nntk_shim_dense_frag3(const void *d_frag, const float *d_wp, const float *d_bias, int act_kind, float relu_a,
                           float *d_out, int B, int T, int K, int N);
 

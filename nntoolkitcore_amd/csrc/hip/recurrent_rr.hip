@@ -530,6 +530,18 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
                 __builtin_amdgcn_raw_buffer_store_b128(o0, rso, vo, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(o1, rso, vo + 16, 0, 0);
                 RR_BOUND(2, (size_t)b0 * o_row_bytes, vo + 16, 0, o_range < 0x7fffffffL ? o_range : 0x7fffffffL, 16);
+            } else if (p.out_h2 && !RR_DBG(1024)) {
+                // the same eight values as the FRAG2H block of (row block, k step ct): this lane IS lane 32 kh + n of the fragment, so the two
+                // images leave as two coalesced 1 KB stores -- in the slot of the two f32 stores above (the host passes one form or the other).
+                // Ordinary stores: the consumer is a later kernel
+                const float v8[8] = {__uint_as_float(o0.x), __uint_as_float(o0.y), __uint_as_float(o0.z), __uint_as_float(o0.w),
+                                     __uint_as_float(o1.x), __uint_as_float(o1.y), __uint_as_float(o1.z), __uint_as_float(o1.w)};
+                rr_v4u h2hi, h2lo;
+                rr_split8_h2(v8, h2hi, h2lo);
+                const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.out_h2 + (size_t)t * p.h2step), 0, (int)p.h2step, 0x00020000);
+                const int vo = lane16 + (((bt_abs * 2 + half) * NKS + ct) * 2) * 1024;
+                __builtin_amdgcn_raw_buffer_store_b128(h2hi, rs2, vo, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(h2lo, rs2, vo + 1024, 0, 0);
             }
             if (LAST) {
                 int b0e = b0;
@@ -916,14 +928,15 @@ struct RRIo {
     const float *x; const void *xf3; float *out; float *hseq; float *work;
     const float *h0, *c0; float *hT, *cT; float *c_cache, *z_cache;
     int x_tm, out_tm;
+    float *out_h2;            // the sequence output as a FRAG2H tensor (frag3.hip) instead of the f32 rows, or NULL
 };
 static int rr_launch(const RRIo &io, const float *d_img, const float *d_bi, const float *d_bh,
                      int B, int T, int in, int H, int return_sequences, int cell);
 
 extern "C" int nntk_shim_lstm_rr(const float *d_x, const void *d_xf3, const float *d_img, const float *d_img4, const float *d_bi, const float *d_bh,
-                                 const float *d_h0, const float *d_c0, float *d_out, float *d_hseq, float *d_hT, float *d_cT,
+                                 const float *d_h0, const float *d_c0, float *d_out, float *d_out_h2, float *d_hseq, float *d_hT, float *d_cT,
                                  float *d_work, int B, int T, int in, int H, int return_sequences) {
-    RRIo io = {d_img4, d_x, d_xf3, d_out, d_hseq, d_work, d_h0, d_c0, d_hT, d_cT, nullptr, nullptr, 0, 0};
+    RRIo io = {d_img4, d_x, d_xf3, d_out, d_hseq, d_work, d_h0, d_c0, d_hT, d_cT, nullptr, nullptr, 0, 0, d_out_h2};
     return rr_launch(io, d_img, d_bi, d_bh, B, T, in, H, return_sequences, 0);
 }
 // GRU on the same kernel frame (gru_rr_kernel): d_img packed from the four-slot matrices [U_z | U_r | U_h | 0] / [W_z | W_r | 0 | W_h],
@@ -931,19 +944,19 @@ extern "C" int nntk_shim_lstm_rr(const float *d_x, const void *d_xf3, const floa
 // x_tm / out_tm: d_x is [T][B][in] / the sequence output is written as [T][B][H]
 extern "C" int nntk_shim_gru_rr(const float *d_x, const void *d_xf3, const float *d_img, const float *d_img4, const float *d_b4, const float *d_h0, float *d_out,
                                 float *d_hseq, float *d_hT, float *d_work, int B, int T, int in, int H, int return_sequences, int x_tm, int out_tm) {
-    RRIo io = {d_img4, d_x, d_xf3, d_out, d_hseq, d_work, d_h0, d_h0, d_hT, nullptr, nullptr, nullptr, x_tm, out_tm};
+    RRIo io = {d_img4, d_x, d_xf3, d_out, d_hseq, d_work, d_h0, d_h0, d_hT, nullptr, nullptr, nullptr, x_tm, out_tm, nullptr};
     return rr_launch(io, d_img, d_b4, nullptr, B, T, in, H, return_sequences, 1);
 }
 // GRU training forward: zero initial state, h of every step to d_h [B][T][H], caches d_hU [B][T][H] (h.U_h + b_h) and d_Zg [B][T][6H]
 extern "C" int nntk_shim_gru_rr_train_forward(const float *d_x, const float *d_img, const float *d_b4, float *d_h, float *d_hU, float *d_Zg,
                                               float *d_hseq, float *d_work, int B, int T, int in, int H) {
-    RRIo io = {nullptr, d_x, nullptr, d_h, d_hseq, d_work, nullptr, nullptr, nullptr, nullptr, d_hU, d_Zg, 0, 0};
+    RRIo io = {nullptr, d_x, nullptr, d_h, d_hseq, d_work, nullptr, nullptr, nullptr, nullptr, d_hU, d_Zg, 0, 0, nullptr};
     return rr_launch(io, d_img, d_b4, nullptr, B, T, in, H, 1, 1);
 }
 // training forward: zero initial state, h of every step to d_h [B][T][H], caches d_c [B][T][H] and d_zifgo [B][T][8H]
 extern "C" int nntk_shim_lstm_rr_train_forward(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,
                                                float *d_h, float *d_c, float *d_zifgo, float *d_hseq, float *d_work, int B, int T, int in, int H) {
-    RRIo io = {nullptr, d_x, nullptr, d_h, d_hseq, d_work, nullptr, nullptr, nullptr, nullptr, d_c, d_zifgo, 0, 0};
+    RRIo io = {nullptr, d_x, nullptr, d_h, d_hseq, d_work, nullptr, nullptr, nullptr, nullptr, d_c, d_zifgo, 0, 0, nullptr};
     return rr_launch(io, d_img, d_bi, d_bh, B, T, in, H, 1, 0);
 }
 
@@ -964,6 +977,8 @@ static int rr_launch(const RRIo &io, const float *d_img, const float *d_bi, cons
     // time-major tensors are addressed across the whole batch with 32-bit buffer offsets
     if (io.x_tm && (double)T * B * in * 4 >= 2.0e9) return 1;
     if (io.out_tm && (!return_sequences || !io.out || (double)T * B * H * 4 >= 2.0e9)) return 1;
+    // the FRAG2H output takes the f32 rows' store slot and exists in the split-K family only (the host routes full-K shapes through f32)
+    if (io.out_h2 && (io.out || io.img4 || train || !return_sequences)) return nntk_fail_msg("lstm_rr: frag2h output with an f32 output / on the full-K family");
     const NntkOptions &opt = nntk_options();
     if (opt.rec_rr == 0 || opt.rec_persistent == 0 || nntk_persistent_disabled()) return 1;
     int KH, KX;
@@ -1015,6 +1030,7 @@ static int rr_launch(const RRIo &io, const float *d_img, const float *d_bi, cons
     q.spin_ticks = (unsigned long long)(opt.rec_spin_us > 0 ? opt.rec_spin_us : 0) * 100ull;
     q.B = B; q.T = T; q.H = H; q.in = in; q.NCT = NCT; q.return_sequences = return_sequences;
     q.NHT = nbt_total * 2;
+    q.out_h2 = (char *)io.out_h2; q.h2step = step / 3 * 2;
 #ifdef NNTK_REC_STAMPS
     q.stamp = nullptr;
     const char *stamp_path = getenv("NNTK_REC_STAMP_FILE");

@@ -59,6 +59,24 @@ __device__ __forceinline__ void rr_split8(const float (&v)[8], rr_v4u &hi, rr_v4
     lo = (rr_v4u){l[0], l[1], l[2], l[3]};
 }
 
+// eight consecutive f32 of magnitude < 2 -> the two 16-byte f16 fragments of x * 2^15: hi = f16(x 2^15), lo = f16(x 2^15 - hi) (frag3.hip FRAG2H)
+typedef _Float16 rr_f16x2 __attribute__((ext_vector_type(2)));
+#define RR_H2_SCALE 32768.0f
+__device__ __forceinline__ void rr_split8_h2(const float (&v)[8], rr_v4u &hi, rr_v4u &lo) {
+#pragma clang fp contract(off)    // the residual is that of the ROUNDED product
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x0 = v[2 * i] * RR_H2_SCALE, x1 = v[2 * i + 1] * RR_H2_SCALE;       // power of two: exact
+        const rr_f16x2 hh = __builtin_convertvector((rr_f32x2){x0, x1}, rr_f16x2);
+        const rr_f16x2 ll = __builtin_convertvector((rr_f32x2){x0 - (float)hh[0], x1 - (float)hh[1]}, rr_f16x2);
+        h[i] = __builtin_bit_cast(unsigned, hh);
+        l[i] = __builtin_bit_cast(unsigned, ll);
+    }
+    hi = (rr_v4u){h[0], h[1], h[2], h[3]};
+    lo = (rr_v4u){l[0], l[1], l[2], l[3]};
+}
+
 struct RRParams {
     const float *x;            // [B][T][in]
     const rr_v4u *img;         // weight images (rr_pack_kernel)
@@ -82,6 +100,10 @@ struct RRParams {
     int B, T, H, in, NBT, NCT, b_base, return_sequences;
     int NKSx;                  // k steps of 16 the x frag3 tensor stores per row block
     int NHT;                   // half-tiles (32 rows) the frag3 tensors hold: 2 ceil(B / 64) (recurrent_rr4.hip masks streams past it)
+    // the sequence output once more as a FRAG2H tensor (frag3.hip: two f16 images of h * 2^15, [T][NHT][NKS][2] blocks of 1 KB) for the dense
+    // GEMM's three-product contraction, or NULL; written by the wave that would write the f32 rows (p.out must be NULL then).  recurrent_rr.hip only
+    char *out_h2;
+    size_t h2step;             // bytes per timestep = NHT * NKS * 2048
 #ifdef NNTK_REC_STAMPS
     unsigned long long *stamp; // [T + 1][4 streams][16] s_memtime of workgroup 0, wave 0 (diagnostics build only; the two-stream kernels use streams 0, 1)
 #endif

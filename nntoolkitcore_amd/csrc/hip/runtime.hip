@@ -47,6 +47,7 @@ static const OptDesc g_opt_table[] = {
     {"rec_xf", "NNTK_REC_XF", &NntkOptions::rec_xf},
     {"rec_fk", "NNTK_REC_FK", &NntkOptions::rec_fk},
     {"dense_frag3", "NNTK_DENSE_FRAG3", &NntkOptions::dense_frag3},
+    {"dense_f16x2", "NNTK_DENSE_F16X2", &NntkOptions::dense_f16x2},
     {"train_bptt", "NNTK_TRAIN_BPTT", &NntkOptions::train_bptt},
     {"train_outer_plain", "NNTK_TRAIN_OUTER_PLAIN", &NntkOptions::train_outer_plain},
     {"spec_ppw", "NNTK_SPEC_PPW", &NntkOptions::spec_ppw},

@@ -6,6 +6,7 @@
  * element) is one row of a single MFMA GEMM with the bias and the activation
  * fused; softmax (which spans a row) runs as a second wave-per-row kernel.
  */
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #include "nntk_internal.h"
@@ -15,6 +16,10 @@ struct DenseStruct {
     DenseWeights *weights;
     nntk_wblock wb;
     float *d_wp, *d_bias;
+    /* FRAG2H operand form of W (frag3.hip): two f16 images of W * wh2_scale behind the bf16 ones' pattern; wh2_scale = 0: not available
+     * (a non-finite weight, or a block whose largest magnitude no power of two brings to 32 768) */
+    void *d_wh2;
+    float wh2_scale;
     nntk_devbuf d_in, d_out;
     /* training (dense.c:18-48): x | z | a kept from DenseApplyTrainingBatch for DenseCalculateGradient */
     int training, mini_batch;
@@ -52,6 +57,7 @@ void DenseDestroy(Dense filter) {
     if (!filter) return;
     nntk_shim_synchronize();
     nntk_shim_free(filter->d_wp);
+    nntk_shim_free(filter->d_wh2);
     nntk_shim_free(filter->d_bias);
     nntk_devbuf_free(&filter->d_in);
     nntk_devbuf_free(&filter->d_out);
@@ -63,9 +69,34 @@ void DenseDestroy(Dense filter) {
     free(filter);
 }
 
+/* the scale of W's FRAG2H images: the largest power of two with max |W| * scale <= 32 768 (half of f16's range: a row's hi image cannot
+ * overflow, and its low image stays out of the subnormals for every weight within 2^-17 of the largest); 0 = the form is not available */
+static float dense_h2_scale(const float *W, size_t n) {
+    float mx = 0.f;
+    for (size_t i = 0; i < n; ++i) {
+        union { float f; unsigned u; } v = { W[i] };
+        if (((v.u >> 23) & 0xffu) == 0xffu) return 0.f;              /* inf / NaN */
+        float a = W[i] < 0.f ? -W[i] : W[i];
+        if (a > mx) mx = a;
+    }
+    if (!(mx > 1e-30f) || mx > 1e30f) return 0.f;
+    int e;
+    (void)frexpf(mx, &e);                                            /* mx = m 2^e, 0.5 <= m < 1: mx 2^(15 - e) <= 32 768 */
+    return ldexpf(1.f, 15 - e);
+}
 static int dense_upload(Dense f) {
     if (nntk_upload_gemm_weights(&f->d_wp, f->weights->W, f->config.input_size, f->config.output_size)) return -1;
     if (nntk_upload_floats(&f->d_bias, f->weights->b, (size_t)f->config.output_size)) return -1;
+    {
+        int K_p, N_p;
+        nntk_shim_conv_pack_sizes(f->config.input_size, f->config.output_size, 1, &K_p, &N_p);
+        const size_t n_w = (size_t)K_p * N_p;
+        f->wh2_scale = dense_h2_scale(f->weights->W, (size_t)f->config.input_size * f->config.output_size);
+        if (f->wh2_scale > 0.f) {
+            if (!f->d_wh2 && !(f->d_wh2 = nntk_shim_malloc(n_w * 2 * sizeof(unsigned short)))) return -1;
+            if (nntk_shim_split_f16x2(f->d_wp, f->d_wh2, N_p, K_p, f->wh2_scale)) return -1;
+        }
+    }
     nntk_wblock_mark_uploaded(&f->wb);
     return 0;
 }
@@ -129,6 +160,39 @@ static int dense_frag3_device(Dense f, const float *d_in_f3, float *d_out, int B
     if (rc == 1) {
         float *xs = nntk_devbuf_reserve(&f->d_in, (size_t)B * T * f->config.input_size);
         if (!xs || nntk_shim_frag3_unpack(d_in_f3, xs, B, T, f->config.input_size)) return -1;
+        return dense_rows_device(f, xs, d_out, (long)B * T);
+    }
+    if (!fused) {
+        if ((long)act->input_size * act->vector_size != f->config.output_size)
+            NNTK_FAIL("dense: softmax input_size * vector_size must equal the dense output_size");
+        return nntk_shim_activation(NNTK_ACT_SOFTMAX, 1.f, act->vector_size, d_out, d_out, (long)B * T * f->config.output_size);
+    }
+    return 0;
+}
+
+/* rows (b, t) of a FRAG2H tensor [B][T][in] (frag3.hip: two f16 images, three products per k step): dense_frag3_kernel's f16 instantiation when
+ * it takes the shape and W has the form, else the tensor is unpacked and the ordinary GEMM runs (other products: results agree to the
+ * tolerance of the layer, not bit for bit -- see the header) */
+static int dense_frag2h_takes(Dense f, float *d_out, int B, int T) {
+    ActivationFunction act = f->config.activation;
+    int kind = nntk_act_kind(act);
+    if (kind == NNTK_ACT_CUSTOM || !(f->wh2_scale > 0.f)) return 0;
+    const int fused = nntk_act_fusable(act);
+    return nntk_shim_dense_frag2h(NULL, f->d_wh2, f->wh2_scale, f->d_bias, fused ? kind : NNTK_ACT_IDENTITY, act ? act->relu_a : 1.f, d_out,
+                                  B, T, f->config.input_size, f->config.output_size, 1) == 0;
+}
+static int dense_frag2h_device(Dense f, const float *d_in_h2, float *d_out, int B, int T) {
+    if (B <= 0 || T <= 0) return 0;
+    ActivationFunction act = f->config.activation;
+    int kind = nntk_act_kind(act);
+    if (kind == NNTK_ACT_CUSTOM) NNTK_FAIL("dense: custom host-callback activation cannot run on the device");
+    const int fused = nntk_act_fusable(act);
+    int rc = f->wh2_scale > 0.f ? nntk_shim_dense_frag2h(d_in_h2, f->d_wh2, f->wh2_scale, f->d_bias, fused ? kind : NNTK_ACT_IDENTITY,
+                                                         act ? act->relu_a : 1.f, d_out, B, T, f->config.input_size, f->config.output_size, 0) : 1;
+    if (rc < 0) return -1;
+    if (rc == 1) {
+        float *xs = nntk_devbuf_reserve(&f->d_in, (size_t)B * T * f->config.input_size);
+        if (!xs || nntk_shim_frag2h_unpack(d_in_h2, xs, B, T, f->config.input_size)) return -1;
         return dense_rows_device(f, xs, d_out, (long)B * T);
     }
     if (!fused) {
@@ -394,9 +458,21 @@ int TimeDistributedDenseApplyDeviceFrag3(TimeDistributedDense filter, const floa
     if (dense_ensure(filter->dense, 0)) return -1;
     return dense_frag3_device(filter->dense, d_input_frag3, d_output, batch, filter->config.ts);
 }
-/* additive: LSTM (return_sequences) -> TimeDistributedDense without an f32 tensor in between.  The LSTM's hand-off buffer is its
- * output in frag3 form; the dense GEMM reads it as its A operand.  Results = LSTMApplyDevice then TimeDistributedDenseApplyDevice,
- * bit for bit (the frag3 images are the f32 values exactly, and the GEMM sums the same products in the same order). */
+/* additive: the input as a FRAG2H tensor [batch][ts][input_size] (LSTMApplyDeviceFrag2h, nntk_frag2h_pack_device) */
+int TimeDistributedDenseApplyDeviceFrag2h(TimeDistributedDense filter, const float *d_input_frag2h, float *d_output, int batch) {
+    nntk_shim_clear_error();
+    if (!filter || !d_input_frag2h || !d_output) NNTK_FAIL("TimeDistributedDenseApplyDeviceFrag2h: NULL argument");
+    if (dense_ensure(filter->dense, 0)) return -1;
+    return dense_frag2h_device(filter->dense, d_input_frag2h, d_output, batch, filter->config.ts);
+}
+/* additive: LSTM (return_sequences) -> TimeDistributedDense without an f32 tensor in between.
+ * Default (option dense_f16x2 = -1 / 1, an LSTM with the standard activations, finite dense weights, a shape dense_frag3_kernel takes): the
+ * LSTM's output wave writes h as a FRAG2H tensor -- two f16 images of h * 2^15, |h| < 1 -- and the dense GEMM sums three products per k step
+ * on it and on W's two f16 images: half the MFMA work of the frag3 route, operands rounded to 2^-23 relative (at worst one f32 ulp), measured
+ * error against f64 below the frag3 route's (frag3.hip; tests/test_gpu_frag2h.py).  Not bit-identical to the two separate f32 calls.
+ * Otherwise / option dense_f16x2 = 0: the LSTM's hand-off buffer is its output in frag3 form and the dense GEMM reads it as its A operand:
+ * results = LSTMApplyDevice then TimeDistributedDenseApplyDevice, bit for bit (the frag3 images are the f32 values exactly, and the GEMM
+ * sums the same products in the same order). */
 int LSTMTimeDistributedDenseApplyDevice(LSTM lstm, TimeDistributedDense tdd, const float *d_input, float *d_output, int batch) {
     nntk_shim_clear_error();
     if (!lstm || !tdd || !d_input || !d_output) NNTK_FAIL("LSTMTimeDistributedDenseApplyDevice: NULL argument");
@@ -405,6 +481,14 @@ int LSTMTimeDistributedDenseApplyDevice(LSTM lstm, TimeDistributedDense tdd, con
     if (!seq || tdd->config.ts != T || tdd->dense->config.input_size != H)
         NNTK_FAIL("LSTMTimeDistributedDenseApplyDevice: the LSTM must return sequences and feed the dense layer (ts = timesteps, input_size = H)");
     if (batch <= 0) return 0;
+    if (dense_ensure(tdd->dense, 0)) return -1;
+    if (dense_frag2h_takes(tdd->dense, d_output, batch, T)) {
+        float *d_h2 = nntk_lstm_frag2h_scratch(lstm, batch);
+        if (!d_h2) return -1;
+        int rc = nntk_lstm_apply_device_h2(lstm, d_input, NULL, d_h2, batch);
+        if (rc < 0) return -1;
+        if (rc == 0) return dense_frag2h_device(tdd->dense, d_h2, d_output, batch, T);
+    }
     float *d_h3 = nntk_lstm_frag3_scratch(lstm, batch);
     if (!d_h3) return -1;
     if (LSTMApplyDeviceFrag3(lstm, d_input, NULL, NULL, d_h3, batch)) return -1;

@@ -79,6 +79,9 @@ int nntk_spectrogram_apply_mel_device(Spectrogram filter, const float *d_input, 
 /* recurrent.c, for the fused LSTM -> TimeDistributedDense call in dense.c */
 void nntk_lstm_dims(LSTM f, int *T, int *in, int *H, int *return_sequences);
 float *nntk_lstm_frag3_scratch(LSTM f, int batch);       /* the handle's own frag3 output buffer [batch][T][H] */
+float *nntk_lstm_frag2h_scratch(LSTM f, int batch);      /* ... and its FRAG2H one */
+/* the LSTM's sequence output as a FRAG2H tensor: 0 done, 1 not available for this layer (non-standard activations), -1 error */
+int nntk_lstm_apply_device_h2(LSTM f, const float *d_in, const float *d_in_f3, float *d_out_h2, int B);
 
 void nntk_set_error(const char *msg);
 #define NNTK_FAIL(msg) do { nntk_set_error(msg); return -1; } while (0)

@@ -62,6 +62,7 @@ typedef struct {
     volatile unsigned *flag;
     unsigned seq;
     nntk_devbuf d_in, d_out, d_xw, d_work, d_work_rr, d_rr_stage;
+    nntk_devbuf d_h2;           /* the fused LSTM -> TimeDistributedDense call: the sequence output in FRAG2H form */
     nntk_devbuf d_hseq;         /* register-resident kernels: their T-deep hand-off = the layer output in frag3 form (when the caller supplies no buffer) */
     nntk_devbuf d_xf3;          /* ... and the input packed into frag3 form (when the call packs it) */
 } rec_core;
@@ -113,7 +114,7 @@ static void core_free(rec_core *c) {
     nntk_shim_host_free(c->pin_in); nntk_shim_host_free(c->pin_out); nntk_shim_host_free((void *)c->flag);
     nntk_shim_free(c->d_done);
     nntk_devbuf_free(&c->d_in); nntk_devbuf_free(&c->d_out); nntk_devbuf_free(&c->d_xw); nntk_devbuf_free(&c->d_work); nntk_devbuf_free(&c->d_work_rr); nntk_devbuf_free(&c->d_rr_stage);
-    nntk_devbuf_free(&c->d_hseq); nntk_devbuf_free(&c->d_xf3);
+    nntk_devbuf_free(&c->d_hseq); nntk_devbuf_free(&c->d_xf3); nntk_devbuf_free(&c->d_h2);
     nntk_wblock_free(&c->wb);
     free(c->weights);
 }
@@ -203,6 +204,7 @@ typedef struct {
     const float *d_in_f3;   /* the input in frag3 form, or NULL */
     float *d_out;           /* f32 output, or NULL */
     float *d_out_f3;        /* frag3 output [B][T][H] (nntk_frag3_floats), or NULL: handle scratch */
+    float *d_out_h2;        /* LSTM only: the sequence output as a FRAG2H tensor (nntk_frag2h_floats) instead of d_out (which must be NULL), or NULL */
 } rr_io;
 
 /* decides the x form and provides it: 0 = f32 rows, 1 = frag3 (*xf3 set; packed here when the caller passed f32), 2 = shape not taken */
@@ -259,7 +261,7 @@ static int core_try_lstm_rr(rec_core *c, int use_bh, const int *acts, const rr_i
     if (!d_work || !d_hseq) return -1;
     const float *h0 = stateful ? c->d_h[c->cur] : NULL, *c0 = stateful ? c->d_c[c->cur] : NULL;
     float *hT = stateful ? c->d_h[c->cur ^ 1] : NULL, *cT = stateful ? c->d_c[c->cur ^ 1] : NULL;
-    return nntk_shim_lstm_rr(xm ? NULL : io->d_in, xm ? xf3 : NULL, c->d_rr, c->d_rr4, c->d_bi, use_bh ? c->d_bh : NULL, h0, c0, io->d_out, d_hseq,
+    return nntk_shim_lstm_rr(xm ? NULL : io->d_in, xm ? xf3 : NULL, c->d_rr, c->d_rr4, c->d_bi, use_bh ? c->d_bh : NULL, h0, c0, io->d_out, io->d_out_h2, d_hseq,
                              hT, cT, d_work, B, c->T, c->in, c->H, c->return_sequences);
 }
 
@@ -338,7 +340,7 @@ static int core_apply_device(rec_core *c, int is_lstm, int use_bh, const int *ac
                              const float *d_in, float *d_out, int B, int stateful) {
     int G = c->G, H = c->H, T = c->T;
     if (B <= 0 || T <= 0) return 0;
-    const rr_io io = { d_in, NULL, d_out, NULL };
+    const rr_io io = { d_in, NULL, d_out, NULL, NULL };
     if (is_lstm) {
         int rc = core_try_lstm_rr(c, use_bh, acts, &io, B, stateful);
         if (rc <= 0) return rc;
@@ -373,7 +375,7 @@ static int core_apply_device_f3(rec_core *c, int is_lstm, int use_bh, const int 
     if (!d_in && !d_in_f3) NNTK_FAIL("ApplyDeviceFrag3: no input tensor");
     if (!d_out && !d_out_f3) NNTK_FAIL("ApplyDeviceFrag3: no output tensor");
     if (d_out_f3 && !c->return_sequences) NNTK_FAIL("ApplyDeviceFrag3: a frag3 output needs return_sequences");
-    const rr_io io = { d_in, d_in_f3, d_out, d_out_f3 };
+    const rr_io io = { d_in, d_in_f3, d_out, d_out_f3, NULL };
     int rc = 1;
     if (is_lstm) rc = core_try_lstm_rr(c, use_bh, acts, &io, B, 0);
     else if (c->G == 3) rc = core_try_gru_rr(c, acts, &io, B, 0);
@@ -866,11 +868,11 @@ int GRUStack2ApplyDevice(GRU l1, GRU l2, const float *d_input, float *d_output, 
         if (gru_acts(l1, a1, s1) || gru_acts(l2, a2, s2)) return -1;
         float *d_h1 = nntk_devbuf_reserve(&c1->d_hseq, nntk_shim_rr_hseq_floats(B, T, H));
         if (!d_h1) return -1;
-        const rr_io io1 = { d_input, NULL, NULL, d_h1 };
+        const rr_io io1 = { d_input, NULL, NULL, d_h1, NULL };
         int rc = core_try_gru_rr(c1, a1, &io1, B, 0);
         if (rc < 0) return -1;
         if (rc == 0) {
-            const rr_io io2 = { NULL, d_h1, d_output, NULL };
+            const rr_io io2 = { NULL, d_h1, d_output, NULL, NULL };
             rc = core_try_gru_rr(c2, a2, &io2, B, 0);
             if (rc <= 0) return rc;
             /* layer 2 not taken after all (cannot happen for a pair that qualified): both layers again, through an f32 tensor */
@@ -1162,6 +1164,41 @@ int LSTMApplyDeviceFrag3(LSTM filter, const float *d_input, const float *d_input
     if (lstm_acts(filter, acts, sc)) return -1;
     if (core_ensure(&filter->core, 0)) return -1;
     return core_apply_device_f3(&filter->core, 1, filter->config.v2, acts, sc, d_input, d_input_frag3, d_output, d_output_frag3, batch);
+}
+/* The sequence output as a FRAG2H tensor (frag3.hip: two f16 images of h * 2^15 -- the dense GEMM's three-product operand form).  The form
+ * holds magnitudes below 2, so it exists for the standard activations only (|h| = |o tanh(c)| < 1).  The split-K register-resident kernels
+ * write it themselves (the wave that would write the f32 rows); every other kernel goes through an f32 scratch tensor and the pack pass:
+ * the same bits, because the form is a function of the f32 value.  0 = done; 1 = not available for this layer; -1 = error. */
+static int lstm_apply_device_h2(LSTM filter, const float *d_in, const float *d_in_f3, float *d_out_h2, int B) {
+    rec_core *c = &filter->core;
+    int acts[5];
+    float sc[5];
+    if (lstm_acts(filter, acts, sc)) return -1;
+    if (!lstm_std_acts(acts) || !c->return_sequences) return 1;
+    if (B <= 0 || c->T <= 0) return 0;
+    if (core_ensure(c, 0)) return -1;
+    if (!nntk_shim_fk_image_floats(c->H, c->in)) {       /* (the full-K family has no FRAG2H store; its shapes take the f32 way below) */
+        const rr_io io = { d_in, d_in_f3, NULL, NULL, d_out_h2 };
+        int rc = core_try_lstm_rr(c, filter->config.v2, acts, &io, B, 0);
+        if (rc <= 0) return rc;
+    }
+    float *o = nntk_devbuf_reserve(&c->d_out, (size_t)B * c->T * c->H);
+    if (!o) return -1;
+    if (core_apply_device_f3(c, 1, filter->config.v2, acts, sc, d_in, d_in_f3, o, NULL, B)) return -1;
+    return nntk_shim_frag2h_pack(o, d_out_h2, B, c->T, c->H);
+}
+int nntk_lstm_apply_device_h2(LSTM filter, const float *d_in, const float *d_in_f3, float *d_out_h2, int B) {
+    return lstm_apply_device_h2(filter, d_in, d_in_f3, d_out_h2, B);
+}
+float *nntk_lstm_frag2h_scratch(LSTM f, int batch) {
+    return nntk_devbuf_reserve(&f->core.d_h2, nntk_shim_frag2h_floats(batch, f->core.T, f->core.H));
+}
+int LSTMApplyDeviceFrag2h(LSTM filter, const float *d_input, const float *d_input_frag3, float *d_output_frag2h, int batch) {
+    nntk_shim_clear_error();
+    if (!filter || (!d_input && !d_input_frag3) || !d_output_frag2h) NNTK_FAIL("LSTMApplyDeviceFrag2h: NULL argument");
+    int rc = lstm_apply_device_h2(filter, d_input, d_input_frag3, d_output_frag2h, batch);
+    if (rc == 1) NNTK_FAIL("LSTMApplyDeviceFrag2h: the frag2h form holds |h| < 2 -- standard activations and return_sequences only");
+    return rc;
 }
 /* accessors for the fused LSTM -> TimeDistributedDense call (dense.c) */
 void nntk_lstm_dims(LSTM f, int *T, int *in, int *H, int *return_sequences) {

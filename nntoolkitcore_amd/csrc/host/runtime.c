@@ -59,6 +59,17 @@ int nntk_frag3_pack_device(const float *d_x, float *d_frag3, int batch, int T, i
     if (!d_x || !d_frag3) NNTK_FAIL("nntk_frag3_pack_device: NULL argument");
     return nntk_shim_frag3_pack(d_x, d_frag3, batch, T, C);
 }
+size_t nntk_frag2h_floats(int batch, int T, int C) { return nntk_shim_frag2h_floats(batch, T, C); }
+int nntk_frag2h_pack_device(const float *d_x, float *d_frag2h, int batch, int T, int C) {
+    nntk_shim_clear_error();
+    if (!d_x || !d_frag2h) NNTK_FAIL("nntk_frag2h_pack_device: NULL argument");
+    return nntk_shim_frag2h_pack(d_x, d_frag2h, batch, T, C);
+}
+int nntk_frag2h_unpack_device(const float *d_frag2h, float *d_x, int batch, int T, int C) {
+    nntk_shim_clear_error();
+    if (!d_x || !d_frag2h) NNTK_FAIL("nntk_frag2h_unpack_device: NULL argument");
+    return nntk_shim_frag2h_unpack(d_frag2h, d_x, batch, T, C);
+}
 int nntk_frag3_unpack_device(const float *d_frag3, float *d_x, int batch, int T, int C) {
     nntk_shim_clear_error();
     if (!d_x || !d_frag3) NNTK_FAIL("nntk_frag3_unpack_device: NULL argument");

@@ -281,6 +281,45 @@ def tdd_apply_device_frag3(tdd, x_f3, batch, out=None):
     return out
 
 
+# ---- frag2h tensors (nntoolkitcore_hip.h: a bounded activation tensor, |x| < 2, as two f16 images for the three-product contraction) ----
+
+def frag2h_pack_device(x):
+    """[B, T, C] f32 device tensor with |x| < 2 -> its frag2h form (a flat f32-typed device buffer of nntk_frag2h_floats(B, T, C) floats)."""
+    B, T, Cc = x.shape
+    L = capi.load()
+    out = x.new_empty(L.nntk_frag2h_floats(B, T, Cc))
+    check(L.nntk_frag2h_pack_device(_dp(x), _dp(out), B, T, Cc), "nntk_frag2h_pack_device")
+    return out
+
+
+def frag2h_unpack_device(h2, B, T, Cc):
+    """frag2h buffer -> [B, T, C] f32 device tensor ((hi + lo) 2^-15: the value to 2^-23 relative at worst)."""
+    out = h2.new_empty((B, T, Cc))
+    check(capi.load().nntk_frag2h_unpack_device(_dp(h2), _dp(out), B, T, Cc), "nntk_frag2h_unpack_device")
+    return out
+
+
+def lstm_apply_device_frag2h(lstm, x=None, x_f3=None, batch=None, out_h2=None):
+    """LSTMApplyDeviceFrag2h: input as f32 `x` [B, T, in] or frag3 `x_f3` (then `batch` is required); returns the sequence output in frag2h form."""
+    L = capi.load()
+    B = x.shape[0] if x is not None else batch
+    src = x if x is not None else x_f3
+    H, T = lstm.cfg.base.output_feature_channels, lstm.cfg.base.timesteps
+    if out_h2 is None:
+        out_h2 = src.new_empty(L.nntk_frag2h_floats(B, T, H))
+    check(L.LSTMApplyDeviceFrag2h(lstm.h, _dp(x) if x is not None else None, _dp(x_f3) if x_f3 is not None else None, _dp(out_h2), B),
+          "LSTMApplyDeviceFrag2h")
+    return out_h2
+
+
+def tdd_apply_device_frag2h(tdd, x_h2, batch, out=None):
+    """TimeDistributedDenseApplyDeviceFrag2h: the input [batch, ts, in] in frag2h form."""
+    if out is None:
+        out = x_h2.new_empty((batch, tdd.cfg.ts, tdd.cfg.dense.output_size))
+    check(capi.load().TimeDistributedDenseApplyDeviceFrag2h(tdd.h, _dp(x_h2), _dp(out), batch), "TimeDistributedDenseApplyDeviceFrag2h")
+    return out
+
+
 def lstm_tdd_apply_device(lstm, tdd, x, out=None):
     """LSTMTimeDistributedDenseApplyDevice: LSTM (return_sequences) -> TimeDistributedDense with the tensor in between in frag3 form."""
     if out is None:

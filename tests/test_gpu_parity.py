@@ -634,19 +634,34 @@ def test_full_size_config4_two_layer_gru(gpu):
 
 
 def test_full_size_config5_stack_one_gpu_shard(gpu):
-    """The bench workload itself: 512 utterances x 1000 frames through the whole stack (the conv layer hands its output to the LSTM, and the
-    LSTM its output to the dense layer, in frag3 form).  Every stage of rows 0 and 511 against the oracle; and over the WHOLE batch: the f32 route (LSTMApplyDevice then
-    TimeDistributedDenseApplyDevice) equal to the frag3 route bit for bit, and the exact kernels (rec_rr = 0, gemm_split_bf16 = 0)
-    within the summation-order bound -- the race detector VERDICT r03 asked for."""
+    """The bench workload itself: 512 utterances x 1000 frames through the whole stack (the conv layer hands its output to the LSTM in frag3 form, the
+    LSTM its output to the dense layer in FRAG2H form -- the default -- or in frag3 form).  Every stage of rows 0 and 511 against the oracle on
+    both routes; and over the WHOLE batch: the f32 route (LSTMApplyDevice then TimeDistributedDenseApplyDevice) equal to the frag3 route bit
+    for bit, the FRAG2H route within its stated rounding of them, and the exact kernels (rec_rr = 0, gemm_split_bf16 = 0) within the
+    summation-order bound -- the race detector VERDICT r03 asked for."""
     import torch
     import bench
     w = bench.make_weights("stack", 3)
     wl = bench.Workload("stack", 512, 1000, w, torch, NL)
+    assert wl.h2_route
+    wl.step()
+    torch.cuda.synchronize()
+    y_h2 = wl.tdd_out.clone()
+    h_h2 = NL.frag2h_unpack_device(wl.lstm_h2, 512, 996, 512)
+    wl.step()
+    torch.cuda.synchronize()
+    assert torch.equal(y_h2, wl.tdd_out)                      # a second run of the default route: same bits
+    wl.h2_route = False                                       # ... from here on the frag3 route (option dense_f16x2 = 0)
     wl.step()
     torch.cuda.synchronize()
     assert wl.tdd_out.shape == (512, 996, 1000) and not wl.f32_route and wl.conv_f3_route
     assert capi.load().nntk_hip_last_conv_kernel().decode() == "conv1d_mfma_bf16x3_kernel<frag3>"
     lstm_out = NL.frag3_unpack_device(wl.lstm_f3, 512, 996, 512)
+    # the FRAG2H tensor is the same h rounded to 2^-23 relative at worst, over the whole batch; the stack output on it within the contraction's noise
+    d_hh, d_yy = float((h_h2 - lstm_out).abs().max()), float((y_h2 - wl.tdd_out).abs().max())
+    print("stack B=512: frag2h vs frag3 route, whole batch: LSTM output %.2e, stack output %.2e" % (d_hh, d_yy))
+    assert d_hh <= 2.0 ** -23 and 0.0 < d_yy < 3e-6
+    del h_h2
     # the conv layer's output exists in frag3 form only (its epilogue wrote it): the f32 route of the same layer, same bits over the whole batch
     conv_out = wl.conv.apply_device(wl.spec_out, out=wl.conv_out, bn=wl.bn, act=wl.relu)
     assert torch.equal(NL.frag3_unpack_device(wl.conv_f3, 512, 996, 128), conv_out)
@@ -662,6 +677,11 @@ def test_full_size_config5_stack_one_gpu_shard(gpu):
         close(lstm_out[i].cpu().numpy(), h, atol=1e-4, rtol=1e-4)
         y = O.time_distributed_dense(h, w["tdd_W"], w["tdd_b"])
         close(wl.tdd_out[i].cpu().numpy(), y, atol=1e-4, rtol=1e-4)
+        close(y_h2[i].cpu().numpy(), y, atol=1e-4, rtol=1e-4)
+        e3, e2 = float(np.abs(wl.tdd_out[i].cpu().numpy() - y).max()), float(np.abs(y_h2[i].cpu().numpy() - y).max())
+        print("stack row %d: max abs err of the stack output vs oracle: frag3 route %.2e, frag2h route %.2e" % (i, e3, e2))
+        assert e2 < 1e-5 and e3 < 1e-5
+    del y_h2
     # whole batch, the f32 route: same bits
     h32 = wl.lstm.apply_device(wl.conv_out)
     assert torch.equal(h32, lstm_out)

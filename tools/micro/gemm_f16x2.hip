@@ -1,7 +1,7 @@
 // Microbenchmark: what would the CONTRACTION FORMAT buy?  ("next" (1): the step is power-limited, so MFMA work is the currency.)
 //   The product multiplies f32 operands as three bf16 images (x = hi + mid + lo exactly) and sums six products per k step: hi.hi, hi.mid,
 //   mid.hi, mid.mid, hi.lo, lo.hi (dropped: terms below 2^-24).  Two fp16 images of a pre-scaled operand, x 2^p = hi + lo with hi = f16(x 2^p),
-//   lo = f16(x 2^p - hi), carry 11 + 1 + 11 = 23 significand bits (the residual's sign is the extra bit) and need THREE products hi.hi, hi.lo,
+//   lo = f16(x 2^p - hi), hold x to 2^-23 relative at worst (one f32 ulp; 0.3 ulp rms) and need THREE products hi.hi, hi.lo,
 //   lo.hi (dropped: lo.lo, 2^-24 again): half the MFMA work at the same instruction rate (v_mfma_f32_32x32x16_{bf16,f16}: 8 passes each).
 //   fp16's range is what the power-of-two scale is for: an unscaled low image of a value below 0.25 is a subnormal.
 //   This file runs the stack's TimeDistributedDense (out[b][t][:] = h[b][t][:] . W + bias, 512 x 996 rows, K = 512, N = 1000) both ways with the
