@@ -232,7 +232,10 @@ __global__ __launch_bounds__(256) void dense_frag3_kernel(DF3Params p) {
     for (int j = 0; j < TN; ++j) w_vo[j] = lane16 + (((n0 >> 5) + wn * TN + j) * NKS) * 1024;
     const int img = (int)p.img_bytes;
 
-    f3_v4u av[2][TM][NIMG], wv[2][TN][NIMG];
+    // FRAG2H: THREE operand sets, requested two k steps ahead -- a k step is 48 MFMAs per wavefront there, less than an L2 round trip under
+    // load, and a set is 64 registers instead of 96: the same 192 operand registers (1.57 -> 1.49 ms, tools/micro/gemm_f16x2.hip)
+    constexpr int NSETS = FMT == 0 ? 2 : 3;
+    f3_v4u av[NSETS][TM][NIMG], wv[NSETS][TN][NIMG];
     // requested in the order the products need them (lo of A and hi of W first, see PA / PW below), so the consumer's counted waits
     // release its first MFMAs before the whole set has landed
     constexpr int MA[3] = {NIMG - 1, 0, 1}, MW[3] = {0, NIMG - 1, 1};
@@ -295,6 +298,7 @@ __global__ __launch_bounds__(256) void dense_frag3_kernel(DF3Params p) {
         }
         __builtin_amdgcn_sched_barrier(0);
     };
+    if constexpr (NSETS == 2) {
     for (; ks + 1 < NKS; ks += 2) {
         load(I1{}, ks + 1);
         mma(I0{});
@@ -304,6 +308,23 @@ __global__ __launch_bounds__(256) void dense_frag3_kernel(DF3Params p) {
         interleave();
     }
     if (ks < NKS) mma(I0{});                              // odd K / 16
+    } else {
+    using I2 = std::integral_constant<int, 2>;
+    load(I1{}, NKS > 1 ? 1 : 0);
+    for (; ks + 2 < NKS; ks += 3) {                       // sets 0, 1 hold k steps ks, ks + 1
+        load(I2{}, ks + 2);
+        mma(I0{});
+        interleave();
+        load(I0{}, ks + 3 < NKS ? ks + 3 : NKS - 1);      // (past the end: re-requests a k step nobody reads -- no branch)
+        mma(I1{});
+        interleave();
+        load(I1{}, ks + 4 < NKS ? ks + 4 : NKS - 1);
+        mma(I2{});
+        interleave();
+    }
+    if (ks < NKS) mma(I0{});
+    if (ks + 1 < NKS) mma(I1{});
+    }
     }
 
     // ---- epilogue: bias + activation (chosen once, outside the loops), 16-byte stores of channel quads into out[(b, t), :] ----

@@ -542,6 +542,7 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
                 const int vo = lane16 + (((bt_abs * 2 + half) * NKS + ct) * 2) * 1024;
                 __builtin_amdgcn_raw_buffer_store_b128(h2hi, rs2, vo, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(h2lo, rs2, vo + 1024, 0, 0);
+                RR_BOUND(5, (size_t)t * p.h2step, vo + 1024, 0, p.h2step, 16);
             }
             if (LAST) {
                 int b0e = b0;

@@ -115,7 +115,7 @@ struct RRParams {
 // -DNNTK_RR_BOUNDS (tools/rr_bounds_check.py, tests/test_gpu_lstm_rr.py): every request the kernel sends towards a CALLER-visible tensor
 // records the last byte it really touches -- lanes whose vector offset falls outside the descriptor's range touch nothing and are
 // skipped, exactly as the hardware skips them -- as an offset from the tensor's base: word 0 x (f32 rows), 1 x (frag3), 2 f32 output,
-// 3 frag3 hand-off / output (hseq), 4 the h_0 slot.  The host compares them with the tensors' sizes.  Round 3 closed a read past the
+// 3 frag3 hand-off / output (hseq), 4 the h_0 slot, 5 the FRAG2H output.  The host compares them with the tensors' sizes.  Round 3 closed a read past the
 // end of x that the buffer range check could not see (the half-tile rode in the scalar offset); this makes such a read visible.
 #ifdef NNTK_RR_BOUNDS
 #define RR_BOUND(word, base_off, vo, so, range, bytes) do { \

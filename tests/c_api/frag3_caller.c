@@ -1,7 +1,8 @@
 /* frag3_caller.c -- a C caller of the additive frag3 entry points (include/nntoolkitcore_hip.h): an LSTM feeding a
  * TimeDistributedDense with the tensor in between kept in frag3 form on the GPU (lstm.c:426-475 then time_distributed_dense.c:52-58
  * semantics).  It runs the tail of the stack three ways -- two f32 device calls, the fused call, the piece-by-piece frag3 calls -- and
- * writes each result; tests/test_c_dropin.py checks them against each other (bit for bit) and against the CPU oracle.
+ * writes each result; tests/test_c_dropin.py checks them against each other (the f32 and frag3 routes bit for bit; the fused call, which
+ * hands h over as two f16 images by default, within its stated rounding and bit for bit with NNTK_DENSE_F16X2=0) and against the CPU oracle.
  *   frag3_caller <dir>      <dir>: shape.txt "B T I H V", x.bin, W.bin, U.bin, bi.bin, bh.bin, dW.bin, db.bin */
 #include <stdio.h>
 #include <stdlib.h>
@@ -58,7 +59,7 @@ int main(int argc, char **argv) {
     CHECK(LSTMApplyDevice(lstm, d_x, d_h, B));                                  /* 1: through an f32 tensor */
     CHECK(TimeDistributedDenseApplyDevice(tdd, d_h, d_y, B));
     dump(dir, "out_f32.bin", d_y, ny);
-    CHECK(LSTMTimeDistributedDenseApplyDevice(lstm, tdd, d_x, d_y, B));         /* 2: the fused call */
+    CHECK(LSTMTimeDistributedDenseApplyDevice(lstm, tdd, d_x, d_y, B));         /* 2: the fused call (FRAG2H between the layers by default) */
     dump(dir, "out_fused.bin", d_y, ny);
     CHECK(nntk_frag3_pack_device(d_x, d_x3, B, T, I));                          /* 3: piece by piece, frag3 on both sides of the LSTM */
     CHECK(LSTMApplyDeviceFrag3(lstm, NULL, d_x3, NULL, d_h3, B));

@@ -22,6 +22,8 @@ timeout -k 10 300 python tools/rec_ab.py 1024 500 2>&1 | grep -v amdgpu.ids > $O
 NNTK_REC_FUSED2=1 timeout -k 10 300 python bench.py --workload gru --no-cpu-baseline > $O/bench_gru_fused.json 2> /dev/null; tail -c 200 $O/bench_gru_fused.json; echo
 # north_star's own batch on ONE GPU (4096 utterances = 8 back-to-back launches of the 256-workgroup LSTM kernel), and the round-3 route
 timeout -k 10 300 python bench.py --batch-per-gpu 4096 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_stack_b4096.json 2> $O/bench_stack_b4096.err; tail -c 300 $O/bench_stack_b4096.json; echo
+# the LSTM -> dense seam on the frag3 form (six products; bit-identical to the f32 route) instead of the default FRAG2H form (three products)
+NNTK_DENSE_F16X2=0 timeout -k 10 300 python bench.py --no-cpu-baseline > $O/bench_stack_frag3route.json 2> /dev/null; tail -c 200 $O/bench_stack_frag3route.json; echo
 NNTK_BENCH_STACK_F32=1 NNTK_REC_XF=0 timeout -k 10 300 python bench.py --no-cpu-baseline > $O/bench_stack_f32route.json 2> /dev/null; tail -c 200 $O/bench_stack_f32route.json; echo
 NNTK_CONV_FLATK=0 timeout -k 10 300 python bench.py --workload conv --no-cpu-baseline > $O/bench_conv_chunked.json 2> /dev/null; tail -c 200 $O/bench_conv_chunked.json; echo
 # the GRU pair with the full-K family off (both layers split-K: the round-4 default) and on for every shape it takes (layer 1 too)

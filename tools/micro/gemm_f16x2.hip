@@ -120,8 +120,13 @@ __device__ __forceinline__ f32x16 mfma(v4u w, v4u a, f32x16 c) {
     else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), c, 0, 0, 0);
 }
 
-// dense_frag3_kernel<2, 2, 4, 4> of frag3.hip with the number of images a parameter.  NOSTORE: the epilogue's arithmetic without its stores.
-template <int FMT, int NOSTORE>
+// dense_frag3_kernel<2, 2, 4, 4> of frag3.hip with the number of images a parameter.  NOSTORE (timing probes, WRONG results): 1 the epilogue's
+// arithmetic without its stores; 2 every k step fetches the operands of k step 0 (the same requests, served by the L1 / L2 they already sit in);
+// 3 both
+// DEPTH: operand register sets.  2 = the product's schedule (the set of k step k + 1 in flight under the MFMAs of k step k); 3 = two k steps ahead:
+// with three products a k step is 1 536 MFMA cycles per wavefront, less than an L2 round trip under load, and two f16 images need a third less
+// registers per set (3 x 64 = the 192 operand registers of 2 x 96).
+template <int FMT, int NOSTORE, int DEPTH = 2>
 __global__ __launch_bounds__(256) void gemm_kernel(GP p) {
     constexpr int NIMG = FMT == 0 ? 3 : 2, NPROD = FMT == 0 ? 6 : 3;
     constexpr int WN = 2, TM = 4, TN = 4, BM_RB = 8, BN = 256;
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GP p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) w_vo[j] = lane16 + (((n0 >> 5) + wn * TN + j) * NKS) * 1024;
     const int img = (int)p.img_bytes;
-    v4u av[2][TM][NIMG], wv[2][TN][NIMG];
+    v4u av[DEPTH][TM][NIMG], wv[DEPTH][TN][NIMG];
     // images: 0 = hi ... NIMG - 1 = lowest; requested in the order the products need them (lowest A image and hi of W first)
     constexpr int MA3[3] = {2, 0, 1}, MW3[3] = {0, 2, 1}, MA2[2] = {1, 0}, MW2[2] = {0, 1};
     auto load = [&](auto buf_tag, int ks) __attribute__((always_inline)) {
@@ -156,9 +161,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GP p) {
         for (int q = 0; q < NIMG; ++q) {
             const int ma = NIMG == 3 ? MA3[q] : MA2[q], mw = NIMG == 3 ? MW3[q] : MW2[q];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) av[buf][i][ma] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_vo[i] + ma * 1024, ks * NIMG * 1024, 0);
+            for (int i = 0; i < TM; ++i) av[buf][i][ma] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_vo[i] + ma * 1024, ((NOSTORE & 2) ? 0 : ks) * NIMG * 1024, 0);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) wv[buf][j][mw] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_vo[j], ks * 1024 + mw * img, 0);
+            for (int j = 0; j < TN; ++j) wv[buf][j][mw] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_vo[j], ((NOSTORE & 2) ? 0 : ks) * 1024 + mw * img, 0);
         }
     };
     f32x16 acc[TM][TN];
@@ -197,6 +202,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GP p) {
         }
         __builtin_amdgcn_sched_barrier(0);
     };
+    if constexpr (DEPTH == 2) {
     for (; ks + 1 < NKS; ks += 2) {
         load(I1{}, ks + 1);
         mma(I0{});
@@ -206,6 +212,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(GP p) {
         interleave();
     }
     if (ks < NKS) mma(I0{});
+    } else {
+    using I2 = std::integral_constant<int, 2>;
+    load(I1{}, NKS > 1 ? 1 : 0);
+    for (; ks + 2 < NKS; ks += 3) {            // sets 0, 1 hold k steps ks, ks + 1
+        load(I2{}, ks + 2);
+        mma(I0{});
+        interleave();
+        load(I0{}, ks + 3 < NKS ? ks + 3 : NKS - 1);      // (past the end: re-requests a k step nobody reads -- no branch)
+        mma(I1{});
+        interleave();
+        load(I1{}, ks + 4 < NKS ? ks + 4 : NKS - 1);
+        mma(I2{});
+        interleave();
+    }
+    if (ks < NKS) mma(I0{});
+    if (ks + 1 < NKS) mma(I1{});
+    }
 
     __shared__ v4u epi_lds[4][2][256];
     int le = lane;
@@ -237,17 +260,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GP p) {
                 const int row = 8 * s + rd_r;
                 const v4u x = buf[row * 8 + (rd_q ^ ((row >> 1) & 7))];
                 const int b = ht * 32 + row, c = cw + 4 * rd_q;
-                if (NOSTORE ? (x.x == 0x12345678u && b < p.B && c < p.N) : (b < p.B && c < p.N))
+                if ((NOSTORE & 1) ? (x.x == 0x12345678u && b < p.B && c < p.N) : (b < p.B && c < p.N))
                     *reinterpret_cast<v4u *>(p.out + ((size_t)b * p.T + t) * p.N + c) = x;
             }
         });
     });
 }
 
-template <int FMT, int NOSTORE>
+template <int FMT, int NOSTORE, int DEPTH = 2>
 static void launch(const GP &p) {
     const long blocks = (long)((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
-    hipLaunchKernelGGL((gemm_kernel<FMT, NOSTORE>), dim3((unsigned)blocks), dim3(256), 0, 0, p);
+    hipLaunchKernelGGL((gemm_kernel<FMT, NOSTORE, DEPTH>), dim3((unsigned)blocks), dim3(256), 0, 0, p);
 }
 
 int main(int argc, char **argv) {
@@ -291,11 +314,12 @@ int main(int argc, char **argv) {
 
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    double sum[4] = {0, 0, 0, 0}, mn[4] = {1e9, 1e9, 1e9, 1e9};
+    double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mn[8] = {1e9, 1e9, 1e9, 1e9, 1e9, 1e9, 1e9, 1e9};
     for (int r = -3; r < reps; ++r) {
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 8; ++k) {
             CK(hipEventRecord(e0, 0));
-            if (k == 0) launch<0, 0>(p3); else if (k == 1) launch<1, 0>(p2s); else if (k == 2) launch<0, 1>(p3); else launch<1, 1>(p2s);
+            if (k == 0) launch<0, 0>(p3); else if (k == 1) launch<1, 0>(p2s); else if (k == 2) launch<0, 1>(p3); else if (k == 3) launch<1, 1>(p2s);
+            else if (k == 4) launch<1, 2>(p2s); else if (k == 5) launch<1, 3>(p2s); else if (k == 6) launch<1, 1, 3>(p2s); else launch<1, 0, 3>(p2s);
             CK(hipEventRecord(e1, 0));
             CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -303,10 +327,12 @@ int main(int argc, char **argv) {
         }
     }
     launch<1, 0>(p2);
+    launch<1, 0, 3>(p2s);                     // (the probes above left wrong results in its output)
     CK(hipDeviceSynchronize());
     const double flop = 2.0 * B * T * (double)K * N;
-    const char *nm[4] = {"bf16 x 3, six products  ", "f16 x 2, three products ", "bf16 x 3, no stores     ", "f16 x 2, no stores      "};
-    for (int k = 0; k < 4; ++k)
+    const char *nm[8] = {"bf16 x 3, six products  ", "f16 x 2, three products ", "bf16 x 3, no stores     ", "f16 x 2, no stores      ",
+                         "f16 x 2, operands cached", "f16 x 2, cached + no st.", "f16 x 2, 3 sets, no st. ", "f16 x 2, 3 operand sets "};
+    for (int k = 0; k < 8; ++k)
         printf("%s mean %.3f ms  min %.3f ms  (%.0f TFLOP/s algorithmic at the mean)\n", nm[k], sum[k] / reps, mn[k], flop / (sum[k] / reps * 1e-3) * 1e-12);
 
     // ---- errors on sampled rows against f64 (same f32 operands) ----
@@ -336,7 +362,7 @@ int main(int argc, char **argv) {
         for (int c = 0; c < N; ++c) refsq += ref[c] * ref[c];
         cnt += N;
     }
-    const char *en[4] = {"bf16 x 3 (six products)      ", "f16 x 2 unscaled (three)     ", "f16 x 2 scaled (three)       ", "f32 left-to-right (reference)"};
+    const char *en[4] = {"bf16 x 3 (six products)      ", "f16 x 2 unscaled (three)     ", "f16 x 2 scaled, 3 sets      ", "f32 left-to-right (reference)"};
     printf("errors against an f64 dot product of the same f32 operands, %d rows x %d columns (output rms %.3e, non-finite %d):\n", NS, N, sqrt(refsq / cnt), nonfinite);
     for (int v = 0; v < 4; ++v) printf("  %s max %.3e  rms %.3e\n", en[v], maxe[v], sqrt(sq[v] / cnt));
     return 0;

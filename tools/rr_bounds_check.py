@@ -79,6 +79,17 @@ def run():
                       "  ".join("%s %d/%d" % (n, g, lim) for n, g, lim in zip(names, got, limits)),
                       "" if ok and live else "   <-- %s" % ("OUT OF BOUNDS" if not ok else "instrument silent")))
                 bad += (not ok) or (not live)
+            if cell == "lstm":                                          # the FRAG2H form of the output (the output wave's two 1 KB stores per block)
+                NL.lstm_apply_device_frag2h(layer, x_f3=x3, batch=B)
+                kern = L.nntk_hip_last_recurrent_kernel().decode()
+                got = (C.c_ulonglong * 8)()
+                assert fetch(got) == 0
+                lim = 4 * L.nntk_frag2h_floats(B, T, H)
+                ok = got[5] <= lim and got[2] == 0 and got[3] <= f3_out
+                live = got[5] == lim or "_fk_kernel" in kern            # (the full-K family writes f32 and the pack pass makes the form)
+                print("%s B=%d in=%d H=%d T=%d %-12s %-22s out frag2h %d/%d%s" % (cell, B, I, H, T, "frag3->frag2h", kern, got[5], lim,
+                      "" if ok and live else "   <-- %s" % ("OUT OF BOUNDS" if not ok else "instrument silent")))
+                bad += (not ok) or (not live)
             capi.set_option("rec_xf", "auto")
             layer.destroy()
     print("rr bounds: %d violation(s)" % bad)
