@@ -3,7 +3,7 @@
 # usage: bash tools/collect_profiles.sh <dir-under-gpurun_out> <prefix>        e.g.  r03_final r03
 R=$(cd $(dirname $0)/.. && pwd)
 S=$R/gpurun_out/$1; P=$R/profiles/$2
-for w in stack gru conv spectrogram conv_exact stack_exact gru_fused gru_fk0 gru_fk1 stack_b4096 stack_f32route conv_chunked; do [ -s $S/bench_$w.json ] && cp $S/bench_$w.json ${P}_bench_$w.json; done
+for w in stack gru conv spectrogram conv_exact stack_exact gru_fused gru_fk0 gru_fk1 stack_b4096 stack_f32route stack_frag3route conv_chunked; do [ -s $S/bench_$w.json ] && cp $S/bench_$w.json ${P}_bench_$w.json; done
 for w in stack gru conv spectrogram elementwise lstm_train; do
   f=$(ls -t $S/prof_$w/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f ${P}_${w}_kernel_stats.csv
 done

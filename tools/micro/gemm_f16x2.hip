@@ -126,7 +126,8 @@ __device__ __forceinline__ f32x16 mfma(v4u w, v4u a, f32x16 c) {
 // DEPTH: operand register sets.  2 = the product's schedule (the set of k step k + 1 in flight under the MFMAs of k step k); 3 = two k steps ahead:
 // with three products a k step is 1 536 MFMA cycles per wavefront, less than an L2 round trip under load, and two f16 images need a third less
 // registers per set (3 x 64 = the 192 operand registers of 2 x 96).
-template <int FMT, int NOSTORE, int DEPTH = 2>
+// MPL: MFMAs the scheduler places between two operand requests (the product: 2; 0 = no prescription)
+template <int FMT, int NOSTORE, int DEPTH = 2, int MPL = 2>
 __global__ __launch_bounds__(256) void gemm_kernel(GP p) {
     constexpr int NIMG = FMT == 0 ? 3 : 2, NPROD = FMT == 0 ? 6 : 3;
     constexpr int WN = 2, TM = 4, TN = 4, BM_RB = 8, BN = 256;
@@ -195,10 +196,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GP p) {
     int ks = 0;
     load(I0{}, 0);
     auto interleave = [&]() __attribute__((always_inline)) {
+        if constexpr (MPL > 0) {
 #pragma unroll
         for (int q = 0; q < NIMG * (TM + TN); ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, MPL, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -267,10 +270,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GP p) {
     });
 }
 
-template <int FMT, int NOSTORE, int DEPTH = 2>
+template <int FMT, int NOSTORE, int DEPTH = 2, int MPL = 2>
 static void launch(const GP &p) {
     const long blocks = (long)((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
-    hipLaunchKernelGGL((gemm_kernel<FMT, NOSTORE, DEPTH>), dim3((unsigned)blocks), dim3(256), 0, 0, p);
+    hipLaunchKernelGGL((gemm_kernel<FMT, NOSTORE, DEPTH, MPL>), dim3((unsigned)blocks), dim3(256), 0, 0, p);
 }
 
 int main(int argc, char **argv) {
@@ -314,12 +317,13 @@ int main(int argc, char **argv) {
 
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mn[8] = {1e9, 1e9, 1e9, 1e9, 1e9, 1e9, 1e9, 1e9};
+    double sum[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, mn[11] = {1e9, 1e9, 1e9, 1e9, 1e9, 1e9, 1e9, 1e9, 1e9, 1e9, 1e9};
     for (int r = -3; r < reps; ++r) {
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 11; ++k) {
             CK(hipEventRecord(e0, 0));
             if (k == 0) launch<0, 0>(p3); else if (k == 1) launch<1, 0>(p2s); else if (k == 2) launch<0, 1>(p3); else if (k == 3) launch<1, 1>(p2s);
-            else if (k == 4) launch<1, 2>(p2s); else if (k == 5) launch<1, 3>(p2s); else if (k == 6) launch<1, 1, 3>(p2s); else launch<1, 0, 3>(p2s);
+            else if (k == 4) launch<1, 2>(p2s); else if (k == 5) launch<1, 3>(p2s); else if (k == 6) launch<1, 1, 3>(p2s); else if (k == 7) launch<1, 0, 3>(p2s);
+            else if (k == 8) launch<1, 0, 3, 1>(p2s); else if (k == 9) launch<1, 0, 3, 3>(p2s); else launch<1, 0, 3, 0>(p2s);
             CK(hipEventRecord(e1, 0));
             CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -330,9 +334,10 @@ int main(int argc, char **argv) {
     launch<1, 0, 3>(p2s);                     // (the probes above left wrong results in its output)
     CK(hipDeviceSynchronize());
     const double flop = 2.0 * B * T * (double)K * N;
-    const char *nm[8] = {"bf16 x 3, six products  ", "f16 x 2, three products ", "bf16 x 3, no stores     ", "f16 x 2, no stores      ",
-                         "f16 x 2, operands cached", "f16 x 2, cached + no st.", "f16 x 2, 3 sets, no st. ", "f16 x 2, 3 operand sets "};
-    for (int k = 0; k < 8; ++k)
+    const char *nm[11] = {"bf16 x 3, six products  ", "f16 x 2, three products ", "bf16 x 3, no stores     ", "f16 x 2, no stores      ",
+                         "f16 x 2, operands cached", "f16 x 2, cached + no st.", "f16 x 2, 3 sets, no st. ", "f16 x 2, 3 operand sets ",
+                         "f16 x 2, 3 sets, 1 MFMA/ld", "f16 x 2, 3 sets, 3 MFMA/ld", "f16 x 2, 3 sets, free sch."};
+    for (int k = 0; k < 11; ++k)
         printf("%s mean %.3f ms  min %.3f ms  (%.0f TFLOP/s algorithmic at the mean)\n", nm[k], sum[k] / reps, mn[k], flop / (sum[k] / reps * 1e-3) * 1e-12);
 
     // ---- errors on sampled rows against f64 (same f32 operands) ----

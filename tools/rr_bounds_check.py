@@ -85,8 +85,9 @@ def run():
                 got = (C.c_ulonglong * 8)()
                 assert fetch(got) == 0
                 lim = 4 * L.nntk_frag2h_floats(B, T, H)
-                ok = got[5] <= lim and got[2] == 0 and got[3] <= f3_out
-                live = got[5] == lim or "_fk_kernel" in kern            # (the full-K family writes f32 and the pack pass makes the form)
+                fk = "_fk_kernel" in kern                                # (the full-K family writes f32 rows and the pack pass makes the form)
+                ok = got[5] <= lim and got[3] <= f3_out and (got[2] <= limits[2] if fk else got[2] == 0)
+                live = fk or got[5] == lim
                 print("%s B=%d in=%d H=%d T=%d %-12s %-22s out frag2h %d/%d%s" % (cell, B, I, H, T, "frag3->frag2h", kern, got[5], lim,
                       "" if ok and live else "   <-- %s" % ("OUT OF BOUNDS" if not ok else "instrument silent")))
                 bad += (not ok) or (not live)
