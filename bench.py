@@ -365,12 +365,19 @@ def roofline_for(wl, phase_ms, prof):
         n_in = 128
         flops = 2.0 * B * (H + n_in) * G * H * tpl
         ach = flops / (ms * 1e-3) / 1e12
-        peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
+        # the HF instantiation (",hf>"): the h part on two f16 images = THREE products per f32 product, the x part on three bf16 images = six:
+        # the ceiling of the products actually issued is the dense 16-bit MFMA peak / the k-weighted mean of the two
+        hf = last.endswith(",hf>")
+        products = (3.0 * H + 6.0 * n_in) / (H + n_in) if hf else float(SPLIT_PRODUCTS)
+        peak = BF16_MFMA_PEAK_TFLOPS / products
         traffic, traffic_source = pmc_traffic("lstm_rr_kernel", B)
-        # 6 products x 2 tiles x (H + in) / 16 k steps per half, two halves: MFMA instructions per wave and timestep
-        mfma_cycles = 6 * 2 * ((H + n_in) // 16) // 4 * 2 * 32
+        # products x 2 tiles x k steps per half, two halves, over four wavefronts: MFMA pipe cycles per wave and timestep
+        mfma_cycles = int((3 if hf else 6) * 2 * (H // 16) // 4 * 2 * 32 + 6 * 2 * (n_in // 16) // 4 * 2 * 32)
         return {"kernel": last, "bound": "mfma", "achieved": ach, "peak": peak,
-                "peak_note": "dense bf16 MFMA peak / 6 products per f32 product (split-bf16 x 3 contraction)",
+                "peak_note": ("dense f16 / bf16 MFMA peak / %.2f products per f32 product (h.U: two f16 images of h and U, three products; x.W: three bf16 "
+                              "images, six products)" % products) if hf else
+                             "dense bf16 MFMA peak / 6 products per f32 product (split-bf16 x 3 contraction)",
+                "frac_of_six_product_ceiling": ach / (BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS),
                 "unit": "TFLOP/s", "frac": ach / peak, "frac_of_exact_f32_mfma_peak": ach / F32_MFMA_PEAK_TFLOPS,
                 "traffic": traffic, "traffic_source": traffic_source, "ms_per_launch": ms, "algorithmic_flops": flops,
                 "algorithmic_flops_note": "recurrent h x U AND the fused input projection x_t x W, all T steps of one launch",
@@ -683,14 +690,17 @@ def main():
                              "bit-identical to the f32 route" if getattr(wl, "conv_f3_route", False) else
                              "f32 tensor, packed into frag3 form inside the LSTM call") if a.workload == "stack" else None,
             "lstm_to_tdd": ("f32 tensor" if getattr(wl, "f32_route", True) else
-                            "frag2h tensor: h as two f16 images of h * 2^15 (|h| < 1; operands to 2^-23 relative at worst) written by the LSTM kernel's output wave, "
+                            "frag2h tensor: h as two f16 images of h * 2^15 (|h| < 1; operands to 2^-23 relative at worst) -- the LSTM kernel's own hand-off buffer, "
                             "W as two f16 images of W * 2^q; the dense GEMM sums three products per k step (f32 accumulation); error vs f64 below the "
                             "frag3 route's (tests/test_gpu_frag2h.py, profiles/r05_gemm_f16x2_micro.log); NNTK_DENSE_F16X2=0 selects the frag3 route"
                             if getattr(wl, "h2_route", False) else
                             "frag3 tensor: the LSTM kernel's T-deep hand-off buffer (h already split into three bf16 images, MFMA fragment order) "
                             "is the dense GEMM's A operand; bit-identical to the f32 route") if a.workload == "stack" else None,
             "gemm": gemm_mode() + " for conv / TDD" + (
-                ("; LSTM: " + prof["rec_kernel"] + " (split-bf16x3 recurrence with the input projection fused into the step)")
+                ("; LSTM: " + prof["rec_kernel"] + (" (recurrence h.U on two f16 images of h * 2^15 and U * 2^q, three products per k step; the fused input "
+                                                   "projection x.W on three bf16 images, six products; NNTK_REC_HF=0: all six-product)"
+                                                   if prof["rec_kernel"].endswith(",hf>") else
+                                                   " (split-bf16x3 recurrence with the input projection fused into the step)"))
                 if prof.get("rec_kernel", "").startswith("lstm_rr") else
                 ("; GRU layers: register-resident split-bf16x3 recurrences with the input projections fused into the step (gru_rr_kernel: split-K over "
                  "four wavefronts; gru_fk_kernel: full K per wavefront); layer 1 hands h over in frag3 form")

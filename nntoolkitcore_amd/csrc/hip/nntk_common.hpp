@@ -24,6 +24,7 @@ struct NntkOptions {
     int rec_rr = -1;             // register-resident split-bf16 LSTM kernel with the fused input projection (0 off, 1 also for small batches)
     int rec_xf = -1;             // register-resident kernels: f32 input packed into frag3 form first (1 always, 0 only when the f32 path cannot take the shape; auto: see recurrent.c)
     int rec_fk = -1;             // full-K register-resident kernels (recurrent_fk.hip): 1 every shape they take, 0 none; auto: 256-wide inputs (where they beat the split-K family)
+    int rec_hf = -1;             // LSTM (H > 256) -> FRAG2H output: the HF instantiation of lstm_rr_kernel (h.U on two f16 images, three products); 0 off
     int dense_frag3 = -1;        // dense GEMM with a frag3 A operand (0: consumers unpack to f32 and run the LDS-staged GEMM)
     int dense_f16x2 = -1;        // LSTM -> TimeDistributedDense: the tensor in between as two f16 images, three products (frag3.hip FRAG2H); 0: the frag3 route
     int train_outer_plain = -1;  // weight-gradient products of plain matrices on the VALU-free MFMA kernel (0: the general one; A/B)

@@ -213,6 +213,14 @@ int nntk_shim_lstm_rr(const float *d_x, const void *d_xf3, const float *d_img, c
                       const float *d_h0, const float *d_c0, float *d_out, float *d_out_h2 /* frag2h form of the sequence output, or NULL; needs d_out == NULL */,
                       float *d_hseq, float *d_hT, float *d_cT, float *d_work, int B, int T, int in, int H, int return_sequences);
 
+/* The HF instantiations of lstm_rr_kernel (H > 256): the h part of Z on two f16 images (three products per k step), the hand-off = the layer's
+ * sequence output as a FRAG2H tensor (d_h2: nntk_shim_frag2h_floats(B, T, H) floats).  Zero initial state, x as a frag3 tensor.  Images:
+ * nntk_shim_lstm_rr_pack_hf with uscale = a power of two with max |U| uscale <= 32768 and wscale = 32768 uscale; z_scale = 1 / wscale. */
+int nntk_shim_lstm_rr_hf_ok(int H, int in);
+int nntk_shim_lstm_rr_pack_hf(const float *d_ut, const float *d_wp, float *d_img, int H, int in, float uscale, float wscale);
+int nntk_shim_lstm_rr_hf(const void *d_xf3, const float *d_img, const float *d_bi, const float *d_bh, float *d_h2, float *d_work,
+                         int B, int T, int in, int H, float z_scale);
+
 /* ---- frag3 tensors (frag3.hip): a [B][T][C] f32 tensor as three bf16 images (x = hi + mid + lo exactly) in MFMA fragment order,
  * [T][2 ceil(B / 64)][ceil(C / 16)][3] blocks of 1 KB.  nntk_shim_dense_frag3: out [B][T][N] = act(h . W + b) with h in frag3 form and
  * d_wp the packed weights of a Dense layer; returns 1 when the shape is not taken. */

@@ -71,10 +71,12 @@ __host__ __device__ inline int rr_blocks_per_ct(int KH, int KX) { return 4 * KH 
 // ut [4][Hj_p][Hk_p] f32 (U^T per gate), wp [4H padded][Kin_p] f32 (W^T, K-contiguous) -> images.
 // RAW: the sources are the caller's own layout instead, U [H][4H] and W [in][4H] (recurrent_private.c:29-36): the training
 // forward re-packs every mini-batch (the weights change with every optimiser step) straight from the uploaded block.
+// HF (uscale > 0): the images of the HF instantiations (h.U on two f16 images): UH [..][m = hi, lo] are the two f16 images of U * uscale, UL is
+// unused (zeros), WX the three bf16 images of W * wscale (wscale = 2^15 uscale: both parts of Z then carry the same power of two).
 template <bool RAW>
 __global__ __launch_bounds__(256) void rr_pack_kernel(const float *__restrict__ ut, const float *__restrict__ wp,
                                                       rr_v4u *__restrict__ img, int H, int in, int Hj_p, int Hk_p, int Kin_p,
-                                                      int KH, int KX, int NCT) {
+                                                      int KH, int KX, int NCT, float uscale = 0.0f, float wscale = 1.0f) {
     const int bpc = rr_blocks_per_ct(KH, KX);
     const long total = (long)NCT * bpc * 64;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -108,6 +110,18 @@ __global__ __launch_bounds__(256) void rr_pack_kernel(const float *__restrict__ 
             v[q] = val;
         }
         rr_v4u hi, mid, lo;
+        if (uscale > 0.0f) {
+            if (part == 0) {
+                unsigned h4[4], l4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rr_split_pair_f16(v[2 * q] * uscale, v[2 * q + 1] * uscale, h4[q], l4[q]);
+                img[e] = m == 0 ? (rr_v4u){h4[0], h4[1], h4[2], h4[3]} : (rr_v4u){l4[0], l4[1], l4[2], l4[3]};
+                continue;
+            }
+            if (part == 1) { img[e] = (rr_v4u){0u, 0u, 0u, 0u}; continue; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] *= wscale;
+        }
         rr_split8(v, hi, mid, lo);
         img[e] = m == 0 ? hi : m == 1 ? mid : lo;
     }
@@ -177,8 +191,13 @@ __global__ __launch_bounds__(256) void rr_tile_h0_kernel(const float *__restrict
 // blocks of one timestep contiguous): 3 KX coalesced 1 KB requests per half-step straight into the MFMA operand registers instead
 // of 2 KX requests that touch 32 rows each plus the 44-instruction split (DESIGN K4b "what the x part costs": the requests, not
 // the split, were 0.5 us of a 6.7 us step).  Each half owns an operand set, requested a whole half-step ahead.
-template <int KH, int KX, bool TRAIN, int CELL, bool XF>
+// HF (LSTM, H > 256, XF): the h part of Z on TWO f16 images (frag3.hip FRAG2H: |h| < 1, h 2^15 = hi + lo) and three products per k step
+// instead of three bf16 images and six: U's two f16 images of U 2^q sit in the registers that hold hi / mid (its LDS image is unused), the
+// hand-off carries two blocks per (row block, k step) -- and IS the dense layer's FRAG2H operand -- W's bf16 images are packed
+// pre-multiplied by 2^(15 + q), so both parts accumulate at one scale, taken out (exactly) where the bias is added.
+template <int KH, int KX, bool TRAIN, int CELL, bool XF, bool HF = false>
 __device__ __forceinline__ void rr_body(const RRParams &p) {
+    constexpr int NH = HF ? 2 : 3;                    // images of the h hand-off
 #ifndef RR_ULR8
 #define RR_ULR8 0
 #endif
@@ -218,7 +237,8 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
     constexpr int own_lo = S_PUB + NPRE < KH ? S_PUB + NPRE : KH, own_hi = S_E1 + NPRE < KH ? S_E1 + NPRE : KH;
     constexpr int NXR = XF ? 3 * KX : 2 * KX;         // vector-memory requests of one x fetch
     constexpr int N_X_AFTER_PUB = (X_LATE || S_XSPL >= S_E1) ? 0 : NXR;      // (S_XSPL == S_E1: the arrival precedes the x requests in its k step)
-    constexpr int N_AFTER_PUB = 3 * (own_hi - own_lo) + N_X_AFTER_PUB;
+    constexpr int N_AFTER_PUB = NH * (own_hi - own_lo) + N_X_AFTER_PUB;
+    static_assert(!HF || (!PEND && !TRAIN && XF && CELL == 0 && !ULR), "HF: the flag-protocol LSTM instantiations with a frag3 x operand");
     static_assert(NST >= 5 && S_XSPL >= KX && S_XSPL > S_PUB && KH - NPRE <= S_E2 && S_HEAD > S_PUB && S_HEAD <= S_E2, "slice schedule");
     // flag protocol: the flags are requested POLL_LEAD k steps before they are looked at.  Two k steps (~1 k cycles) cover the load's round
     // trip; with one the check waited for it: LSTM-512 5.94-5.98 -> 5.78-5.85 ms in four alternating rounds, three k steps 5.82-5.85
@@ -343,8 +363,8 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
     using I1 = std::integral_constant<int, 1>;
     using Tt = std::true_type;
     using Ff = std::false_type;
-    rr_v4u hf[2][KH][3];           // the h operand of each half
-    constexpr bool ULPRE = !ULR && KH == 8;
+    rr_v4u hf[2][KH][NH];          // the h operand of each half
+    constexpr bool ULPRE = !ULR && KH == 8 && !HF;
     rr_bf16x8 ulo_n[2];            // ULPRE: U's low image of the next h k step (LDS -> registers one k step ahead)
     rr_v4u xr[XF ? 1 : KX][2];     // raw x_t (f32) of the half that multiplies next (not with XF)
     rr_bf16x8 xf[XF ? 2 : 1][KX][3];   // ... and its three bf16 images; XF: one set per half, filled by the loads themselves
@@ -356,13 +376,13 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
     // KX + NPRE k steps before the MFMAs that consume it.
     auto issue_h = [&](auto half_tag, int t, int j0, int j1) __attribute__((always_inline)) {      // fragments [j0, j1): constants once unrolled
         constexpr int half = decltype(half_tag)::value;
-        const int so = ((bt_abs * 2 + half) * NKS + w * KH) * 3 * 1024;
+        const int so = ((bt_abs * 2 + half) * NKS + w * KH) * NH * 1024;
         const __amdgpu_buffer_rsrc_t rs = rs_rd(t);
 #pragma unroll
-        for (int blk = 0; blk < 3 * KH; ++blk) {
+        for (int blk = 0; blk < NH * KH; ++blk) {
             if (blk < j0 || blk >= j1) continue;
             // four 1 KB blocks per scalar offset: the rest of the address rides in the instruction's immediate
-            const int i = blk / 3, m = blk % 3;
+            const int i = blk / NH, m = blk % NH;
             hf[half][i][m] = __builtin_amdgcn_raw_buffer_load_b128(rs, hvo[i] + (blk & 3) * 1024, so + (blk >> 2) * 4096, 16 /* sc1 */);
             RR_BOUND(t ? 3 : 4, t ? (size_t)(t - 1) * p.hstep : 0, hvo[i] + (blk & 3) * 1024, so + (blk >> 2) * 4096, hb_bytes, 16);
         }
@@ -436,7 +456,7 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
         for (int e = 0; e < 2; ++e) {
             if (RR_DBG(64)) { hn[e] = z[0][e] + z[1][e] + z[2][e] + z[3][e] + cst[half][e]; continue; }
 #pragma unroll
-            for (int g = 0; g < 4; ++g) zc[g][e] = z[g][e] + bsum[g][e];
+            for (int g = 0; g < 4; ++g) zc[g][e] = HF ? fmaf(z[g][e], p.z_scale, bsum[g][e]) : z[g][e] + bsum[g][e];
             if (CELL == 1) {
                 // gru.c:144-186 (same expressions as rec_persistent_kernel's): slots z | r | h.U_h + b_h | x.W_h + b_i
                 const float zg = nntk_fast_sigmoid(zc[0][e]);
@@ -466,7 +486,12 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
         // (Publishing from here as well -- every lane storing its own word of the fragment slot, three write-through 4-byte stores, no
         // LDS round trip and no publishing wave -- was measured SLOWER with the pending-pattern protocol: GRU-256 pair 10.33 vs 9.90 ms,
         // profiles/r04_rr_direct_publication.log: the quarter-filled stores reach the consumers later than three full 1 KB ones.)
-        if (!RR_DBG(128)) {
+        if (HF && !RR_DBG(128)) {                       // the hand-off's two f16 words (images 0, 1 of `hs`)
+            unsigned sh, sl;
+            rr_split_pair_h2(hn[0], hn[1], sh, sl);
+            unsigned *d = hs + n * RR_HS_LD + (jl >> 1);
+            d[0] = sh; d[32 * RR_HS_LD] = sl;
+        } else if (!RR_DBG(128)) {
             unsigned sh, sm, sl;
             rr_split_pair(hn[0], hn[1], sh, sm, sl);
             // PEND: no published word may equal the "not yet written" pattern (two bf16 NaNs with every payload bit set): such a pair
@@ -509,18 +534,18 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
                 const unsigned *src = hs + n * RR_HS_LD + 4 * kh;
                 a = *reinterpret_cast<const rr_v4u *>(src);
                 b = *reinterpret_cast<const rr_v4u *>(src + 32 * RR_HS_LD);
-                c = *reinterpret_cast<const rr_v4u *>(src + 2 * 32 * RR_HS_LD);
+                if (!HF) c = *reinterpret_cast<const rr_v4u *>(src + 2 * 32 * RR_HS_LD);
             }
             // the block's offset rides in the VECTOR offset and soffset stays immediate 0: a wide buffer store with an SGPR
             // soffset followed by a VALU write of its data registers stores the overwritten value in some lanes on MI355X, and
             // the compiler inserts no wait state for that form (tools/check_store_hazard.py, tests/test_isa_lint.py)
-            const int vo = lane16 + (((bt_abs * 2 + half) * NKS + ct) * 3) * 1024;
+            const int vo = lane16 + (((bt_abs * 2 + half) * NKS + ct) * NH) * 1024;
             if (!RR_DBG(128)) {
                 const __amdgpu_buffer_rsrc_t rs = rs_wr(t);
                 __builtin_amdgcn_raw_buffer_store_b128(a, rs, vo, 0, RR_ST_AUX /* sc1 */);
                 __builtin_amdgcn_raw_buffer_store_b128(b, rs, vo + 1024, 0, RR_ST_AUX);
-                __builtin_amdgcn_raw_buffer_store_b128(c, rs, vo + 2048, 0, RR_ST_AUX);
-                RR_BOUND(3, (size_t)t * p.hstep, vo + 2048, 0, hb_bytes, 16);
+                if (!HF) __builtin_amdgcn_raw_buffer_store_b128(c, rs, vo + 2048, 0, RR_ST_AUX);
+                RR_BOUND(3, (size_t)t * p.hstep, vo + (NH - 1) * 1024, 0, hb_bytes, 16);
             }
         } else if (w == 2 * half + 1) {                 // the output wave: the same row pieces in f32
             const rr_v4u o0 = *reinterpret_cast<const rr_v4u *>(hx + n * RR_HX_LD + 8 * kh);
@@ -694,6 +719,7 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
             } else if (ULR) {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) ulo[mt] = ulr[s - KX][mt];
+            } else if (HF) {                              // (both images of U are in registers)
             } else {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
@@ -710,9 +736,9 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
                 if (s == S_E2 - POLL_LEAD && NEXT && POLL && !RR_DBG(4)) poll_a(X);
                 if (s == S_E2 && NEXT && POLL && !RR_DBG(4)) poll_b(X, tX + 1);
             }
-            if (s == S_HEAD && NEXT && !RR_DBG(1)) issue_h(XT{}, tX + 1, 0, 3 * NPRE);        // head of X's next operand (PEND: speculative, checked where it is used)
+            if (s == S_HEAD && NEXT && !RR_DBG(1)) issue_h(XT{}, tX + 1, 0, NH * NPRE);        // head of X's next operand (PEND: speculative, checked where it is used)
             if (s == S_E2 && X_LATE && XLIVE && !RR_DBG(8)) issue_x(y_tag, t + 1);            // (xr is free since this half-step's S_XSPL)
-            if (s + NPRE < KH && !RR_DBG(1)) issue_h(y_tag, t, 3 * (s + NPRE), 3 * (s + NPRE + 1));       // THIS half's operand, k step s + NPRE (published long ago)
+            if (s + NPRE < KH && !RR_DBG(1)) issue_h(y_tag, t, NH * (s + NPRE), NH * (s + NPRE + 1));       // THIS half's operand, k step s + NPRE (published long ago)
             // ---- multiply ----
             if (RR_DBG(16)) {
             } else if (s < KX) {
@@ -724,6 +750,28 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
             } else {
                 const int i = s - KX;
                 if (YCHK && t > 0 && !RR_DBG(4) && !RR_DBG(1)) settle_h(y_tag, t, i, pend_next);   // (step 0 reads the h_0 slot, written before the launch)
+                if constexpr (HF) {
+                    // three products per tile, smallest terms first: (U image, h image) = (hi, lo) (lo, hi) (hi, hi); the last k step tile by tile, as below
+                    constexpr int QA[3] = {0, 1, 0}, QB[3] = {1, 0, 0};
+                    rr_f16x8 bh[2];
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) bh[m] = __builtin_bit_cast(rr_f16x8, hf[Y][i][m]);
+                    if (s == NST - 1) {
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                            for (int pr = 0; pr < 3; ++pr)
+                                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rr_f16x8, uh[i][mt][QA[pr]]), bh[QB[pr]], acc[mt], 0, 0, 0);
+                            if (mt == 0) exchange(acc, 0, 2);
+                        }
+                    } else {
+#pragma unroll
+                        for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                            for (int mt = 0; mt < 2; ++mt)
+                                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rr_f16x8, uh[i][mt][QA[pr]]), bh[QB[pr]], acc[mt], 0, 0, 0);
+                    }
+                } else {
                 rr_bf16x8 b[3];
 #pragma unroll
                 for (int m = 0; m < 3; ++m) b[m] = __builtin_bit_cast(rr_bf16x8, hf[Y][i][m]);
@@ -747,6 +795,7 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
                         const rr_bf16x8 av = PA[pr] == 2 ? ulo[mt] : uh[i][mt][PA[pr]];
                         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b[PB[pr]], acc[mt], 0, 0, 0);
                     }
+                }
                 }
             }
             if (YCHK && s + 1 >= KX && s + 1 < NST && !RR_DBG(4) && !RR_DBG(1)) pend_next = probe_h(y_tag, s + 1 - KX);
@@ -806,7 +855,7 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
 
     // prologue: operands of half A, step 0 (h_0 sits in parity 0: no poll); x_0 of half B
     issue_x(I0{}, 0);
-    issue_h(I0{}, 0, 0, 3 * NPRE);
+    issue_h(I0{}, 0, 0, NH * NPRE);
     split_x();
     issue_x(I1{}, 0);
     if (T > 1) {
@@ -837,8 +886,8 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
         }
     }
 }
-template <int KH, int KX, bool TRAIN = false, bool XF = false>
-__global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) { rr_body<KH, KX, TRAIN, 0, XF>(p); }
+template <int KH, int KX, bool TRAIN = false, bool XF = false, bool HF = false>
+__global__ __launch_bounds__(256) void lstm_rr_kernel(RRParams p) { rr_body<KH, KX, TRAIN, 0, XF, HF>(p); }
 template <int KH, int KX, bool TRAIN = false, bool XF = false>
 __global__ __launch_bounds__(256) void gru_rr_kernel(RRParams p) { rr_body<KH, KX, TRAIN, 1, XF>(p); }
 
@@ -930,6 +979,8 @@ struct RRIo {
     const float *h0, *c0; float *hT, *cT; float *c_cache, *z_cache;
     int x_tm, out_tm;
     float *out_h2;            // the sequence output as a FRAG2H tensor (frag3.hip) instead of the f32 rows, or NULL
+    int hf;                   // the HF instantiation: `hseq` is a FRAG2H tensor (two images per block), `img` packed by nntk_shim_lstm_rr_pack_hf
+    float z_scale;            // ... and the scale its sums carry, inverted
 };
 static int rr_launch(const RRIo &io, const float *d_img, const float *d_bi, const float *d_bh,
                      int B, int T, int in, int H, int return_sequences, int cell);
@@ -937,27 +988,54 @@ static int rr_launch(const RRIo &io, const float *d_img, const float *d_bi, cons
 extern "C" int nntk_shim_lstm_rr(const float *d_x, const void *d_xf3, const float *d_img, const float *d_img4, const float *d_bi, const float *d_bh,
                                  const float *d_h0, const float *d_c0, float *d_out, float *d_out_h2, float *d_hseq, float *d_hT, float *d_cT,
                                  float *d_work, int B, int T, int in, int H, int return_sequences) {
-    RRIo io = {d_img4, d_x, d_xf3, d_out, d_hseq, d_work, d_h0, d_c0, d_hT, d_cT, nullptr, nullptr, 0, 0, d_out_h2};
+    RRIo io = {d_img4, d_x, d_xf3, d_out, d_hseq, d_work, d_h0, d_c0, d_hT, d_cT, nullptr, nullptr, 0, 0, d_out_h2, 0, 0.0f};
     return rr_launch(io, d_img, d_bi, d_bh, B, T, in, H, return_sequences, 0);
+}
+// The HF instantiations (H > 256: KH = 8): zero initial state, x as a frag3 tensor, the sequence output ONLY as the FRAG2H tensor the
+// kernel's hand-off is (d_h2: nntk_shim_frag2h_floats(B, T, H) floats).  d_img: nntk_shim_lstm_rr_pack_hf(.., uscale, wscale = 2^15 uscale),
+// z_scale = 1 / wscale.  1 = shape not taken.
+extern "C" int nntk_shim_lstm_rr_hf_ok(int H, int in) {
+    int KH, KX;
+    return rr_shape(H, in, true, &KH, &KX) && KH == 8 && KX <= 2 && nntk_options().rec_hf != 0;
+}
+extern "C" int nntk_shim_lstm_rr_pack_hf(const float *d_ut, const float *d_wp, float *d_img, int H, int in, float uscale, float wscale) {
+    int KH, KX;
+    if (!rr_shape(H, in, true, &KH, &KX) || KH != 8) return nntk_fail_msg("lstm_rr_pack_hf: shape not taken");
+    const int Hj_p = (H + 15) & ~15, Hk_p = (H + 31) & ~31;
+    int Kin_p, N_p;
+    nntk_shim_conv_pack_sizes(in, 4 * H, 1, &Kin_p, &N_p);
+    const int NCT = (H + 15) / 16;
+    const long total = (long)NCT * rr_blocks_per_ct(KH, KX) * 64;
+    long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(rr_pack_kernel<false>, dim3((unsigned)g), dim3(256), 0, nntk_stream(), d_ut, d_wp, (rr_v4u *)d_img, H, in,
+                       Hj_p, Hk_p, Kin_p, KH, KX, NCT, uscale, wscale);
+    NNTK_LAUNCH_CHECK("rr_pack_kernel");
+    return 0;
+}
+extern "C" int nntk_shim_lstm_rr_hf(const void *d_xf3, const float *d_img, const float *d_bi, const float *d_bh, float *d_h2, float *d_work,
+                                    int B, int T, int in, int H, float z_scale) {
+    RRIo io = {nullptr, nullptr, d_xf3, nullptr, d_h2, d_work, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 1, z_scale};
+    return rr_launch(io, d_img, d_bi, d_bh, B, T, in, H, 1, 0);
 }
 // GRU on the same kernel frame (gru_rr_kernel): d_img packed from the four-slot matrices [U_z | U_r | U_h | 0] / [W_z | W_r | 0 | W_h],
 // d_b4 [4H] = b_i,z + b_h,z | b_i,r + b_h,r | b_h,h | b_i,h.  The f32 state register starts from h_0 (which is also the published operand).
 // x_tm / out_tm: d_x is [T][B][in] / the sequence output is written as [T][B][H]
 extern "C" int nntk_shim_gru_rr(const float *d_x, const void *d_xf3, const float *d_img, const float *d_img4, const float *d_b4, const float *d_h0, float *d_out,
                                 float *d_hseq, float *d_hT, float *d_work, int B, int T, int in, int H, int return_sequences, int x_tm, int out_tm) {
-    RRIo io = {d_img4, d_x, d_xf3, d_out, d_hseq, d_work, d_h0, d_h0, d_hT, nullptr, nullptr, nullptr, x_tm, out_tm, nullptr};
+    RRIo io = {d_img4, d_x, d_xf3, d_out, d_hseq, d_work, d_h0, d_h0, d_hT, nullptr, nullptr, nullptr, x_tm, out_tm, nullptr, 0, 0.0f};
     return rr_launch(io, d_img, d_b4, nullptr, B, T, in, H, return_sequences, 1);
 }
 // GRU training forward: zero initial state, h of every step to d_h [B][T][H], caches d_hU [B][T][H] (h.U_h + b_h) and d_Zg [B][T][6H]
 extern "C" int nntk_shim_gru_rr_train_forward(const float *d_x, const float *d_img, const float *d_b4, float *d_h, float *d_hU, float *d_Zg,
                                               float *d_hseq, float *d_work, int B, int T, int in, int H) {
-    RRIo io = {nullptr, d_x, nullptr, d_h, d_hseq, d_work, nullptr, nullptr, nullptr, nullptr, d_hU, d_Zg, 0, 0, nullptr};
+    RRIo io = {nullptr, d_x, nullptr, d_h, d_hseq, d_work, nullptr, nullptr, nullptr, nullptr, d_hU, d_Zg, 0, 0, nullptr, 0, 0.0f};
     return rr_launch(io, d_img, d_b4, nullptr, B, T, in, H, 1, 1);
 }
 // training forward: zero initial state, h of every step to d_h [B][T][H], caches d_c [B][T][H] and d_zifgo [B][T][8H]
 extern "C" int nntk_shim_lstm_rr_train_forward(const float *d_x, const float *d_img, const float *d_bi, const float *d_bh,
                                                float *d_h, float *d_c, float *d_zifgo, float *d_hseq, float *d_work, int B, int T, int in, int H) {
-    RRIo io = {nullptr, d_x, nullptr, d_h, d_hseq, d_work, nullptr, nullptr, nullptr, nullptr, d_c, d_zifgo, 0, 0, nullptr};
+    RRIo io = {nullptr, d_x, nullptr, d_h, d_hseq, d_work, nullptr, nullptr, nullptr, nullptr, d_c, d_zifgo, 0, 0, nullptr, 0, 0.0f};
     return rr_launch(io, d_img, d_bi, d_bh, B, T, in, H, 1, 0);
 }
 
@@ -985,6 +1063,8 @@ static int rr_launch(const RRIo &io, const float *d_img, const float *d_bi, cons
     int KH, KX;
     if (!rr_shape(H, in, xf, &KH, &KX)) return 1;
     if (!xf && ((((size_t)io.x) & 15) != 0 || (in % 4) != 0)) return 1;
+    const bool hf = io.hf != 0;
+    if (hf && (KH != 8 || KX > 2 || cell != 0 || !xf || train || io.h0 || io.out || io.out_h2 || io.img4 || !return_sequences || opt.rec_hf == 0)) return 1;
     const int NCT = H / 16;
     // the x and out rows of one 64-row batch tile are addressed with 32-bit buffer offsets
     if ((double)64 * T * in * 4 >= 2.0e9 || (double)64 * T * H * 4 >= 2.0e9) return 1;
@@ -994,6 +1074,7 @@ static int rr_launch(const RRIo &io, const float *d_img, const float *d_bi, cons
     else if (KH == 4 && KX == 4) kern = rr_pick<4, 4>(cell, train, xf);
     else if (KH == 4 && KX == 2) kern = rr_pick<4, 2>(cell, train, xf);
     else if (KH == 4 && KX == 1) kern = rr_pick<4, 1>(cell, train, xf);
+    if (hf) kern = KX == 2 ? lstm_rr_kernel<8, 2, false, true, true> : lstm_rr_kernel<8, 1, false, true, true>;
     if (!kern) return 1;
     const size_t lds = rr_lds_bytes(KH, KX, train);
     if (lds > 160 * 1024) return 1;
@@ -1003,7 +1084,7 @@ static int rr_launch(const RRIo &io, const float *d_img, const float *d_bi, cons
     if (tiles_per_launch < 1) return 1;
     unsigned *fault = nntk_fault_word();
     if (!fault) return 1;
-    const size_t step = rr_step_bytes(B, H);
+    const size_t step = hf ? rr_step_bytes(B, H) / 3 * 2 : rr_step_bytes(B, H);      // (HF: two images per block)
     if (step >= (size_t)RR_OOB_F) return 1;
     const int nbt_total = (B + 63) / 64;
     const size_t xstep = (size_t)nbt_total * 2 * ((in + 15) / 16) * 3 * 1024;
@@ -1031,7 +1112,8 @@ static int rr_launch(const RRIo &io, const float *d_img, const float *d_bi, cons
     q.spin_ticks = (unsigned long long)(opt.rec_spin_us > 0 ? opt.rec_spin_us : 0) * 100ull;
     q.B = B; q.T = T; q.H = H; q.in = in; q.NCT = NCT; q.return_sequences = return_sequences;
     q.NHT = nbt_total * 2;
-    q.out_h2 = (char *)io.out_h2; q.h2step = step / 3 * 2;
+    q.out_h2 = (char *)io.out_h2; q.h2step = rr_step_bytes(B, H) / 3 * 2;
+    q.z_scale = io.z_scale;
 #ifdef NNTK_REC_STAMPS
     q.stamp = nullptr;
     const char *stamp_path = getenv("NNTK_REC_STAMP_FILE");
@@ -1083,6 +1165,7 @@ static int rr_launch(const RRIo &io, const float *d_img, const float *d_bi, cons
     NNTK_LAUNCH_CHECK("lstm_rr_kernel");
     static const char *const names[2][2][3] = {{{"lstm_rr_kernel<4,1>", "lstm_rr_kernel<4,2>", "lstm_rr_kernel<4,4>"}, {"lstm_rr_kernel<8,1>", "lstm_rr_kernel<8,2>", ""}},
                                                {{"gru_rr_kernel<4,1>", "gru_rr_kernel<4,2>", "gru_rr_kernel<4,4>"}, {"gru_rr_kernel<8,1>", "gru_rr_kernel<8,2>", ""}}};
-    if (took4 == 1) nntk_set_last_rec_kernel(names[cell == 1][KH == 8][KX == 1 ? 0 : KX == 2 ? 1 : 2]);
+    if (hf) nntk_set_last_rec_kernel(KX == 2 ? "lstm_rr_kernel<8,2,hf>" : "lstm_rr_kernel<8,1,hf>");
+    else if (took4 == 1) nntk_set_last_rec_kernel(names[cell == 1][KH == 8][KX == 1 ? 0 : KX == 2 ? 1 : 2]);
     return 0;
 }

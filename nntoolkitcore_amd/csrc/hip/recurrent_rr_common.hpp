@@ -61,18 +61,24 @@ __device__ __forceinline__ void rr_split8(const float (&v)[8], rr_v4u &hi, rr_v4
 
 // eight consecutive f32 of magnitude < 2 -> the two 16-byte f16 fragments of x * 2^15: hi = f16(x 2^15), lo = f16(x 2^15 - hi) (frag3.hip FRAG2H)
 typedef _Float16 rr_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 rr_f16x8 __attribute__((ext_vector_type(8)));
 #define RR_H2_SCALE 32768.0f
+// two f32 already multiplied by their power-of-two scale -> hi = f16(y), lo = f16(y - hi), packed
+__device__ __forceinline__ void rr_split_pair_f16(float y0, float y1, unsigned &hi, unsigned &lo) {
+#pragma clang fp contract(off)    // the residual is that of the ROUNDED value
+    const rr_f16x2 hh = __builtin_convertvector((rr_f32x2){y0, y1}, rr_f16x2);
+    const rr_f16x2 ll = __builtin_convertvector((rr_f32x2){y0 - (float)hh[0], y1 - (float)hh[1]}, rr_f16x2);
+    hi = __builtin_bit_cast(unsigned, hh);
+    lo = __builtin_bit_cast(unsigned, ll);
+}
+__device__ __forceinline__ void rr_split_pair_h2(float v0, float v1, unsigned &hi, unsigned &lo) {
+#pragma clang fp contract(off)
+    rr_split_pair_f16(v0 * RR_H2_SCALE, v1 * RR_H2_SCALE, hi, lo);       // power of two: exact
+}
 __device__ __forceinline__ void rr_split8_h2(const float (&v)[8], rr_v4u &hi, rr_v4u &lo) {
-#pragma clang fp contract(off)    // the residual is that of the ROUNDED product
     unsigned h[4], l[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float x0 = v[2 * i] * RR_H2_SCALE, x1 = v[2 * i + 1] * RR_H2_SCALE;       // power of two: exact
-        const rr_f16x2 hh = __builtin_convertvector((rr_f32x2){x0, x1}, rr_f16x2);
-        const rr_f16x2 ll = __builtin_convertvector((rr_f32x2){x0 - (float)hh[0], x1 - (float)hh[1]}, rr_f16x2);
-        h[i] = __builtin_bit_cast(unsigned, hh);
-        l[i] = __builtin_bit_cast(unsigned, ll);
-    }
+    for (int i = 0; i < 4; ++i) rr_split_pair_h2(v[2 * i], v[2 * i + 1], h[i], l[i]);
     hi = (rr_v4u){h[0], h[1], h[2], h[3]};
     lo = (rr_v4u){l[0], l[1], l[2], l[3]};
 }
@@ -104,6 +110,7 @@ struct RRParams {
     // GEMM's three-product contraction, or NULL; written by the wave that would write the f32 rows (p.out must be NULL then).  recurrent_rr.hip only
     char *out_h2;
     size_t h2step;             // bytes per timestep = NHT * NKS * 2048
+    float z_scale;             // HF instantiations: 2^-(15 + q), the operands' scales taken out of Z (recurrent_rr.hip)
 #ifdef NNTK_REC_STAMPS
     unsigned long long *stamp; // [T + 1][4 streams][16] s_memtime of workgroup 0, wave 0 (diagnostics build only; the two-stream kernels use streams 0, 1)
 #endif

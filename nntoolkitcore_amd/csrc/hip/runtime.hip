@@ -46,6 +46,7 @@ static const OptDesc g_opt_table[] = {
     {"rec_rr", "NNTK_REC_RR", &NntkOptions::rec_rr},
     {"rec_xf", "NNTK_REC_XF", &NntkOptions::rec_xf},
     {"rec_fk", "NNTK_REC_FK", &NntkOptions::rec_fk},
+    {"rec_hf", "NNTK_REC_HF", &NntkOptions::rec_hf},
     {"dense_frag3", "NNTK_DENSE_FRAG3", &NntkOptions::dense_frag3},
     {"dense_f16x2", "NNTK_DENSE_F16X2", &NntkOptions::dense_f16x2},
     {"train_bptt", "NNTK_TRAIN_BPTT", &NntkOptions::train_bptt},

@@ -69,21 +69,6 @@ void DenseDestroy(Dense filter) {
     free(filter);
 }
 
-/* the scale of W's FRAG2H images: the largest power of two with max |W| * scale <= 32 768 (half of f16's range: a row's hi image cannot
- * overflow, and its low image stays out of the subnormals for every weight within 2^-17 of the largest); 0 = the form is not available */
-static float dense_h2_scale(const float *W, size_t n) {
-    float mx = 0.f;
-    for (size_t i = 0; i < n; ++i) {
-        union { float f; unsigned u; } v = { W[i] };
-        if (((v.u >> 23) & 0xffu) == 0xffu) return 0.f;              /* inf / NaN */
-        float a = W[i] < 0.f ? -W[i] : W[i];
-        if (a > mx) mx = a;
-    }
-    if (!(mx > 1e-30f) || mx > 1e30f) return 0.f;
-    int e;
-    (void)frexpf(mx, &e);                                            /* mx = m 2^e, 0.5 <= m < 1: mx 2^(15 - e) <= 32 768 */
-    return ldexpf(1.f, 15 - e);
-}
 static int dense_upload(Dense f) {
     if (nntk_upload_gemm_weights(&f->d_wp, f->weights->W, f->config.input_size, f->config.output_size)) return -1;
     if (nntk_upload_floats(&f->d_bias, f->weights->b, (size_t)f->config.output_size)) return -1;
@@ -91,7 +76,7 @@ static int dense_upload(Dense f) {
         int K_p, N_p;
         nntk_shim_conv_pack_sizes(f->config.input_size, f->config.output_size, 1, &K_p, &N_p);
         const size_t n_w = (size_t)K_p * N_p;
-        f->wh2_scale = dense_h2_scale(f->weights->W, (size_t)f->config.input_size * f->config.output_size);
+        f->wh2_scale = nntk_f16_scale(f->weights->W, (size_t)f->config.input_size * f->config.output_size);
         if (f->wh2_scale > 0.f) {
             if (!f->d_wh2 && !(f->d_wh2 = nntk_shim_malloc(n_w * 2 * sizeof(unsigned short)))) return -1;
             if (nntk_shim_split_f16x2(f->d_wp, f->d_wh2, N_p, K_p, f->wh2_scale)) return -1;

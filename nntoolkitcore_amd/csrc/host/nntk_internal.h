@@ -45,6 +45,9 @@ int nntk_upload_floats(float **d_dst, const float *h_src, size_t n);
 
 /* pack a row-major [K, N] matrix into the conv/GEMM kernel's [N_p][K_p] (K-contiguous) layout and upload */
 int nntk_upload_gemm_weights(float **d_wp, const float *W, int K, int N);
+/* the scale of a weight block's two f16 images (frag3.hip FRAG2H): the largest power of two with max |W| * scale <= 32 768; 0 = not available
+ * (a non-finite value, or a block whose largest magnitude no power of two brings there) */
+float nntk_f16_scale(const float *W, size_t n);
 /* training products (train.c): VALU in the reference's order when small, the MFMA GEMM when large */
 int nntk_train_outer_accumulate(const float *d_A, const float *d_B, float *d_C, float *d_c, long rows, int I, int K, int a_shift_T);
 int nntk_train_rows_times_rowmat(const float *d_d, const float *d_M, float *d_out, long rows, int I, int K);

@@ -12,6 +12,7 @@
  * start every sequence from zeros (gru.c:260, lstm.c:439).
  */
 #include <stdio.h>
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -47,6 +48,9 @@ typedef struct {
     float *d_rr4;               /* the same weights as images of the full-K kernels (recurrent_fk.hip), packed with d_rr */
     float *d_rr;                /* LSTM: weight images of the register-resident split-bf16 kernel (recurrent_rr.hip), made on first use */
     int rr_valid;
+    float *d_rr_hf;             /* LSTM, H > 256: the images of the HF instantiation (h.U on two f16 images), packed on first use */
+    int rr_hf_valid;
+    float hf_wscale;            /* ... the scale W's images (and therefore Z) carry: 2^15 * (U's scale); 0: the form does not hold these weights */
     float *d_b4, *d_b4_train;   /* GRU on those kernels: the four-slot bias vector (core_try_gru_rr; the training forward's copy) */
     float *d_rr_train;          /* ... and the training forward's own copy, re-packed every mini-batch from the raw block */
     /* persistent single-sequence state [H], double-buffered: a stateful call reads state[cur] and writes
@@ -109,6 +113,7 @@ static int core_init(rec_core *c, int G, RecurrentConfig base) {
 static void core_free(rec_core *c) {
     nntk_shim_synchronize();
     nntk_shim_free(c->d_wp); nntk_shim_free(c->d_bi); nntk_shim_free(c->d_ut); nntk_shim_free(c->d_bh); nntk_shim_free(c->d_wt);
+    nntk_shim_free(c->d_rr_hf);
     nntk_shim_free(c->d_rr); nntk_shim_free(c->d_rr4); nntk_shim_free(c->d_rr_train); nntk_shim_free(c->d_b4); nntk_shim_free(c->d_b4_train);
     nntk_shim_free(c->d_h[0]);
     nntk_shim_host_free(c->pin_in); nntk_shim_host_free(c->pin_out); nntk_shim_host_free((void *)c->flag);
@@ -140,6 +145,7 @@ static int core_upload(rec_core *c) {
     if (rc) return rc;
     c->wt_valid = 0;
     c->rr_valid = 0;
+    c->rr_hf_valid = 0;
     c->rr_exact_only = rr_unsplittable(c->weights->W, (size_t)c->in * G * H + (size_t)H * G * H);      /* W | U are contiguous */
     nntk_wblock_mark_uploaded(&c->wb);
     return 0;
@@ -1177,6 +1183,41 @@ static int lstm_apply_device_h2(LSTM filter, const float *d_in, const float *d_i
     if (!lstm_std_acts(acts) || !c->return_sequences) return 1;
     if (B <= 0 || c->T <= 0) return 0;
     if (core_ensure(c, 0)) return -1;
+    /* H > 256: the HF instantiation of the register-resident kernel -- its recurrence itself runs on two f16 images of h (three products per
+     * k step), and its hand-off buffer IS the FRAG2H output.  Another contraction than the bf16 x 3 kernels' (same tolerance): the choice
+     * depends on the layer only (shape, weights, option rec_hf), never on the call. */
+    {
+        int on = -1;
+        (void)nntk_shim_get_option("rec_rr", &on);
+        if (on != 0 && !c->rr_exact_only && nntk_shim_lstm_rr_hf_ok(c->H, c->in)) {
+            if (!c->rr_hf_valid) {
+                const size_t nW = (size_t)c->in * 4 * c->H, nU = (size_t)c->H * 4 * c->H;
+                float us = nntk_f16_scale(c->weights->U, nU), mw = 0.f;
+                for (size_t i = 0; i < nW; ++i) { float a = fabsf(c->weights->W[i]); if (a > mw) mw = a; }
+                /* W's bf16 images are packed times 2^15 us: they must stay inside bf16's range (and the sums inside f32's) */
+                c->hf_wscale = (us > 0.f && us < 1e15f && us > 1e-15f && mw * 32768.f * us < 1e30f) ? 32768.f * us : 0.f;
+                if (c->hf_wscale > 0.f) {
+                    size_t img = nntk_shim_rr_image_floats_xf(c->H, c->in);
+                    if (!c->d_rr_hf && !(c->d_rr_hf = (float *)nntk_shim_malloc(img * sizeof(float)))) return -1;
+                    if (nntk_shim_lstm_rr_pack_hf(c->d_ut, c->d_wp, c->d_rr_hf, c->H, c->in, us, c->hf_wscale)) return -1;
+                }
+                c->rr_hf_valid = 1;
+            }
+            if (c->hf_wscale > 0.f) {
+                const float *xf3 = d_in_f3;
+                if (!xf3) {
+                    float *buf = nntk_devbuf_reserve(&c->d_xf3, nntk_shim_frag3_floats(B, c->T, c->in));
+                    if (!buf || nntk_shim_frag3_pack(d_in, buf, B, c->T, c->in)) return -1;
+                    xf3 = buf;
+                }
+                float *d_work = nntk_devbuf_reserve(&c->d_work_rr, nntk_shim_lstm_rr_work_floats(B, c->H));
+                if (!d_work) return -1;
+                int rc = nntk_shim_lstm_rr_hf(xf3, c->d_rr_hf, c->d_bi, filter->config.v2 ? c->d_bh : NULL, d_out_h2, d_work, B, c->T, c->in, c->H,
+                                              1.f / c->hf_wscale);
+                if (rc <= 0) return rc;
+            }
+        }
+    }
     if (!nntk_shim_fk_image_floats(c->H, c->in)) {       /* (the full-K family has no FRAG2H store; its shapes take the f32 way below) */
         const rr_io io = { d_in, d_in_f3, NULL, NULL, d_out_h2 };
         int rc = core_try_lstm_rr(c, filter->config.v2, acts, &io, B, 0);

@@ -3,6 +3,7 @@
  * stream selection, error string, raw device memory) and the shared weight-block
  * and scratch helpers of the host layer.
  */
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #include "nntk_internal.h"
@@ -205,6 +206,21 @@ int nntk_upload_packed_weights(float **d_wp, const float *h_packed, int rows, in
     return nntk_shim_split_bf16x3(*d_wp, *d_wp + n, rows, ktot);
 }
 
+/* the scale of W's FRAG2H images: the largest power of two with max |W| * scale <= 32 768 (half of f16's range: a row's hi image cannot
+ * overflow, and its low image stays out of the subnormals for every weight within 2^-17 of the largest); 0 = the form is not available */
+float nntk_f16_scale(const float *W, size_t n) {
+    float mx = 0.f;
+    for (size_t i = 0; i < n; ++i) {
+        union { float f; unsigned u; } v = { W[i] };
+        if (((v.u >> 23) & 0xffu) == 0xffu) return 0.f;              /* inf / NaN */
+        float a = W[i] < 0.f ? -W[i] : W[i];
+        if (a > mx) mx = a;
+    }
+    if (!(mx > 1e-30f) || mx > 1e30f) return 0.f;
+    int e;
+    (void)frexpf(mx, &e);                                            /* mx = m 2^e, 0.5 <= m < 1: mx 2^(15 - e) <= 32 768 */
+    return ldexpf(1.f, 15 - e);
+}
 int nntk_upload_gemm_weights(float **d_wp, const float *W, int K, int N) {
     int K_p, N_p;
     nntk_shim_conv_pack_sizes(K, N, 1, &K_p, &N_p);

@@ -32,7 +32,7 @@ def gpu(built_lib):
     return torch.device("cuda:0")
 
 
-OPTION_NAMES = ("rec_persistent", "rec_xw", "rec_pingpong", "rec_groups", "rec_spin_us", "rec_stream", "rec_fused2", "rec_rr", "rec_xf", "rec_fk", "dense_frag3", "dense_f16x2", "train_bptt", "train_outer_plain",
+OPTION_NAMES = ("rec_persistent", "rec_xw", "rec_pingpong", "rec_groups", "rec_spin_us", "rec_stream", "rec_fused2", "rec_rr", "rec_xf", "rec_fk", "rec_hf", "dense_frag3", "dense_f16x2", "train_bptt", "train_outer_plain",
                 "spec_ppw", "spec_variant", "bn_fast", "gemm_tm_batch", "gemm_split_bf16", "gemm_wide", "conv_store", "conv_frag3_out", "conv_flatk", "conv_a4", "weights_check")
 
 

@@ -108,7 +108,8 @@ def test_dense_frag2h_weight_scale_follows_the_weights_magnitude(gpu, scale):
 
 
 @pytest.mark.parametrize("B,I,H,T", [
-    (64, 128, 512, 12),      # the stack's LSTM shape: lstm_rr_kernel<8,2> writes the form itself
+    (64, 128, 512, 12),      # the stack's LSTM shape: the HF instantiation (and, with rec_hf = 0, lstm_rr_kernel<8,2>'s output wave)
+    (130, 64, 384, 40),      # KH = 8 / KX = 1, ragged tiles, 40 steps of recurrence
     (33, 40, 128, 9),        # KH = 4 (pending-pattern hand-off), ragged second half-tile
     (130, 100, 256, 7),      # in % 8 != 0: frag3 input form inside the call
     (65, 256, 256, 6),       # the full-K family's shape: f32 scratch, then the pack pass
@@ -126,10 +127,24 @@ def test_lstm_frag2h_output_is_the_pack_of_the_f32_output(gpu, B, I, H, T):
     xd = torch.from_numpy(x).cuda()
     base = lstm.apply_device(xd).clone()
     want = NL.frag2h_unpack_device(NL.frag2h_pack_device(base), B, T, H)
+    if H > 256:
+        # H > 256: the HF instantiation -- the recurrence itself on two f16 images of h (three products per k step), its hand-off IS the tensor.
+        # Another contraction than the bf16 x 3 kernel's: same tolerance against the oracle, not the same bits
+        got = NL.frag2h_unpack_device(NL.lstm_apply_device_frag2h(lstm, x=xd), B, T, H)
+        kern = capi.load().nntk_hip_last_recurrent_kernel().decode()
+        assert kern.startswith("lstm_rr_kernel<8,") and kern.endswith(",hf>"), kern
+        got3 = NL.frag2h_unpack_device(NL.lstm_apply_device_frag2h(lstm, x_f3=NL.frag3_pack_device(xd), batch=B), B, T, H)
+        assert torch.equal(got3, got)                  # the form of x does not matter, and a second run repeats
+        d = float((got - base).abs().max())
+        print("LSTM-%d T=%d: HF kernel vs bf16 x 3 kernel %.2e" % (H, T, d))
+        assert d < 2e-6
+        np.testing.assert_allclose(got.cpu().numpy(), O.lstm(x, W, U, bi, bh, v2=True), rtol=2e-5, atol=2e-5)
+        capi.set_option("rec_hf", 0)                   # ... from here on the bf16 x 3 kernel, whose output wave writes the form
     got = NL.frag2h_unpack_device(NL.lstm_apply_device_frag2h(lstm, x=xd), B, T, H)
     assert torch.equal(got, want)
     got3 = NL.frag2h_unpack_device(NL.lstm_apply_device_frag2h(lstm, x_f3=NL.frag3_pack_device(xd), batch=B), B, T, H)
     assert torch.equal(got3, want)
+    capi.set_option("rec_hf", "auto")
     assert float((got - base).abs().max()) <= 2.0 ** -23
     ref = O.lstm(x, W, U, bi, bh, v2=True)
     np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)

@@ -657,10 +657,11 @@ def test_full_size_config5_stack_one_gpu_shard(gpu):
     assert wl.tdd_out.shape == (512, 996, 1000) and not wl.f32_route and wl.conv_f3_route
     assert capi.load().nntk_hip_last_conv_kernel().decode() == "conv1d_mfma_bf16x3_kernel<frag3>"
     lstm_out = NL.frag3_unpack_device(wl.lstm_f3, 512, 996, 512)
-    # the FRAG2H tensor is the same h rounded to 2^-23 relative at worst, over the whole batch; the stack output on it within the contraction's noise
+    # the FRAG2H route's LSTM is the HF instantiation (its recurrence on two f16 images of h, three products per k step): the same h within
+    # the contraction's noise over 996 steps and the whole batch, and the stack output likewise
     d_hh, d_yy = float((h_h2 - lstm_out).abs().max()), float((y_h2 - wl.tdd_out).abs().max())
     print("stack B=512: frag2h vs frag3 route, whole batch: LSTM output %.2e, stack output %.2e" % (d_hh, d_yy))
-    assert d_hh <= 2.0 ** -23 and 0.0 < d_yy < 3e-6
+    assert 0.0 < d_hh < 3e-6 and 0.0 < d_yy < 5e-6
     del h_h2
     # the conv layer's output exists in frag3 form only (its epilogue wrote it): the f32 route of the same layer, same bits over the whole batch
     conv_out = wl.conv.apply_device(wl.spec_out, out=wl.conv_out, bn=wl.bn, act=wl.relu)

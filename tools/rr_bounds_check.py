@@ -86,8 +86,9 @@ def run():
                 assert fetch(got) == 0
                 lim = 4 * L.nntk_frag2h_floats(B, T, H)
                 fk = "_fk_kernel" in kern                                # (the full-K family writes f32 rows and the pack pass makes the form)
-                ok = got[5] <= lim and got[3] <= f3_out and (got[2] <= limits[2] if fk else got[2] == 0)
-                live = fk or got[5] == lim
+                hfk = kern.endswith(",hf>")                             # (the HF instantiation's hand-off IS the FRAG2H tensor: word 3)
+                ok = got[5] <= lim and got[3] <= (lim if hfk else f3_out) and (got[2] <= limits[2] if fk else got[2] == 0)
+                live = fk or (got[3] == lim and got[5] == 0 if hfk else got[5] == lim)
                 print("%s B=%d in=%d H=%d T=%d %-12s %-22s out frag2h %d/%d%s" % (cell, B, I, H, T, "frag3->frag2h", kern, got[5], lim,
                       "" if ok and live else "   <-- %s" % ("OUT OF BOUNDS" if not ok else "instrument silent")))
                 bad += (not ok) or (not live)
