@@ -571,6 +571,11 @@ int Conv1dBatchNormActivationApplyDeviceFrag3(Conv1d filter, BatchNorm bn, Activ
  * operands the error is below the frag3 / f32-input GEMM's and below that of the reference's own f32 accumulation order
  * (profiles/r05_gemm_f16x2_micro.log; tests/test_gpu_frag2h.py) -- but the results are NOT bit-identical to those routes.
  *   LSTMApplyDeviceFrag2h: the layer's sequence output in this form; -1 for non-standard activations / return_sequences == false.
+ *     For 256 < H <= 512 the call runs the HF instantiation of the register-resident kernel: the RECURRENCE ITSELF multiplies h -- the same
+ *     bounded operand -- as two f16 images against two f16 images of U 2^q (three products per k step; the input projection x.W keeps its
+ *     three bf16 images and six products), and the kernel's hand-off buffer IS the frag2h tensor.  Same tolerance against the reference as the
+ *     six-product kernel (tests/test_gpu_frag2h.py: T = 996 against the oracle and float64), not the same bits; option rec_hf = 0 keeps the
+ *     six-product recurrence (its output wave then writes the form).  Which kernel runs depends on the layer only, never on the call.
  *   TimeDistributedDenseApplyDeviceFrag2h: valid for every layer (shapes / weights the f16 kernel does not take unpack to f32).
  *   LSTMTimeDistributedDenseApplyDevice takes this route by default when it applies (option dense_f16x2 = 0: the frag3 route). */
 size_t nntk_frag2h_floats(int batch, int T, int C);

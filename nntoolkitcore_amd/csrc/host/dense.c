@@ -452,7 +452,8 @@ int TimeDistributedDenseApplyDeviceFrag2h(TimeDistributedDense filter, const flo
 }
 /* additive: LSTM (return_sequences) -> TimeDistributedDense without an f32 tensor in between.
  * Default (option dense_f16x2 = -1 / 1, an LSTM with the standard activations, finite dense weights, a shape dense_frag3_kernel takes): the
- * LSTM's output wave writes h as a FRAG2H tensor -- two f16 images of h * 2^15, |h| < 1 -- and the dense GEMM sums three products per k step
+ * LSTM hands h over as a FRAG2H tensor -- two f16 images of h * 2^15, |h| < 1: the hand-off buffer of the HF kernel (H > 256, whose recurrence
+ * runs on that form too), else written by the output wave of the six-product kernel -- and the dense GEMM sums three products per k step
  * on it and on W's two f16 images: half the MFMA work of the frag3 route, operands rounded to 2^-23 relative (at worst one f32 ulp), measured
  * error against f64 below the frag3 route's (frag3.hip; tests/test_gpu_frag2h.py).  Not bit-identical to the two separate f32 calls.
  * Otherwise / option dense_f16x2 = 0: the LSTM's hand-off buffer is its output in frag3 form and the dense GEMM reads it as its A operand:

@@ -224,3 +224,46 @@ def test_fused_call_with_weights_the_f16_form_cannot_hold_takes_the_frag3_route(
     one = NL.lstm_tdd_apply_device(lstm, tdd, xd)
     assert torch.equal(one, two)
     lstm.destroy(); tdd.destroy()
+
+
+def test_achieved_error_lstm_hf_512_T996_and_full_grid_repeat(gpu):
+    """The stack's LSTM(128 -> 512, v2) over 996 steps on the HF instantiation (recurrence on two f16 images of h): the deviation from the
+    oracle (libm gates, scalar k order) and from torch float64 as NUMBERS, asserted at the bar of the bf16 x 3 kernel's own test
+    (tests/test_gpu_lstm_rr.py); and, at the bench's own launch (512 rows: all 256 workgroups), a second run and a 64-row shard equal to the
+    first run bit for bit over the whole batch -- the race detector for the flag protocol's counted drains with two stores per publication."""
+    import torch
+    r = rng(502)
+    B, I, H, T = 512, 128, 512, 996
+    uw = lambda fan, *s: r.uniform(-fan ** -0.5, fan ** -0.5, s).astype(np.float32)
+    W, U, bi, bh = uw(I, I, 4 * H), uw(H, H, 4 * H), uw(H, 4 * H), uw(H, 4 * H)
+    lstm = NL.LSTM(I, H, True, T, v2=True)
+    lstm.set_weights(W, U, bi, bh)
+    xd = torch.randn(B, T, I, device="cuda", generator=torch.Generator(device="cuda").manual_seed(7))
+    h2 = NL.lstm_apply_device_frag2h(lstm, x=xd)
+    assert capi.load().nntk_hip_last_recurrent_kernel().decode() == "lstm_rr_kernel<8,2,hf>"
+    got = NL.frag2h_unpack_device(h2, B, T, H)
+    again = NL.frag2h_unpack_device(NL.lstm_apply_device_frag2h(lstm, x=xd), B, T, H)
+    assert torch.equal(again, got)
+    del again
+    shard = NL.frag2h_unpack_device(NL.lstm_apply_device_frag2h(lstm, x=xd[448:].contiguous()), 64, T, H)
+    assert torch.equal(shard, got[448:])
+    del shard
+    rows = [0, 31, 32, 63, 511]
+    x = xd[rows].cpu().numpy()
+    ref = O.lstm(x, W, U, bi, bh, v2=True)
+    ref = ref[0] if isinstance(ref, tuple) else ref
+    import torch as t
+    m = t.nn.LSTM(I, H, batch_first=True).double()
+    with t.no_grad():
+        m.weight_ih_l0.copy_(t.tensor(W).double().T); m.weight_hh_l0.copy_(t.tensor(U).double().T)
+        m.bias_ih_l0.copy_(t.tensor(bi).double()); m.bias_hh_l0.copy_(t.tensor(bh).double())
+        r64 = m(t.tensor(x).double())[0].numpy()
+    g = got[rows].cpu().numpy()
+    base = lstm.apply_device(xd[:64].contiguous())[[0, 31, 32, 63]].cpu().numpy()       # the bf16 x 3 kernel on the same rows
+    e_or, e_64 = float(np.abs(g - ref).max()), float(np.abs(g - r64).max())
+    b_64 = float(np.abs(base - r64[:4]).max())
+    print("lstm HF LSTM(128->512, v2) T=996: max abs err vs oracle %.2e, vs torch float64 %.2e (bf16 x 3 kernel vs float64 %.2e; oracle vs float64 %.2e)"
+          % (e_or, e_64, b_64, float(np.abs(ref - r64).max())))
+    assert e_or < 3e-6 and e_64 < 3e-6
+    assert capi.load().nntk_hip_device_status() == 0
+    lstm.destroy()
