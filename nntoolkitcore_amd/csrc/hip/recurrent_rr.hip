@@ -218,7 +218,15 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
 #ifndef RR_S_E1_XLATE
 #define RR_S_E1_XLATE 2           // the KX = 4 shapes (x requests behind the poll) may arrive from k step 2 on: 6.82 -> 6.66 us per step; 4: 8.3 -- the chain is that tight
 #endif
-    constexpr int S_E1 = (KX > 2 ? RR_S_E1_XLATE : RR_S_E1) + S_RED;                  // (flag protocol only)
+    // HF: a k step of the h part is 6 MFMAs, not 12 -- the same number of k steps is half the time, and the flag chain (publication -> drain ->
+    // flag -> the consumers' poll -> their fetch) is what the half-step waits for.  RR_HF_* are that instantiation's own knobs, measured on
+    // LSTM-512 (same box, alternating processes, profiles/r05_lstm_hf_knobs.log): arrival at k step 3 / 5 / 2: 5.27 / 5.63 / 4.73-5.10 ms -- the
+    // flag goes up as early as the frame allows; operand k steps requested ahead 1 / 2 / 3 / 4 / 5 / 6 / 8 (at arrival 2): 5.27 / 5.10 / 4.93 /
+    // 4.76 / 4.71 / 4.70 / 4.96; flags requested 1 / 3 / 4 k steps before they are looked at instead of 2: +0.05 / +-0 / +0.27 ms.
+#ifndef RR_HF_S_E1
+#define RR_HF_S_E1 2
+#endif
+    constexpr int S_E1 = (KX > 2 ? RR_S_E1_XLATE : HF ? RR_HF_S_E1 : RR_S_E1) + S_RED;                  // (flag protocol only)
     // X_LATE (KX = 4): the eight x requests of a half-step touch 32 rows each (2 x 16 bytes per row and request): they hold the
     // address path for ~2 k cycles and take ~3 us to return, and the poll's vmcnt(0) at S_E2 waited for them (stamps: 6 k cycles
     // in that k step).  They go out AFTER the poll instead, at the end of the half-step, and have the next half-step up to its
@@ -231,7 +239,10 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
     constexpr int S_HEAD = !PEND ? S_E2 : S_E2 - RR_HEAD_LEAD > S_PUB ? S_E2 - RR_HEAD_LEAD : S_PUB + 1;
     // Operand schedule: the fragments of h k step i are requested NPRE k steps ... see issue_h below: i < NPRE at S_HEAD of the
     // OTHER half's sequence (flag protocol: after the poll), i >= NPRE at k step i - NPRE of the half's own sequence (needed at KX + i).
-    constexpr int NPRE = RR_NPRE < KH ? RR_NPRE : KH;
+#ifndef RR_HF_NPRE
+#define RR_HF_NPRE 5
+#endif
+    constexpr int NPRE = (HF ? RR_HF_NPRE : RR_NPRE) < KH ? (HF ? RR_HF_NPRE : RR_NPRE) : KH;
     // flag protocol: vector-memory operations a wave issues between a publication (S_PUB) and its arrival (S_E1): the own-sequence
     // operand requests of k steps S_PUB .. S_E1 - 1 and the x request at S_XSPL -- what the arrival's counted wait leaves in flight
     constexpr int own_lo = S_PUB + NPRE < KH ? S_PUB + NPRE : KH, own_hi = S_E1 + NPRE < KH ? S_E1 + NPRE : KH;
@@ -246,7 +257,10 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
 #ifndef RR_POLL_LEAD_RR
 #define RR_POLL_LEAD_RR (NST >= 9 ? 2 : RR_POLL_LEAD)
 #endif
-    constexpr int POLL_LEAD = RR_POLL_LEAD_RR;
+#ifndef RR_HF_POLL_LEAD
+#define RR_HF_POLL_LEAD RR_POLL_LEAD_RR
+#endif
+    constexpr int POLL_LEAD = HF ? RR_HF_POLL_LEAD : RR_POLL_LEAD_RR;
     static_assert(PEND ? S_XSPL < S_E2 : (S_E1 < S_E2 && S_E1 > S_PUB && S_XSPL < S_E2 - POLL_LEAD), "slice schedule");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     rr_v4u *ULs = reinterpret_cast<rr_v4u *>(smem);                       // [4][KH][2] blocks (not with ULR)
