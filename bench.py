@@ -370,7 +370,8 @@ def roofline_for(wl, phase_ms, prof):
         hf = last.endswith(",hf>")
         products = (3.0 * H + 6.0 * n_in) / (H + n_in) if hf else float(SPLIT_PRODUCTS)
         peak = BF16_MFMA_PEAK_TFLOPS / products
-        traffic, traffic_source = pmc_traffic("lstm_rr_kernel", B)
+        # (the profile's own instantiation: the HF kernel and the six-product one move different bytes)
+        traffic, traffic_source = pmc_traffic("lstm_rr_kernel<8, 2, false, true, true>" if hf else "lstm_rr_kernel<8, 2, false, true>", B)
         # products x 2 tiles x k steps per half, two halves, over four wavefronts: MFMA pipe cycles per wave and timestep
         mfma_cycles = int((3 if hf else 6) * 2 * (H // 16) // 4 * 2 * 32 + 6 * 2 * (n_in // 16) // 4 * 2 * 32)
         return {"kernel": last, "bound": "mfma", "achieved": ach, "peak": peak,
