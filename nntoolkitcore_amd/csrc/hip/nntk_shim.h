@@ -216,7 +216,8 @@ int nntk_shim_lstm_rr(const float *d_x, const void *d_xf3, const float *d_img, c
 /* The HF instantiations of lstm_rr_kernel (H > 256): the h part of Z on two f16 images (three products per k step), the hand-off = the layer's
  * sequence output as a FRAG2H tensor (d_h2: nntk_shim_frag2h_floats(B, T, H) floats).  Zero initial state, x as a frag3 tensor.  Images:
  * nntk_shim_lstm_rr_pack_hf with uscale = a power of two with max |U| uscale <= 32768 and wscale = 32768 uscale; z_scale = 1 / wscale. */
-int nntk_shim_lstm_rr_hf_ok(int H, int in);
+int nntk_shim_lstm_rr_hf_ok(int H, int in);                     /* 256 < H <= 512, H % 16 == 0, in <= 256 (U has no LDS image: a 256-wide W fits), option rec_hf */
+size_t nntk_shim_lstm_rr_hf_image_floats(int H, int in);
 int nntk_shim_lstm_rr_pack_hf(const float *d_ut, const float *d_wp, float *d_img, int H, int in, float uscale, float wscale);
 int nntk_shim_lstm_rr_hf(const void *d_xf3, const float *d_img, const float *d_bi, const float *d_bh, float *d_h2, float *d_work,
                          int B, int T, int in, int H, float z_scale);

@@ -201,7 +201,7 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
 #ifndef RR_ULR8
 #define RR_ULR8 0
 #endif
-    constexpr bool ULR = KX > 2 || (RR_ULR8 && KH == 8 && !TRAIN);
+    constexpr bool ULR = !HF && (KX > 2 || (RR_ULR8 && KH == 8 && !TRAIN));      // (HF: U has no low image at all)
     constexpr int NST = KX + KH;                      // k steps one wavefront multiplies per half
 #ifndef RR_S_RED
 #define RR_S_RED 0               // k step of the reduce + gates slice; 1 (KH = 8: the half-step's first 12 MFMAs issue before its barrier) measured
@@ -264,7 +264,7 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
     static_assert(PEND ? S_XSPL < S_E2 : (S_E1 < S_E2 && S_E1 > S_PUB && S_XSPL < S_E2 - POLL_LEAD), "slice schedule");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     rr_v4u *ULs = reinterpret_cast<rr_v4u *>(smem);                       // [4][KH][2] blocks (not with ULR)
-    rr_v4u *WXs = ULs + (ULR ? 0 : 4 * KH * 2 * 64);                      // [4][KX][2][3] blocks
+    rr_v4u *WXs = ULs + ((ULR || HF) ? 0 : 4 * KH * 2 * 64);              // [4][KX][2][3] blocks
     rr_v4u *red = WXs + 4 * KX * 6 * 64;                                  // [dst 4][src 4][2] blocks: split-K exchange
     float *hx = reinterpret_cast<float *>(red + 32 * 64);                 // [32][RR_HX_LD] h exchange (f32: the output wave's rows)
     unsigned *hs = reinterpret_cast<unsigned *>(hx + 32 * RR_HX_LD);      // [3 images][32][RR_HS_LD] the same h, already split (the publishing wave's rows)
@@ -294,12 +294,14 @@ __device__ __forceinline__ void rr_body(const RRParams &p) {
                 RR_PIN_A(uh[i][mt][m]);
             }
     rr_bf16x8 ulr[ULR ? KH : 1][2];
-    if (ULR) {
+    if (ULR || HF) {
+        if constexpr (ULR) {
 #pragma unroll
         for (int i = 0; i < KH; ++i)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
                 ulr[i][mt] = __builtin_bit_cast(rr_bf16x8, img[(size_t)4 * KH * 4 * 64 + ((w * KH + i) * 2 + mt) * 64 + lane]);
+        }
         const rr_v4u *src = img + (size_t)4 * KH * 4 * 64 + (size_t)4 * KH * 2 * 64;      // WX only
         constexpr int n16 = 4 * KX * 6 * 64;
         for (int e = tid; e < n16; e += 256) WXs[e] = src[e];
@@ -928,8 +930,15 @@ static bool rr_shape(int H, int in, bool xf, int *KH, int *KX) {
     *KX = in <= 64 ? 1 : in <= 128 ? 2 : (in <= 256 && *KH == 4) ? 4 : 0;
     return *KX != 0;
 }
-static size_t rr_lds_bytes(int KH, int KX, bool train = false) {
-    const bool ulr = KX > 2 || (RR_ULR8 && KH == 8 && !train);
+// the HF instantiations (H > 256): U has no LDS image, so the 96 KB of W images of a 256-wide input fit there too
+static bool rr_shape_hf(int H, int in, int *KH, int *KX) {
+    if (H <= 256 || H > 512 || (H % 16) != 0 || in < 1) return false;
+    *KH = 8;
+    *KX = in <= 64 ? 1 : in <= 128 ? 2 : in <= 256 ? 4 : 0;
+    return *KX != 0;
+}
+static size_t rr_lds_bytes(int KH, int KX, bool train = false, bool hf = false) {
+    const bool ulr = hf || KX > 2 || (RR_ULR8 && KH == 8 && !train);
     return (size_t)((ulr ? 0 : 4 * KH * 2) + 4 * KX * 6 + 32) * 1024 + 32 * RR_HX_LD * 4 + 3 * 32 * RR_HS_LD * 4;
 }
 // one timestep of the frag3 hand-off / layer output: [NHT = 2 * batch tiles][H / 16 k steps][3 images] blocks of 1 KB
@@ -1010,11 +1019,16 @@ extern "C" int nntk_shim_lstm_rr(const float *d_x, const void *d_xf3, const floa
 // z_scale = 1 / wscale.  1 = shape not taken.
 extern "C" int nntk_shim_lstm_rr_hf_ok(int H, int in) {
     int KH, KX;
-    return rr_shape(H, in, true, &KH, &KX) && KH == 8 && KX <= 2 && nntk_options().rec_hf != 0;
+    return rr_shape_hf(H, in, &KH, &KX) && nntk_options().rec_hf != 0;
+}
+extern "C" size_t nntk_shim_lstm_rr_hf_image_floats(int H, int in) {
+    int KH, KX;
+    if (!rr_shape_hf(H, in, &KH, &KX)) return 0;
+    return (size_t)((H + 15) / 16) * rr_blocks_per_ct(KH, KX) * 256;
 }
 extern "C" int nntk_shim_lstm_rr_pack_hf(const float *d_ut, const float *d_wp, float *d_img, int H, int in, float uscale, float wscale) {
     int KH, KX;
-    if (!rr_shape(H, in, true, &KH, &KX) || KH != 8) return nntk_fail_msg("lstm_rr_pack_hf: shape not taken");
+    if (!rr_shape_hf(H, in, &KH, &KX)) return nntk_fail_msg("lstm_rr_pack_hf: shape not taken");
     const int Hj_p = (H + 15) & ~15, Hk_p = (H + 31) & ~31;
     int Kin_p, N_p;
     nntk_shim_conv_pack_sizes(in, 4 * H, 1, &Kin_p, &N_p);
@@ -1075,10 +1089,10 @@ static int rr_launch(const RRIo &io, const float *d_img, const float *d_bi, cons
     const NntkOptions &opt = nntk_options();
     if (opt.rec_rr == 0 || opt.rec_persistent == 0 || nntk_persistent_disabled()) return 1;
     int KH, KX;
-    if (!rr_shape(H, in, xf, &KH, &KX)) return 1;
-    if (!xf && ((((size_t)io.x) & 15) != 0 || (in % 4) != 0)) return 1;
     const bool hf = io.hf != 0;
-    if (hf && (KH != 8 || KX > 2 || cell != 0 || !xf || train || io.h0 || io.out || io.out_h2 || io.img4 || !return_sequences || opt.rec_hf == 0)) return 1;
+    if (!(hf ? rr_shape_hf(H, in, &KH, &KX) : rr_shape(H, in, xf, &KH, &KX))) return 1;
+    if (!xf && ((((size_t)io.x) & 15) != 0 || (in % 4) != 0)) return 1;
+    if (hf && (KH != 8 || cell != 0 || !xf || train || io.h0 || io.out || io.out_h2 || io.img4 || !return_sequences || opt.rec_hf == 0)) return 1;
     const int NCT = H / 16;
     // the x and out rows of one 64-row batch tile are addressed with 32-bit buffer offsets
     if ((double)64 * T * in * 4 >= 2.0e9 || (double)64 * T * H * 4 >= 2.0e9) return 1;
@@ -1088,9 +1102,9 @@ static int rr_launch(const RRIo &io, const float *d_img, const float *d_bi, cons
     else if (KH == 4 && KX == 4) kern = rr_pick<4, 4>(cell, train, xf);
     else if (KH == 4 && KX == 2) kern = rr_pick<4, 2>(cell, train, xf);
     else if (KH == 4 && KX == 1) kern = rr_pick<4, 1>(cell, train, xf);
-    if (hf) kern = KX == 2 ? lstm_rr_kernel<8, 2, false, true, true> : lstm_rr_kernel<8, 1, false, true, true>;
+    if (hf) kern = KX == 4 ? lstm_rr_kernel<8, 4, false, true, true> : KX == 2 ? lstm_rr_kernel<8, 2, false, true, true> : lstm_rr_kernel<8, 1, false, true, true>;
     if (!kern) return 1;
-    const size_t lds = rr_lds_bytes(KH, KX, train);
+    const size_t lds = rr_lds_bytes(KH, KX, train, hf);
     if (lds > 160 * 1024) return 1;
     if (nntk_set_max_dynamic_lds((const void *)kern, lds)) return -1;
     const int resident = nntk_resident_blocks((const void *)kern, 256, lds, 1);
@@ -1179,7 +1193,7 @@ static int rr_launch(const RRIo &io, const float *d_img, const float *d_bi, cons
     NNTK_LAUNCH_CHECK("lstm_rr_kernel");
     static const char *const names[2][2][3] = {{{"lstm_rr_kernel<4,1>", "lstm_rr_kernel<4,2>", "lstm_rr_kernel<4,4>"}, {"lstm_rr_kernel<8,1>", "lstm_rr_kernel<8,2>", ""}},
                                                {{"gru_rr_kernel<4,1>", "gru_rr_kernel<4,2>", "gru_rr_kernel<4,4>"}, {"gru_rr_kernel<8,1>", "gru_rr_kernel<8,2>", ""}}};
-    if (hf) nntk_set_last_rec_kernel(KX == 2 ? "lstm_rr_kernel<8,2,hf>" : "lstm_rr_kernel<8,1,hf>");
+    if (hf) nntk_set_last_rec_kernel(KX == 4 ? "lstm_rr_kernel<8,4,hf>" : KX == 2 ? "lstm_rr_kernel<8,2,hf>" : "lstm_rr_kernel<8,1,hf>");
     else if (took4 == 1) nntk_set_last_rec_kernel(names[cell == 1][KH == 8][KX == 1 ? 0 : KX == 2 ? 1 : 2]);
     return 0;
 }

@@ -1197,7 +1197,7 @@ static int lstm_apply_device_h2(LSTM filter, const float *d_in, const float *d_i
                 /* W's bf16 images are packed times 2^15 us: they must stay inside bf16's range (and the sums inside f32's) */
                 c->hf_wscale = (us > 0.f && us < 1e15f && us > 1e-15f && mw * 32768.f * us < 1e30f) ? 32768.f * us : 0.f;
                 if (c->hf_wscale > 0.f) {
-                    size_t img = nntk_shim_rr_image_floats_xf(c->H, c->in);
+                    size_t img = nntk_shim_lstm_rr_hf_image_floats(c->H, c->in);
                     if (!c->d_rr_hf && !(c->d_rr_hf = (float *)nntk_shim_malloc(img * sizeof(float)))) return -1;
                     if (nntk_shim_lstm_rr_pack_hf(c->d_ut, c->d_wp, c->d_rr_hf, c->H, c->in, us, c->hf_wscale)) return -1;
                 }

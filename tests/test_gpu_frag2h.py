@@ -112,6 +112,8 @@ def test_dense_frag2h_weight_scale_follows_the_weights_magnitude(gpu, scale):
     (130, 64, 384, 40),      # KH = 8 / KX = 1, ragged tiles, 40 steps of recurrence
     (64, 128, 512, 1),       # a single step: the peeled prologue / drain only
     (33, 100, 320, 2),       # two steps, in % 8 != 0, H between the compiled depths
+    (70, 256, 512, 9),       # in > 128 at H = 512: only the HF instantiation holds W's images next to U (KX = 4); rec_hf = 0: the exact kernels
+    (64, 200, 384, 5),
     (33, 40, 128, 9),        # KH = 4 (pending-pattern hand-off), ragged second half-tile
     (130, 100, 256, 7),      # in % 8 != 0: frag3 input form inside the call
     (65, 256, 256, 6),       # the full-K family's shape: f32 scratch, then the pack pass
