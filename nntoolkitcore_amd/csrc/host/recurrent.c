@@ -1246,7 +1246,11 @@ void nntk_lstm_dims(LSTM f, int *T, int *in, int *H, int *return_sequences) {
     *T = f->core.T; *in = f->core.in; *H = f->core.H; *return_sequences = f->core.return_sequences ? 1 : 0;
 }
 float *nntk_lstm_frag3_scratch(LSTM f, int batch) {
-    return nntk_devbuf_reserve(&f->core.d_hseq, nntk_shim_rr_hseq_floats(batch, f->core.T, f->core.H));
+    /* the register-resident kernels' hand-off size counts H / 16 k steps (they take H % 16 == 0 only); a layer they do not take writes a
+     * frag3 tensor of ceil(H / 16) k steps into this buffer through the pack pass: the larger of the two (found by the FRAG2H soak: for
+     * H % 16 != 0 the fused LSTM -> dense call wrote one k step per row block past the end of the smaller one) */
+    size_t a = nntk_shim_rr_hseq_floats(batch, f->core.T, f->core.H), b = nntk_shim_frag3_floats(batch, f->core.T, f->core.H);
+    return nntk_devbuf_reserve(&f->core.d_hseq, a > b ? a : b);
 }
 const char *LSTMKernelPlan(LSTM filter) {
     static _Thread_local char buf[320];

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Random-shape soak of the conv / dense / recurrent kernels against the oracle (~835 cases incl. round 5's conv -> frag3 epilogue, dense-on-frag3 and full-K shapes, spectrogram geometries, the RNN, and round 2's streaming / fused-GRU / mixed-radix / log-mel paths and the training path, ~1.5 min on the GPU):
+"""Random-shape soak of the conv / dense / recurrent kernels against the oracle (~915 cases incl. round 5's FRAG2H routes and HF kernels, round 5's conv -> frag3 epilogue, dense-on-frag3 and full-K shapes, spectrogram geometries, the RNN, and round 2's streaming / fused-GRU / mixed-radix / log-mel paths and the training path, ~1.5 min on the GPU):
 python tools/soak.py [seed]"""
 import os, sys
 import numpy as np
@@ -226,4 +226,29 @@ for _ in range(30):
     W, U, bi, bh = u(I, 4 * H, sc=I ** -0.5), u(H, 4 * H, sc=H ** -0.5), u(4 * H, sc=0.1), u(4 * H, sc=0.1)
     l = NL.LSTM(I, H, False, T); l.set_weights(W, U, bi, bh)
     close(l.apply(x), O.lstm(x, W, U, bi, bh, return_sequences=False), 1e-4); l.destroy(); n += 2
+# ---- round 5, late: FRAG2H -- the fused LSTM -> TimeDistributedDense call on random shapes (the HF instantiations for 256 < H <= 512 and inputs up to
+#      256 channels, the six-product kernels' output wave for H <= 256, the pack pass behind every other kernel; dense shapes the f16 kernel takes and
+#      does not take) against the oracle, and the frag2h LSTM output against the oracle ----
+for _ in range(40):
+    H = int(r.integers(4, 33)) * 16 if r.integers(0, 4) else int(r.integers(1, 100)) * 4
+    I = int(r.integers(1, 257))
+    T, B, N = int(r.integers(1, 14)), int(r.integers(1, 200)), int(r.integers(1, 40)) * (32 if r.integers(0, 3) else 1)
+    x = u(B, T, I)
+    W, U, bi, bh = u(I, 4 * H, sc=I ** -0.5), u(H, 4 * H, sc=H ** -0.5), u(4 * H, sc=0.1), u(4 * H, sc=0.1)
+    Wd, bd = u(H, N, sc=H ** -0.5), u(N, sc=0.1)
+    l = NL.LSTM(I, H, True, T); l.set_weights(W, U, bi, bh)
+    tdd = NL.TimeDistributedDense(T, H, N); tdd.set_weights(Wd, bd)
+    xd = torch.from_numpy(x).cuda()
+    h = O.lstm(x, W, U, bi, bh)
+    h = h[0] if isinstance(h, tuple) else h
+    try:
+        close(NL.lstm_tdd_apply_device(l, tdd, xd).cpu().numpy(), O.time_distributed_dense(h, Wd, bd), 1e-4)
+        close(NL.frag2h_unpack_device(NL.lstm_apply_device_frag2h(l, x=xd), B, T, H).cpu().numpy(), h, 1e-4)
+    except AssertionError:
+        print("FRAG2H soak case failed: B=%d T=%d in=%d H=%d N=%d, kernel %s" % (B, T, I, H, N, capi.load().nntk_hip_last_recurrent_kernel().decode()))
+        raise
+    if H % 16 == 0 and 256 < H <= 512:
+        k = capi.load().nntk_hip_last_recurrent_kernel().decode()
+        assert k.startswith("lstm_rr_kernel<8,") and k.endswith(",hf>"), (I, H, k)
+    l.destroy(); tdd.destroy(); n += 2
 print("soak ok:", n, "cases")
