@@ -697,7 +697,8 @@ def main():
                             if getattr(wl, "h2_route", False) else
                             "frag3 tensor: the LSTM kernel's T-deep hand-off buffer (h already split into three bf16 images, MFMA fragment order) "
                             "is the dense GEMM's A operand; bit-identical to the f32 route") if a.workload == "stack" else None,
-            "gemm": gemm_mode() + " for conv / TDD" + (
+            "gemm": gemm_mode() + (" for conv; TDD on two f16 images of h and W, three products (dense_frag3_kernel<...,1>)"
+                                   if getattr(wl, "h2_route", False) else " for conv / TDD") + (
                 ("; LSTM: " + prof["rec_kernel"] + (" (recurrence h.U on two f16 images of h * 2^15 and U * 2^q, three products per k step; the fused input "
                                                    "projection x.W on three bf16 images, six products; NNTK_REC_HF=0: all six-product)"
                                                    if prof["rec_kernel"].endswith(",hf>") else
