@@ -13,5 +13,7 @@ for f in pmc_traffic pmc_traffic_gru pmc_traffic_conv pmc_traffic_spectrogram pm
 [ -s $S/train_bench.log ] && cp $S/train_bench.log ${P}_train_bench.log
 [ -s $S/rec_ab.log ] && cp $S/rec_ab.log ${P}_rec_ab.log
 [ -s $S/rr_repeat_check.log ] && cp $S/rr_repeat_check.log ${P}_rr_repeat_check.log
+[ -s $S/hf_soak.log ] && cp $S/hf_soak.log ${P}_hf_soak.log
+[ -s $S/hf_wide_time.log ] && cp $S/hf_wide_time.log ${P}_hf_wide_time.log
 [ -s $S/elementwise.log ] && grep -v "rocprofv3\|amdgpu.ids\|output_stream\|tool.cpp" $S/elementwise.log > ${P}_elementwise.log
 ls $R/profiles | grep "^$2_" | wc -l

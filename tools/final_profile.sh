@@ -20,6 +20,9 @@ timeout -k 10 300 python tools/train_bench.py 2>&1 | grep -v amdgpu.ids > $O/tra
 timeout -k 10 300 python tools/rr_repeat_check.py 40 2>&1 | grep -v amdgpu.ids > $O/rr_repeat_check.log; tail -1 $O/rr_repeat_check.log
 timeout -k 10 300 python tools/rec_ab.py 1024 500 2>&1 | grep -v amdgpu.ids > $O/rec_ab.log; cat $O/rec_ab.log
 NNTK_REC_FUSED2=1 timeout -k 10 300 python bench.py --workload gru --no-cpu-baseline > $O/bench_gru_fused.json 2> /dev/null; tail -c 200 $O/bench_gru_fused.json; echo
+# the two-f16-image kernels: race detector at the full grid, the 256-wide-input instantiation against the exact kernels, the contraction microbenchmark
+timeout -k 10 300 python tools/hf_soak.py 8 2>&1 | grep -v amdgpu.ids > $O/hf_soak.log; tail -1 $O/hf_soak.log
+timeout -k 10 200 python tools/hf_wide_time.py 2>&1 | grep -v amdgpu.ids > $O/hf_wide_time.log; cat $O/hf_wide_time.log
 # north_star's own batch on ONE GPU (4096 utterances = 8 back-to-back launches of the 256-workgroup LSTM kernel), and the round-3 route
 timeout -k 10 300 python bench.py --batch-per-gpu 4096 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_stack_b4096.json 2> $O/bench_stack_b4096.err; tail -c 300 $O/bench_stack_b4096.json; echo
 # the LSTM -> dense seam on the frag3 form (six products; bit-identical to the f32 route) instead of the default FRAG2H form (three products)
